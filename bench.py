@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py -- genomic elements tested per second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the burden-test hot path over one batch of synthetic input that is
+already resident in HBM:
+
+    per-cohort sufficient statistics -> (RCCL all-gather when N > 1) -> scale factors cj
+    dig_accumulate_elements  (genic_driver_tools.py:300-431 for all elements x cohorts)
+    dig_element_stats        (transfer_tools.py:272-302,343-344,473-482,594-615,731-747,1086-1087)
+
+Workload at N=1: BASELINE.json configs[2] ("whole genome, 37 cohorts batched, 1 MI355X"; the
+metric is quoted on whole-genome x 37 cohorts and this fits one GPU): 288 000 10-kb bins,
+37 cohorts, 120 091 elements (20 091 gene-like + 100 000 noncoding), K = 192 substitution types,
+synthetic data per SURVEY 8d.  One "element tested" = one (element, cohort) pair.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); every rank holds its own
+shard of elements (weak scaling) and the only exchange is the all-gather of the per-cohort
+sufficient statistics.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md chip table
+
+
+# --------------------------------------------------------------------------------------
+# synthetic workload: seeded, no reference code or data needed
+# --------------------------------------------------------------------------------------
+def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, window=10_000, max_blocks=3):
+    """Returns a dict of host arrays in the HBM layouts of include/dig_hip.h."""
+    from digdriver_amd import engine
+    rng = np.random.default_rng(seed)
+    N, E, C = n_bins, n_elements, n_cohorts
+    # bins: 22 "chromosomes" of equal size, genome ordered
+    per_chrom = (N + 21) // 22
+    bin_chrom = (np.arange(N) // per_chrom + 1).astype(np.int32)
+    bin_start = ((np.arange(N) % per_chrom) * window).astype(np.int64)
+    bin_mu = rng.gamma(9.0, 3.0, (N, C))
+    bin_std = rng.gamma(4.0, 1.0, (N, C))
+    bin_y = rng.poisson(bin_mu).astype(np.int32)
+    bin_flag = (rng.uniform(size=(N, 1)) < 0.1).repeat(C, axis=1).astype(np.uint8)
+    ctx_p = rng.dirichlet(np.ones(64))
+    bin_ctx = rng.multinomial(window, ctx_p, size=N).astype(np.int32)
+    # elements: 1..max_blocks blocks of 200-3000 bp, sorted by genome position
+    first_bin = np.sort(rng.integers(0, N, E))
+    nblk = rng.integers(1, max_blocks + 1, E)
+    blk_ptr = np.concatenate([[0], np.cumsum(nblk)]).astype(np.int64)
+    nb_tot = int(blk_ptr[-1])
+    owner = np.repeat(np.arange(E), nblk)
+    rank_in_elt = np.arange(nb_tot) - blk_ptr[owner]
+    blen = rng.integers(200, 3000, nb_tot)
+    gap = rng.integers(0, 4000, nb_tot)
+    step = blen + gap
+    # running offset inside each element
+    cs = np.cumsum(step) - step
+    off = cs - cs[blk_ptr[owner]]
+    base = bin_start[first_bin][owner] + rng.integers(0, window, E)[owner]
+    blk_start = base + off
+    blk_end = blk_start + blen
+    # keep every block inside its chromosome's bin table
+    chrom_end = ((np.bincount(bin_chrom, minlength=24)[bin_chrom[first_bin]]) * window)[owner]
+    over = np.maximum(blk_end - chrom_end, 0)
+    shift = np.zeros(E, np.int64)
+    np.maximum.at(shift, owner, over)
+    blk_start = np.maximum(blk_start - shift[owner], 0)
+    blk_end = blk_start + blen
+    elt_chrom = bin_chrom[first_bin]
+    ov_ptr, ov_idx = engine.ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bin_start)
+    elt_len = np.zeros(E, np.int64)
+    np.add.at(elt_len, owner, blen)
+    # per-context element counts: Poisson around len * composition (integer counts, sum ~ len)
+    L64 = rng.poisson(np.outer(elt_len, ctx_p)).astype(np.int32)
+    L = np.repeat(L64, 3, axis=1)[:, None, :].astype(np.int32)
+    strand_minus = (rng.uniform(size=E) < 0.5).astype(np.uint8)
+    d_pr = rng.dirichlet(np.ones(192), size=C) * 1e-6 * 192
+    cj = rng.uniform(0.2, 3.0, C)
+    cj_indel = rng.uniform(0.02, 0.3, C)
+    # observed counts ~ Gamma-Poisson around the (approximate) expectation, 1 % planted 5x drivers
+    seg_mu = np.add.reduceat(bin_mu[ov_idx], ov_ptr[:-1], axis=0)
+    nbin = np.diff(ov_ptr)[:, None]
+    frac = (elt_len[:, None] / (nbin * float(window)))
+    lam = seg_mu * frac * cj[None, :]
+    driver = (rng.uniform(size=(E, 1)) < 0.01)
+    lam_obs = lam * np.where(driver, 5.0, 1.0) * rng.gamma(4.0, 0.25, (E, C))
+    obs_snv = rng.poisson(lam_obs).astype(np.int32)
+    obs_samples = rng.binomial(obs_snv, 0.93).astype(np.int32)
+    obs_indel = rng.poisson(seg_mu * frac * cj_indel[None, :] * np.where(driver, 5.0, 1.0)).astype(np.int32)
+    # per-cohort totals used by the genome-mode scale factor (transfer_tools.py:148-156)
+    exp_unflagged = (bin_mu * (bin_flag == 0)).sum(axis=0)
+    n_snv_obs = np.rint(exp_unflagged * cj)          # so that N_SNV_OBS / sum(Y_PRED[~FLAG]) ~= cj
+    n_ind_obs = np.rint(exp_unflagged * cj_indel)
+    return dict(bin_mu=bin_mu, bin_std=bin_std, bin_y=bin_y, bin_flag=bin_flag, bin_ctx=bin_ctx,
+                ov_ptr=ov_ptr, ov_idx=ov_idx, L=L, strand_minus=strand_minus, d_pr=d_pr, cj=cj, cj_indel=cj_indel,
+                obs_snv=obs_snv, obs_samples=obs_samples, obs_indel=obs_indel, n_snv_obs=n_snv_obs,
+                n_ind_obs=n_ind_obs, window=window)
+
+
+def algorithmic_bytes(E, C, nbar_ov):
+    """SURVEY 8d definitions (unfused)."""
+    acc = E * (784 + 260 * nbar_ov) + E * C * (21 * nbar_ov + 32)
+    stats = 100.0 * E * C
+    return acc, stats
+
+
+# --------------------------------------------------------------------------------------
+def cpu_baseline(w, sample_elements, want_seconds=15.0):
+    """Time the oracle (numpy + the same scipy ufuncs the reference calls) on a bounded sample of
+    the same workload, single thread.  Test infrastructure: the oracle is the checker/baseline,
+    never the product."""
+    from oracle import dig_oracle as O
+    E = w["L"].shape[0]
+    C = w["d_pr"].shape[0]
+    n = min(sample_elements, E)
+    ptr = w["ov_ptr"][: n + 1]
+    idx = w["ov_idx"][: ptr[-1]]
+
+    def one_pass():
+        t0 = time.perf_counter()
+        acc = O.accumulate_elements_fast(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], ptr, idx,
+                                         w["L"][:n], w["strand_minus"][:n].astype(bool), w["d_pr"])
+        O.element_stats(acc["MU"], acc["SIGMA"], acc["P"][:, 0, :], acc["P_INDEL"][:, None], w["obs_snv"][:n],
+                        w["obs_samples"][:n], w["obs_indel"][:n], w["cj"][None, :], w["cj_indel"][None, :])
+        return time.perf_counter() - t0
+
+    dt = one_pass()
+    reps = 1
+    total = dt
+    while total < want_seconds and reps < 8:
+        total += one_pass()
+        reps += 1
+    value = n * C * reps / total
+    out = {"value": value, "unit": "element-cohort tests/s", "cores": 1, "kind": "port",
+           "sample": "first %d of %d elements x %d cohorts, %d pass(es), oracle/dig_oracle.py "
+                     "(vectorised numpy accumulate + scipy betainc/nbinom.pmf/chi2.sf), 1 thread" % (n, E, C, reps)}
+    return out
+
+
+# --------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bins", type=int, default=288_000)
+    ap.add_argument("--elements", type=int, default=120_091)
+    ap.add_argument("--cohorts", type=int, default=37)
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="elements in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--seed", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    from digdriver_amd import _lib, engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    _lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
+    E, C = w["L"].shape[0], w["d_pr"].shape[0]
+    N = w["bin_mu"].shape[0]
+    nbar = float(len(w["ov_idx"])) / E
+    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
+    unflag = (td["bin_flag"] == 0)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    k_acc, k_stat = [], []
+
+    def step(timed):
+        # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156)
+        part = torch.stack([(td["bin_mu"] * unflag).sum(dim=0), td["n_snv_obs"], td["n_ind_obs"]])   # [3, C]
+        if world > 1:
+            gathered = [torch.empty_like(part) for _ in range(world)]
+            dist.all_gather(gathered, part)          # RCCL over xGMI; 3*C doubles per rank
+            part = torch.stack(gathered).sum(dim=0)  # fixed rank order -> bit-reproducible
+        cj = part[1] / part[0]     # cj = N_SNV_OBS / sum(Y_PRED[~FLAG])
+        cji = part[2] / part[0]    # cj_indel = N_IND_OBS / sum(Y_PRED[~FLAG])
+        e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
+        if timed:
+            e0.record()
+        acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                         td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"])
+        if timed:
+            e1.record()
+        engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], td["obs_snv"],
+                             td["obs_samples"], td["obs_indel"], cj, cji, out=out_stats)
+        if timed:
+            e2.record()
+            k_acc.append((e0, e1))
+            k_stat.append((e1, e2))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_acc = float(np.mean([a.elapsed_time(b) for a, b in k_acc]))
+    ms_stat = float(np.mean([a.elapsed_time(b) for a, b in k_stat]))
+    ok = bool(torch.isfinite(out_stats[1]).all().item())
+
+    if rank == 0:
+        units = float(E) * C * world * args.steps
+        b_acc, b_stat = algorithmic_bytes(E, C, nbar)
+        dominant = "dig_element_stats" if ms_stat >= ms_acc else "dig_accumulate_elements"
+        d_bytes, d_ms = (b_stat, ms_stat) if ms_stat >= ms_acc else (b_acc, ms_acc)
+        achieved = d_bytes / (d_ms * 1e-3) / 1e9
+        res = {
+            "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
+            "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: whole genome, %d 10-kb bins, %d cohorts batched, %d elements "
+                                   "per GPU, K=192 substitution types, mean %.2f bins/element" % (N, C, E, nbar),
+                       "bins": N, "cohorts": C, "elements_per_gpu": E, "parallelism": "elements sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "algorithmic_bytes_per_launch": d_bytes, "avg_launch_ms": d_ms},
+            "kernels": {"dig_accumulate_elements": {"avg_ms": ms_acc, "algorithmic_GBps": b_acc / (ms_acc * 1e-3) / 1e9},
+                        "dig_element_stats": {"avg_ms": ms_stat, "algorithmic_GBps": b_stat / (ms_stat * 1e-3) / 1e9}},
+            "finite_pvalues": ok,
+        }
+        if args.cpu_sample > 0 and world == 1:
+            res["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""ctypes binding of libdig_hip.so (the C ABI declared in include/dig_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C digdriver_amd/csrc``.  There is NO CPU fallback: if the shared library
+is missing or a call fails, a ``DigHipError`` is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdig_hip.so")
+
+DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
+ES_PLANES = ("EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "THETA_INDEL", "EXP_INDEL",
+             "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN")
+
+
+class DigHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+
+# name -> argtypes (restype is always int); mirrors include/dig_hip.h one to one
+_SIGNATURES = {
+    "dig_nb_midp_upper": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dig_nb_midp_upper_host": [_vp, _vp, _vp, _vp, _i64, _int],
+    "dig_nb_exact": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dig_nb_exact_host": [_vp, _vp, _vp, _vp, _i64, _int],
+    "dig_nb_greater": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dig_nb_greater_host": [_vp, _vp, _vp, _vp, _i64, _int],
+    "dig_nb_midp_twosided": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dig_nb_midp_twosided_host": [_vp, _vp, _vp, _vp, _i64, _int],
+    "dig_fisher": [_vp, _vp, _vp, _i64, _vp],
+    "dig_fisher_host": [_vp, _vp, _vp, _i64, _int],
+    "dig_normal_params_to_gamma": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dig_normal_params_to_gamma_host": [_vp, _vp, _vp, _vp, _i64, _int],
+    "dig_element_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "dig_element_stats_host": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int],
+    "dig_accumulate_elements": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _vp],
+    "dig_accumulate_elements_host": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _int],
+    "dig_ideal_overlaps_host": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp],
+    "dig_gather_bins": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp],
+    "dig_gather_bins_host": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _int],
+    "dig_tiled_nb_test": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("dig_abi_version", "dig_last_error", "dig_device_count")
+
+
+def load():
+    """Load libdig_hip.so once; raise DigHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DigHipError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C digdriver_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise DigHipError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.dig_abi_version.restype = ctypes.c_int
+    lib.dig_last_error.restype = ctypes.c_char_p
+    lib.dig_device_count.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().dig_last_error().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero status -> DigHipError(dig_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DigHipError("%s failed (%d): %s" % (name, rc, last_error()))
+
+
+def device_count():
+    """Number of gfx950 devices (0 when HIP reports none)."""
+    n = load().dig_device_count()
+    return max(n, 0)
+
+
+def require_device():
+    if device_count() < 1:
+        raise DigHipError("no gfx950 (MI355X) device is visible; the burden-test path has no CPU fallback")
+
+
+# ---- pointer helpers -------------------------------------------------------
+def host_ptr(arr):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if arr is None:
+        return None
+    assert isinstance(arr, np.ndarray) and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_host(x, dtype):
+    """C-contiguous numpy array of `dtype` (copying only when needed)."""
+    return np.ascontiguousarray(np.asarray(x), dtype=dtype)
+
+
+def dev_ptr(t):
+    """void* of a contiguous torch CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device entry points need contiguous CUDA tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    """hipStream_t of a torch stream (default: torch's current stream)."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

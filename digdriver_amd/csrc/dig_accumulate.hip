@@ -1,0 +1,348 @@
+// dig_accumulate.hip -- per-element expected-count accumulation for all cohorts at once.
+//
+// Reference loops replaced (one Python iteration per element, ~6 k elements/s/process):
+//   genic_driver_tools.py:300-431 nonc_model, :31-203 genic_model, :599-690 tiled_nonc_model,
+//   driver_model/onthefly_tools.py:109-164 (loop body of DIG_onthefly).
+//
+// Mapping onto CDNA4
+//   * one 64-lane wave per element; a workgroup of W waves (W = 16 / 8 / 4 by LDS budget) walks
+//     groups of W consecutive elements, one workgroup per CU, persistent grid;
+//   * phase 1, lanes = the 64 trinucleotide contexts: the wave sums the 256-B context rows of the
+//     element's overlapped bins (one coalesced dword load per bin) and stages the reverse-
+//     complement-permuted counts and the 192 L counts of the element as doubles in LDS;
+//     in the same bin loop, lanes = cohorts read the [N, C] rate tables (C*8 contiguous bytes
+//     per bin) and accumulate MU / VAR / R_OBS / FLAG;
+//   * phase 2, lanes = cohorts: the per-cohort trinucleotide parameters d_pr[C,192] live in LDS
+//     transposed ([192][C], conflict-free 8-byte reads) next to their per-context sums
+//     ([64][C]); each lane runs the 64-term denominator and the 192-term numerator dot products
+//     against LDS-broadcast element counts -- no cross-lane reduction in the hot loop;
+//   * blockIdx -> element-group mapping is XCD-aware: workgroups that share an XCD (b % 8)
+//     walk one contiguous eighth of the genome-ordered element list, so the bin rows that
+//     neighbouring elements share stay in that XCD's L2.
+#include <algorithm>
+#include <vector>
+
+#include "dig_common.hpp"
+#include "dig_math.hpp"
+
+namespace dig {
+
+constexpr int kAccLdsBudget = 160 * 1024 - 1024;
+
+struct AccArgs {
+    const double *bin_mu, *bin_std;
+    const int32_t* bin_y;
+    const uint8_t* bin_flag;
+    const int32_t* bin_ctx;
+    const int64_t* ov_ptr;
+    const int32_t* ov_idx;
+    const int32_t* L;
+    const uint8_t* strand_minus;
+    const int32_t* gene_length;
+    const double* d_pr;
+    double *MU, *SIGMA;
+    int32_t *R_OBS, *FLAG;
+    double* P;
+    int32_t *R_SIZE, *ELT_SIZE;
+    double* P_INDEL;
+    int64_t E, C;
+    int c0, Cc;   // cohort chunk handled by this launch: lanes 0..Cc-1 <-> cohorts c0..c0+Cc-1
+};
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// reverse complement of a context index (A=0,C=1,G=2,T=3; idx = 16 b0 + 4 b1 + b2)
+__device__ __forceinline__ int revcomp_ctx(int c)
+{
+    const int b0 = c >> 4, b1 = (c >> 2) & 3, b2 = c & 3;
+    return ((3 - b2) << 4) | ((3 - b1) << 2) | (3 - b0);
+}
+
+template <int NCLASS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
+{
+    extern __shared__ double smem[];
+    const int Cc = a.Cc;
+    double* dprT = smem;                 // [192][Cc]
+    double* d64T = dprT + 192 * Cc;      // [64][Cc]
+    double* stage = d64T + 64 * Cc;      // [WAVES][NCLASS*192 + 64]
+    constexpr int kStage = NCLASS * 192 + 64;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    // ---- stage the per-cohort trinucleotide parameters (once per workgroup) ----
+    for (int idx = tid; idx < Cc * 192; idx += WAVES * 64) {
+        const int c = idx / 192, j = idx - c * 192;
+        dprT[j * Cc + c] = a.d_pr[(int64_t)(a.c0 + c) * 192 + j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Cc * 64; idx += WAVES * 64) {
+        const int ctx = idx / Cc, c = idx - ctx * Cc;
+        d64T[idx] = (dprT[(3 * ctx) * Cc + c] + dprT[(3 * ctx + 1) * Cc + c]) + dprT[(3 * ctx + 2) * Cc + c];
+    }
+    __syncthreads();
+
+    double* st = stage + wave * kStage;
+    const int64_t n_groups = (a.E + WAVES - 1) / WAVES;
+    // XCD-aware walk: workgroups with equal blockIdx % 8 share one contiguous range of groups
+    const int nx = (gridDim.x >= 8) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const int nslots = (gridDim.x - xcd + nx - 1) / nx;
+    const int64_t per_x = (n_groups + nx - 1) / nx;
+    const int64_t g_begin = (int64_t)xcd * per_x;
+    const int64_t g_end = (g_begin + per_x < n_groups) ? g_begin + per_x : n_groups;
+    const int64_t trips = (per_x + nslots - 1) / nslots;
+
+    const bool cohort_lane = lane < Cc;
+    const int64_t col = a.c0 + lane;
+
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t g = g_begin + slot + it * nslots;
+        const int64_t e = g * WAVES + wave;
+        const bool active = (g < g_end) && (e < a.E);
+
+        double mu = 0.0, var = 0.0;
+        int robs = 0, flag = 0, rsize = 0, lsum = 0;
+        if (active) {
+            const int64_t q0 = a.ov_ptr[e], q1 = a.ov_ptr[e + 1];
+            int rc = 0;
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t b = a.ov_idx[q];
+                rc += a.bin_ctx[b * 64 + lane];
+                if (cohort_lane) {
+                    const int64_t o = b * a.C + col;
+                    const double sd = a.bin_std[o];
+                    mu += a.bin_mu[o];            // genic_driver_tools.py:265
+                    var = fma(sd, sd, var);       // :266
+                    robs += a.bin_y[o];           // :267
+                    flag |= (a.bin_flag[o] != 0); // :268 (numpy bool '+' is a logical OR)
+                }
+            }
+            rsize = wave_sum_i32(rc);
+            const int dst = a.strand_minus[e] ? revcomp_ctx(lane) : lane;   // sequence_tools.py:633-634
+            st[NCLASS * 192 + dst] = (double)rc;
+            const int32_t* Le = a.L + e * (int64_t)(NCLASS * 192);
+#pragma unroll
+            for (int r = 0; r < NCLASS * 3; ++r) {
+                const int v = Le[r * 64 + lane];
+                st[r * 64 + lane] = (double)v;
+                lsum += v;
+            }
+            lsum = wave_sum_i32(lsum);
+        }
+        __syncthreads();
+        if (active) {
+            if (cohort_lane) {
+                const double* rcs = st + NCLASS * 192;
+                double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll 4
+                for (int j = 0; j < 64; j += 4) {   // sum(region_counts * d_pr), :361
+                    d0 = fma(rcs[j + 0], d64T[(j + 0) * Cc + lane], d0);
+                    d1 = fma(rcs[j + 1], d64T[(j + 1) * Cc + lane], d1);
+                    d2 = fma(rcs[j + 2], d64T[(j + 2) * Cc + lane], d2);
+                    d3 = fma(rcs[j + 3], d64T[(j + 3) * Cc + lane], d3);
+                }
+                const double denom = (d0 + d1) + (d2 + d3);
+                const int64_t o = e * a.C + col;
+                a.MU[o] = mu;
+                a.SIGMA[o] = sqrt(var);             // :271
+                a.R_OBS[o] = robs;
+                a.FLAG[o] = flag;
+#pragma unroll
+                for (int q = 0; q < NCLASS; ++q) {
+                    const double* Ls = st + q * 192;
+                    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+#pragma unroll 4
+                    for (int j = 0; j < 192; j += 4) {   // sum(t_pi * L), :364-366
+                        n0 = fma(Ls[j + 0], dprT[(j + 0) * Cc + lane], n0);
+                        n1 = fma(Ls[j + 1], dprT[(j + 1) * Cc + lane], n1);
+                        n2 = fma(Ls[j + 2], dprT[(j + 2) * Cc + lane], n2);
+                        n3 = fma(Ls[j + 3], dprT[(j + 3) * Cc + lane], n3);
+                    }
+                    a.P[(e * NCLASS + q) * a.C + col] = ((n0 + n1) + (n2 + n3)) / denom;
+                }
+            }
+            if (lane == 0 && a.c0 == 0) {
+                const int esize = lsum / 3;                               // :380
+                a.R_SIZE[e] = rsize;                                      // :375
+                a.ELT_SIZE[e] = esize;
+                const double num = a.gene_length ? (double)a.gene_length[e] : (double)esize;
+                a.P_INDEL[e] = num / (double)rsize;                       // :381 / :159
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NCLASS>
+static int launch_acc(const AccArgs& a, hipStream_t stream)
+{
+    const size_t fixed = (size_t)(192 + 64) * a.Cc * sizeof(double);
+    const size_t per_wave = (size_t)(NCLASS * 192 + 64) * sizeof(double);
+    int waves = 16;
+    while (waves > 4 && fixed + per_wave * waves > (size_t)kAccLdsBudget) waves >>= 1;
+    const size_t lds = fixed + per_wave * waves;
+    if (lds > (size_t)kAccLdsBudget) return set_error(DIG_EINVAL, "accumulate: LDS budget exceeded (Cc=%d)", a.Cc);
+    const int64_t n_groups = (a.E + waves - 1) / waves;
+    int grid = cu_count();
+    if ((int64_t)grid > n_groups) grid = (int)(n_groups > 0 ? n_groups : 1);
+    auto go = [&](auto kern) -> int {
+        DIG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, stream, a);
+        DIG_HIP_TRY(hipGetLastError());
+        return DIG_OK;
+    };
+    if (waves == 16) return go(accumulate_kernel<NCLASS, 16>);
+    if (waves == 8) return go(accumulate_kernel<NCLASS, 8>);
+    return go(accumulate_kernel<NCLASS, 4>);
+}
+
+}  // namespace dig
+
+using namespace dig;
+
+extern "C" {
+
+int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                            const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
+                            int n_class, const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
+                            double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE,
+                            int32_t* ELT_SIZE, double* P_INDEL, int64_t N, int64_t E, int64_t C, void* stream)
+{
+    DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
+    DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(bin_mu && bin_std && bin_y && bin_flag && bin_ctx && ov_ptr && ov_idx && L && strand_minus && d_pr,
+                "non-null inputs");
+    DIG_REQUIRE(MU && SIGMA && R_OBS && FLAG && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
+    for (int64_t c0 = 0; c0 < C; c0 += 64) {
+        AccArgs a{bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
+                  MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, (int)c0,
+                  (int)std::min<int64_t>(64, C - c0)};
+        int rc = (n_class == 1) ? launch_acc<1>(a, (hipStream_t)stream) : launch_acc<4>(a, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return DIG_OK;
+}
+
+int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,
+                                 const uint8_t* bin_flag, const int32_t* bin_ctx, const int64_t* ov_ptr,
+                                 const int32_t* ov_idx, const int32_t* L, int n_class, const uint8_t* strand_minus,
+                                 const int32_t* gene_length, const double* d_pr, double* MU, double* SIGMA,
+                                 int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
+                                 double* P_INDEL, int64_t N, int64_t E, int64_t C, int device)
+{
+    DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
+    DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(bin_mu && bin_std && bin_y && bin_flag && bin_ctx && ov_ptr && ov_idx && L && strand_minus && d_pr,
+                "non-null inputs");
+    DIG_REQUIRE(MU && SIGMA && R_OBS && FLAG && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
+    DIG_HIP_TRY(hipSetDevice(device));
+    const int64_t nnz = ov_ptr[E];
+    DIG_REQUIRE(nnz >= 0, "ov_ptr[E] >= 0");
+    for (int64_t q = 0; q < nnz; ++q) DIG_REQUIRE(ov_idx[q] >= 0 && ov_idx[q] < N, "ov_idx within [0, N)");
+    const size_t nNC = (size_t)N * C, nEC = (size_t)E * C;
+    DevBuf d_mu, d_sd, d_y, d_fl, d_ctx, d_ptr, d_idx, d_L, d_st, d_gl, d_dpr;
+    DevBuf o_mu, o_sg, o_ro, o_fl, o_p, o_rs, o_es, o_pi;
+#define UP(buf, src, bytes)                       \
+    DIG_HIP_TRY(buf.alloc(bytes));                \
+    DIG_HIP_TRY(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice))
+    UP(d_mu, bin_mu, nNC * 8);
+    UP(d_sd, bin_std, nNC * 8);
+    UP(d_y, bin_y, nNC * 4);
+    UP(d_fl, bin_flag, nNC);
+    UP(d_ctx, bin_ctx, (size_t)N * 64 * 4);
+    UP(d_ptr, ov_ptr, (size_t)(E + 1) * 8);
+    UP(d_idx, ov_idx, (size_t)nnz * 4);
+    UP(d_L, L, (size_t)E * n_class * 192 * 4);
+    UP(d_st, strand_minus, (size_t)E);
+    if (gene_length) { UP(d_gl, gene_length, (size_t)E * 4); }
+    UP(d_dpr, d_pr, (size_t)C * 192 * 8);
+#undef UP
+    DIG_HIP_TRY(o_mu.alloc(nEC * 8));
+    DIG_HIP_TRY(o_sg.alloc(nEC * 8));
+    DIG_HIP_TRY(o_ro.alloc(nEC * 4));
+    DIG_HIP_TRY(o_fl.alloc(nEC * 4));
+    DIG_HIP_TRY(o_p.alloc(nEC * n_class * 8));
+    DIG_HIP_TRY(o_rs.alloc((size_t)E * 4));
+    DIG_HIP_TRY(o_es.alloc((size_t)E * 4));
+    DIG_HIP_TRY(o_pi.alloc((size_t)E * 8));
+    int rc = dig_accumulate_elements(d_mu.as<double>(), d_sd.as<double>(), d_y.as<int32_t>(), d_fl.as<uint8_t>(),
+                                     d_ctx.as<int32_t>(), d_ptr.as<int64_t>(), d_idx.as<int32_t>(), d_L.as<int32_t>(),
+                                     n_class, d_st.as<uint8_t>(), gene_length ? d_gl.as<int32_t>() : nullptr,
+                                     d_dpr.as<double>(), o_mu.as<double>(), o_sg.as<double>(), o_ro.as<int32_t>(),
+                                     o_fl.as<int32_t>(), o_p.as<double>(), o_rs.as<int32_t>(), o_es.as<int32_t>(),
+                                     o_pi.as<double>(), N, E, C, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(MU, o_mu.p, nEC * 8, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(SIGMA, o_sg.p, nEC * 8, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(R_OBS, o_ro.p, nEC * 4, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(FLAG, o_fl.p, nEC * 4, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(P, o_p.p, nEC * n_class * 8, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(R_SIZE, o_rs.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(ELT_SIZE, o_es.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(P_INDEL, o_pi.p, (size_t)E * 8, hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+// Host-side integer index construction (genic_driver_tools.py:275-283).
+int dig_ideal_overlaps_host(const int32_t* elt_chrom, const int64_t* blk_ptr, const int64_t* blk_start,
+                            const int64_t* blk_end, int64_t E, int64_t window, const int32_t* bin_chrom,
+                            const int64_t* bin_start, int64_t N, int64_t* ov_ptr, int32_t* ov_idx)
+{
+    DIG_REQUIRE(E >= 0 && N >= 0 && window > 0, "E, N >= 0 and window > 0");
+    DIG_REQUIRE(ov_ptr, "ov_ptr non-null");
+    if (E == 0) {
+        ov_ptr[0] = 0;
+        return DIG_OK;
+    }
+    DIG_REQUIRE(elt_chrom && blk_ptr && blk_start && blk_end && bin_chrom && bin_start, "non-null inputs");
+    for (int64_t i = 1; i < N; ++i)
+        DIG_REQUIRE(bin_chrom[i] > bin_chrom[i - 1] || (bin_chrom[i] == bin_chrom[i - 1] && bin_start[i] > bin_start[i - 1]),
+                    "bin table sorted by (chrom, start), no duplicates");
+    std::vector<int64_t> starts;
+    int64_t nnz = 0;
+    ov_ptr[0] = 0;
+    for (int64_t e = 0; e < E; ++e) {
+        starts.clear();
+        for (int64_t b = blk_ptr[e]; b < blk_ptr[e + 1]; ++b) {
+            const int64_t s = blk_start[b], en = blk_end[b];
+            DIG_REQUIRE(s >= 0 && en >= 0, "non-negative coordinates");
+            const int64_t low = (s / window) * window;                       // floor(start / w) * w
+            const int64_t high = ((en + window - 1) / window) * window;      // ceil(end / w) * w
+            for (int64_t x = low; x < high; x += window) starts.push_back(x);
+        }
+        std::sort(starts.begin(), starts.end());
+        starts.erase(std::unique(starts.begin(), starts.end()), starts.end());   // list(set(...))
+        if (ov_idx) {
+            for (int64_t x : starts) {
+                // binary search (chrom, start) in the sorted table
+                int64_t lo = 0, hi = N;
+                const int32_t ch = elt_chrom[e];
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (bin_chrom[mid] < ch || (bin_chrom[mid] == ch && bin_start[mid] < x)) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo >= N || bin_chrom[lo] != ch || bin_start[lo] != x)
+                    return set_error(DIG_EINVAL, "element %lld overlaps bin chr%d:%lld which is not in the bin table",
+                                     (long long)e, (int)ch, (long long)x);
+                ov_idx[nnz++] = (int32_t)lo;
+            }
+        } else {
+            nnz += (int64_t)starts.size();
+        }
+        ov_ptr[e + 1] = nnz;
+    }
+    return DIG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// dig_common.hpp -- error plumbing and launch helpers shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/dig_hip.h"
+
+namespace dig {
+
+std::string& last_error_ref();
+int set_error(int code, const char* fmt, ...);
+
+#define DIG_HIP_TRY(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return ::dig::set_error(DIG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                                    __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define DIG_REQUIRE(cond, msg)                                                                  \
+    do {                                                                                        \
+        if (!(cond)) return ::dig::set_error(DIG_EINVAL, "%s: requirement failed: %s", __func__, msg); \
+    } while (0)
+
+// number of CUs of the current device (cached per device)
+int cu_count();
+
+// RAII device buffer used only by the *_host twins
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T>
+    T* as()
+    {
+        return static_cast<T*>(p);
+    }
+};
+
+inline int grid_for(int64_t n, int block, int max_blocks_per_cu = 8)
+{
+    int64_t want = (n + block - 1) / block;
+    int64_t cap = (int64_t)cu_count() * max_blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+}  // namespace dig

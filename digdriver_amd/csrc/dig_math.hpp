@@ -1,0 +1,240 @@
+// dig_math.hpp -- FP64 device math for the DIGDriver burden tests on gfx950.
+//
+// Everything here is __device__ code for CDNA4; there is no host/CPU fallback.
+//
+// What is computed (reference: DIGDriver/sequence_model/nb_model.py:237-337):
+//   I_x(a, b)            regularised incomplete beta  (scipy.special.betainc)
+//   pmf(k; n, p)         negative-binomial pmf        (scipy.stats.nbinom.pmf)
+//   mid-p upper tail     0.5 pmf(k) + I_{1-p}(k+1, alpha)          (nb_model.py:271-278)
+//   exact / greater / two-sided mid-p siblings         (nb_model.py:243-256,298-337)
+//   Fisher(p1, p2)       chi2.sf(-2 (ln p1 + ln p2), 4) = q (1 - ln q)   (transfer_tools.py:1086-1087)
+//
+// Numerical design (tolerance contract: <=1e-6 relative for p >= 1e-250):
+//   * k is an integer count in every live call, so the NB tail is evaluated from the pmf
+//     recurrence  t_{j+1} = t_j (alpha + j) x / (j + 1),  t_0 = p^alpha :
+//       - small k  : S = sum_{j<k} t_j directly; result 1 - S - t_k/2 when that is not small
+//                    (no lgamma, no continued fraction; ~4 FP64 ops per step);
+//       - otherwise: modified-Lentz continued fraction for I_x(a,b) with the usual
+//                    x <-> 1-x switch at x = (a+1)/(a+b+2); the prefactor
+//                    x^a y^b / (a B(a,b)) is pmf(k) (k+alpha) x / (k+1), so one pmf serves
+//                    both terms of the mid-p sum.
+//   * the inputs alpha = mu^2/sigma^2, theta = sigma^2/mu * cj, p = 1/(theta Pi + 1) and
+//     x = 1 - p are formed with FP contraction OFF so they are bit-identical to the
+//     reference's numpy expressions (the tail is ~x^(k+1): a 1-ulp change in p matters).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dig {
+
+constexpr double kCfEps = 1e-15;
+constexpr int kCfMaxIt = 20000;
+constexpr double kFpMin = 1e-300;
+constexpr int kSmallK = 64;          // direct-summation limit
+constexpr double kDirectMin = 1e-3;  // accept 1 - S - t/2 when >= this (abs err ~1e-14)
+
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// ---- exact-rounding input preparation (no FMA contraction) -------------------------
+struct GammaParams {
+    double alpha, theta;
+};
+
+// nb_model.py:237-241
+__device__ __forceinline__ GammaParams normal_params_to_gamma(double mu, double sigma)
+{
+#pragma clang fp contract(off)
+    GammaParams g;
+    double m2 = mu * mu;
+    double s2 = sigma * sigma;
+    g.alpha = m2 / s2;
+    g.theta = s2 / mu;
+    return g;
+}
+
+// p = 1 / (theta * Pi + 1)   (transfer_tools.py:476-481)
+__device__ __forceinline__ double nb_success_prob(double theta, double pi)
+{
+#pragma clang fp contract(off)
+    double t = theta * pi;
+    double d = t + 1.0;
+    return 1.0 / d;
+}
+
+__device__ __forceinline__ double mul_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+
+// ---- continued fraction for I_x(a,b) (fast for x < (a+1)/(a+b+2)) -------------------
+__device__ inline double betacf(double a, double b, double x)
+{
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < kFpMin) d = kFpMin;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= kCfMaxIt; ++m) {
+        const double dm = (double)m, m2 = 2.0 * dm;
+        double aa = dm * (b - dm) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < kFpMin) d = kFpMin;
+        c = 1.0 + aa / c;
+        if (fabs(c) < kFpMin) c = kFpMin;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + dm) * (qab + dm) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < kFpMin) d = kFpMin;
+        c = 1.0 + aa / c;
+        if (fabs(c) < kFpMin) c = kFpMin;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) <= kCfEps) break;
+    }
+    return h;
+}
+
+// scipy.special.betainc(a, b, x), general real a, b
+__device__ inline double betainc(double a, double b, double x)
+{
+    if (isnan(a) || isnan(b) || isnan(x)) return dnan();
+    if (a <= 0.0 || b <= 0.0 || x < 0.0 || x > 1.0) return dnan();  // scipy 1.15.3: a==0 or b==0 -> nan
+    if (isinf(a) || isinf(b)) return dnan();
+    if (x == 0.0) return 0.0;
+    if (x == 1.0) return 1.0;
+    const double y = 1.0 - x;
+    const double lfront = a * log(x) + b * log(y) + lgamma(a + b) - lgamma(a) - lgamma(b);
+    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lfront) * betacf(a, b, x) / a;
+    return 1.0 - exp(lfront) * betacf(b, a, y) / b;
+}
+
+// scipy.stats.nbinom.pmf(k, n, p)
+__device__ inline double nbinom_pmf(double k, double n, double p)
+{
+    if (isnan(k) || isnan(n) || isnan(p)) return dnan();
+    if (!(n > 0.0) || !(p > 0.0) || !(p <= 1.0) || isinf(n)) return dnan();
+    if (k < 0.0 || floor(k) != k) return 0.0;
+    if (p == 1.0) return k == 0.0 ? 1.0 : 0.0;
+    const double l = lgamma(k + n) - lgamma(k + 1.0) - lgamma(n) + n * log(p) + k * log1p(-p);
+    return exp(l);
+}
+
+// log pmf(k) for integer k >= 0, 0 < p < 1, finite n > 0 (no argument checks)
+__device__ __forceinline__ double nbinom_logpmf_unchecked(double k, double n, double p)
+{
+    return lgamma(k + n) - lgamma(k + 1.0) - lgamma(n) + n * log(p) + k * log1p(-p);
+}
+
+// P(X > k) for integer k >= 0 given pmf(k):  I_x(k+1, alpha) with prefactor folded into pmf(k).
+__device__ inline double nb_upper_tail_from_pmf(double k, double alpha, double p, double x, double pmfk)
+{
+    const double a = k + 1.0, b = alpha;
+    if (x < (a + 1.0) / (a + b + 2.0)) {
+        // I = pmf(k+1) * cf(a,b,x),  pmf(k+1) = pmf(k) (k+alpha) x / (k+1)
+        return pmfk * ((k + alpha) * x / a) * betacf(a, b, x);
+    }
+    // 1 - I_y(b, a),  prefactor y^b x^a /(b B(a,b)) = pmf(k) (k+alpha) x / alpha
+    return 1.0 - pmfk * ((k + alpha) * x / alpha) * betacf(b, a, p);
+}
+
+// nb_model.py:271-278:  0.5 * nbinom.pmf(k, alpha, p) + betainc(k + 1, alpha, 1 - p)
+__device__ inline double nb_midp_upper(double k, double alpha, double p)
+{
+    if (isnan(k) || isnan(alpha) || isnan(p)) return dnan();
+    if (!(alpha > 0.0) || !(p > 0.0) || !(p <= 1.0) || isinf(alpha)) return dnan();
+    const double x = 1.0 - p;
+    const bool kint = (floor(k) == k);
+    if (k < 0.0 || !kint || isinf(k)) {
+        // never produced by the live callers (counts); keep scipy's semantics
+        const double pmf = (k >= 0.0 && kint) ? nbinom_pmf(k, alpha, p) : 0.0;
+        return 0.5 * pmf + betainc(k + 1.0, alpha, x);
+    }
+    if (p == 1.0) return k == 0.0 ? 0.5 : 0.0;
+    const double lp0 = alpha * log(p);   // log t_0
+    double pmfk;
+    if (k <= (double)kSmallK && lp0 > -690.0) {
+        double t = exp(lp0), S = 0.0;
+        const int ki = (int)k;
+        for (int j = 0; j < ki; ++j) {
+            S += t;
+            t *= (alpha + (double)j) * x / (double)(j + 1);
+        }
+        const double r = 1.0 - S - 0.5 * t;
+        if (r >= kDirectMin) return r;
+        pmfk = t;
+        if (!(pmfk > 1e-290)) pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
+    } else {
+        pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
+    }
+    return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);
+}
+
+// nb_model.py:243-256
+__device__ inline double nb_greater(double k, double alpha, double p)
+{
+    if (k == 0.0) return 1.0;
+    double pv = betainc(k, alpha, 1.0 - p);
+    if (pv == 0.0) pv = nbinom_pmf(k, alpha, p);
+    return pv;
+}
+
+// P(X <= k) = I_p(alpha, k+1) by direct summation for small integer k (all terms positive);
+// returns false when the fast path does not apply.
+__device__ __forceinline__ bool nb_lower_cdf_small(double k, double alpha, double p, double* out)
+{
+    if (!(alpha > 0.0) || !(p > 0.0) || !(p < 1.0) || isinf(alpha)) return false;
+    if (!(k >= 0.0) || k > (double)kSmallK || floor(k) != k) return false;
+    const double lp0 = alpha * log(p);
+    if (!(lp0 > -690.0)) return false;
+    const double x = 1.0 - p;
+    double t = exp(lp0), S = t;
+    const int ki = (int)k;
+    for (int j = 0; j < ki; ++j) {
+        t *= (alpha + (double)j) * x / (double)(j + 1);
+        S += t;
+    }
+    *out = S;
+    return true;
+}
+
+// nb_model.py:298-314 (mu defaults to alpha (1-p)/p)
+__device__ inline double nb_exact(double k, double alpha, double p)
+{
+    const double mu = alpha * (1.0 - p) / p;
+    if (k < mu) {
+        double s;
+        if (nb_lower_cdf_small(k, alpha, p, &s)) return s;
+        return betainc(alpha, k + 1.0, p);
+    }
+    double pv = betainc(k, alpha, 1.0 - p);
+    if (pv == 0.0) pv = nbinom_pmf(k, alpha, p);
+    return pv;
+}
+
+// nb_model.py:316-337
+__device__ inline double nb_midp_twosided(double k, double alpha, double p)
+{
+    const double mu = alpha * (1.0 - p) / p;
+    const double pmf = nbinom_pmf(k, alpha, p);
+    if (k < mu) {
+        if (k > 0.0) return 0.5 * pmf + betainc(alpha, k, p);
+        return 0.5 * pmf;
+    }
+    return 0.5 * pmf + betainc(k + 1.0, alpha, 1.0 - p);
+}
+
+// transfer_tools.py:860-861,1086-1087: chi2.sf(-2 (ln p1 + ln p2), df=4)
+__device__ __forceinline__ double fisher_combine(double p1, double p2)
+{
+    if (isnan(p1) || isnan(p2)) return dnan();
+    const double h = -(log(p1) + log(p2));
+    if (isnan(h)) return dnan();
+    if (h < 0.0) return 1.0;
+    if (isinf(h)) return 0.0;
+    return exp(-h) * (1.0 + h);
+}
+
+}  // namespace dig

@@ -1,0 +1,378 @@
+// dig_nb.hip -- negative-binomial burden tests on gfx950 (FP64 VALU + HBM streaming).
+//
+// Kernels:
+//   nb3_kernel<Op>          elementwise (k, alpha, p) -> p-value   (nb_model.py:243-337)
+//   fisher_kernel           chi2.sf(-2(ln p1 + ln p2), 4)         (transfer_tools.py:1086-1087)
+//   gamma_kernel            normal_params_to_gamma                (nb_model.py:237-241)
+//   element_stats_kernel    the seven-column statistics block per (element, cohort)
+//                           (transfer_tools.py:17-19,300,343-344,473-482,594-615,731-747,1086-1087)
+//   tiled_nb_kernel         per-base / per-tile exact test        (nb_model.py:141-178)
+//
+// All of them are one work item per test with a grid-stride loop: 8-byte coalesced loads
+// (512 B per wave-instruction per operand), grid capped at 8 blocks/CU.  The arithmetic per
+// item is the FP64 recurrence / continued fraction in dig_math.hpp.
+#include "dig_common.hpp"
+#include "dig_math.hpp"
+
+namespace dig {
+
+constexpr int kBlock = 256;
+
+struct OpMidpUpper {
+    __device__ static double apply(double k, double a, double p) { return nb_midp_upper(k, a, p); }
+};
+struct OpExact {
+    __device__ static double apply(double k, double a, double p) { return nb_exact(k, a, p); }
+};
+struct OpGreater {
+    __device__ static double apply(double k, double a, double p) { return nb_greater(k, a, p); }
+};
+struct OpMidpTwo {
+    __device__ static double apply(double k, double a, double p) { return nb_midp_twosided(k, a, p); }
+};
+
+template <typename Op>
+__global__ __launch_bounds__(kBlock) void nb3_kernel(const double* __restrict__ k, const double* __restrict__ alpha,
+                                                     const double* __restrict__ p, double* __restrict__ out,
+                                                     int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = Op::apply(k[i], alpha[i], p[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void fisher_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
+                                                        double* __restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = fisher_combine(p1[i], p2[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void gamma_kernel(const double* __restrict__ mu, const double* __restrict__ sigma,
+                                                       double* __restrict__ alpha, double* __restrict__ theta,
+                                                       int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        GammaParams g = normal_params_to_gamma(mu[i], sigma[i]);
+        alpha[i] = g.alpha;
+        theta[i] = g.theta;
+    }
+}
+
+struct ElementStatsArgs {
+    const double *mu, *sigma, *mu_indel, *sigma_indel, *pi_sum, *pi_indel;
+    const int32_t *obs_snv, *obs_samples, *obs_indel;
+    const double *cj, *cj_indel;
+    double* out;
+    int64_t E, C;
+    int pi_indel_per_cohort;
+};
+
+__global__ __launch_bounds__(kBlock) void element_stats_kernel(ElementStatsArgs a)
+{
+    const int64_t n = a.E * a.C;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t e = i / a.C;
+        const int64_t c = i - e * a.C;
+        const double mu = a.mu[i], sigma = a.sigma[i];
+        const double pi_s = a.pi_sum[i];
+        const double pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
+        const double k_snv = (double)a.obs_snv[i];
+        const double k_smp = (double)a.obs_samples[i];
+        const double k_ind = (double)a.obs_indel[i];
+        const double cj = a.cj[c], cji = a.cj_indel[c];
+
+        const GammaParams g = normal_params_to_gamma(mu, sigma);
+        const double theta = mul_rn(g.theta, cj);                       // transfer_tools.py:300
+        const double exp_snv = mul_rn(mul_rn(g.alpha, theta), pi_s);    // :343-344
+        const double p = nb_success_prob(theta, pi_s);
+        const double pv_snv = nb_midp_upper(k_snv, g.alpha, p);         // :473-482
+        const double pv_smp = (k_smp == k_snv) ? pv_snv : nb_midp_upper(k_smp, g.alpha, p);  // :594-615
+
+        GammaParams gi = g;
+        if (a.mu_indel) gi = normal_params_to_gamma(a.mu_indel[i], a.sigma_indel[i]);
+        const double theta_i = mul_rn(gi.theta, cji);                   // :737
+        const double exp_ind = mul_rn(mul_rn(gi.alpha, theta_i), pi_i); // :738
+        const double p_i = nb_success_prob(theta_i, pi_i);
+        const double pv_ind = nb_midp_upper(k_ind, gi.alpha, p_i);      // :741-745
+        const double pv_mut = fisher_combine(pv_snv, pv_ind);           // :1086-1087
+
+        a.out[0 * n + i] = exp_snv;
+        a.out[1 * n + i] = pv_snv;
+        a.out[2 * n + i] = pv_smp;
+        a.out[3 * n + i] = theta_i;
+        a.out[4 * n + i] = exp_ind;
+        a.out[5 * n + i] = pv_ind;
+        a.out[6 * n + i] = pv_mut;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restrict__ pt, int pt_per_cohort,
+                                                          const int32_t* __restrict__ k, const double* __restrict__ mu,
+                                                          const double* __restrict__ sigma, double* __restrict__ pval,
+                                                          double* __restrict__ exp_out, int64_t C, int64_t n_bins,
+                                                          int64_t n_tiles)
+{
+    const int64_t per_cohort = n_bins * n_tiles;
+    const int64_t n = C * per_cohort;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t cb = i / n_tiles;   // c * n_bins + b
+        const double m = mu[cb], s = sigma[cb];
+        const double ptv = pt_per_cohort ? pt[i] : pt[i % per_cohort];
+        const GammaParams g = normal_params_to_gamma(m, s);
+        const double p = nb_success_prob(ptv, g.theta);   // 1 / (pt * theta + 1), nb_model.py:151
+        pval[i] = nb_exact((double)k[i], g.alpha, p);      // :152
+        exp_out[i] = mul_rn(ptv, m);                       // :157
+    }
+}
+
+template <typename Op>
+static int launch_nb3(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
+{
+    if (n == 0) return DIG_OK;
+    if (!k || !alpha || !p || !out || n < 0) return set_error(DIG_EINVAL, "nb3: null pointer or negative n");
+    hipLaunchKernelGGL(nb3_kernel<Op>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, k, alpha, p,
+                       out, n);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+template <typename Op>
+static int host_nb3(const double* k, const double* alpha, const double* p, double* out, int64_t n, int device)
+{
+    if (n == 0) return DIG_OK;
+    if (!k || !alpha || !p || !out || n < 0) return set_error(DIG_EINVAL, "nb3_host: null pointer or negative n");
+    DIG_HIP_TRY(hipSetDevice(device));
+    DevBuf dk, da, dp, dout;
+    const size_t bytes = (size_t)n * sizeof(double);
+    DIG_HIP_TRY(dk.alloc(bytes));
+    DIG_HIP_TRY(da.alloc(bytes));
+    DIG_HIP_TRY(dp.alloc(bytes));
+    DIG_HIP_TRY(dout.alloc(bytes));
+    DIG_HIP_TRY(hipMemcpy(dk.p, k, bytes, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(da.p, alpha, bytes, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dp.p, p, bytes, hipMemcpyHostToDevice));
+    int rc = launch_nb3<Op>(dk.as<double>(), da.as<double>(), dp.as<double>(), dout.as<double>(), n, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+}  // namespace dig
+
+using namespace dig;
+
+extern "C" {
+
+int dig_nb_midp_upper(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
+{
+    return launch_nb3<OpMidpUpper>(k, alpha, p, out, n, stream);
+}
+int dig_nb_midp_upper_host(const double* k, const double* alpha, const double* p, double* out, int64_t n, int device)
+{
+    return host_nb3<OpMidpUpper>(k, alpha, p, out, n, device);
+}
+int dig_nb_exact(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
+{
+    return launch_nb3<OpExact>(k, alpha, p, out, n, stream);
+}
+int dig_nb_exact_host(const double* k, const double* alpha, const double* p, double* out, int64_t n, int device)
+{
+    return host_nb3<OpExact>(k, alpha, p, out, n, device);
+}
+int dig_nb_greater(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
+{
+    return launch_nb3<OpGreater>(k, alpha, p, out, n, stream);
+}
+int dig_nb_greater_host(const double* k, const double* alpha, const double* p, double* out, int64_t n, int device)
+{
+    return host_nb3<OpGreater>(k, alpha, p, out, n, device);
+}
+int dig_nb_midp_twosided(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
+{
+    return launch_nb3<OpMidpTwo>(k, alpha, p, out, n, stream);
+}
+int dig_nb_midp_twosided_host(const double* k, const double* alpha, const double* p, double* out, int64_t n,
+                              int device)
+{
+    return host_nb3<OpMidpTwo>(k, alpha, p, out, n, device);
+}
+
+int dig_fisher(const double* p1, const double* p2, double* out, int64_t n, void* stream)
+{
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(p1 && p2 && out && n > 0, "non-null pointers, n >= 0");
+    hipLaunchKernelGGL(fisher_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, p1, p2, out, n);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_fisher_host(const double* p1, const double* p2, double* out, int64_t n, int device)
+{
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(p1 && p2 && out && n > 0, "non-null pointers, n >= 0");
+    DIG_HIP_TRY(hipSetDevice(device));
+    DevBuf d1, d2, dout;
+    const size_t bytes = (size_t)n * sizeof(double);
+    DIG_HIP_TRY(d1.alloc(bytes));
+    DIG_HIP_TRY(d2.alloc(bytes));
+    DIG_HIP_TRY(dout.alloc(bytes));
+    DIG_HIP_TRY(hipMemcpy(d1.p, p1, bytes, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(d2.p, p2, bytes, hipMemcpyHostToDevice));
+    int rc = dig_fisher(d1.as<double>(), d2.as<double>(), dout.as<double>(), n, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+int dig_normal_params_to_gamma(const double* mu, const double* sigma, double* alpha, double* theta, int64_t n,
+                               void* stream)
+{
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(mu && sigma && alpha && theta && n > 0, "non-null pointers, n >= 0");
+    hipLaunchKernelGGL(gamma_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, mu, sigma, alpha,
+                       theta, n);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_normal_params_to_gamma_host(const double* mu, const double* sigma, double* alpha, double* theta, int64_t n,
+                                    int device)
+{
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(mu && sigma && alpha && theta && n > 0, "non-null pointers, n >= 0");
+    DIG_HIP_TRY(hipSetDevice(device));
+    DevBuf dm, ds, da, dt;
+    const size_t bytes = (size_t)n * sizeof(double);
+    DIG_HIP_TRY(dm.alloc(bytes));
+    DIG_HIP_TRY(ds.alloc(bytes));
+    DIG_HIP_TRY(da.alloc(bytes));
+    DIG_HIP_TRY(dt.alloc(bytes));
+    DIG_HIP_TRY(hipMemcpy(dm.p, mu, bytes, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(ds.p, sigma, bytes, hipMemcpyHostToDevice));
+    int rc = dig_normal_params_to_gamma(dm.as<double>(), ds.as<double>(), da.as<double>(), dt.as<double>(), n, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(alpha, da.p, bytes, hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(theta, dt.p, bytes, hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+int dig_element_stats(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
+                      const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
+                      const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
+                      double* out, int64_t E, int64_t C, void* stream)
+{
+    DIG_REQUIRE(E >= 0 && C >= 0, "E, C >= 0");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(mu && sigma && pi_sum && pi_indel && obs_snv && obs_samples && obs_indel && cj && cj_indel && out,
+                "non-null pointers");
+    DIG_REQUIRE((mu_indel == nullptr) == (sigma_indel == nullptr), "mu_indel and sigma_indel both set or both NULL");
+    ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
+                       cj, cj_indel, out, E, C, pi_indel_per_cohort};
+    hipLaunchKernelGGL(element_stats_kernel, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_element_stats_host(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
+                           const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort,
+                           const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel,
+                           const double* cj, const double* cj_indel, double* out, int64_t E, int64_t C, int device)
+{
+    DIG_REQUIRE(E >= 0 && C >= 0, "E, C >= 0");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(mu && sigma && pi_sum && pi_indel && obs_snv && obs_samples && obs_indel && cj && cj_indel && out,
+                "non-null pointers");
+    DIG_HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)E * (size_t)C;
+    const size_t nd = n * sizeof(double), ni = n * sizeof(int32_t);
+    const size_t npi = (pi_indel_per_cohort ? n : (size_t)E) * sizeof(double);
+    DevBuf dmu, dsg, dmui, dsgi, dps, dpi, dk1, dk2, dk3, dcj, dcji, dout;
+    DIG_HIP_TRY(dmu.alloc(nd));
+    DIG_HIP_TRY(dsg.alloc(nd));
+    DIG_HIP_TRY(dps.alloc(nd));
+    DIG_HIP_TRY(dpi.alloc(npi));
+    DIG_HIP_TRY(dk1.alloc(ni));
+    DIG_HIP_TRY(dk2.alloc(ni));
+    DIG_HIP_TRY(dk3.alloc(ni));
+    DIG_HIP_TRY(dcj.alloc((size_t)C * sizeof(double)));
+    DIG_HIP_TRY(dcji.alloc((size_t)C * sizeof(double)));
+    DIG_HIP_TRY(dout.alloc(nd * DIG_ES_NPLANES));
+    DIG_HIP_TRY(hipMemcpy(dmu.p, mu, nd, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dsg.p, sigma, nd, hipMemcpyHostToDevice));
+    if (mu_indel) {
+        DIG_REQUIRE(sigma_indel, "sigma_indel with mu_indel");
+        DIG_HIP_TRY(dmui.alloc(nd));
+        DIG_HIP_TRY(dsgi.alloc(nd));
+        DIG_HIP_TRY(hipMemcpy(dmui.p, mu_indel, nd, hipMemcpyHostToDevice));
+        DIG_HIP_TRY(hipMemcpy(dsgi.p, sigma_indel, nd, hipMemcpyHostToDevice));
+    }
+    DIG_HIP_TRY(hipMemcpy(dps.p, pi_sum, nd, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dpi.p, pi_indel, npi, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dk1.p, obs_snv, ni, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dk2.p, obs_samples, ni, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dk3.p, obs_indel, ni, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dcj.p, cj, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dcji.p, cj_indel, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    int rc = dig_element_stats(dmu.as<double>(), dsg.as<double>(), mu_indel ? dmui.as<double>() : nullptr,
+                               mu_indel ? dsgi.as<double>() : nullptr, dps.as<double>(), dpi.as<double>(),
+                               pi_indel_per_cohort, dk1.as<int32_t>(), dk2.as<int32_t>(), dk3.as<int32_t>(),
+                               dcj.as<double>(), dcji.as<double>(), dout.as<double>(), E, C, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(out, dout.p, nd * DIG_ES_NPLANES, hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+int dig_tiled_nb_test(const double* pt, int pt_per_cohort, const int32_t* k, const double* mu, const double* sigma,
+                      double* pval, double* exp_out, int64_t C, int64_t n_bins, int64_t n_tiles, void* stream)
+{
+    DIG_REQUIRE(C >= 0 && n_bins >= 0 && n_tiles >= 0, "non-negative sizes");
+    const int64_t n = C * n_bins * n_tiles;
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(pt && k && mu && sigma && pval && exp_out, "non-null pointers");
+    hipLaunchKernelGGL(tiled_nb_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pt,
+                       pt_per_cohort, k, mu, sigma, pval, exp_out, C, n_bins, n_tiles);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_tiled_nb_test_host(const double* pt, int pt_per_cohort, const int32_t* k, const double* mu,
+                           const double* sigma, double* pval, double* exp_out, int64_t C, int64_t n_bins,
+                           int64_t n_tiles, int device)
+{
+    DIG_REQUIRE(C >= 0 && n_bins >= 0 && n_tiles >= 0, "non-negative sizes");
+    const size_t n = (size_t)C * n_bins * n_tiles;
+    if (n == 0) return DIG_OK;
+    DIG_REQUIRE(pt && k && mu && sigma && pval && exp_out, "non-null pointers");
+    DIG_HIP_TRY(hipSetDevice(device));
+    const size_t npt = (pt_per_cohort ? n : (size_t)n_bins * n_tiles) * sizeof(double);
+    const size_t ncb = (size_t)C * n_bins * sizeof(double);
+    DevBuf dpt, dk, dmu, dsg, dpv, dex;
+    DIG_HIP_TRY(dpt.alloc(npt));
+    DIG_HIP_TRY(dk.alloc(n * sizeof(int32_t)));
+    DIG_HIP_TRY(dmu.alloc(ncb));
+    DIG_HIP_TRY(dsg.alloc(ncb));
+    DIG_HIP_TRY(dpv.alloc(n * sizeof(double)));
+    DIG_HIP_TRY(dex.alloc(n * sizeof(double)));
+    DIG_HIP_TRY(hipMemcpy(dpt.p, pt, npt, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dk.p, k, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dmu.p, mu, ncb, hipMemcpyHostToDevice));
+    DIG_HIP_TRY(hipMemcpy(dsg.p, sigma, ncb, hipMemcpyHostToDevice));
+    int rc = dig_tiled_nb_test(dpt.as<double>(), pt_per_cohort, dk.as<int32_t>(), dmu.as<double>(), dsg.as<double>(),
+                               dpv.as<double>(), dex.as<double>(), C, n_bins, n_tiles, nullptr);
+    if (rc) return rc;
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpy(pval, dpv.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    DIG_HIP_TRY(hipMemcpy(exp_out, dex.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return DIG_OK;
+}
+
+}  // extern "C"

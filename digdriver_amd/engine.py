@@ -1,0 +1,236 @@
+"""Batched, device-resident burden-test engine: all elements x all cohorts per launch.
+
+This is the MI355X-first form of the path the reference walks one cohort and one
+element at a time:
+
+    accumulate_elements  <- genic_driver_tools.nonc_model / genic_model / tiled_nonc_model
+                            (genic_driver_tools.py:300-431, 31-203, 599-690)
+    element_stats        <- transfer_tools.transfer_element_model_with_indels, element_expected_muts_nb,
+                            element_pvalue_burden_nb(_by_sample), element_pvalue_indel, Fisher
+                            (transfer_tools.py:272-302,343-344,473-482,594-615,731-747,1086-1087)
+    gather_bins          <- LazyLoadDatasetFromH5.__getitem__ (mut_dataset.py:76-81)
+    tiled_nb_test        <- nb_model.apply_nb_to_region arithmetic (nb_model.py:141-178)
+
+Every function takes either torch CUDA tensors (device entry points, enqueued on
+torch's current stream, zero copies) or numpy arrays (``*_host`` twins).  PyTorch is
+used only for device memory and streams.
+"""
+import numpy as np
+
+from . import _lib
+
+ES_PLANES = _lib.ES_PLANES
+
+
+def _is_cuda(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def _t(x, dtype, device):
+    import torch
+    if x is None:
+        return None
+    t = torch.as_tensor(x, device=device)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, cj, cj_indel,
+                  mu_indel=None, sigma_indel=None, device=0, out=None):
+    """Seven result planes for a dense [E, C] problem.
+
+    mu, sigma, pi_sum : f64 [E, C];  pi_indel : f64 [E] or [E, C];  obs_* : i32 [E, C];
+    cj, cj_indel : f64 [C].  Returns a dict plane-name -> [E, C] array/tensor (views of one
+    [7, E, C] buffer).  CUDA tensors in -> CUDA tensors out.
+    """
+    if _is_cuda(mu):
+        import torch
+        dev = mu.device
+        f64, i32 = torch.float64, torch.int32
+        mu, sigma, pi_sum = (_t(v, f64, dev) for v in (mu, sigma, pi_sum))
+        E, C = mu.shape
+        pi_indel = _t(pi_indel, f64, dev)
+        per_cohort = int(pi_indel.dim() == 2)
+        obs_snv, obs_samples, obs_indel = (_t(v, i32, dev) for v in (obs_snv, obs_samples, obs_indel))
+        cj, cj_indel = _t(cj, f64, dev).reshape(-1), _t(cj_indel, f64, dev).reshape(-1)
+        assert cj.numel() == C and cj_indel.numel() == C
+        mu_indel, sigma_indel = _t(mu_indel, f64, dev), _t(sigma_indel, f64, dev)
+        if out is None:
+            out = torch.empty((len(ES_PLANES), E, C), dtype=f64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("dig_element_stats", _lib.dev_ptr(mu), _lib.dev_ptr(sigma), _lib.dev_ptr(mu_indel),
+                      _lib.dev_ptr(sigma_indel), _lib.dev_ptr(pi_sum), _lib.dev_ptr(pi_indel), per_cohort,
+                      _lib.dev_ptr(obs_snv), _lib.dev_ptr(obs_samples), _lib.dev_ptr(obs_indel), _lib.dev_ptr(cj),
+                      _lib.dev_ptr(cj_indel), _lib.dev_ptr(out), E, C, _lib.stream_ptr())
+        return {name: out[i] for i, name in enumerate(ES_PLANES)}
+    mu = _lib.as_host(mu, np.float64)
+    if mu.ndim == 1:
+        mu = mu[:, None]
+    E, C = mu.shape
+    sigma = _lib.as_host(sigma, np.float64).reshape(E, C)
+    pi_sum = _lib.as_host(pi_sum, np.float64).reshape(E, C)
+    pi_indel = _lib.as_host(pi_indel, np.float64)
+    per_cohort = int(pi_indel.ndim == 2)
+    assert pi_indel.shape == ((E, C) if per_cohort else (E,))
+    obs = [_lib.as_host(v, np.int32).reshape(E, C) for v in (obs_snv, obs_samples, obs_indel)]
+    cj = _lib.as_host(np.broadcast_to(np.asarray(cj, np.float64).reshape(-1), (C,)), np.float64)
+    cj_indel = _lib.as_host(np.broadcast_to(np.asarray(cj_indel, np.float64).reshape(-1), (C,)), np.float64)
+    mi = None if mu_indel is None else _lib.as_host(mu_indel, np.float64).reshape(E, C)
+    si = None if sigma_indel is None else _lib.as_host(sigma_indel, np.float64).reshape(E, C)
+    res = np.empty((len(ES_PLANES), E, C), np.float64)
+    _lib.call("dig_element_stats_host", _lib.host_ptr(mu), _lib.host_ptr(sigma), _lib.host_ptr(mi), _lib.host_ptr(si),
+              _lib.host_ptr(pi_sum), _lib.host_ptr(pi_indel), per_cohort, _lib.host_ptr(obs[0]), _lib.host_ptr(obs[1]),
+              _lib.host_ptr(obs[2]), _lib.host_ptr(cj), _lib.host_ptr(cj_indel), _lib.host_ptr(res), E, C, device)
+    return {name: res[i] for i, name in enumerate(ES_PLANES)}
+
+
+# ---------------------------------------------------------------------------
+def ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bin_start):
+    """CSR of overlapped bin rows per element (genic_driver_tools.py:275-283), ascending rows.
+    Host-side integer index construction in the C++ runtime."""
+    elt_chrom = _lib.as_host(elt_chrom, np.int32)
+    blk_ptr = _lib.as_host(blk_ptr, np.int64)
+    blk_start = _lib.as_host(blk_start, np.int64)
+    blk_end = _lib.as_host(blk_end, np.int64)
+    bin_chrom = _lib.as_host(bin_chrom, np.int32)
+    bin_start = _lib.as_host(bin_start, np.int64)
+    E, N = len(elt_chrom), len(bin_chrom)
+    ov_ptr = np.zeros(E + 1, np.int64)
+    args = [_lib.host_ptr(elt_chrom), _lib.host_ptr(blk_ptr), _lib.host_ptr(blk_start), _lib.host_ptr(blk_end), E,
+            int(window), _lib.host_ptr(bin_chrom), _lib.host_ptr(bin_start), N, _lib.host_ptr(ov_ptr)]
+    _lib.call("dig_ideal_overlaps_host", *args, None)
+    ov_idx = np.zeros(max(int(ov_ptr[E]), 1), np.int32)
+    _lib.call("dig_ideal_overlaps_host", *args, _lib.host_ptr(ov_idx))
+    return ov_ptr, ov_idx[:int(ov_ptr[E])]
+
+
+def accumulate_elements(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr,
+                        gene_length=None, device=0):
+    """Per-element accumulation for all cohorts (see include/dig_hip.h: dig_accumulate_elements).
+
+    Returns dict(MU, SIGMA [E,C] f64; R_OBS, FLAG [E,C] i32; P [E,n_class,C] f64;
+                 R_SIZE, ELT_SIZE [E] i32; P_INDEL [E] f64)."""
+    if _is_cuda(bin_mu):
+        import torch
+        dev = bin_mu.device
+        f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
+        bin_mu, bin_std = _t(bin_mu, f64, dev), _t(bin_std, f64, dev)
+        N, C = bin_mu.shape
+        bin_y, bin_flag, bin_ctx = _t(bin_y, i32, dev), _t(bin_flag, u8, dev), _t(bin_ctx, i32, dev)
+        ov_ptr, ov_idx = _t(ov_ptr, i64, dev), _t(ov_idx, i32, dev)
+        L = _t(L, i32, dev)
+        if L.dim() == 2:
+            L = L[:, None, :]
+        E, n_class, K = L.shape
+        assert K == 192 and bin_ctx.shape == (N, 64) and ov_ptr.numel() == E + 1
+        strand_minus = _t(strand_minus, u8, dev)
+        gene_length = _t(gene_length, i32, dev)
+        d_pr = _t(d_pr, f64, dev)
+        assert d_pr.shape == (C, 192)
+        o = dict(MU=torch.empty((E, C), dtype=f64, device=dev), SIGMA=torch.empty((E, C), dtype=f64, device=dev),
+                 R_OBS=torch.empty((E, C), dtype=i32, device=dev), FLAG=torch.empty((E, C), dtype=i32, device=dev),
+                 P=torch.empty((E, n_class, C), dtype=f64, device=dev), R_SIZE=torch.empty(E, dtype=i32, device=dev),
+                 ELT_SIZE=torch.empty(E, dtype=i32, device=dev), P_INDEL=torch.empty(E, dtype=f64, device=dev))
+        with torch.cuda.device(dev):
+            _lib.call("dig_accumulate_elements", _lib.dev_ptr(bin_mu), _lib.dev_ptr(bin_std), _lib.dev_ptr(bin_y),
+                      _lib.dev_ptr(bin_flag), _lib.dev_ptr(bin_ctx), _lib.dev_ptr(ov_ptr), _lib.dev_ptr(ov_idx),
+                      _lib.dev_ptr(L), n_class, _lib.dev_ptr(strand_minus), _lib.dev_ptr(gene_length), _lib.dev_ptr(d_pr),
+                      _lib.dev_ptr(o["MU"]), _lib.dev_ptr(o["SIGMA"]), _lib.dev_ptr(o["R_OBS"]), _lib.dev_ptr(o["FLAG"]),
+                      _lib.dev_ptr(o["P"]), _lib.dev_ptr(o["R_SIZE"]), _lib.dev_ptr(o["ELT_SIZE"]),
+                      _lib.dev_ptr(o["P_INDEL"]), N, E, C, _lib.stream_ptr())
+        return o
+    bin_mu = _lib.as_host(bin_mu, np.float64)
+    if bin_mu.ndim == 1:
+        bin_mu = bin_mu[:, None]
+    N, C = bin_mu.shape
+    bin_std = _lib.as_host(bin_std, np.float64).reshape(N, C)
+    bin_y = _lib.as_host(bin_y, np.int32).reshape(N, C)
+    bin_flag = _lib.as_host(bin_flag, np.uint8).reshape(N, C)
+    bin_ctx = _lib.as_host(bin_ctx, np.int32).reshape(N, 64)
+    ov_ptr, ov_idx = _lib.as_host(ov_ptr, np.int64), _lib.as_host(ov_idx, np.int32)
+    L = _lib.as_host(L, np.int32)
+    if L.ndim == 2:
+        L = L[:, None, :]
+    L = np.ascontiguousarray(L)
+    E, n_class, K = L.shape
+    assert K == 192 and len(ov_ptr) == E + 1
+    strand_minus = _lib.as_host(strand_minus, np.uint8)
+    gl = None if gene_length is None else _lib.as_host(gene_length, np.int32)
+    d_pr = _lib.as_host(d_pr, np.float64).reshape(C, 192)
+    o = dict(MU=np.empty((E, C)), SIGMA=np.empty((E, C)), R_OBS=np.empty((E, C), np.int32),
+             FLAG=np.empty((E, C), np.int32), P=np.empty((E, n_class, C)), R_SIZE=np.empty(E, np.int32),
+             ELT_SIZE=np.empty(E, np.int32), P_INDEL=np.empty(E))
+    if len(ov_idx) == 0:
+        ov_idx = np.zeros(1, np.int32)
+    _lib.call("dig_accumulate_elements_host", _lib.host_ptr(bin_mu), _lib.host_ptr(bin_std), _lib.host_ptr(bin_y),
+              _lib.host_ptr(bin_flag), _lib.host_ptr(bin_ctx), _lib.host_ptr(ov_ptr), _lib.host_ptr(ov_idx),
+              _lib.host_ptr(L), n_class, _lib.host_ptr(strand_minus), _lib.host_ptr(gl), _lib.host_ptr(d_pr),
+              _lib.host_ptr(o["MU"]), _lib.host_ptr(o["SIGMA"]), _lib.host_ptr(o["R_OBS"]), _lib.host_ptr(o["FLAG"]),
+              _lib.host_ptr(o["P"]), _lib.host_ptr(o["R_SIZE"]), _lib.host_ptr(o["ELT_SIZE"]), _lib.host_ptr(o["P_INDEL"]),
+              N, E, C, device)
+    return o
+
+
+# ---------------------------------------------------------------------------
+_NP_DT = {np.dtype(np.float32): _lib.DIG_F32, np.dtype(np.float64): _lib.DIG_F64, np.dtype(np.int16): _lib.DIG_I16}
+
+
+def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False, device=0):
+    """x_data[bin_rows, :, tracks] as float32 (or bf16) -- mut_dataset.py:76-81 for a batch.
+    transpose=True returns channels-first [B, T_sel, L] (cnn_predictors.py:131)."""
+    if _is_cuda(x_data):
+        import torch
+        dev = x_data.device
+        tmap = {torch.float32: _lib.DIG_F32, torch.float64: _lib.DIG_F64, torch.int16: _lib.DIG_I16}
+        assert x_data.dtype in tmap and x_data.is_contiguous() and x_data.dim() == 3
+        N, L, T = x_data.shape
+        rows = _t(bin_rows, torch.int64, dev)
+        tr = _t(np.arange(T) if tracks is None else tracks, torch.int32, dev)
+        B, Ts = rows.numel(), tr.numel()
+        odt = torch.float32 if out_dtype == "f32" else torch.bfloat16
+        out = torch.empty((B, Ts, L) if transpose else (B, L, Ts), dtype=odt, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("dig_gather_bins", _lib.dev_ptr(x_data), tmap[x_data.dtype], N, L, T, _lib.dev_ptr(rows), B,
+                      _lib.dev_ptr(tr), Ts, _lib.dev_ptr(out), _lib.DIG_F32 if out_dtype == "f32" else _lib.DIG_BF16,
+                      int(transpose), _lib.stream_ptr())
+        return out
+    x = np.ascontiguousarray(x_data)
+    assert x.dtype in _NP_DT and x.ndim == 3
+    N, L, T = x.shape
+    rows = _lib.as_host(bin_rows, np.int64).ravel()
+    tr = _lib.as_host(np.arange(T) if tracks is None else tracks, np.int32).ravel()
+    B, Ts = len(rows), len(tr)
+    if out_dtype != "f32":
+        raise ValueError("host path returns float32 only")
+    out = np.empty((B, Ts, L) if transpose else (B, L, Ts), np.float32)
+    _lib.call("dig_gather_bins_host", _lib.host_ptr(x), _NP_DT[x.dtype], N, L, T, _lib.host_ptr(rows), B,
+              _lib.host_ptr(tr), Ts, _lib.host_ptr(out), _lib.DIG_F32, int(transpose), device)
+    return out
+
+
+def tiled_nb_test(pt, k, mu, sigma, device=0):
+    """Per-tile exact NB test (nb_model.py:141-178).  pt f64 [n_bins, n_tiles] or [C, n_bins, n_tiles];
+    k i32 [C, n_bins, n_tiles]; mu, sigma f64 [C, n_bins].  Returns (pval, exp) [C, n_bins, n_tiles]."""
+    if _is_cuda(k):
+        import torch
+        dev = k.device
+        k = _t(k, torch.int32, dev)
+        C, nb, nt = k.shape
+        pt = _t(pt, torch.float64, dev)
+        mu, sigma = _t(mu, torch.float64, dev).reshape(C, nb), _t(sigma, torch.float64, dev).reshape(C, nb)
+        pval = torch.empty((C, nb, nt), dtype=torch.float64, device=dev)
+        ex = torch.empty_like(pval)
+        with torch.cuda.device(dev):
+            _lib.call("dig_tiled_nb_test", _lib.dev_ptr(pt), int(pt.dim() == 3), _lib.dev_ptr(k), _lib.dev_ptr(mu),
+                      _lib.dev_ptr(sigma), _lib.dev_ptr(pval), _lib.dev_ptr(ex), C, nb, nt, _lib.stream_ptr())
+        return pval, ex
+    k = _lib.as_host(k, np.int32)
+    C, nb, nt = k.shape
+    pt = _lib.as_host(pt, np.float64)
+    mu, sigma = _lib.as_host(mu, np.float64).reshape(C, nb), _lib.as_host(sigma, np.float64).reshape(C, nb)
+    pval, ex = np.empty((C, nb, nt)), np.empty((C, nb, nt))
+    _lib.call("dig_tiled_nb_test_host", _lib.host_ptr(pt), int(pt.ndim == 3), _lib.host_ptr(k), _lib.host_ptr(mu),
+              _lib.host_ptr(sigma), _lib.host_ptr(pval), _lib.host_ptr(ex), C, nb, nt, device)
+    return pval, ex

@@ -1,0 +1,183 @@
+/*
+ * dig_hip.h -- C ABI of libdig_hip.so: the MI355X (gfx950) implementation of DIGDriver's
+ * mutation-rate + burden-test hot path.
+ *
+ * The reference (maxwellsh/DIGDriver) is pure Python and has no FFI layer; the entry points
+ * below are the ones a binding for this path would need, one per vectorised reference
+ * function (cited as file:line relative to the reference tree).  See INTEGRATION.md for the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C symbols, caller-owned buffers, no allocation ownership crosses the boundary;
+ *   - every function returns 0 on success, a negative DIG_E* code on failure; the message of
+ *     the last failure on the calling thread is available from dig_last_error();
+ *   - functions WITHOUT the _host suffix take DEVICE pointers valid on the current HIP device
+ *     and enqueue on `stream` (a hipStream_t passed as void*; NULL = default stream); they do
+ *     not synchronise and do not allocate, so they may be captured into a hipGraph;
+ *   - _host twins take HOST pointers, stage through device memory on `device`, run the same
+ *     kernels and synchronise before returning;
+ *   - NaN/inf inputs propagate to NaN outputs exactly as the reference's numpy/scipy
+ *     expressions do; there is no CPU fallback: without a HIP device every call fails.
+ *   - matrices are row-major; "[E, C]" means cohort index fastest.
+ */
+#ifndef DIG_HIP_H
+#define DIG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIG_OK 0
+#define DIG_EINVAL (-1)   /* bad argument */
+#define DIG_EHIP (-2)     /* HIP runtime error */
+#define DIG_ENODEV (-3)   /* no usable gfx950 device */
+
+#define DIG_ABI_VERSION 1
+
+/* dtype codes for dig_gather_bins */
+#define DIG_F32 0
+#define DIG_F64 1
+#define DIG_I16 2
+#define DIG_BF16 3
+
+/* indices of the seven result planes written by dig_element_stats */
+#define DIG_ES_EXP_SNV 0
+#define DIG_ES_PVAL_SNV_BURDEN 1
+#define DIG_ES_PVAL_SAMPLE_BURDEN 2
+#define DIG_ES_THETA_INDEL 3
+#define DIG_ES_EXP_INDEL 4
+#define DIG_ES_PVAL_INDEL_BURDEN 5
+#define DIG_ES_PVAL_MUT_BURDEN 6
+#define DIG_ES_NPLANES 7
+
+int dig_abi_version(void);
+const char *dig_last_error(void);
+/* number of HIP devices whose gcnArchName starts with "gfx950"; negative on HIP error */
+int dig_device_count(void);
+
+/* ---- negative-binomial tests (DIGDriver/sequence_model/nb_model.py) ------------------ */
+
+/* nb_pvalue_greater_midp(k, alpha, p)  nb_model.py:271-278
+ *   out[i] = 0.5 * nbinom.pmf(k[i]; alpha[i], p[i]) + betainc(k[i] + 1, alpha[i], 1 - p[i]) */
+int dig_nb_midp_upper(const double *k, const double *alpha, const double *p, double *out, int64_t n, void *stream);
+int dig_nb_midp_upper_host(const double *k, const double *alpha, const double *p, double *out, int64_t n, int device);
+
+/* nb_pvalue_exact(k, alpha, p)  nb_model.py:298-314 (mu = alpha (1-p)/p) */
+int dig_nb_exact(const double *k, const double *alpha, const double *p, double *out, int64_t n, void *stream);
+int dig_nb_exact_host(const double *k, const double *alpha, const double *p, double *out, int64_t n, int device);
+
+/* nb_pvalue_greater(k, alpha, p)  nb_model.py:243-256 */
+int dig_nb_greater(const double *k, const double *alpha, const double *p, double *out, int64_t n, void *stream);
+int dig_nb_greater_host(const double *k, const double *alpha, const double *p, double *out, int64_t n, int device);
+
+/* nb_pvalue_midp(k, alpha, p)  nb_model.py:316-337 */
+int dig_nb_midp_twosided(const double *k, const double *alpha, const double *p, double *out, int64_t n, void *stream);
+int dig_nb_midp_twosided_host(const double *k, const double *alpha, const double *p, double *out, int64_t n,
+                              int device);
+
+/* Fisher combination  chi2.sf(-2 (ln p1 + ln p2), df=4)
+ * DIGDriver/driver_model/transfer_tools.py:860-861,1086-1087; onthefly_tools.py:182-187 */
+int dig_fisher(const double *p1, const double *p2, double *out, int64_t n, void *stream);
+int dig_fisher_host(const double *p1, const double *p2, double *out, int64_t n, int device);
+
+/* normal_params_to_gamma(mu, sigma)  nb_model.py:237-241: alpha = mu^2/sigma^2, theta = sigma^2/mu */
+int dig_normal_params_to_gamma(const double *mu, const double *sigma, double *alpha, double *theta, int64_t n,
+                               void *stream);
+int dig_normal_params_to_gamma_host(const double *mu, const double *sigma, double *alpha, double *theta, int64_t n,
+                                    int device);
+
+/* ---- element statistics block (DIGDriver/driver_model/transfer_tools.py) ------------- *
+ * One (element, cohort) pair per work item, dense [E, C]:
+ *   ALPHA, THETA            load_pretrained_model            :17-19,46-48
+ *   THETA *= cj[c]          transfer_element_model_with_indels :300
+ *   EXP_SNV                 element_expected_muts_nb         :343-344
+ *   PVAL_SNV_BURDEN         element_pvalue_burden_nb         :473-482
+ *   PVAL_SAMPLE_BURDEN      element_pvalue_burden_nb_by_sample :594-615
+ *   THETA_INDEL, EXP_INDEL, PVAL_INDEL_BURDEN  element_pvalue_indel :731-747
+ *   PVAL_MUT_BURDEN         Fisher                           :1086-1087
+ * mu_indel/sigma_indel may be NULL (= mu/sigma, the reference's indels_direct=False route,
+ * genic_driver_tools.py:383-386).  pi_indel is [E] when pi_indel_per_cohort == 0, else [E, C].
+ * out holds DIG_ES_NPLANES planes of E*C doubles: out[plane * E * C + e * C + c].
+ * The same entry point serves the gene twins (transfer_tools.py:331-340,425-454,554-583,
+ * 709-727): call it once per mutation class with that class's Pi_* / OBS_* / N_SAMP_*. */
+int dig_element_stats(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
+                      const double *pi_sum, const double *pi_indel, int pi_indel_per_cohort, const int32_t *obs_snv,
+                      const int32_t *obs_samples, const int32_t *obs_indel, const double *cj, const double *cj_indel,
+                      double *out, int64_t E, int64_t C, void *stream);
+int dig_element_stats_host(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
+                           const double *pi_sum, const double *pi_indel, int pi_indel_per_cohort,
+                           const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel,
+                           const double *cj, const double *cj_indel, double *out, int64_t E, int64_t C, int device);
+
+/* ---- per-element accumulation (DIGDriver/sequence_model/genic_driver_tools.py) ------- *
+ * nonc_model :300-431 (n_class = 1), genic_model :31-203 (n_class = 4: silent, missense,
+ * nonsense, splice columns of L_data), tiled_nonc_model :599-690 (one bin per element), and the
+ * loop body of DIG_onthefly (driver_model/onthefly_tools.py:109-164), for all C cohorts at once:
+ *   MU = sum Y_PRED, SIGMA = sqrt(sum STD^2), R_OBS = sum Y_TRUE, FLAG = OR of FLAG over the
+ *   element's overlapped bins (the reference adds numpy bools: logical OR, result 0/1)
+ *                                                     get_region_params_direct :258-272
+ *   region_counts = sum of the bins' 64 context counts, each repeated x3, reverse-complement
+ *   permuted for '-' strand elements                  sequence_tools.py:630-634
+ *   t_pi = d_pr / sum(region_counts * d_pr);  P = sum(t_pi * L)        :361-367
+ *   R_SIZE = int(sum(region_counts)/3); ELT_SIZE = int(sum(L)/3); P_INDEL = ELT_SIZE/R_SIZE :375-381
+ *   (gene_length != NULL: P_INDEL = gene_length / R_SIZE, genic_driver_tools.py:158-159)
+ * Inputs (device): bin_mu, bin_std f64 [N, C]; bin_y i32 [N, C]; bin_flag u8 [N, C];
+ *   bin_ctx i32 [N, 64] (contexts in sorted ACGT^3 order); ov_ptr i64 [E+1], ov_idx i32 [nnz]
+ *   (CSR of overlapped bin rows, see dig_ideal_overlaps_host); L i32 [E, n_class, 192] in sorted
+ *   substitution order ("XYZ>XaZ"); strand_minus u8 [E]; d_pr f64 [C, 192] = FREQ re-indexed by
+ *   sorted substitution string (genic_driver_tools.py:321-325).
+ * Outputs (device): MU, SIGMA f64 [E, C]; R_OBS, FLAG i32 [E, C]; P f64 [E, n_class, C];
+ *   R_SIZE, ELT_SIZE i32 [E]; P_INDEL f64 [E]. */
+int dig_accumulate_elements(const double *bin_mu, const double *bin_std, const int32_t *bin_y,
+                            const uint8_t *bin_flag, const int32_t *bin_ctx, const int64_t *ov_ptr,
+                            const int32_t *ov_idx, const int32_t *L, int n_class, const uint8_t *strand_minus,
+                            const int32_t *gene_length, const double *d_pr, double *MU, double *SIGMA,
+                            int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
+                            double *P_INDEL, int64_t N, int64_t E, int64_t C, void *stream);
+int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, const int32_t *bin_y,
+                                 const uint8_t *bin_flag, const int32_t *bin_ctx, const int64_t *ov_ptr,
+                                 const int32_t *ov_idx, const int32_t *L, int n_class, const uint8_t *strand_minus,
+                                 const int32_t *gene_length, const double *d_pr, double *MU, double *SIGMA,
+                                 int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
+                                 double *P_INDEL, int64_t N, int64_t E, int64_t C, int device);
+
+/* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
+ * elements (host-side index construction, integer only): block b of element e covers bins
+ * floor(start/w)*w ... ceil(end/w)*w; duplicates removed; rows are looked up in the sorted bin
+ * table (bin_chrom, bin_start) of N rows.  Two-call protocol: with ov_idx == NULL only ov_ptr
+ * (E+1) is filled so the caller can size ov_idx = ov_ptr[E].  A bin that is not in the table
+ * is an error (the reference raises KeyError at df.loc, genic_driver_tools.py:265). */
+int dig_ideal_overlaps_host(const int32_t *elt_chrom, const int64_t *blk_ptr, const int64_t *blk_start,
+                            const int64_t *blk_end, int64_t E, int64_t window, const int32_t *bin_chrom,
+                            const int64_t *bin_start, int64_t N, int64_t *ov_ptr, int32_t *ov_idx);
+
+/* ---- per-bin epigenomic-track gather (region_model/data_aux/mut_dataset.py:76-81) ---- *
+ * out[b, l, t] = (float) x_data[bin_rows[b], l, tracks[t]]      (transpose_out == 0)
+ * out[b, t, l] = ...                                            (transpose_out != 0: the
+ *   channels-first layout SimpleMultiTaskResNet.forward makes with transpose(x, 1, 2),
+ *   region_model/nets/cnn_predictors.py:131)
+ * x_data is [N, L, T] of src_dtype (DIG_F32 | DIG_F64 | DIG_I16); out is DIG_F32 or DIG_BF16. */
+int dig_gather_bins(const void *x_data, int src_dtype, int64_t N, int64_t L, int64_t T, const int64_t *bin_rows,
+                    int64_t B, const int32_t *tracks, int64_t T_sel, void *out, int out_dtype, int transpose_out,
+                    void *stream);
+int dig_gather_bins_host(const void *x_data, int src_dtype, int64_t N, int64_t L, int64_t T, const int64_t *bin_rows,
+                         int64_t B, const int32_t *tracks, int64_t T_sel, void *out, int out_dtype, int transpose_out,
+                         int device);
+
+/* ---- per-base tiled NB test (nb_model.py:126-186, arithmetic of apply_nb_to_region) --- *
+ * For cohort c, bin b, tile t:  alpha, theta = normal_params_to_gamma(mu[c,b], sigma[c,b]);
+ *   p = 1/(pt * theta + 1);  pval = nb_pvalue_exact(k, alpha, p);  exp = pt * mu   (:141-178)
+ * pt f64 [C or 1, n_bins, n_tiles] (pt_per_cohort selects), k i32 [C, n_bins, n_tiles],
+ * mu, sigma f64 [C, n_bins]; pval, exp f64 [C, n_bins, n_tiles]. */
+int dig_tiled_nb_test(const double *pt, int pt_per_cohort, const int32_t *k, const double *mu, const double *sigma,
+                      double *pval, double *exp_out, int64_t C, int64_t n_bins, int64_t n_tiles, void *stream);
+int dig_tiled_nb_test_host(const double *pt, int pt_per_cohort, const int32_t *k, const double *mu,
+                           const double *sigma, double *pval, double *exp_out, int64_t C, int64_t n_bins,
+                           int64_t n_tiles, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIG_HIP_H */

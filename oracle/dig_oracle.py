@@ -1,0 +1,361 @@
+"""CPU oracle for the DIGDriver burden-test hot path (TEST INFRASTRUCTURE ONLY).
+
+This module is a plain numpy/scipy restatement of the reference's algorithm for
+the hot path named in BASELINE.json.  It exists to CHECK the HIP path.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it; the product package ``digdriver_amd`` never does.
+
+Pinning: every function below is checked against golden vectors produced by
+running the real reference in the build container (``tests/golden/make_golden.py``,
+scipy 1.15.3) -- see ``tests/test_oracle_golden.py``.  The third-party arithmetic
+the reference calls (scipy.special.betainc, scipy.stats.nbinom.pmf,
+scipy.stats.chi2.sf) is called here the same way, so the oracle inherits the
+reference's numerics exactly for the NB tests.  GP calibration has no pinned
+oracle (gpytorch is absent and unpinned): "parity unpinned" for that row.
+
+All ``file:line`` citations are relative to the reference tree.
+"""
+import itertools as _it
+
+import numpy as np
+import scipy.special
+import scipy.stats
+
+# --------------------------------------------------------------------------
+# substitution index (sequence_tools.py:232-289) and '-' strand permutation
+# (sequence_tools.py:610-614,633-634)
+# --------------------------------------------------------------------------
+_DNA = "ACGT"
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def reverse_complement(seq):
+    """sequence_tools.py:18-19"""
+    return "".join(_COMP[c] for c in reversed(seq))
+
+
+def context64():
+    """The 64 trinucleotide contexts in the order of mk_context_sequences
+    (sequence_tools.py:30-40): itertools.product over ACGT^3 == sorted order."""
+    return ["".join(t) for t in _it.product(_DNA, _DNA, _DNA)]
+
+
+def subst_idx192():
+    """Sorted 'XYZ>XaZ' strings (mk_trans_idx, sequence_tools.py:282-289)."""
+    out = []
+    for ctx in context64():
+        for alt in _DNA:
+            if alt != ctx[1]:
+                out.append(ctx + ">" + ctx[0] + alt + ctx[2])
+    return sorted(out)
+
+
+def model_rows192():
+    """(MUT_TYPE, CONTEXT) rows in the order of mk_mutation_context(collapse=False)
+    (sequence_tools.py:232-262): A-, C-, G-, T-centred blocks; within a block the
+    three mutation types are the outer loop."""
+    rows = []
+    muts = {"A": ["A>T", "A>C", "A>G"], "C": ["C>A", "C>G", "C>T"],
+            "G": ["G>T", "G>C", "G>A"], "T": ["T>A", "T>G", "T>C"]}
+    for ref in "ACGT":
+        keys = ["".join(t) for t in _it.product(_DNA, ref, _DNA)]
+        for m in muts[ref]:
+            for k in keys:
+                rows.append((m, k))
+    return rows
+
+
+def model_rows_to_sorted_perm():
+    """Index array `perm` such that d_pr_sorted = FREQ[perm]: the reference builds
+    the string 'CONTEXT>C0 ALT C2' for each model row and sorts the index
+    (genic_driver_tools.py:321-325)."""
+    rows = model_rows192()
+    names = [c + ">" + c[0] + m[2] + c[2] for m, c in rows]
+    order = sorted(range(192), key=lambda i: names[i])
+    assert [names[i] for i in order] == subst_idx192()
+    return np.array(order)
+
+
+def minus_strand_gather192():
+    """new[i] = old[g[i]] for a '-' strand element (sequence_tools.py:633-634):
+    positions are re-ordered by the sort rank of their reverse-complemented name."""
+    s = subst_idx192()
+    revc = [reverse_complement(x.split(">")[0]) + ">" + reverse_complement(x.split(">")[1]) for x in s]
+    return np.array(sorted(range(192), key=lambda i: revc[i]))
+
+
+def minus_strand_gather64():
+    """The same permutation on the 64 context counts: new64[c] = old64[rho[c]],
+    rho = reverse-complement of the context."""
+    ctx = context64()
+    pos = {c: i for i, c in enumerate(ctx)}
+    return np.array([pos[reverse_complement(c)] for c in ctx])
+
+
+# --------------------------------------------------------------------------
+# NB arithmetic (nb_model.py:237-337)
+# --------------------------------------------------------------------------
+def normal_params_to_gamma(mu, sigma):
+    """nb_model.py:237-241"""
+    alpha = mu ** 2 / sigma ** 2
+    theta = sigma ** 2 / mu
+    return alpha, theta
+
+
+def nb_pvalue_greater_midp(k, alpha, p):
+    """nb_model.py:271-278"""
+    return 0.5 * scipy.stats.nbinom.pmf(k, alpha, p) + scipy.special.betainc(k + 1, alpha, 1 - p)
+
+
+def nb_pvalue_greater(k, alpha, p):
+    """nb_model.py:243-256 (vectorised over the scalar branches)"""
+    k, alpha, p = np.broadcast_arrays(*(np.asarray(v, float) for v in (k, alpha, p)))
+    with np.errstate(all="ignore"):
+        pval = scipy.special.betainc(k, alpha, 1 - p)
+        pmf = scipy.stats.nbinom.pmf(k, alpha, p)
+    pval = np.where(pval == 0, pmf, pval)
+    return np.where(k == 0, 1.0, pval)
+
+
+def nb_pvalue_exact(k, alpha, p):
+    """nb_model.py:298-314 (mu defaults to alpha*(1-p)/p)"""
+    k, alpha, p = np.broadcast_arrays(*(np.asarray(v, float) for v in (k, alpha, p)))
+    with np.errstate(all="ignore"):
+        mu = alpha * (1 - p) / p
+        lower = scipy.special.betainc(alpha, k + 1, p)
+        upper = scipy.special.betainc(k, alpha, 1 - p)
+        pmf = scipy.stats.nbinom.pmf(k, alpha, p)
+    upper = np.where(upper == 0, pmf, upper)
+    return np.where(k < mu, lower, upper)
+
+
+def nb_pvalue_midp(k, alpha, p):
+    """nb_model.py:316-337"""
+    k, alpha, p = np.broadcast_arrays(*(np.asarray(v, float) for v in (k, alpha, p)))
+    with np.errstate(all="ignore"):
+        mu = alpha * (1 - p) / p
+        pmf = scipy.stats.nbinom.pmf(k, alpha, p)
+        low = np.where(k > 0, 0.5 * pmf + scipy.special.betainc(alpha, k, p), 0.5 * pmf)
+        up = 0.5 * pmf + scipy.special.betainc(k + 1, alpha, 1 - p)
+    return np.where(k < mu, low, up)
+
+
+def fisher_combine(p1, p2):
+    """transfer_tools.py:860-861,1086-1087"""
+    with np.errstate(all="ignore"):
+        x2 = -2 * (np.log(p1) + np.log(p2))
+    return scipy.stats.chi2.sf(x2, df=4)
+
+
+# --------------------------------------------------------------------------
+# element statistics block (transfer_tools.py:272-302,343-344,473-482,594-615,
+# 731-747,1086-1087)
+# --------------------------------------------------------------------------
+def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, cj, cj_indel,
+                  mu_indel=None, sigma_indel=None):
+    """All arrays broadcast to a common shape (e.g. [E, C]); cj/cj_indel broadcast
+    along the cohort axis.  Returns the seven result columns + ALPHA/THETA."""
+    mu_indel = mu if mu_indel is None else mu_indel
+    sigma_indel = sigma if sigma_indel is None else sigma_indel
+    with np.errstate(all="ignore"):
+        alpha, theta = normal_params_to_gamma(mu, sigma)            # load_pretrained_model :17-19
+        alpha_i, theta_i = normal_params_to_gamma(mu_indel, sigma_indel)  # :46-48
+        theta = theta * cj                                          # transfer_element_model_with_indels :300
+        exp_snv = alpha * theta * pi_sum                            # :343-344
+        p = 1 / (theta * pi_sum + 1)
+        pval_snv = nb_pvalue_greater_midp(obs_snv, alpha, p)        # :473-482
+        pval_samp = nb_pvalue_greater_midp(obs_samples, alpha, p)   # :594-615
+        theta_i = theta_i * cj_indel                                # :737
+        exp_indel = alpha_i * theta_i * pi_indel                    # :738
+        pval_indel = nb_pvalue_greater_midp(obs_indel, alpha_i, 1 / (theta_i * pi_indel + 1))  # :741-745
+        pval_mut = fisher_combine(pval_snv, pval_indel)             # :1086-1087
+    return dict(ALPHA=alpha, THETA=theta, EXP_SNV=exp_snv, PVAL_SNV_BURDEN=pval_snv,
+                PVAL_SAMPLE_BURDEN=pval_samp, THETA_INDEL=theta_i, EXP_INDEL=exp_indel,
+                PVAL_INDEL_BURDEN=pval_indel, PVAL_MUT_BURDEN=pval_mut)
+
+
+GENE_CLASSES = ["SYN", "MIS", "NONS", "SPL", "TRUNC", "NONSYN"]
+
+
+def gene_stats(mu, sigma, pi, obs, n_samp, cj, pi_indel=None, obs_indel=None, t_indel=None,
+               mu_indel=None, sigma_indel=None):
+    """gene twins: transfer_tools.py:331-340 (EXP_*), :425-454 (PVAL_*_BURDEN),
+    :554-583 (PVAL_*_BURDEN_SAMPLE), :709-727 (indel), :860-861 (Fisher on TRUNC+INDEL).
+    `pi`, `obs`, `n_samp` are dicts keyed by GENE_CLASSES."""
+    out = {}
+    with np.errstate(all="ignore"):
+        alpha, theta = normal_params_to_gamma(mu, sigma)
+        theta = theta * cj
+        out["ALPHA"], out["THETA"] = alpha, theta
+        for c in GENE_CLASSES:
+            out["EXP_" + c] = alpha * theta * pi[c]
+            p = 1 / (theta * pi[c] + 1)
+            out["PVAL_%s_BURDEN" % c] = nb_pvalue_greater_midp(obs[c], alpha, p)
+            out["PVAL_%s_BURDEN_SAMPLE" % c] = nb_pvalue_greater_midp(n_samp[c], alpha, p)
+        if pi_indel is not None:
+            mu_indel = mu if mu_indel is None else mu_indel
+            sigma_indel = sigma if sigma_indel is None else sigma_indel
+            alpha_i, theta_i = normal_params_to_gamma(mu_indel, sigma_indel)
+            theta_i = theta_i * t_indel
+            out["THETA_INDEL"] = theta_i
+            out["EXP_INDEL"] = alpha_i * theta_i * pi_indel
+            out["PVAL_INDEL_BURDEN"] = nb_pvalue_greater_midp(obs_indel, alpha_i, 1 / (theta_i * pi_indel + 1))
+            out["PVAL_MUT_BURDEN"] = fisher_combine(out["PVAL_TRUNC_BURDEN"], out["PVAL_INDEL_BURDEN"])
+    return out
+
+
+# --------------------------------------------------------------------------
+# bin overlaps (genic_driver_tools.py:275-283)
+# --------------------------------------------------------------------------
+def ideal_overlap_starts(starts, ends, window):
+    """Sorted, de-duplicated bin START coordinates touched by the blocks.
+    low=floor(s/w)*w, high=ceil(e/w)*w, bins [low, high) in steps of w; a block that
+    ends exactly on a bin edge does not add the next bin; a zero-length block on an
+    edge adds nothing."""
+    out = set()
+    for s, e in zip(starts, ends):
+        low = int(np.floor(s / window)) * window
+        high = int(np.ceil(e / window)) * window
+        for b in range(low, high, window):
+            out.add(b)
+    return sorted(out)
+
+
+def build_overlap_csr(elt_chrom, block_starts, block_ends, bin_index, window):
+    """CSR (ov_ptr[E+1], ov_idx[nnz]) of bin row numbers per element, ascending.
+    `bin_index` maps (chrom, start) -> row of the bin tables."""
+    ptr = [0]
+    idx = []
+    for c, bs, be in zip(elt_chrom, block_starts, block_ends):
+        bs = [s for s in bs if s >= 0]
+        be = [e for e in be if e >= 0]
+        for b in ideal_overlap_starts(bs, be, window):
+            idx.append(bin_index[(int(c), int(b))])
+        ptr.append(len(idx))
+    return np.array(ptr, np.int64), np.array(idx, np.int32)
+
+
+# --------------------------------------------------------------------------
+# per-element accumulation (genic_driver_tools.py:258-272 region part,
+# :361-381 sequence part; genic: :110-158; tiled: :645-667)
+# --------------------------------------------------------------------------
+def accumulate_elements(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr,
+                        gene_length=None):
+    """
+    bin_mu, bin_std : float64 [N, C]     Y_PRED, STD of region_params per cohort
+    bin_y           : int     [N, C]     Y_TRUE
+    bin_flag        : bool/u8 [N, C]     FLAG (the result FLAG is the logical OR over the bins: the
+                      reference adds numpy bools, `False + np.True_ + np.True_ == True`)
+    bin_ctx         : int     [N, 64]    full_window_si_values
+    ov_ptr, ov_idx  : CSR of overlapped bin rows per element
+    L               : [E, n_class, 192]  L_counts (n_class = 1 elements, 4 genes)
+    strand_minus    : bool [E]
+    d_pr            : float64 [C, 192]   FREQ re-indexed by sorted substitution string
+    gene_length     : optional int [E]; when given P_INDEL = gene_length / R_SIZE
+                      (genic_driver_tools.py:158-159) instead of ELT_SIZE / R_SIZE (:380-381)
+    returns dict of MU, SIGMA [E,C] f64; R_OBS, FLAG [E,C] int64; P [E,n_class,C] f64;
+            R_SIZE, ELT_SIZE [E] int64; P_INDEL [E] f64
+    """
+    E = len(ov_ptr) - 1
+    C = d_pr.shape[0]
+    n_class = L.shape[1]
+    g192 = minus_strand_gather192()
+    MU = np.zeros((E, C)); VAR = np.zeros((E, C))
+    ROBS = np.zeros((E, C), np.int64); FLAG = np.zeros((E, C), np.int64)
+    P = np.zeros((E, n_class, C))
+    RSIZE = np.zeros(E, np.int64); ESIZE = np.zeros(E, np.int64); PIND = np.zeros(E)
+    with np.errstate(all="ignore"):
+        for e in range(E):
+            bins = ov_idx[ov_ptr[e]:ov_ptr[e + 1]]
+            for b in bins:                          # get_region_params_direct :264-268 (sequential sums)
+                MU[e] += bin_mu[b]
+                VAR[e] += bin_std[b] ** 2
+                ROBS[e] += bin_y[b]
+                FLAG[e] |= bin_flag[b].astype(np.int64)   # False + np.bool_ is a logical OR (:268)
+            rc192 = np.repeat(bin_ctx[bins].sum(axis=0), 3)        # sequence_tools.py:630-631
+            if strand_minus[e]:
+                rc192 = rc192[g192]                                 # :633-634
+            for c in range(C):
+                prob_sum = rc192 * d_pr[c]                          # :361
+                t_pi = d_pr[c] / prob_sum.sum()                     # :364
+                for q in range(n_class):
+                    P[e, q, c] = (t_pi * L[e, q]).sum()             # :366
+            RSIZE[e] = int(rc192.sum() / 3)                         # :375
+            ESIZE[e] = int(np.sum(L[e, 0] if n_class == 1 else L[e]) / 3)  # :380
+            num = ESIZE[e] if gene_length is None else gene_length[e]
+            PIND[e] = np.float64(num) / np.float64(RSIZE[e])        # :381 / :159
+    return dict(MU=MU, SIGMA=np.sqrt(VAR), R_OBS=ROBS, FLAG=FLAG, P=P, R_SIZE=RSIZE, ELT_SIZE=ESIZE, P_INDEL=PIND)
+
+
+def accumulate_elements_fast(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr):
+    """Vectorised form of accumulate_elements for n_class=1 (CPU-baseline timing at
+    bench sizes; same arithmetic up to summation order).  Every element needs >=1 bin."""
+    E = len(ov_ptr) - 1
+    starts = ov_ptr[:-1]
+    MU = np.add.reduceat(bin_mu[ov_idx], starts, axis=0)
+    VAR = np.add.reduceat(bin_std[ov_idx] ** 2, starts, axis=0)
+    ROBS = np.add.reduceat(bin_y[ov_idx].astype(np.int64), starts, axis=0)
+    FLAG = (np.add.reduceat(bin_flag[ov_idx].astype(np.int64), starts, axis=0) > 0).astype(np.int64)
+    rc64 = np.add.reduceat(bin_ctx[ov_idx].astype(np.int64), starts, axis=0)
+    rho = minus_strand_gather64()
+    rc64 = np.where(strand_minus[:, None], rc64[:, rho], rc64)
+    d64 = d_pr.reshape(d_pr.shape[0], 64, 3).sum(axis=2)           # [C,64]
+    denom = rc64.astype(np.float64) @ d64.T                         # [E,C]
+    numer = L[:, 0, :].astype(np.float64) @ d_pr.T                  # [E,C]
+    RSIZE = rc64.sum(axis=1)
+    ESIZE = (L[:, 0, :].sum(axis=1) / 3).astype(np.int64)
+    return dict(MU=MU, SIGMA=np.sqrt(VAR), R_OBS=ROBS, FLAG=FLAG, P=(numer / denom)[:, None, :],
+                R_SIZE=RSIZE, ELT_SIZE=ESIZE, P_INDEL=ESIZE / RSIZE)
+
+
+# --------------------------------------------------------------------------
+# per-bin track gather (mut_dataset.py:76-81)
+# --------------------------------------------------------------------------
+def gather_bins(x_data, bin_rows, tracks):
+    """x_data[idx, :, tracks] -> float32 (B, L, T_sel)"""
+    return np.asarray(x_data)[np.asarray(bin_rows)][:, :, np.asarray(tracks)].astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# per-base tiled test (nb_model.py:126-186, arithmetic only)
+# --------------------------------------------------------------------------
+def tiled_nb_test(pt, k, mu, sigma):
+    """pt [n_bins, n_tiles] tile probabilities (already summed over `binsize` positions and
+    normalised over the bin), k [n_bins, n_tiles] counts, mu/sigma [n_bins].
+    Returns (pval, exp) per tile: nb_model.py:141-178."""
+    with np.errstate(all="ignore"):
+        alpha, theta = normal_params_to_gamma(mu, sigma)
+        p = 1 / (pt * theta[:, None] + 1)
+        pval = nb_pvalue_exact(k, alpha[:, None], p)
+        exp = pt * mu[:, None]
+    return pval, exp
+
+
+# --------------------------------------------------------------------------
+# sequence model training (sequence_tools.py:321-373)
+# --------------------------------------------------------------------------
+def train_sequence_model(mut_type, context, genome_ctx, genome_counts):
+    """Counts of (MUT_TYPE, CONTEXT) over the (already whitelisted, de-duplicated) mutations
+    divided by the genome count of the context.  Returns (rows192, COUNT[192], FREQ[192],
+    ctx64_sorted, FREQ64[64])."""
+    rows = model_rows192()
+    pos = {r: i for i, r in enumerate(rows)}
+    count = np.zeros(192, np.int64)
+    for m, c in zip(mut_type, context):
+        j = pos.get((m, c))
+        if j is not None:
+            count[j] += 1
+    g = dict(zip(genome_ctx, genome_counts))
+    freq = np.array([count[i] / g[rows[i][1]] for i in range(192)])
+    ctx_sorted = sorted(set(c for _, c in rows))
+    freq64 = np.array([sum(freq[i] for i in range(192) if rows[i][1] == c) for c in ctx_sorted])
+    return rows, count, freq, ctx_sorted, freq64
+
+
+# --------------------------------------------------------------------------
+# cohort scale factors (transfer_tools.py:129-159 genome mode)
+# --------------------------------------------------------------------------
+def scale_factor_genome(bin_y_pred, bin_flag, n_snv_obs, n_indel_obs):
+    """cj = N_SNV_OBS / sum(Y_PRED[~FLAG]); cj_indel = N_IND_OBS / same (transfer_tools.py:148-156)"""
+    n_exp = bin_y_pred[~bin_flag.astype(bool)].sum()
+    return n_snv_obs / n_exp, n_indel_obs / n_exp

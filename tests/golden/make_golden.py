@@ -1,0 +1,688 @@
+#!/usr/bin/env python
+"""Generate golden input/output vectors by running the REAL reference here.
+
+Run in the build container only (it needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What this does
+--------------
+* Stubs the reference's I/O-only dependencies that are absent from this image
+  (pysam, h5py, pybedtools, statsmodels, seaborn, bbi, tables, gpytorch,
+  tensorboardX) in ``sys.modules``.  ``h5py.File`` is replaced by a small
+  in-memory, dict-backed fake and ``pandas.read_hdf`` by a dict lookup so that
+  the reference's *own* loops (``nonc_model``, ``genic_model``,
+  ``tiled_nonc_model``) run unmodified on synthetic inputs.
+* Imports the reference modules from /root/reference (never copied).
+* Calls the reference functions on seeded synthetic inputs and stores
+  inputs + outputs as small ``.npz`` / ``.json`` fixtures next to this script.
+
+Nothing from the reference's source text is stored: the fixtures are data only.
+The arithmetic behind the p-values is scipy's (scipy.special.betainc,
+scipy.stats.nbinom.pmf, scipy.stats.chi2.sf); the scipy version used is
+recorded in ``MANIFEST.json``.
+"""
+import io
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import pandas as pd
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("DIG_REFERENCE", "/root/reference")
+
+
+# ----------------------------------------------------------------------------
+# in-memory stand-ins for the I/O modules (test harness only)
+# ----------------------------------------------------------------------------
+class _FakeNode:
+    """dict-backed h5py group/dataset look-alike: supports node['a/b/c'],
+    node[...][:] on datasets, .attrs, .keys(), `in`, context manager, close."""
+
+    def __init__(self, tree, attrs=None):
+        self._tree = tree
+        self.attrs = attrs if attrs is not None else {}
+
+    def _resolve(self, key):
+        node = self._tree
+        for part in [p for p in key.split("/") if p]:
+            node = node[part]
+        return node
+
+    def __getitem__(self, key):
+        node = self._resolve(key)
+        if isinstance(node, dict):
+            return _FakeNode(node, node.get("__attrs__", {}))
+        return _FakeDataset(node)
+
+    def __contains__(self, key):
+        try:
+            self._resolve(key)
+            return True
+        except KeyError:
+            return False
+
+    def keys(self):
+        return [k for k in self._tree.keys() if k != "__attrs__"]
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _FakeDataset:
+    def __init__(self, arr):
+        self._arr = np.asarray(arr)
+
+    def __getitem__(self, idx):
+        return self._arr[idx]
+
+    @property
+    def shape(self):
+        return self._arr.shape
+
+
+_H5_FILES = {}    # path -> nested dict
+_HDF_FRAMES = {}  # (path, key) -> DataFrame
+
+
+def _fake_h5_file(path, mode="r"):
+    tree = _H5_FILES[path]
+    return _FakeNode(tree, tree.get("__attrs__", {}))
+
+
+def _fake_read_hdf(path, key=None, **kw):
+    return _HDF_FRAMES[(str(path), key)].copy()
+
+
+def install_stubs():
+    for name in ["pysam", "pybedtools", "statsmodels", "statsmodels.stats",
+                 "statsmodels.stats.multitest", "seaborn", "bbi", "tables",
+                 "gpytorch", "tensorboardX", "pkg_resources"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    h5 = types.ModuleType("h5py")
+    h5.File = _fake_h5_file
+    sys.modules["h5py"] = h5
+    pd.read_hdf = _fake_read_hdf
+    sys.path.insert(0, REF)
+
+
+install_stubs()
+
+from DIGDriver.sequence_model import nb_model as ref_nb            # noqa: E402
+from DIGDriver.sequence_model import genic_driver_tools as ref_gdt  # noqa: E402
+from DIGDriver.sequence_model import sequence_tools as ref_seq      # noqa: E402
+from DIGDriver.driver_model import transfer_tools as ref_tt         # noqa: E402
+from DIGDriver.data_tools import mutation_tools as ref_mt           # noqa: E402
+
+
+def save_npz(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrays.items()})
+
+
+# ----------------------------------------------------------------------------
+# (i) nb_pvalue_greater_midp
+# ----------------------------------------------------------------------------
+def synth_nb_inputs(rng, n, n_uniform):
+    mu = np.exp(rng.uniform(np.log(0.05), np.log(500.0), n))
+    sigma = mu * np.exp(rng.uniform(np.log(0.05), np.log(1.5), n))
+    pi = np.exp(rng.uniform(np.log(1e-5), np.log(1.0), n))
+    cj = 0.7
+    alpha, theta = ref_nb.normal_params_to_gamma(mu, sigma)
+    theta = theta * cj
+    lam = alpha * theta * pi
+    k = rng.poisson(np.minimum(lam * np.exp(rng.normal(0, 1, n)), 1e6)).astype(np.float64)
+    k[:n_uniform] = rng.integers(0, 3000, n_uniform).astype(np.float64)
+    p = 1 / (theta * pi + 1)
+    return k, alpha, p, mu, sigma, pi
+
+
+def gen_nb_midp():
+    rng = np.random.default_rng(7)
+    k, alpha, p, mu, sigma, pi = synth_nb_inputs(rng, 20000, 2000)
+    # edge rows: k=0, Pi=0 (p=1), mu<0 (p>1), sigma=0, non-integer k,
+    # huge k, tiny / huge alpha, p very close to 0 and 1
+    ek = [0, 0, 1, 5, 0, 3, 2.5, 3000, 1, 10, 100, 0, 7, 50, 500, 20, 1, 1, 40, 2000]
+    ea = [2.5, 4.0, 4.0, 4.0, 1.0, np.inf, 3.0, 4.0, 1e-3, 1e4, 1e5, 1e-8, 0.5, 40, 3, 2.0, 1e6, 300.0, 1e3, 50.0]
+    ep = [0.3, 1.0, 1.0, 1.0, 1.2, 0.5, 0.5, 0.5, 0.5, 0.999, 0.9995, 0.1, 1e-6, 0.1, 1/7., 1 - 1e-12, 1 - 1e-9, 0.01, 0.9, 0.02]
+    k = np.concatenate([k, np.array(ek, float)])
+    alpha = np.concatenate([alpha, np.array(ea, float)])
+    p = np.concatenate([p, np.array(ep, float)])
+    with np.errstate(all="ignore"):
+        pval = ref_nb.nb_pvalue_greater_midp(k, alpha, p)
+        # survey spot values (8c)
+        spot_k = np.array([0, 1, 5, 50, 500], float)
+        spot_a = np.array([2.5, 2.5, 10, 40, 3])
+        spot_t = np.array([.4, .4, .2, 1, 20])
+        spot_pi = np.array([.01, .5, 1, .9, .3])
+        spot = ref_nb.nb_pvalue_greater_midp(spot_k, spot_a, 1 / (spot_t * spot_pi + 1))
+    save_npz("nb_midp_golden.npz", k=k, alpha=alpha, p=p, pval=pval,
+             spot_k=spot_k, spot_alpha=spot_a, spot_theta=spot_t, spot_pi=spot_pi, spot_pval=spot)
+
+
+# ----------------------------------------------------------------------------
+# (ii) scalar siblings: nb_pvalue_exact / _greater / _midp
+# ----------------------------------------------------------------------------
+def gen_nb_exact():
+    rng = np.random.default_rng(11)
+    k, alpha, p, *_ = synth_nb_inputs(rng, 4000, 300)
+    ek = [0, 10, 4, 3000, 0, 1, 2, 7]
+    ea = [4, 4, 4, 4, 0.3, 0.3, 50, 1e3]
+    ep = [.5, .5, .5, .5, .9, .01, .5, .99]
+    k = np.concatenate([k, np.array(ek, float)])
+    alpha = np.concatenate([alpha, np.array(ea, float)])
+    p = np.concatenate([p, np.array(ep, float)])
+    ex, gr, mp_ = [], [], []
+    with np.errstate(all="ignore"):
+        for ki, ai, pi_ in zip(k, alpha, p):
+            ex.append(ref_nb.nb_pvalue_exact(ki, ai, pi_))
+            gr.append(ref_nb.nb_pvalue_greater(ki, ai, pi_))
+            mp_.append(ref_nb.nb_pvalue_midp(ki, ai, pi_))
+    save_npz("nb_exact_golden.npz", k=k, alpha=alpha, p=p,
+             pval_exact=np.array(ex, float), pval_greater=np.array(gr, float),
+             pval_midp=np.array(mp_, float))
+
+
+# ----------------------------------------------------------------------------
+# (iii) element / gene statistics block on a frame
+# ----------------------------------------------------------------------------
+def gen_element_stats():
+    rng = np.random.default_rng(3)
+    n = 6000
+    mu = np.exp(rng.uniform(np.log(0.5), np.log(400.0), n))
+    sigma = mu * np.exp(rng.uniform(np.log(0.05), np.log(1.2), n))
+    pi_sum = np.exp(rng.uniform(np.log(1e-4), np.log(0.5), n))
+    pi_indel = np.exp(rng.uniform(np.log(1e-4), np.log(0.5), n))
+    cj, cj_indel = 1.37, 0.061
+    alpha, theta = ref_nb.normal_params_to_gamma(mu, sigma)
+    lam = alpha * theta * cj * pi_sum
+    boost = np.where(rng.uniform(size=n) < 0.02, 6.0, 1.0)
+    obs_snv = rng.poisson(lam * boost * np.exp(rng.normal(0, 0.5, n)))
+    obs_samples = rng.binomial(obs_snv, 0.9)
+    obs_indel = rng.poisson(alpha * theta * cj_indel * pi_indel * boost)
+    # a few edge rows: mu<0, sigma=0, Pi=0
+    mu[:3] = [-1.0, 5.0, 3.0]
+    sigma[:3] = [1.0, 0.0, 1.0]
+    pi_sum[2] = 0.0
+    df_pre = pd.DataFrame(dict(
+        ELT_SIZE=rng.integers(100, 5000, n), FLAG=rng.integers(0, 2, n),
+        R_SIZE=rng.integers(9000, 30000, n), R_OBS=rng.integers(0, 500, n), R_INDEL=rng.integers(0, 500, n),
+        MU=mu, SIGMA=sigma, MU_INDEL=mu, SIGMA_INDEL=sigma, Pi_SUM=pi_sum, Pi_INDEL=pi_indel),
+        index=["elt%d" % i for i in range(n)])
+    with np.errstate(all="ignore"):
+        a, t = ref_nb.normal_params_to_gamma(df_pre.MU, df_pre.SIGMA)
+        df_pre["ALPHA"], df_pre["THETA"] = a, t
+        df_pre["ALPHA_INDEL"], df_pre["THETA_INDEL"] = a.copy(), t.copy()
+        # ~30% of elements are absent from the tabulation (left join -> NaN -> 0)
+        present = rng.uniform(size=n) > 0.3
+        df_tab = pd.DataFrame(dict(OBS_SAMPLES=obs_samples, OBS_SNV=obs_snv, OBS_INDEL=obs_indel),
+                              index=df_pre.index)[present]
+        df = ref_tt.transfer_element_model_with_indels(df_tab, df_pre, cj)
+        df = ref_tt.element_expected_muts_nb(df)
+        df = ref_tt.element_pvalue_burden_nb(df)
+        df = ref_tt.element_pvalue_burden_nb_by_sample(df)
+        df = ref_tt.element_pvalue_indel(df, cj_indel)
+        x2 = -2 * (np.log(df.PVAL_SNV_BURDEN) + np.log(df.PVAL_INDEL_BURDEN))
+        df["PVAL_MUT_BURDEN"] = scipy.stats.chi2.sf(x2, df=4)
+    out_cols = ["ALPHA", "THETA", "EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "THETA_INDEL",
+                "EXP_INDEL", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN", "OBS_SNV", "OBS_SAMPLES", "OBS_INDEL"]
+    save_npz("element_stats_golden.npz",
+             mu=mu, sigma=sigma, pi_sum=pi_sum, pi_indel=pi_indel,
+             cj=np.float64(cj), cj_indel=np.float64(cj_indel), present=present,
+             tab_obs_snv=obs_snv, tab_obs_samples=obs_samples, tab_obs_indel=obs_indel,
+             columns=np.array(list(df.columns)),
+             **{"out_" + c: df[c].values.astype(float) for c in out_cols})
+
+    # Fisher spot values straight from scipy as the reference calls it
+    p1 = np.array([1e-3, 0.5, 1.0, 0.0, 1e-300, 3e-17])
+    p2 = np.array([0.5, 0.5, 1.0, 0.5, 1e-300, 0.2])
+    with np.errstate(all="ignore"):
+        fisher = scipy.stats.chi2.sf(-2 * (np.log(p1) + np.log(p2)), df=4)
+    save_npz("fisher_golden.npz", p1=p1, p2=p2, out=fisher)
+
+
+def gen_gene_stats():
+    rng = np.random.default_rng(5)
+    n = 3000
+    genes = ["G%d" % i for i in range(n)]
+    genes[7] = "TP53"
+    mu = np.exp(rng.uniform(np.log(0.5), np.log(300.0), n))
+    sigma = mu * np.exp(rng.uniform(np.log(0.05), np.log(1.2), n))
+    P = {c: np.exp(rng.uniform(np.log(1e-4), np.log(0.2), n)) for c in ["SILENT", "MIS", "NONS", "SPLICE", "INDEL"]}
+    frame = pd.DataFrame(dict(
+        CHROM=rng.integers(1, 23, n).astype(str), GENE=genes, GENE_LENGTH=rng.integers(300, 9000, n),
+        R_SIZE=rng.integers(9000, 50000, n), R_OBS=rng.integers(0, 800, n), R_INDEL=rng.integers(0, 800, n),
+        MU=mu, SIGMA=sigma, MU_INDEL=mu, SIGMA_INDEL=sigma, FLAG=rng.integers(0, 3, n),
+        P_MIS=P["MIS"], P_NONS=P["NONS"], P_SILENT=P["SILENT"], P_SPLICE=P["SPLICE"],
+        P_TRUNC=P["NONS"] + P["SPLICE"], P_INDEL=P["INDEL"]))
+    _HDF_FRAMES[("mem://genes.h5", "genic_model")] = frame
+    df_pre = ref_tt.load_pretrained_model("mem://genes.h5")
+    # synthetic CDS mutation table
+    annots = np.array(["Synonymous", "Missense", "Nonsense", "Essential_Splice", "INDEL"])
+    rows = []
+    m = 40000
+    gi = rng.integers(0, n, m)
+    # hot genes
+    gi[:1500] = rng.integers(0, 20, 1500)
+    for j in range(m):
+        rows.append((str(frame.CHROM.iloc[gi[j]]), int(rng.integers(1, 10 ** 6)), 0, "A", "T",
+                     "S%d" % rng.integers(0, 300), genes[gi[j]], annots[rng.choice(5, p=[.25, .5, .05, .03, .17])],
+                     "A>T", "CAG"))
+    df_mut = pd.DataFrame(rows, columns=["CHROM", "START", "END", "REF", "ALT", "SAMPLE", "GENE", "ANNOT",
+                                         "MUT_TYPE", "CONTEXT"])
+    df_mut["END"] = df_mut.START + 1
+    df_mut["CHROM"] = df_mut.CHROM.astype(int)
+    df_mut_f = ref_mt.filter_hypermut_samples(df_mut, 170)
+    df_cnt = ref_mt.mutations_per_gene(df_mut_f, max_muts_per_gene_per_sample=3)
+    exp_mut = (df_pre[df_pre.index != 'TP53'].MU * df_pre[df_pre.index != 'TP53'].Pi_SYN).sum()
+    cj = len(df_mut_f[(df_mut_f.GENE != 'TP53') & (df_mut_f.ANNOT == 'Synonymous')]) / exp_mut
+    with np.errstate(all="ignore"):
+        df = ref_tt.transfer_gene_model(df_mut_f, df_cnt, df_pre, cj)
+        df = ref_tt.gene_expected_muts_nb(df)
+        df = ref_tt.gene_pvalue_burden_nb(df)
+        df = ref_tt.gene_pvalue_burden_nb_by_sample(df)
+        # gene_pvalue_indel reads a packaged gene panel via pkg_resources; restate its two
+        # lines with an explicit null set (the reference formula is transfer_tools.py:709-727)
+        null = ~df.index.isin(["G1", "G2", "G3"])
+        t_indel = df[null].OBS_INDEL.sum() / (df[null].Pi_INDEL * df[null].ALPHA_INDEL * df[null].THETA_INDEL).sum()
+        df['THETA_INDEL'] = df.THETA_INDEL * t_indel
+        df['EXP_INDEL'] = df.ALPHA_INDEL * df.THETA_INDEL * df.Pi_INDEL
+        df['PVAL_INDEL_BURDEN'] = ref_nb.nb_pvalue_greater_midp(df.OBS_INDEL, df.ALPHA_INDEL,
+                                                               1 / (df.THETA_INDEL * df.Pi_INDEL + 1))
+        x2 = -2 * (np.log(df.PVAL_TRUNC_BURDEN) + np.log(df.PVAL_INDEL_BURDEN))
+        df['PVAL_MUT_BURDEN'] = scipy.stats.chi2.sf(x2, df=4)
+    buf = io.StringIO()
+    df_mut.to_csv(buf, sep="\t", header=False, index=False)
+    with open(os.path.join(HERE, "gene_mutations.tsv"), "w") as f:
+        f.write(buf.getvalue())
+    num_cols = [c for c in df.columns if c != "CHROM"]
+    save_npz("gene_stats_golden.npz", genes=np.array(genes),
+             frame_cols=np.array([c for c in frame.columns if c not in ("GENE", "CHROM")]),
+             frame_vals=frame[[c for c in frame.columns if c not in ("GENE", "CHROM")]].values.astype(float),
+             frame_chrom=frame.CHROM.values.astype(str),
+             max_muts_per_sample=np.int64(170), max_muts_per_gene_per_sample=np.int64(3),
+             cj=np.float64(cj), t_indel=np.float64(t_indel), null_excluded=np.array(["G1", "G2", "G3"]),
+             cnt_index=np.array(df_cnt.index), cnt_cols=np.array(df_cnt.columns), cnt_vals=df_cnt.values.astype(np.int64),
+             out_index=np.array(df.index), out_cols=np.array(num_cols), out_vals=df[num_cols].values.astype(float))
+
+
+# ----------------------------------------------------------------------------
+# (iv) get_ideal_overlaps
+# ----------------------------------------------------------------------------
+def gen_overlaps():
+    rng = np.random.default_rng(9)
+    cases = []
+    fixed = [
+        (1, [[100], [900]], 10000),
+        (1, [[10000], [20000]], 10000),           # both ends on bin edges
+        (2, [[9999], [10001]], 10000),
+        (3, [[0], [10000]], 10000),
+        (4, [[5, 25000, 99990], [500, 31000, 100010]], 10000),
+        (5, [[19990, 20010], [20000, 20020]], 10000),  # block ending exactly on an edge
+        (6, [[12345], [12345]], 10000),                # zero-length block
+        (7, [[20000], [20000]], 10000),                # zero-length block on an edge -> no bin
+        (8, [[150], [950]], 100),
+    ]
+    for chrom, iv, w in fixed:
+        cases.append((chrom, iv, w))
+    for _ in range(60):
+        nb = int(rng.integers(1, 5))
+        starts = np.sort(rng.integers(0, 2_000_000, nb))
+        ends = starts + rng.integers(1, 30000, nb)
+        cases.append((int(rng.integers(1, 23)), [starts.tolist(), ends.tolist()], int(rng.choice([10000, 1000, 50]))))
+    out = []
+    for chrom, iv, w in cases:
+        res = ref_gdt.get_ideal_overlaps(chrom, np.array(iv), w)
+        out.append(dict(chrom=chrom, intervals=iv, window=w,
+                        overlaps=sorted([[int(a), int(b), int(c)] for a, b, c in res])))
+    with open(os.path.join(HERE, "overlaps_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote overlaps_golden.json", len(out))
+
+
+# ----------------------------------------------------------------------------
+# (vii) substitution index + reverse-complement permutation
+# ----------------------------------------------------------------------------
+def gen_subst_index():
+    trans_idx = ref_seq.mk_trans_idx(n_up=1, n_down=1, collapse=False)
+    ctx64 = list(ref_seq.mk_context_sequences(n_up=1, n_down=1, collapse=False).keys())
+    df_empty = ref_seq.mk_mutation_context(n_up=1, n_down=1, collapse=False, return_df=True)
+    # the permutation applied to a 192-vector for '-' strand elements (sequence_tools.py:610-634)
+    subst_idx = sorted(trans_idx)
+    revc = [ref_seq.reverse_complement(s.split('>')[0]) + '>' + ref_seq.reverse_complement(s.split('>')[-1])
+            for s in subst_idx]
+    revc_dic = dict(zip(subst_idx, revc))
+    probe = np.arange(192)
+    permuted = [r[1] for r in sorted(enumerate(probe), key=lambda k: revc_dic[subst_idx[k[0]]])]
+    # 96-type (collapse=True) listing kept for the optional K=96 mode
+    trans96 = ref_seq.mk_trans_idx(n_up=1, n_down=1, collapse=True)
+    with open(os.path.join(HERE, "subst_index.json"), "w") as f:
+        json.dump(dict(subst_idx=subst_idx, context64=ctx64, revc=revc,
+                       minus_strand_gather=[int(x) for x in permuted],
+                       model_rows=[[a, b] for a, b in zip(df_empty.MUT_TYPE, df_empty.CONTEXT)],
+                       subst_idx_96=trans96), f)
+    print("wrote subst_index.json")
+    return subst_idx, ctx64, df_empty
+
+
+# ----------------------------------------------------------------------------
+# (v) accumulation: the reference's own nonc_model / tiled_nonc_model / genic_model
+#     executed over in-memory h5 stand-ins
+# ----------------------------------------------------------------------------
+def synth_region_params(rng, chroms, bins_per_chrom, window):
+    rows = []
+    for c in chroms:
+        for b in range(bins_per_chrom):
+            rows.append((c, b * window, (b + 1) * window))
+    idx = np.array(rows, dtype=np.int64)
+    n = len(idx)
+    y_pred = rng.gamma(9.0, 3.0, n)
+    std = rng.gamma(4.0, 1.0, n)
+    y_true = rng.poisson(y_pred)
+    flag = rng.uniform(size=n) < 0.1
+    df = pd.DataFrame(dict(CHROM=idx[:, 0], START=idx[:, 1], END=idx[:, 2], Y_TRUE=y_true,
+                           Y_PRED=y_pred, STD=std, MAPP=rng.uniform(0.4, 1, n), QUANT=rng.uniform(0, 1, n),
+                           FLAG=flag))
+    df.index = ['chr{}:{}-{}'.format(*r) for r in idx]
+    return idx, df
+
+
+def gen_accumulate(subst_idx, ctx64, df_empty):
+    rng = np.random.default_rng(21)
+    window = 10000
+    chroms = [1, 2, 21]
+    idx, df_reg = synth_region_params(rng, chroms, 60, window)
+    n = len(idx)
+    # 64-context counts per bin ~ Multinomial(window, Dirichlet(1))
+    ctx_p = rng.dirichlet(np.ones(64))
+    bin_ctx = rng.multinomial(window, ctx_p, size=n).astype(np.int64)
+    # sequence_model_192 frame in the reference's row order (mk_mutation_context)
+    freq = rng.dirichlet(np.ones(192)) * 1e-6 * 192
+    df_seq = df_empty.copy()
+    df_seq["COUNT"] = rng.integers(0, 1000, 192)
+    df_seq["FREQ"] = freq
+    f_pre, f_dat = "mem://pretrained.h5", "mem://element_data.h5"
+    _HDF_FRAMES[(f_pre, "region_params")] = df_reg
+    _HDF_FRAMES[(f_pre, "sequence_model_192")] = df_seq
+    idx_dict = {tuple(int(v) for v in r): i for i, r in enumerate(idx)}
+
+    revc = [ref_seq.reverse_complement(s.split('>')[0]) + '>' + ref_seq.reverse_complement(s.split('>')[-1])
+            for s in subst_idx]
+    revc_dic = dict(zip(subst_idx, revc))
+
+    # elements: 1-3 blocks, 200-3000 bp, +/- strand; L = per-context counts repeated x3
+    E = 400
+    save_key = "elts"
+    tree = {"window_%d" % window: {save_key: {}, "full_window_si_values": bin_ctx, "full_window_si_index": idx}}
+    elt_names, strands, blocks_s, blocks_e, chrom_of, L_all, rc_all, ov_all = [], [], [], [], [], [], [], []
+    for e in range(E):
+        chrom = int(rng.choice(chroms))
+        nb = int(rng.integers(1, 4))
+        base = int(rng.integers(0, 58 * window))
+        starts, ends = [], []
+        pos = base
+        for _ in range(nb):
+            s = pos + int(rng.integers(0, 4000))
+            ln = int(rng.integers(200, 3000))
+            starts.append(s)
+            ends.append(s + ln)
+            pos = s + ln
+        if e % 37 == 0:   # block ending exactly on a bin edge
+            ends[-1] = (ends[-1] // window + 1) * window
+        strand = "+" if rng.uniform() < 0.5 else "-"
+        iv = np.vstack((starts, ends))
+        overlaps = ref_gdt.get_ideal_overlaps(chrom, iv, window)
+        # region_counts exactly as sequence_tools.preprocess_nonc builds them (:630-634)
+        region_counts = np.array([np.repeat(bin_ctx[idx_dict[r], :], 3) for r in overlaps]).sum(axis=0)
+        if strand == '-':
+            region_counts = [r[1] for r in sorted(enumerate(region_counts), key=lambda k: revc_dic[subst_idx[k[0]]])]
+        region_counts = np.asarray(region_counts)
+        tot = int(sum(e_ - s_ for s_, e_ in zip(starts, ends)))
+        L64 = rng.multinomial(tot, ctx_p)
+        L = np.repeat(L64, 3).astype(np.float64)
+        name = "elt_%04d" % e
+        tree["window_%d" % window][save_key][name] = {
+            "L_counts": L, "region_counts": region_counts,
+            "__attrs__": {"overlaps": np.array(overlaps)}}
+        elt_names.append(name); strands.append(strand); chrom_of.append(chrom)
+        blocks_s.append(starts); blocks_e.append(ends)
+        L_all.append(L); rc_all.append(region_counts)
+        ov_all.append(sorted([idx_dict[tuple(int(v) for v in r)] for r in overlaps]))
+    _H5_FILES[f_dat] = tree
+
+    df_out = ref_gdt.nonc_model(elt_names, f_pre, f_dat, save_key, False)
+
+    # tiled route: elements are "chr{c}:{s}-{e}" tiles inside one bin; L table via read_hdf
+    tiles, tile_L = [], []
+    for t in range(150):
+        chrom = int(rng.choice(chroms))
+        b = int(rng.integers(0, 60))
+        s = b * window + int(rng.integers(0, window - 50))
+        tiles.append("chr{}:{}-{}".format(chrom, s, s + 50))
+        tile_L.append(np.repeat(rng.multinomial(50, ctx_p), 3).astype(np.float64))
+    tile_key = "tiles"
+    _HDF_FRAMES[(f_dat, "{}/L_counts".format(tile_key))] = pd.DataFrame(np.array(tile_L), index=tiles, columns=subst_idx)
+    df_tiled = ref_gdt.tiled_nonc_model(pd.Index(tiles), f_pre, f_dat, tile_key)
+
+    cols = ['ELT_SIZE', 'FLAG', 'R_SIZE', 'R_OBS', 'R_INDEL', 'MU', 'SIGMA', 'MU_INDEL', 'SIGMA_INDEL', 'P_SUM', 'P_INDEL']
+    max_ov = max(len(o) for o in ov_all)
+    ov_pad = -np.ones((E, max_ov), dtype=np.int64)
+    for i, o in enumerate(ov_all):
+        ov_pad[i, :len(o)] = o
+    maxb = 3
+    bs = -np.ones((E, maxb), np.int64); be = -np.ones((E, maxb), np.int64)
+    for i in range(E):
+        bs[i, :len(blocks_s[i])] = blocks_s[i]; be[i, :len(blocks_e[i])] = blocks_e[i]
+    save_npz("accumulate_golden.npz",
+             window=np.int64(window), bin_idx=idx, bin_y_pred=df_reg.Y_PRED.values, bin_std=df_reg.STD.values,
+             bin_y_true=df_reg.Y_TRUE.values.astype(np.int64), bin_flag=df_reg.FLAG.values,
+             bin_ctx=bin_ctx, seq_mut_type=df_seq.MUT_TYPE.values.astype(str), seq_context=df_seq.CONTEXT.values.astype(str),
+             seq_freq=freq, elt_names=np.array(elt_names), elt_chrom=np.array(chrom_of), elt_strand=np.array(strands),
+             block_starts=bs, block_ends=be, elt_L=np.array(L_all), elt_region_counts=np.array(rc_all),
+             elt_overlap_bins=ov_pad, out_cols=np.array(cols), out_vals=df_out[cols].values.astype(float),
+             tile_names=np.array(tiles), tile_L=np.array(tile_L), tile_out_names=df_tiled.ELT.values.astype(str),
+             tile_out_vals=df_tiled[cols].values.astype(float))
+
+    # ---- genic_model (4 mutation classes) through the same in-memory stand-ins ----
+    G = 120
+    f_gen = "mem://genic.h5"
+    gtree = {"substitution_idx": np.array([s.encode() for s in subst_idx]), "chr": {}, "cds_intervals": {},
+             "L_data": {}}
+    counts_rows, gnames = [], []
+    g_int, g_L, g_chr, g_ov = [], [], [], []
+    for g in range(G):
+        chrom = int(rng.choice(chroms))
+        nb = int(rng.integers(1, 6))
+        base = int(rng.integers(0, 55 * window))
+        starts, ends, pos = [], [], base
+        for _ in range(nb):
+            s = pos + int(rng.integers(50, 9000)); ln = int(rng.integers(60, 900))
+            starts.append(s); ends.append(s + ln); pos = s + ln
+        iv = np.vstack((starts, ends))
+        overlaps = ref_gdt.get_ideal_overlaps(str(chrom), iv, window)
+        rc = np.array([np.repeat(bin_ctx[idx_dict[(int(a), int(b), int(c))], :], 3) for a, b, c in overlaps]).sum(axis=0)
+        Ld = np.zeros((4, 192))
+        tot = sum(e_ - s_ + 1 for s_, e_ in zip(starts, ends))
+        split = rng.multinomial(3 * tot, [0.22, 0.68, 0.04, 0.06])
+        for c in range(4):
+            Ld[c] = rng.multinomial(split[c], np.repeat(ctx_p, 3) / 3.0)
+        name = "GENE%03d" % g
+        gnames.append(name)
+        gtree["chr"][name] = np.array([str(chrom).encode()])
+        gtree["cds_intervals"][name] = iv
+        gtree["L_data"][name] = Ld
+        counts_rows.append(rc)
+        g_int.append(iv); g_L.append(Ld); g_chr.append(chrom)
+        g_ov.append(sorted(idx_dict[(int(a), int(b), int(c))] for a, b, c in overlaps))
+    gtree["chr"]["GENEX"] = np.array([b"X"])   # sex-chromosome gene must be skipped (genic_driver_tools.py:90-92)
+    gtree["cds_intervals"]["GENEX"] = np.array([[100], [400]])
+    gtree["L_data"]["GENEX"] = np.zeros((4, 192))
+    _H5_FILES[f_gen] = gtree
+    _HDF_FRAMES[(f_gen, "window_10kb/counts")] = pd.DataFrame(np.array(counts_rows + [np.zeros(192)]),
+                                                              index=gnames + ["GENEX"], columns=subst_idx)
+    df_gen = ref_gdt.genic_model(gnames + ["GENEX"], f_pre, f_gen, "window_10kb/counts", False)
+    gcols = ['GENE_LENGTH', 'R_SIZE', 'R_OBS', 'R_INDEL', 'MU', 'SIGMA', 'MU_INDEL', 'SIGMA_INDEL', 'FLAG',
+             'P_MIS', 'P_NONS', 'P_SILENT', 'P_SPLICE', 'P_TRUNC', 'P_INDEL']
+    maxb = max(iv.shape[1] for iv in g_int)
+    gs = -np.ones((G, maxb), np.int64); ge = -np.ones((G, maxb), np.int64)
+    for i, iv in enumerate(g_int):
+        gs[i, :iv.shape[1]] = iv[0]; ge[i, :iv.shape[1]] = iv[1]
+    max_ov = max(len(o) for o in g_ov)
+    gov = -np.ones((G, max_ov), np.int64)
+    for i, o in enumerate(g_ov):
+        gov[i, :len(o)] = o
+    save_npz("genic_golden.npz", gene_names=np.array(gnames), gene_chrom=np.array(g_chr), cds_starts=gs, cds_ends=ge,
+             L_data=np.array(g_L), region_counts=np.array(counts_rows), gene_overlap_bins=gov,
+             out_genes=df_gen.GENE.values.astype(str), out_chrom=df_gen.CHROM.values.astype(str),
+             out_cols=np.array(gcols), out_vals=df_gen[gcols].values.astype(float))
+
+
+# ----------------------------------------------------------------------------
+# (viii) integer mutation tabulation helpers
+# ----------------------------------------------------------------------------
+def gen_mutation_tools():
+    rng = np.random.default_rng(13)
+    m = 5000
+    genes = ["G%d" % i for i in range(40)]
+    annots = np.array(["Synonymous", "Missense", "Nonsense", "Essential_Splice", "INDEL", "Noncoding"])
+    df = pd.DataFrame(dict(
+        CHROM=rng.integers(1, 23, m), START=rng.integers(1, 5000, m), REF=rng.choice(list("ACGT"), m),
+        ALT=rng.choice(list("ACGT"), m), SAMPLE=["S%d" % s for s in rng.integers(0, 60, m)],
+        GENE=rng.choice(genes, m), ANNOT=rng.choice(annots, m, p=[.2, .4, .05, .05, .2, .1]),
+        MUT_TYPE="A>T", CONTEXT="CAG"))
+    df.insert(2, "END", df.START + 1)
+    df = pd.concat([df, df.iloc[:300]])  # exact duplicates
+    path = os.path.join(HERE, "mutations_small.tsv")
+    df.to_csv(path, sep="\t", header=False, index=False)
+    rd = ref_mt.read_mutation_file(path, drop_sex=True, drop_duplicates=True, unique_indels=True)
+    rd2 = ref_mt.read_mutation_file(path, drop_sex=True, drop_duplicates=False, unique_indels=True)
+    filt, black = ref_mt.filter_hypermut_samples(rd2, 95, return_blacklist=True)
+    cnt = ref_mt.mutations_per_gene(rd2[rd2.GENE != '.'], max_muts_per_gene_per_sample=2)
+    # bed12
+    bed = []
+    for i in range(25):
+        chrom = "chr%d" % rng.integers(1, 23) if i % 2 else str(rng.integers(1, 23))
+        nb = int(rng.integers(1, 4)); start = int(rng.integers(0, 10 ** 6))
+        sizes = rng.integers(50, 500, nb); rel = np.concatenate([[0], np.cumsum(sizes + rng.integers(10, 300, nb))[:-1]])
+        bed.append([chrom, start, start + int(rel[-1] + sizes[-1]), "E%d" % i, 0, "+-"[i % 2], start, start, ".", nb,
+                    ",".join(map(str, sizes)) + ("," if i % 3 == 0 else ""), ",".join(map(str, rel)) + ("," if i % 3 == 0 else "")])
+    bed.append(["chrX", 5, 100, "EX", 0, "+", 5, 5, ".", 1, "95,", "0,"])
+    # bed12_boundaries lstrips 'chr' only if the FIRST row has it -> keep first row 'chr'-prefixed
+    bed[0][0] = "chr3"
+    for r in bed:
+        if not str(r[0]).startswith("chr"):
+            r[0] = "chr" + str(r[0])
+    bed_path = os.path.join(HERE, "elements_small.bed")
+    pd.DataFrame(bed).to_csv(bed_path, sep="\t", header=False, index=False)
+    bb = ref_mt.bed12_boundaries(bed_path)
+    with open(os.path.join(HERE, "mutation_tools_golden.json"), "w") as f:
+        json.dump(dict(
+            n_read_dedup=int(len(rd)), n_read_nodedup=int(len(rd2)),
+            read_dedup_rows=rd.astype(str).values.tolist()[:50],
+            read_dedup_checksum=int(pd.util.hash_pandas_object(rd.reset_index(drop=True).astype(str), index=False).sum() % (2 ** 61)),
+            blacklist=sorted(black), n_filtered=int(len(filt)),
+            cnt_index=list(cnt.index), cnt_cols=list(cnt.columns), cnt_vals=cnt.values.astype(int).tolist(),
+            bed12=dict(CHROM=[int(c) for c in bb.CHROM], ELT=list(bb.ELT), STRAND=list(bb.STRAND),
+                       BLOCK_STARTS=[list(map(int, x)) for x in bb.BLOCK_STARTS],
+                       BLOCK_ENDS=[list(map(int, x)) for x in bb.BLOCK_ENDS])), f)
+    print("wrote mutation_tools_golden.json")
+
+
+# ----------------------------------------------------------------------------
+# (ix) sequence model training (192 / 64 frequency tables)
+# ----------------------------------------------------------------------------
+def gen_sequence_model(df_empty):
+    rng = np.random.default_rng(17)
+    # whitelisting by bed needs bedtools; the golden uses an identity whitelist (all mutations inside)
+    ref_mt.restrict_mutations_by_bed = lambda df_mut, df_bed, unique=True, remove_X=True, replace_cols=False: \
+        (df_mut.drop_duplicates() if unique else df_mut).copy()
+    m = 30000
+    rows = df_empty.sample(m, replace=True, random_state=1).reset_index(drop=True)
+    df_mut = pd.DataFrame(dict(CHROM=rng.integers(1, 23, m), START=rng.integers(0, 10 ** 7, m)))
+    df_mut["END"] = df_mut.START + 1
+    df_mut["REF"] = [c[1] for c in rows.CONTEXT]
+    df_mut["ALT"] = [t[2] for t in rows.MUT_TYPE]
+    df_mut["SAMPLE"] = ["S%d" % s for s in rng.integers(0, 50, m)]
+    df_mut["ANNOT"] = "Noncoding"
+    df_mut["MUT_TYPE"] = rows.MUT_TYPE.values
+    df_mut["CONTEXT"] = rows.CONTEXT.values
+    ctx = sorted(set(df_empty.CONTEXT))
+    S_genome = pd.Series(rng.integers(10 ** 6, 10 ** 8, 64), index=ctx)
+    regions = np.array([[1, 0, 10000]])
+    df192, df64 = ref_seq.train_sequence_model(regions, df_mut, S_genome)
+    save_npz("sequence_model_golden.npz", mut_type=df_mut.MUT_TYPE.values.astype(str),
+             context=df_mut.CONTEXT.values.astype(str),
+             dedup_key=pd.util.hash_pandas_object(df_mut, index=False).values,
+             genome_ctx=np.array(ctx), genome_counts=S_genome.values.astype(np.int64),
+             out_mut_type=df192.MUT_TYPE.values.astype(str), out_context=df192.CONTEXT.values.astype(str),
+             out_count=df192.COUNT.values.astype(np.int64), out_freq=df192.FREQ.values,
+             out64_context=np.array(df64.index).astype(str), out64_freq=df64.FREQ.values)
+
+
+# ----------------------------------------------------------------------------
+# (vi) CNN forward (seeded weights regenerated from the seed; only data stored)
+# ----------------------------------------------------------------------------
+def gen_cnn():
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location(
+        "ref_cnn", os.path.join(REF, "DIGDriver/region_model/nets/cnn_predictors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    T, L, C, B = 32, 100, 3, 6
+    torch.manual_seed(0)
+    net = mod.SimpleMultiTaskResNet((B, L, T), C)
+    # non-trivial BatchNorm statistics, drawn in module order from a dedicated generator
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    gx = torch.Generator().manual_seed(2)
+    x = torch.round(torch.rand(B, L, T, generator=gx), decimals=2) * 100
+    with torch.no_grad():
+        outs, feats, att = net(x)
+    assert att is None
+    save_npz("cnn_forward_golden.npz", x=x.numpy(), shape=np.array([B, L, T, C]),
+             outputs=np.stack([o.numpy() for o in outs]), features=np.stack([f.numpy() for f in feats]),
+             n_params=np.int64(sum(p.numel() for p in net.parameters())),
+             first_conv_w_sum=np.float64(net.conv11.weight.double().sum().item()))
+
+
+def main():
+    gen_nb_midp()
+    gen_nb_exact()
+    gen_element_stats()
+    gen_gene_stats()
+    gen_overlaps()
+    subst_idx, ctx64, df_empty = gen_subst_index()
+    gen_accumulate(subst_idx, ctx64, df_empty)
+    gen_mutation_tools()
+    gen_sequence_model(df_empty)
+    gen_cnn()
+    import torch
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,
+                       numpy=np.__version__, scipy=scipy.__version__, pandas=pd.__version__,
+                       torch=torch.__version__, python=sys.version.split()[0]), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

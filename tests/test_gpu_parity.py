@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C ABI of libdig_hip.so) against
+  (a) the committed golden vectors produced by the real reference, and
+  (b) the oracle on seeded inputs,
+plus size-independent properties at BASELINE-scale sizes.
+
+Tolerance contract (BASELINE.json north_star / SURVEY 8c): p-values and expected counts within
+1e-6 relative for p >= 1e-250 (below that scipy itself is not self-consistent: both sides must be
+< 1e-250); integer outputs bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_close
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    from digdriver_amd import _lib
+    _lib.require_device()
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------
+# NB family vs reference goldens
+# ---------------------------------------------------------------------------------------
+def test_nb_midp_upper_golden_host_and_device(torch_dev):
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    d = np.load(os.path.join(GOLDEN, "nb_midp_golden.npz"))
+    got = nb_model.nb_pvalue_greater_midp(d["k"], d["alpha"], d["p"])
+    rel_close(got, d["pval"], RTOL)
+    # device-pointer entry point on torch tensors: same kernel, no copies
+    t = [torch.as_tensor(d[n], device=torch_dev) for n in ("k", "alpha", "p")]
+    got_dev = nb_model.nb_pvalue_greater_midp(*t)
+    assert got_dev.is_cuda
+    assert np.array_equal(got_dev.cpu().numpy(), got, equal_nan=True)
+    # SURVEY 8c spot values
+    spot = nb_model.nb_pvalue_greater_midp(d["spot_k"], d["spot_alpha"], 1 / (d["spot_theta"] * d["spot_pi"] + 1))
+    rel_close(spot, d["spot_pval"], RTOL)
+    # edge conventions measured with the reference
+    e = nb_model.nb_pvalue_greater_midp(np.array([0., 0., 3., 2., 2., 2.]), np.array([2.5, 4., 4., 4., 0., np.nan]),
+                                       np.array([0.3, 1.0, 1.0, 1.2, .5, .5]))
+    assert e[0] == pytest.approx(0.5 * 0.3 ** 2.5 + 1 - 0.3 ** 2.5, rel=1e-13)
+    assert e[1] == 0.5 and e[2] == 0.0 and np.isnan(e[3]) and np.isnan(e[4]) and np.isnan(e[5])
+
+
+def test_nb_scalar_siblings_golden(torch_dev):
+    from digdriver_amd.sequence_model import nb_model
+    d = np.load(os.path.join(GOLDEN, "nb_exact_golden.npz"))
+    rel_close(nb_model.nb_pvalue_exact(d["k"], d["alpha"], d["p"]), d["pval_exact"], RTOL)
+    rel_close(nb_model.nb_pvalue_greater(d["k"], d["alpha"], d["p"]), d["pval_greater"], RTOL)
+    rel_close(nb_model.nb_pvalue_midp(d["k"], d["alpha"], d["p"]), d["pval_midp"], RTOL)
+    assert nb_model.nb_pvalue_exact(0, 4, .5) == pytest.approx(0.0625, rel=1e-13)
+    assert nb_model.nb_pvalue_exact(10, 4, .5) == pytest.approx(0.046142578125, rel=1e-12)
+    assert nb_model.nb_pvalue_exact(4, 4, .5) == pytest.approx(0.5, rel=1e-12)
+    assert nb_model.nb_pvalue_exact(3000, 4, .5) == 0.0
+
+
+def test_fisher_and_gamma(torch_dev):
+    from digdriver_amd.sequence_model import nb_model
+    d = np.load(os.path.join(GOLDEN, "fisher_golden.npz"))
+    rel_close(nb_model.fisher_combine(d["p1"], d["p2"]), d["out"], 1e-12)
+    assert nb_model.fisher_combine(1e-3, 0.5) == pytest.approx(0.004300451229771043, rel=1e-13)
+    e = np.load(os.path.join(GOLDEN, "element_stats_golden.npz"))
+    a, t = nb_model.normal_params_to_gamma(e["mu"], e["sigma"])
+    assert np.array_equal(a, e["out_ALPHA"], equal_nan=True)         # bit-exact: same IEEE operations
+    with np.errstate(all="ignore"):
+        assert np.array_equal(t * float(e["cj"]), e["out_THETA"], equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------
+# element statistics block
+# ---------------------------------------------------------------------------------------
+def _element_obs(d):
+    pres = d["present"]
+    return [np.where(pres, d["tab_" + k], 0).astype(np.int32) for k in ("obs_snv", "obs_samples", "obs_indel")]
+
+
+def test_element_stats_golden(torch_dev):
+    import torch
+    from digdriver_amd import engine
+    d = np.load(os.path.join(GOLDEN, "element_stats_golden.npz"))
+    obs = _element_obs(d)
+    r = engine.element_stats(d["mu"], d["sigma"], d["pi_sum"], d["pi_indel"], *obs, float(d["cj"]), float(d["cj_indel"]))
+    for name in engine.ES_PLANES:
+        rel_close(r[name][:, 0], d["out_" + name], RTOL)
+    # EXP_SNV / THETA_INDEL / EXP_INDEL are plain products: bit-exact
+    for name in ("EXP_SNV", "THETA_INDEL", "EXP_INDEL"):
+        assert np.array_equal(r[name][:, 0], d["out_" + name], equal_nan=True), name
+    # device path, 3 cohorts with different scale factors == three host calls
+    E = len(d["mu"])
+    cjs, cjis = np.array([float(d["cj"]), 0.4, 2.2]), np.array([float(d["cj_indel"]), 0.2, 0.01])
+    rep = lambda v: torch.as_tensor(np.repeat(np.asarray(v)[:, None], 3, axis=1), device=torch_dev)
+    rd = engine.element_stats(rep(d["mu"]), rep(d["sigma"]), rep(d["pi_sum"]), torch.as_tensor(d["pi_indel"], device=torch_dev),
+                              rep(obs[0]), rep(obs[1]), rep(obs[2]), torch.as_tensor(cjs, device=torch_dev),
+                              torch.as_tensor(cjis, device=torch_dev))
+    for c in range(3):
+        rh = engine.element_stats(d["mu"], d["sigma"], d["pi_sum"], d["pi_indel"], *obs, cjs[c], cjis[c])
+        for name in engine.ES_PLANES:
+            assert np.array_equal(rd[name][:, c].cpu().numpy(), rh[name][:, 0], equal_nan=True), (name, c)
+
+
+def test_element_stats_vs_oracle_random_cohorts(torch_dev):
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(5)
+    E, C = 4000, 37
+    mu = np.exp(rng.uniform(np.log(0.05), np.log(500.0), (E, C)))
+    sigma = mu * np.exp(rng.uniform(np.log(0.05), np.log(1.5), (E, C)))
+    pi = np.exp(rng.uniform(np.log(1e-5), np.log(1.0), (E, C)))
+    pii = np.exp(rng.uniform(np.log(1e-5), np.log(1.0), E))
+    cj, cji = rng.uniform(0.2, 3, C), rng.uniform(0.01, 0.5, C)
+    lam = mu * cj * pi
+    k1 = rng.poisson(lam * np.exp(rng.normal(0, 1, (E, C)))).astype(np.int32)
+    k2 = rng.binomial(k1, 0.9).astype(np.int32)
+    k3 = rng.poisson(mu * cji * pii[:, None]).astype(np.int32)
+    mui, sgi = mu * rng.uniform(0.5, 2, (E, C)), sigma * rng.uniform(0.5, 2, (E, C))
+    got = engine.element_stats(mu, sigma, pi, pii, k1, k2, k3, cj, cji, mu_indel=mui, sigma_indel=sgi)
+    want = O.element_stats(mu, sigma, pi, pii[:, None], k1, k2, k3, cj[None, :], cji[None, :], mu_indel=mui, sigma_indel=sgi)
+    for name in engine.ES_PLANES:
+        rel_close(got[name], want[name], RTOL)
+    # empty problem is a no-op
+    r = engine.element_stats(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros((0, 3), np.int32),
+                             np.zeros((0, 3), np.int32), np.zeros((0, 3), np.int32), np.ones(3), np.ones(3))
+    assert r["EXP_SNV"].shape == (0, 3)
+
+
+# ---------------------------------------------------------------------------------------
+# per-element accumulation vs the reference's own loops (goldens)
+# ---------------------------------------------------------------------------------------
+def _sorted_dpr(freq):
+    from oracle import dig_oracle as O
+    return freq[O.model_rows_to_sorted_perm()][None, :]
+
+
+def _csr(ovp):
+    ptr = np.concatenate([[0], np.cumsum((ovp >= 0).sum(axis=1))]).astype(np.int64)
+    return ptr, ovp[ovp >= 0].astype(np.int32)
+
+
+def test_accumulate_nonc_model_golden(torch_dev):
+    from digdriver_amd import engine
+    d = np.load(os.path.join(GOLDEN, "accumulate_golden.npz"))
+    ptr, idx = _csr(d["elt_overlap_bins"])
+    r = engine.accumulate_elements(d["bin_y_pred"], d["bin_std"], d["bin_y_true"], d["bin_flag"], d["bin_ctx"], ptr, idx,
+                                   d["elt_L"].astype(np.int32), (d["elt_strand"] == "-"), _sorted_dpr(d["seq_freq"]))
+    col = {c: i for i, c in enumerate(d["out_cols"])}
+    v = d["out_vals"]
+    rel_close(r["MU"][:, 0], v[:, col["MU"]], 1e-12)
+    rel_close(r["SIGMA"][:, 0], v[:, col["SIGMA"]], 1e-12)
+    rel_close(r["P"][:, 0, 0], v[:, col["P_SUM"]], 1e-11)
+    rel_close(r["P_INDEL"], v[:, col["P_INDEL"]], 1e-15)
+    for name in ("R_OBS", "FLAG"):
+        assert np.array_equal(r[name][:, 0], v[:, col[name]].astype(np.int32)), name
+    for name in ("R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(r[name], v[:, col[name]].astype(np.int32)), name
+
+
+def test_accumulate_tiled_and_genic_golden(torch_dev):
+    from digdriver_amd import engine
+    d = np.load(os.path.join(GOLDEN, "accumulate_golden.npz"))
+    window = int(d["window"])
+    bin_index = {(int(c), int(s)): i for i, (c, s, _) in enumerate(d["bin_idx"])}
+    rows = [bin_index[(int(n.split(":")[0][3:]), int(n.split(":")[1].split("-")[0]) // window * window)]
+            for n in d["tile_names"]]
+    T = len(rows)
+    r = engine.accumulate_elements(d["bin_y_pred"], d["bin_std"], d["bin_y_true"], d["bin_flag"], d["bin_ctx"],
+                                   np.arange(T + 1), np.array(rows), d["tile_L"].astype(np.int32), np.zeros(T, bool),
+                                   _sorted_dpr(d["seq_freq"]))
+    col = {c: i for i, c in enumerate(d["out_cols"])}
+    v = d["tile_out_vals"]
+    rel_close(r["MU"][:, 0], v[:, col["MU"]], 1e-12)
+    rel_close(r["P"][:, 0, 0], v[:, col["P_SUM"]], 1e-11)
+    assert np.array_equal(r["ELT_SIZE"], v[:, col["ELT_SIZE"]].astype(np.int32))
+    assert np.array_equal(r["FLAG"][:, 0], v[:, col["FLAG"]].astype(np.int32))
+
+    g = np.load(os.path.join(GOLDEN, "genic_golden.npz"))
+    ptr, idx = _csr(g["gene_overlap_bins"])
+    glen = ((g["cds_ends"] - g["cds_starts"] + 1) * (g["cds_starts"] >= 0)).sum(axis=1)
+    G = len(glen)
+    r = engine.accumulate_elements(d["bin_y_pred"], d["bin_std"], d["bin_y_true"], d["bin_flag"], d["bin_ctx"], ptr, idx,
+                                   g["L_data"].astype(np.int32), np.zeros(G, bool), _sorted_dpr(d["seq_freq"]),
+                                   gene_length=glen)
+    col = {c: i for i, c in enumerate(g["out_cols"])}
+    v = g["out_vals"]
+    rel_close(r["MU"][:, 0], v[:, col["MU"]], 1e-12)
+    rel_close(r["SIGMA"][:, 0], v[:, col["SIGMA"]], 1e-12)
+    for q, name in enumerate(["P_SILENT", "P_MIS", "P_NONS", "P_SPLICE"]):
+        rel_close(r["P"][:, q, 0], v[:, col[name]], 1e-11)
+    rel_close(r["P_INDEL"], v[:, col["P_INDEL"]], 1e-15)
+    assert np.array_equal(r["R_SIZE"], v[:, col["R_SIZE"]].astype(np.int32))
+    assert np.array_equal(r["R_OBS"][:, 0], v[:, col["R_OBS"]].astype(np.int32))
+    assert np.array_equal(r["FLAG"][:, 0], v[:, col["FLAG"]].astype(np.int32))
+
+
+@pytest.mark.parametrize("C", [1, 37, 64, 70])
+def test_accumulate_vs_oracle_multi_cohort(torch_dev, C):
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    w = make_workload(n_bins=900, n_elements=700, n_cohorts=C, seed=11 + C)
+    # a few ragged cases: an element with no overlapped bin and one with many
+    w["ov_ptr"] = w["ov_ptr"].copy()
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    got = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                     td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"])
+    want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"],
+                                 w["ov_idx"], w["L"], w["strand_minus"].astype(bool), w["d_pr"])
+    rel_close(got["MU"].cpu().numpy(), want["MU"], 1e-12)
+    rel_close(got["SIGMA"].cpu().numpy(), want["SIGMA"], 1e-12)
+    rel_close(got["P"].cpu().numpy(), want["P"], 1e-11)
+    rel_close(got["P_INDEL"].cpu().numpy(), want["P_INDEL"], 1e-15)
+    for name in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(got[name].cpu().numpy(), want[name]), name
+    # host twin == device path bit for bit
+    host = engine.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"],
+                                      w["ov_idx"], w["L"], w["strand_minus"], w["d_pr"])
+    for name in got:
+        assert np.array_equal(host[name], got[name].cpu().numpy(), equal_nan=True), name
+
+
+# ---------------------------------------------------------------------------------------
+# gather and tiles
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src", ["f32", "f64", "i16"])
+def test_gather_bins(torch_dev, src):
+    import torch
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(4)
+    N, L, T = 50, 100, 77
+    x = np.round(rng.uniform(0, 1, (N, L, T)), 2) * 100
+    x = x.astype({"f32": np.float32, "f64": np.float64, "i16": np.int16}[src])
+    rows = rng.integers(0, N, 23)
+    tracks = np.concatenate([np.arange(3, 40), [1, 70, 76, 5]])
+    want = O.gather_bins(x, rows, tracks)
+    got = engine.gather_bins(x, rows, tracks)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    got_t = engine.gather_bins(x, rows, tracks, transpose=True)
+    assert np.array_equal(got_t, want.transpose(0, 2, 1))
+    xd = torch.as_tensor(x, device=torch_dev)
+    assert np.array_equal(engine.gather_bins(xd, rows, None).cpu().numpy(), x[rows].astype(np.float32))
+    b = engine.gather_bins(xd, rows, tracks, out_dtype="bf16", transpose=True)
+    assert b.dtype == torch.bfloat16
+    np.testing.assert_allclose(b.float().cpu().numpy(), want.transpose(0, 2, 1), rtol=2 ** -8)
+    assert engine.gather_bins(x, np.zeros(0, np.int64), tracks).shape == (0, L, len(tracks))
+
+
+def test_tiled_nb_test_vs_oracle(torch_dev):
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(8)
+    C, nb, nt = 3, 40, 200
+    mu = rng.gamma(9.0, 3.0, (C, nb))
+    sigma = rng.gamma(4.0, 1.0, (C, nb))
+    pt = rng.dirichlet(np.ones(nt), size=nb)
+    pt[0, :5] = 0.0                                    # N-masked positions: pt = 0 -> p = 1
+    k = rng.poisson(mu[:, :, None] * pt[None] * 1.5).astype(np.int32)
+    k[1, 3, 7] = 40                                    # a hotspot
+    pval, ex = engine.tiled_nb_test(pt, k, mu, sigma)
+    for c in range(C):
+        wp, we = O.tiled_nb_test(pt, k[c], mu[c], sigma[c])
+        rel_close(pval[c], wp, RTOL)
+        assert np.array_equal(ex[c], we)
+    pt3 = np.stack([pt, pt * 0.5, pt * 0.25])
+    pval3, _ = engine.tiled_nb_test(pt3, k, mu, sigma)
+    assert np.array_equal(pval3[0], pval[0])
+
+
+# ---------------------------------------------------------------------------------------
+# size-independent properties at BASELINE scale (full 288k-bin x 37-cohort problem)
+# ---------------------------------------------------------------------------------------
+def test_properties_at_baseline_size(torch_dev):
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from digdriver_amd.sequence_model import nb_model
+    w = make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3)
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                     td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"])
+    E, C = acc["MU"].shape
+    # (1) checksum of checksums: sum over elements of MU == sum over CSR entries of bin_mu (linearity)
+    want = td["bin_mu"][td["ov_idx"].long()].sum(dim=0)
+    assert torch.allclose(acc["MU"].sum(dim=0), want, rtol=1e-10)
+    assert torch.equal(acc["R_OBS"].sum(dim=0, dtype=torch.int64), td["bin_y"][td["ov_idx"].long()].sum(dim=0, dtype=torch.int64))
+    # (2) strand symmetry: flipping every strand while reverse-complementing both L and d_pr leaves P unchanged
+    from oracle import dig_oracle as O
+    g = torch.as_tensor(O.minus_strand_gather192(), device=torch_dev)
+    flipped = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                         td["ov_ptr"], td["ov_idx"], td["L"][:, :, g].contiguous(), 1 - td["strand_minus"],
+                                         td["d_pr"][:, g].contiguous())
+    assert torch.equal(flipped["MU"], acc["MU"]) and torch.equal(flipped["R_SIZE"], acc["R_SIZE"])
+    assert torch.allclose(flipped["P"], acc["P"], rtol=1e-10, atol=0)
+    # (3) element statistics: p-values in [0, 1], mid-p identity and monotonicity in k
+    st = engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], td["obs_snv"], td["obs_samples"],
+                              td["obs_indel"], td["cj"], td["cj_indel"])
+    for name in ("PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN"):
+        v = st[name]
+        assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0 and float(v.max()) <= 1.0, name
+    # samples <= mutations => sample p-value >= SNV p-value
+    assert bool((st["PVAL_SAMPLE_BURDEN"] >= st["PVAL_SNV_BURDEN"] * (1 - 1e-12)).all())
+    # Fisher of the two planes recomputed from the outputs
+    f = nb_model.fisher_combine(st["PVAL_SNV_BURDEN"], st["PVAL_INDEL_BURDEN"])
+    assert torch.allclose(f, st["PVAL_MUT_BURDEN"], rtol=1e-12, atol=0)
+    # mid-p telescoping identity: midp(k) - midp(k+1) = (pmf(k) + pmf(k+1)) / 2 > 0, and
+    # midp(k) + lower-mid-p(k) = 1, on one million (alpha, p, k) triples taken from the run
+    alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
+    p = 1 / (theta * td["cj"] * acc["P"].view(E, C) + 1)
+    sel = torch.randperm(E * C, device=torch_dev)[:1_000_000]
+    a_s, p_s = alpha.view(-1)[sel].contiguous(), p.view(-1)[sel].contiguous()
+    k_s = td["obs_snv"].view(-1)[sel].double()
+    m0 = nb_model.nb_pvalue_greater_midp(k_s, a_s, p_s)
+    m1 = nb_model.nb_pvalue_greater_midp(k_s + 1, a_s, p_s)
+    assert bool((m0 >= m1).all()) and bool((m0 > m1).float().mean() > 0.9)
+    two = nb_model.nb_pvalue_midp(k_s, a_s, p_s)          # lower or upper mid-p by side of the mean
+    mean = a_s * (1 - p_s) / p_s
+    lower = k_s < mean
+    assert torch.allclose(torch.where(lower & (k_s > 0), two + m0, torch.ones_like(m0)), torch.ones_like(m0), rtol=1e-9)
+    assert torch.allclose(two[~lower], m0[~lower], rtol=1e-12)
