@@ -39,10 +39,12 @@ _SIGNATURES = {
     "dig_fisher_host": [_vp, _vp, _vp, _i64, _int],
     "dig_normal_params_to_gamma": [_vp, _vp, _vp, _vp, _i64, _vp],
     "dig_normal_params_to_gamma_host": [_vp, _vp, _vp, _vp, _i64, _int],
-    "dig_element_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "dig_element_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     "dig_element_stats_host": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int],
-    "dig_accumulate_elements": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _vp],
+    "dig_accumulate_elements": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _vp, _i64, _vp],
     "dig_accumulate_elements_host": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _int],
+    "dig_scale_suffstats": [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp],
+    "dig_scale_suffstats_host": [_vp, _vp, _i64, _i64, _vp, _int],
     "dig_ideal_overlaps_host": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp],
     "dig_gather_bins": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp],
     "dig_gather_bins_host": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _int],
@@ -50,7 +52,15 @@ _SIGNATURES = {
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("dig_abi_version", "dig_last_error", "dig_device_count")
+# entry points that return a byte count (int64) instead of a status
+_SIZE_QUERIES = {
+    "dig_element_stats_workspace": [_i64, _i64],
+    "dig_accumulate_workspace": [_i64, _i64],
+    "dig_scale_suffstats_workspace": [_i64, _i64],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
+                                                                "dig_device_count")
 
 
 def load():
@@ -70,6 +80,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    for name, argtypes in _SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int64
     lib.dig_abi_version.restype = ctypes.c_int
     lib.dig_last_error.restype = ctypes.c_char_p
     lib.dig_device_count.restype = ctypes.c_int
@@ -87,6 +101,14 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise DigHipError("%s failed (%d): %s" % (name, rc, last_error()))
+
+
+def workspace_bytes(kind, E, C):
+    """Scratch bytes needed by dig_element_stats ("element_stats") / dig_accumulate_elements ("accumulate")."""
+    lib = load()
+    fn = {"element_stats": lib.dig_element_stats_workspace, "accumulate": lib.dig_accumulate_workspace,
+          "suffstats": lib.dig_scale_suffstats_workspace}[kind]
+    return int(fn(int(E), int(C)))
 
 
 def device_count():

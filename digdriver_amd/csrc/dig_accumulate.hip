@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
 }
 
 template <int NCLASS>
-static int launch_acc(const AccArgs& a, hipStream_t stream)
+static int launch_acc_v1(const AccArgs& a, hipStream_t stream)
 {
     const size_t fixed = (size_t)(192 + 64) * a.Cc * sizeof(double);
     const size_t per_wave = (size_t)(NCLASS * 192 + 64) * sizeof(double);
@@ -203,17 +203,250 @@ static int launch_acc(const AccArgs& a, hipStream_t stream)
     return go(accumulate_kernel<NCLASS, 4>);
 }
 
+// =======================================================================================
+// v2: two kernels, no LDS in the FMA loop.
+//
+//   acc_region_kernel   one wave per element.  lanes = 64 contexts sum the bins' context rows
+//                       (256-B coalesced loads) and write the strand-permuted counts to a
+//                       workspace row; lanes = cohorts sum Y_PRED / STD^2 / Y_TRUE / FLAG over the
+//                       element's bins ([N, C] tables: C*8 contiguous bytes per bin).  No LDS, no
+//                       barriers: waves run independently, so the dependent ov_ptr -> ov_idx ->
+//                       bin-row loads of different elements overlap.
+//   acc_dot_kernel      one LANE per element, 64 consecutive elements per wave.  The per-cohort
+//                       trinucleotide parameters are wave-uniform, so they are read with SCALAR
+//                       loads (transposed, padded table in the workspace; served by the scalar
+//                       cache / L2) and enter v_fma_f64 as SGPR operands: the 64 + 192-term dot
+//                       products need neither LDS traffic nor cross-lane reductions, all 64 lanes
+//                       are busy whatever C is, and each int32 count is converted to FP64 once per
+//                       CT cohorts.  Cohorts are processed CT at a time (CT accumulators in VGPRs).
+// =======================================================================================
+constexpr int kRegionBlock = 256;
+
+__global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
+    const double* __restrict__ bin_mu, const double* __restrict__ bin_std, const int32_t* __restrict__ bin_y,
+    const uint8_t* __restrict__ bin_flag, const int32_t* __restrict__ bin_ctx, const int64_t* __restrict__ ov_ptr,
+    const int32_t* __restrict__ ov_idx, const uint8_t* __restrict__ strand_minus, double* __restrict__ MU,
+    double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS, int32_t* __restrict__ FLAG, int32_t* __restrict__ R_SIZE,
+    int32_t* __restrict__ rcp, int64_t E, int64_t C)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * kRegionBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kRegionBlock) >> 6;
+    for (int64_t e = wave0; e < E; e += nwaves) {
+        const int64_t q0 = ov_ptr[e], q1 = ov_ptr[e + 1];
+        int rc = 0;
+        for (int64_t q = q0; q < q1; ++q) rc += bin_ctx[(int64_t)ov_idx[q] * 64 + lane];
+        const int rsize = wave_sum_i32(rc);
+        const int dst = strand_minus[e] ? revcomp_ctx(lane) : lane;   // sequence_tools.py:633-634
+        rcp[e * 64 + dst] = rc;
+        if (lane == 0) R_SIZE[e] = rsize;                             // genic_driver_tools.py:375
+        for (int64_t c = lane; c < C; c += 64) {
+            double mu = 0.0, var = 0.0;
+            int robs = 0, flag = 0;
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t o = (int64_t)ov_idx[q] * C + c;
+                const double sd = bin_std[o];
+                mu += bin_mu[o];                 // :265
+                var = fma(sd, sd, var);          // :266
+                robs += bin_y[o];                // :267
+                flag |= (bin_flag[o] != 0);      // :268 (numpy bool '+' is a logical OR)
+            }
+            const int64_t o = e * C + c;
+            MU[o] = mu;
+            SIGMA[o] = sqrt(var);                // :271
+            R_OBS[o] = robs;
+            FLAG[o] = flag;
+        }
+    }
+}
+
+// transposed, zero-padded parameter tables: dT[j][CPAD] (j < 192) and d64T[ctx][CPAD] (ctx < 64)
+__global__ void acc_prep_kernel(const double* __restrict__ d_pr, double* __restrict__ dT, double* __restrict__ d64T,
+                                int C, int CPAD)
+{
+    const int n = 192 * CPAD;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int j = idx / CPAD, c = idx - j * CPAD;
+        dT[idx] = (c < C) ? d_pr[(int64_t)c * 192 + j] : 0.0;
+    }
+    const int n64 = 64 * CPAD;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n64; idx += gridDim.x * blockDim.x) {
+        const int ctx = idx / CPAD, c = idx - ctx * CPAD;
+        const double* d = d_pr + (int64_t)c * 192 + 3 * ctx;
+        d64T[idx] = (c < C) ? (d[0] + d[1]) + d[2] : 0.0;
+    }
+}
+
+// acc_dot_kernel: blockDim = (64 lanes = 64 consecutive elements, nchunk waves = cohort chunks).
+// The waves of a workgroup read the same rcp / L rows (L1/L2 hits) and each keeps CT accumulators.
+template <int NCLASS, int CT>
+__global__ void acc_dot_kernel(const int32_t* __restrict__ rcp, const int32_t* __restrict__ L,
+                               const double* __restrict__ dT, const double* __restrict__ d64T,
+                               const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length,
+                               double* __restrict__ P, int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL,
+                               int64_t E, int C, int CPAD, int chunk0)
+{
+    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int chunk = chunk0 + __builtin_amdgcn_readfirstlane(threadIdx.y);   // wave-uniform
+    const bool live = e < E;
+    const int64_t ec = live ? e : E - 1;
+    const int cbase = chunk * CT;
+    const int4* rcrow = reinterpret_cast<const int4*>(rcp + ec * 64);
+    int lsum = 0;
+
+    double den[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) den[c] = 0.0;
+    {
+        int4 cur = rcrow[0];
+        for (int m = 0; m < 16; ++m) {            // sum(region_counts * d_pr), genic_driver_tools.py:361
+            const int4 nxt = rcrow[m < 15 ? m + 1 : 15];   // prefetch the next 16 B of the lane's row
+            const int rv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = (double)rv[u];
+                const double* row = d64T + (int64_t)(4 * m + u) * CPAD + cbase;   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int c = 0; c < CT; ++c) den[c] = fma(v, row[c], den[c]);
+            }
+            cur = nxt;
+        }
+    }
+#pragma unroll 1
+    for (int q = 0; q < NCLASS; ++q) {
+        double num[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) num[c] = 0.0;
+        const int4* Lrow = reinterpret_cast<const int4*>(L + (ec * NCLASS + q) * 192);
+        int4 cur = Lrow[0];
+        for (int m = 0; m < 48; ++m) {            // sum(t_pi * L), :364-366
+            const int4 nxt = Lrow[m < 47 ? m + 1 : 47];
+            const int rv[4] = {cur.x, cur.y, cur.z, cur.w};
+            lsum += (cur.x + cur.y) + (cur.z + cur.w);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = (double)rv[u];
+                const double* row = dT + (int64_t)(4 * m + u) * CPAD + cbase;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) num[c] = fma(v, row[c], num[c]);
+            }
+            cur = nxt;
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                if (cbase + c < C) P[(e * NCLASS + q) * C + cbase + c] = num[c] / den[c];
+        }
+    }
+    if (live && chunk == 0) {
+        const int esize = lsum / 3;                                        // :380
+        ELT_SIZE[e] = esize;
+        const double numer = gene_length ? (double)gene_length[e] : (double)esize;
+        P_INDEL[e] = numer / (double)R_SIZE[e];                            // :381 / :159
+    }
+}
+
+// Cohorts per wave (CT) and number of chunk-waves per workgroup.  Smaller CT = more waves in flight
+// (the grid is only E/64 workgroups) at the price of one int->f64 convert per CT FMAs.
+static int acc_pick_ct(int64_t E, int64_t C, int* nchunk)
+{
+    static const int cts[] = {4, 8, 10, 13, 16, 20};
+    int forced = 0;
+    if (const char* env = getenv("DIG_ACC_CT")) forced = atoi(env);
+    const int64_t groups = (E + 63) / 64;
+    const int64_t want_waves = (int64_t)cu_count() * 4 * 4;          // >= 4 waves per SIMD
+    int best = 20;
+    for (int i = 5; i >= 0; --i) {                                    // largest CT that still fills the chip
+        const int ct = cts[i];
+        const int64_t nch = (C + ct - 1) / ct;
+        best = ct;
+        if (groups * nch >= want_waves) break;
+    }
+    if (best > C) {                                                   // do not pad far beyond C
+        for (int i = 0; i < 6; ++i)
+            if (cts[i] >= C) { best = cts[i]; break; }
+    }
+    if (forced)
+        for (int ct : cts)
+            if (ct == forced) best = ct;
+    *nchunk = (int)((C + best - 1) / best);
+    if (*nchunk > 16) {                                               // blockDim.y <= 16 waves
+        best = 20;
+        *nchunk = (int)((C + 19) / 20);
+    }
+    return best;
+}
+
+struct AccWorkspace {
+    int32_t* rcp;
+    double *dT, *d64T;
+    int CT, nchunk, CPAD;
+    int64_t bytes;
+};
+
+static AccWorkspace acc_workspace_layout(void* base, int64_t E, int64_t C)
+{
+    AccWorkspace w{};
+    w.CT = acc_pick_ct(E, C, &w.nchunk);
+    w.CPAD = ((w.CT * w.nchunk + 7) / 8) * 8;
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    const int64_t o_rc = 0;
+    const int64_t o_dT = up(o_rc + E * 64 * (int64_t)sizeof(int32_t));
+    const int64_t o_d64 = up(o_dT + 192 * (int64_t)w.CPAD * (int64_t)sizeof(double));
+    w.bytes = up(o_d64 + 64 * (int64_t)w.CPAD * (int64_t)sizeof(double));
+    char* b = (char*)base;
+    w.rcp = (int32_t*)(b + o_rc);
+    w.dT = (double*)(b + o_dT);
+    w.d64T = (double*)(b + o_d64);
+    return w;
+}
+
+template <int NCLASS>
+static int launch_dot(const AccWorkspace& w, const int32_t* L, const int32_t* R_SIZE, const int32_t* gene_length,
+                      double* P, int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, hipStream_t stream)
+{
+    // more than 16 chunk-waves do not fit one workgroup: split the cohort range over several launches
+    for (int ch0 = 0; ch0 < w.nchunk; ch0 += 16) {
+        const int nch = std::min(16, w.nchunk - ch0);
+        const dim3 grid((unsigned)((E + 63) / 64)), block(64, nch);
+#define DIG_DOT(CTV)                                                                                               \
+    case CTV:                                                                                                      \
+        hipLaunchKernelGGL((acc_dot_kernel<NCLASS, CTV>), grid, block, 0, stream, w.rcp, L, w.dT, w.d64T, R_SIZE,  \
+                           gene_length, P, ELT_SIZE, P_INDEL, E, (int)C, w.CPAD, ch0);                             \
+        break;
+        switch (w.CT) {
+            DIG_DOT(4)
+            DIG_DOT(8)
+            DIG_DOT(10)
+            DIG_DOT(13)
+            DIG_DOT(16)
+            DIG_DOT(20)
+            default: return set_error(DIG_EINVAL, "accumulate: no kernel for CT=%d", w.CT);
+        }
+#undef DIG_DOT
+        DIG_HIP_TRY(hipGetLastError());
+    }
+    return DIG_OK;
+}
+
 }  // namespace dig
 
 using namespace dig;
 
 extern "C" {
 
+int64_t dig_accumulate_workspace(int64_t E, int64_t C)
+{
+    if (E <= 0 || C <= 0) return 0;
+    return acc_workspace_layout(nullptr, E, C).bytes;
+}
+
 int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                             const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
                             int n_class, const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
                             double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE,
-                            int32_t* ELT_SIZE, double* P_INDEL, int64_t N, int64_t E, int64_t C, void* stream)
+                            int32_t* ELT_SIZE, double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace,
+                            int64_t workspace_bytes, void* stream)
 {
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
@@ -221,14 +454,33 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
     DIG_REQUIRE(bin_mu && bin_std && bin_y && bin_flag && bin_ctx && ov_ptr && ov_idx && L && strand_minus && d_pr,
                 "non-null inputs");
     DIG_REQUIRE(MU && SIGMA && R_OBS && FLAG && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
-    for (int64_t c0 = 0; c0 < C; c0 += 64) {
-        AccArgs a{bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
-                  MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, (int)c0,
-                  (int)std::min<int64_t>(64, C - c0)};
-        int rc = (n_class == 1) ? launch_acc<1>(a, (hipStream_t)stream) : launch_acc<4>(a, (hipStream_t)stream);
-        if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!workspace) {
+        // no scratch: single-kernel LDS variant (slower; kept for callers that cannot provide a workspace)
+        for (int64_t c0 = 0; c0 < C; c0 += 64) {
+            AccArgs a{bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
+                      MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, (int)c0,
+                      (int)std::min<int64_t>(64, C - c0)};
+            int rc = (n_class == 1) ? launch_acc_v1<1>(a, s) : launch_acc_v1<4>(a, s);
+            if (rc) return rc;
+        }
+        return DIG_OK;
     }
-    return DIG_OK;
+    DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
+    const AccWorkspace w = acc_workspace_layout(workspace, E, C);
+    DIG_REQUIRE(workspace_bytes >= w.bytes, "workspace smaller than dig_accumulate_workspace(E, C)");
+    hipLaunchKernelGGL(acc_prep_kernel, dim3(16), dim3(256), 0, s, d_pr, w.dT, w.d64T, (int)C, w.CPAD);
+    DIG_HIP_TRY(hipGetLastError());
+    {
+        const int64_t want = (E + (kRegionBlock / 64) - 1) / (kRegionBlock / 64);
+        const int64_t cap = (int64_t)cu_count() * 8;
+        const int grid = (int)std::max<int64_t>(1, std::min(want, cap));
+        hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
+                           bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C);
+        DIG_HIP_TRY(hipGetLastError());
+    }
+    return (n_class == 1) ? launch_dot<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
+                          : launch_dot<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
 }
 
 int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,
@@ -274,12 +526,15 @@ int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, co
     DIG_HIP_TRY(o_rs.alloc((size_t)E * 4));
     DIG_HIP_TRY(o_es.alloc((size_t)E * 4));
     DIG_HIP_TRY(o_pi.alloc((size_t)E * 8));
+    DevBuf d_ws;
+    const int64_t wsb = dig_accumulate_workspace(E, C);
+    DIG_HIP_TRY(d_ws.alloc((size_t)wsb));
     int rc = dig_accumulate_elements(d_mu.as<double>(), d_sd.as<double>(), d_y.as<int32_t>(), d_fl.as<uint8_t>(),
                                      d_ctx.as<int32_t>(), d_ptr.as<int64_t>(), d_idx.as<int32_t>(), d_L.as<int32_t>(),
                                      n_class, d_st.as<uint8_t>(), gene_length ? d_gl.as<int32_t>() : nullptr,
                                      d_dpr.as<double>(), o_mu.as<double>(), o_sg.as<double>(), o_ro.as<int32_t>(),
                                      o_fl.as<int32_t>(), o_p.as<double>(), o_rs.as<int32_t>(), o_es.as<int32_t>(),
-                                     o_pi.as<double>(), N, E, C, nullptr);
+                                     o_pi.as<double>(), N, E, C, d_ws.p, wsb, nullptr);
     if (rc) return rc;
     DIG_HIP_TRY(hipDeviceSynchronize());
     DIG_HIP_TRY(hipMemcpy(MU, o_mu.p, nEC * 8, hipMemcpyDeviceToHost));

@@ -31,7 +31,7 @@ constexpr double kCfEps = 1e-15;
 constexpr int kCfMaxIt = 20000;
 constexpr double kFpMin = 1e-300;
 constexpr int kSmallK = 64;          // direct-summation limit
-constexpr double kDirectMin = 1e-3;  // accept 1 - S - t/2 when >= this (abs err ~1e-14)
+constexpr double kDirectMin = 1e-6;  // accept 1 - S - t/2 when >= this: abs err <= ~65 ulp(1) = 7e-15 -> rel 7e-9
 
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
@@ -172,6 +172,70 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
     return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);
 }
 
+// ---- fast mid-p evaluation for small integer counts sharing (alpha, p) ----------------
+// 1/(j+1) for the recurrence t_{j+1} = t_j (alpha + j) x / (j + 1): a constant table (scalar
+// loads, the index is wave-uniform) instead of an FP64 division per step.
+#define DIG_INV4(a) 1.0 / (a), 1.0 / ((a) + 1), 1.0 / ((a) + 2), 1.0 / ((a) + 3)
+#define DIG_INV16(a) DIG_INV4(a), DIG_INV4((a) + 4), DIG_INV4((a) + 8), DIG_INV4((a) + 12)
+__device__ constexpr double kInvTab[kSmallK + 16] = {DIG_INV16(1.0), DIG_INV16(17.0), DIG_INV16(33.0), DIG_INV16(49.0),
+                                                     DIG_INV16(65.0)};   // kInvTab[j] = 1 / (j + 1)
+
+// Resolve 0.5 pmf(k) + P(X > k) for up to two counts (k1, k2) that share (alpha, p) with ONE
+// pass of the pmf recurrence.  Returns a bit mask of the counts that were resolved
+// (bit 0: k1, bit 1: k2); unresolved ones (k > kSmallK, non-integer, p^alpha underflow, or a
+// result < kDirectMin where 1 - S cancels) must go through nb_midp_upper().
+// `want` selects which of the two counts are requested.
+__device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, unsigned want, double alpha, double p,
+                                                        double& r1, double& r2)
+{
+    if (isnan(alpha) || isnan(p) || !(alpha > 0.0) || !(p > 0.0) || !(p <= 1.0) || isinf(alpha)) {
+        // pmf is NaN whatever k is (scipy argcheck) -> NaN, resolved
+        r1 = r2 = dnan();
+        return want;
+    }
+    unsigned done = 0;
+    if (isnan(k1)) { r1 = dnan(); done |= 1u; }
+    if (isnan(k2)) { r2 = dnan(); done |= 2u; }
+    if (p == 1.0) {
+        if ((want & 1u) && k1 >= 0.0 && floor(k1) == k1) { r1 = (k1 == 0.0) ? 0.5 : 0.0; done |= 1u; }
+        if ((want & 2u) && k2 >= 0.0 && floor(k2) == k2) { r2 = (k2 == 0.0) ? 0.5 : 0.0; done |= 2u; }
+        return done & want;
+    }
+    const bool e1 = (want & 1u) && !(done & 1u) && k1 >= 0.0 && k1 <= (double)kSmallK && floor(k1) == k1;
+    const bool e2 = (want & 2u) && !(done & 2u) && k2 >= 0.0 && k2 <= (double)kSmallK && floor(k2) == k2;
+    if (!(e1 || e2)) return done & want;
+    const double lp0 = alpha * log(p);
+    if (!(lp0 > -690.0)) return done & want;
+    const double x = 1.0 - p;
+    const int k1i = e1 ? (int)k1 : -1, k2i = e2 ? (int)k2 : -1;
+    // the lane's loop ends at the larger count; only the smaller one needs recording on the way
+    const int kmax = k1i > k2i ? k1i : k2i;
+    const int kmin = k1i > k2i ? k2i : k1i;
+    double t = exp(lp0), S = 0.0;
+    double u = alpha * x;              // (alpha + j) x, advanced by x per step
+    double Sm = 0.0, tm = t;           // state at j == kmin (kmin == 0: S = 0, t = t_0)
+    double inv = kInvTab[0];
+    for (int j = 0; j < kmax; ++j) {
+        const double inv_next = kInvTab[j + 1];   // prefetch: the scalar load overlaps this step
+        S += t;
+        t *= u * inv;
+        u += x;
+        inv = inv_next;
+        if (j + 1 == kmin) { Sm = S; tm = t; }
+    }
+    const double r_max = 1.0 - S - 0.5 * t;
+    const double r_min = (kmin == kmax) ? r_max : 1.0 - Sm - 0.5 * tm;
+    const double ra = (k1i >= k2i) ? r_max : r_min;   // result for k1
+    const double rb = (k1i >= k2i) ? r_min : r_max;   // result for k2
+    if (e1 && ra >= kDirectMin) { r1 = ra; done |= 1u; }
+    if (e2 && rb >= kDirectMin) { r2 = rb; done |= 2u; }
+    return done & want;
+}
+
+// Fisher via q = p1 p2:  chi2.sf(-2 ln q, 4) = q (1 - ln q); falls back to the log form when q
+// is subnormal/zero or an argument is out of (0, 1].
+__device__ __forceinline__ double fisher_combine_fast(double p1, double p2);
+
 // nb_model.py:243-256
 __device__ inline double nb_greater(double k, double alpha, double p)
 {
@@ -235,6 +299,13 @@ __device__ __forceinline__ double fisher_combine(double p1, double p2)
     if (h < 0.0) return 1.0;
     if (isinf(h)) return 0.0;
     return exp(-h) * (1.0 + h);
+}
+
+__device__ __forceinline__ double fisher_combine_fast(double p1, double p2)
+{
+    const double q = p1 * p2;
+    if (q > 1e-290 && p1 <= 1.0 && p2 <= 1.0) return q * (1.0 - log(q));
+    return fisher_combine(p1, p2);
 }
 
 }  // namespace dig

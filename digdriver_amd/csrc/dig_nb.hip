@@ -61,6 +61,23 @@ __global__ __launch_bounds__(kBlock) void gamma_kernel(const double* __restrict_
     }
 }
 
+// i / C with a host-computed magic multiplier: e = hi64(i * ceil(2^64 / C)), exact while
+// i * C < 2^64 (the per-pair int64 division the flat [E, C] index would otherwise need costs
+// more than a whole recurrence step).
+struct FastDiv {
+    uint64_t magic;   // ceil(2^64 / d), d >= 2
+};
+static FastDiv make_fastdiv(int64_t d)
+{
+    FastDiv f;
+    f.magic = (d >= 2) ? (~(uint64_t)0 / (uint64_t)d) + 1 : 0;
+    return f;
+}
+__device__ __forceinline__ int64_t fastdiv(int64_t i, const FastDiv& f)
+{
+    return (int64_t)__umul64hi((uint64_t)i, f.magic);
+}
+
 struct ElementStatsArgs {
     const double *mu, *sigma, *mu_indel, *sigma_indel, *pi_sum, *pi_indel;
     const int32_t *obs_snv, *obs_samples, *obs_indel;
@@ -68,45 +85,109 @@ struct ElementStatsArgs {
     double* out;
     int64_t E, C;
     int pi_indel_per_cohort;
+    unsigned* worklist;   // [0] = count, entries from [kWorkHeader]; NULL -> slow lanes are resolved inline
+    FastDiv divC;
+    int use_fastdiv;
 };
 
-__global__ __launch_bounds__(kBlock) void element_stats_kernel(ElementStatsArgs a)
+constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
+
+struct PairInputs {
+    double alpha, theta, p, exp_snv, alpha_i, theta_i, p_i, exp_ind, k_snv, k_smp, k_ind;
+};
+
+// Input preparation for one (element, cohort) pair, bit-identical to the reference's numpy
+// expressions (no FMA contraction): transfer_tools.py:17-19,46-48,300,343-344,476-481,737-745.
+__device__ __forceinline__ PairInputs load_pair(const ElementStatsArgs& a, int64_t i)
+{
+    const int64_t e = a.use_fastdiv ? fastdiv(i, a.divC) : i;   // use_fastdiv == 0 only when C == 1
+    const int64_t c = i - e * a.C;
+    const double mu = a.mu[i], sigma = a.sigma[i];
+    const double pi_s = a.pi_sum[i];
+    const double pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
+    PairInputs r;
+    r.k_snv = (double)a.obs_snv[i];
+    r.k_smp = (double)a.obs_samples[i];
+    r.k_ind = (double)a.obs_indel[i];
+    const GammaParams g = normal_params_to_gamma(mu, sigma);
+    r.alpha = g.alpha;
+    r.theta = mul_rn(g.theta, a.cj[c]);
+    r.exp_snv = mul_rn(mul_rn(g.alpha, r.theta), pi_s);
+    r.p = nb_success_prob(r.theta, pi_s);
+    GammaParams gi = g;
+    if (a.mu_indel) gi = normal_params_to_gamma(a.mu_indel[i], a.sigma_indel[i]);
+    r.alpha_i = gi.alpha;
+    r.theta_i = mul_rn(gi.theta, a.cj_indel[c]);
+    r.exp_ind = mul_rn(mul_rn(gi.alpha, r.theta_i), pi_i);
+    r.p_i = nb_success_prob(r.theta_i, pi_i);
+    return r;
+}
+
+// Pass 1: every pair through the division-free pmf recurrence (SNV and SAMPLE counts share one
+// pass).  Pairs with an unresolved test (large k, or a p-value < 1e-3 where 1 - CDF cancels) are
+// appended to the worklist with one wave-aggregated atomic and finished by pass 2.
+__global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStatsArgs a)
 {
     const int64_t n = a.E * a.C;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const int64_t e = i / a.C;
-        const int64_t c = i - e * a.C;
-        const double mu = a.mu[i], sigma = a.sigma[i];
-        const double pi_s = a.pi_sum[i];
-        const double pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
-        const double k_snv = (double)a.obs_snv[i];
-        const double k_smp = (double)a.obs_samples[i];
-        const double k_ind = (double)a.obs_indel[i];
-        const double cj = a.cj[c], cji = a.cj_indel[c];
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool slow = false;
+        if (i < n) {
+            const PairInputs q = load_pair(a, i);
+            double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+            const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
+            const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
+            slow = (d1 != 3u) || (d2 != 1u);
+            if (slow && !a.worklist) {   // single-pass mode: finish inline
+                if (!(d1 & 1u)) pv_snv = nb_midp_upper(q.k_snv, q.alpha, q.p);
+                if (!(d1 & 2u)) pv_smp = nb_midp_upper(q.k_smp, q.alpha, q.p);
+                if (!(d2 & 1u)) pv_ind = nb_midp_upper(q.k_ind, q.alpha_i, q.p_i);
+                slow = false;
+            }
+            a.out[0 * n + i] = q.exp_snv;
+            a.out[3 * n + i] = q.theta_i;
+            a.out[4 * n + i] = q.exp_ind;
+            if (!slow) {
+                a.out[1 * n + i] = pv_snv;
+                a.out[2 * n + i] = pv_smp;
+                a.out[5 * n + i] = pv_ind;
+                a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
+            }
+        }
+        if (a.worklist) {
+            const unsigned long long m = __ballot(slow);
+            if (m) {
+                unsigned base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) base = atomicAdd(a.worklist, (unsigned)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (slow) a.worklist[kWorkHeader + base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+            }
+        }
+    }
+}
 
-        const GammaParams g = normal_params_to_gamma(mu, sigma);
-        const double theta = mul_rn(g.theta, cj);                       // transfer_tools.py:300
-        const double exp_snv = mul_rn(mul_rn(g.alpha, theta), pi_s);    // :343-344
-        const double p = nb_success_prob(theta, pi_s);
-        const double pv_snv = nb_midp_upper(k_snv, g.alpha, p);         // :473-482
-        const double pv_smp = (k_smp == k_snv) ? pv_snv : nb_midp_upper(k_smp, g.alpha, p);  // :594-615
-
-        GammaParams gi = g;
-        if (a.mu_indel) gi = normal_params_to_gamma(a.mu_indel[i], a.sigma_indel[i]);
-        const double theta_i = mul_rn(gi.theta, cji);                   // :737
-        const double exp_ind = mul_rn(mul_rn(gi.alpha, theta_i), pi_i); // :738
-        const double p_i = nb_success_prob(theta_i, pi_i);
-        const double pv_ind = nb_midp_upper(k_ind, gi.alpha, p_i);      // :741-745
-        const double pv_mut = fisher_combine(pv_snv, pv_ind);           // :1086-1087
-
-        a.out[0 * n + i] = exp_snv;
+// Pass 2: the compacted slow pairs, dense in the wave: lgamma-based pmf + continued fraction.
+__global__ __launch_bounds__(kBlock) void element_stats_slow_kernel(ElementStatsArgs a)
+{
+    const int64_t n = a.E * a.C;
+    const unsigned count = a.worklist[0];
+    const unsigned stride = gridDim.x * kBlock;
+    for (unsigned w = blockIdx.x * kBlock + threadIdx.x; w < count; w += stride) {
+        const int64_t i = a.worklist[kWorkHeader + w];
+        const PairInputs q = load_pair(a, i);
+        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
+        const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
+        if (!(d1 & 1u)) pv_snv = nb_midp_upper(q.k_snv, q.alpha, q.p);
+        if (!(d1 & 2u)) pv_smp = (q.k_smp == q.k_snv) ? pv_snv : nb_midp_upper(q.k_smp, q.alpha, q.p);
+        if (!(d2 & 1u)) pv_ind = nb_midp_upper(q.k_ind, q.alpha_i, q.p_i);
         a.out[1 * n + i] = pv_snv;
         a.out[2 * n + i] = pv_smp;
-        a.out[3 * n + i] = theta_i;
-        a.out[4 * n + i] = exp_ind;
         a.out[5 * n + i] = pv_ind;
-        a.out[6 * n + i] = pv_mut;
+        a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
     }
 }
 
@@ -264,20 +345,42 @@ int dig_normal_params_to_gamma_host(const double* mu, const double* sigma, doubl
     return DIG_OK;
 }
 
+int64_t dig_element_stats_workspace(int64_t E, int64_t C)
+{
+    if (E < 0 || C < 0) return 0;
+    const int64_t n = E * C;
+    if (n >= (int64_t)0xffffffffu) return 0;   // 32-bit worklist indices; larger problems run single-pass
+    return (int64_t)sizeof(unsigned) * (kWorkHeader + n);
+}
+
 int dig_element_stats(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
                       const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                       const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
-                      double* out, int64_t E, int64_t C, void* stream)
+                      double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream)
 {
     DIG_REQUIRE(E >= 0 && C >= 0, "E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
     DIG_REQUIRE(mu && sigma && pi_sum && pi_indel && obs_snv && obs_samples && obs_indel && cj && cj_indel && out,
                 "non-null pointers");
     DIG_REQUIRE((mu_indel == nullptr) == (sigma_indel == nullptr), "mu_indel and sigma_indel both set or both NULL");
+    const int64_t need = dig_element_stats_workspace(E, C);
+    unsigned* wl = nullptr;
+    if (workspace && need > 0) {
+        DIG_REQUIRE(workspace_bytes >= need, "workspace smaller than dig_element_stats_workspace(E, C)");
+        DIG_REQUIRE(((uintptr_t)workspace & 3u) == 0, "workspace 4-byte aligned");
+        wl = (unsigned*)workspace;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
-                       cj, cj_indel, out, E, C, pi_indel_per_cohort};
-    hipLaunchKernelGGL(element_stats_kernel, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+                       cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd};
+    if (wl) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
+    hipLaunchKernelGGL(element_stats_fast_kernel, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
+    if (wl) {
+        hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 16 + 1, kBlock, 4)), dim3(kBlock), 0, s, a);
+        DIG_HIP_TRY(hipGetLastError());
+    }
     return DIG_OK;
 }
 
@@ -321,10 +424,14 @@ int dig_element_stats_host(const double* mu, const double* sigma, const double* 
     DIG_HIP_TRY(hipMemcpy(dk3.p, obs_indel, ni, hipMemcpyHostToDevice));
     DIG_HIP_TRY(hipMemcpy(dcj.p, cj, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
     DIG_HIP_TRY(hipMemcpy(dcji.p, cj_indel, (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    DevBuf dws;
+    const int64_t wsb = dig_element_stats_workspace(E, C);
+    if (wsb > 0) DIG_HIP_TRY(dws.alloc((size_t)wsb));
     int rc = dig_element_stats(dmu.as<double>(), dsg.as<double>(), mu_indel ? dmui.as<double>() : nullptr,
                                mu_indel ? dsgi.as<double>() : nullptr, dps.as<double>(), dpi.as<double>(),
                                pi_indel_per_cohort, dk1.as<int32_t>(), dk2.as<int32_t>(), dk3.as<int32_t>(),
-                               dcj.as<double>(), dcji.as<double>(), dout.as<double>(), E, C, nullptr);
+                               dcj.as<double>(), dcji.as<double>(), dout.as<double>(), E, C, wsb > 0 ? dws.p : nullptr,
+                               wsb, nullptr);
     if (rc) return rc;
     DIG_HIP_TRY(hipDeviceSynchronize());
     DIG_HIP_TRY(hipMemcpy(out, dout.p, nd * DIG_ES_NPLANES, hipMemcpyDeviceToHost));

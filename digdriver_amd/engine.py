@@ -36,9 +36,26 @@ def _t(x, dtype, device):
     return t.contiguous()
 
 
+_WS_CACHE = {}
+
+
+def _workspace(kind, E, C, dev):
+    """Cached device scratch (a torch uint8 tensor, 256-byte aligned by the caching allocator)."""
+    import torch
+    need = _lib.workspace_bytes(kind, E, C)
+    if need <= 0:
+        return None, 0
+    key = (kind, dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _WS_CACHE[key] = ws
+    return ws, need
+
+
 # ---------------------------------------------------------------------------
 def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, cj, cj_indel,
-                  mu_indel=None, sigma_indel=None, device=0, out=None):
+                  mu_indel=None, sigma_indel=None, device=0, out=None, use_workspace=True):
     """Seven result planes for a dense [E, C] problem.
 
     mu, sigma, pi_sum : f64 [E, C];  pi_indel : f64 [E] or [E, C];  obs_* : i32 [E, C];
@@ -59,11 +76,12 @@ def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, 
         mu_indel, sigma_indel = _t(mu_indel, f64, dev), _t(sigma_indel, f64, dev)
         if out is None:
             out = torch.empty((len(ES_PLANES), E, C), dtype=f64, device=dev)
+        ws, wsb = _workspace("element_stats", E, C, dev) if use_workspace else (None, 0)
         with torch.cuda.device(dev):
             _lib.call("dig_element_stats", _lib.dev_ptr(mu), _lib.dev_ptr(sigma), _lib.dev_ptr(mu_indel),
                       _lib.dev_ptr(sigma_indel), _lib.dev_ptr(pi_sum), _lib.dev_ptr(pi_indel), per_cohort,
                       _lib.dev_ptr(obs_snv), _lib.dev_ptr(obs_samples), _lib.dev_ptr(obs_indel), _lib.dev_ptr(cj),
-                      _lib.dev_ptr(cj_indel), _lib.dev_ptr(out), E, C, _lib.stream_ptr())
+                      _lib.dev_ptr(cj_indel), _lib.dev_ptr(out), E, C, _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
         return {name: out[i] for i, name in enumerate(ES_PLANES)}
     mu = _lib.as_host(mu, np.float64)
     if mu.ndim == 1:
@@ -87,6 +105,31 @@ def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, 
 
 
 # ---------------------------------------------------------------------------
+def scale_suffstats(bin_mu, bin_flag, device=0, out=None):
+    """Per-cohort sum of Y_PRED over unflagged bins (transfer_tools.py:148-156): [N, C] -> [C]."""
+    if _is_cuda(bin_mu):
+        import torch
+        dev = bin_mu.device
+        bin_mu, bin_flag = _t(bin_mu, torch.float64, dev), _t(bin_flag, torch.uint8, dev)
+        N, C = bin_mu.shape
+        if out is None:
+            out = torch.empty(C, dtype=torch.float64, device=dev)
+        ws, wsb = _workspace("suffstats", N, C, dev)
+        with torch.cuda.device(dev):
+            _lib.call("dig_scale_suffstats", _lib.dev_ptr(bin_mu), _lib.dev_ptr(bin_flag), N, C, _lib.dev_ptr(out),
+                      _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
+        return out
+    bin_mu = _lib.as_host(bin_mu, np.float64)
+    if bin_mu.ndim == 1:
+        bin_mu = bin_mu[:, None]
+    N, C = bin_mu.shape
+    bin_flag = _lib.as_host(bin_flag, np.uint8).reshape(N, C)
+    res = np.empty(C)
+    _lib.call("dig_scale_suffstats_host", _lib.host_ptr(bin_mu), _lib.host_ptr(bin_flag), N, C, _lib.host_ptr(res), device)
+    return res
+
+
+# ---------------------------------------------------------------------------
 def ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bin_start):
     """CSR of overlapped bin rows per element (genic_driver_tools.py:275-283), ascending rows.
     Host-side integer index construction in the C++ runtime."""
@@ -106,8 +149,18 @@ def ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bi
     return ov_ptr, ov_idx[:int(ov_ptr[E])]
 
 
+def alloc_accumulate_outputs(E, C, n_class, dev):
+    """Output tensors of accumulate_elements (reusable across calls through `out=`)."""
+    import torch
+    f64, i32 = torch.float64, torch.int32
+    return dict(MU=torch.empty((E, C), dtype=f64, device=dev), SIGMA=torch.empty((E, C), dtype=f64, device=dev),
+                R_OBS=torch.empty((E, C), dtype=i32, device=dev), FLAG=torch.empty((E, C), dtype=i32, device=dev),
+                P=torch.empty((E, n_class, C), dtype=f64, device=dev), R_SIZE=torch.empty(E, dtype=i32, device=dev),
+                ELT_SIZE=torch.empty(E, dtype=i32, device=dev), P_INDEL=torch.empty(E, dtype=f64, device=dev))
+
+
 def accumulate_elements(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr,
-                        gene_length=None, device=0):
+                        gene_length=None, device=0, out=None, use_workspace=True):
     """Per-element accumulation for all cohorts (see include/dig_hip.h: dig_accumulate_elements).
 
     Returns dict(MU, SIGMA [E,C] f64; R_OBS, FLAG [E,C] i32; P [E,n_class,C] f64;
@@ -129,17 +182,15 @@ def accumulate_elements(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_id
         gene_length = _t(gene_length, i32, dev)
         d_pr = _t(d_pr, f64, dev)
         assert d_pr.shape == (C, 192)
-        o = dict(MU=torch.empty((E, C), dtype=f64, device=dev), SIGMA=torch.empty((E, C), dtype=f64, device=dev),
-                 R_OBS=torch.empty((E, C), dtype=i32, device=dev), FLAG=torch.empty((E, C), dtype=i32, device=dev),
-                 P=torch.empty((E, n_class, C), dtype=f64, device=dev), R_SIZE=torch.empty(E, dtype=i32, device=dev),
-                 ELT_SIZE=torch.empty(E, dtype=i32, device=dev), P_INDEL=torch.empty(E, dtype=f64, device=dev))
+        o = out if out is not None else alloc_accumulate_outputs(E, C, n_class, dev)
+        ws, wsb = _workspace("accumulate", E, C, dev) if use_workspace else (None, 0)
         with torch.cuda.device(dev):
             _lib.call("dig_accumulate_elements", _lib.dev_ptr(bin_mu), _lib.dev_ptr(bin_std), _lib.dev_ptr(bin_y),
                       _lib.dev_ptr(bin_flag), _lib.dev_ptr(bin_ctx), _lib.dev_ptr(ov_ptr), _lib.dev_ptr(ov_idx),
                       _lib.dev_ptr(L), n_class, _lib.dev_ptr(strand_minus), _lib.dev_ptr(gene_length), _lib.dev_ptr(d_pr),
                       _lib.dev_ptr(o["MU"]), _lib.dev_ptr(o["SIGMA"]), _lib.dev_ptr(o["R_OBS"]), _lib.dev_ptr(o["FLAG"]),
                       _lib.dev_ptr(o["P"]), _lib.dev_ptr(o["R_SIZE"]), _lib.dev_ptr(o["ELT_SIZE"]),
-                      _lib.dev_ptr(o["P_INDEL"]), N, E, C, _lib.stream_ptr())
+                      _lib.dev_ptr(o["P_INDEL"]), N, E, C, _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
         return o
     bin_mu = _lib.as_host(bin_mu, np.float64)
     if bin_mu.ndim == 1:

@@ -101,11 +101,16 @@ int dig_normal_params_to_gamma_host(const double *mu, const double *sigma, doubl
  * genic_driver_tools.py:383-386).  pi_indel is [E] when pi_indel_per_cohort == 0, else [E, C].
  * out holds DIG_ES_NPLANES planes of E*C doubles: out[plane * E * C + e * C + c].
  * The same entry point serves the gene twins (transfer_tools.py:331-340,425-454,554-583,
- * 709-727): call it once per mutation class with that class's Pi_* / OBS_* / N_SAMP_*. */
+ * 709-727): call it once per mutation class with that class's Pi_* / OBS_* / N_SAMP_*.
+ * workspace: optional device scratch of at least dig_element_stats_workspace(E, C) bytes.  With it the
+ * rare expensive tests (k > 64 or p-value < 1e-3: lgamma + continued fraction) are compacted into a
+ * worklist and finished by a second, dense launch; with workspace == NULL they are resolved inline
+ * (same results, more wave divergence).  The function never allocates. */
+int64_t dig_element_stats_workspace(int64_t E, int64_t C);
 int dig_element_stats(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
                       const double *pi_sum, const double *pi_indel, int pi_indel_per_cohort, const int32_t *obs_snv,
                       const int32_t *obs_samples, const int32_t *obs_indel, const double *cj, const double *cj_indel,
-                      double *out, int64_t E, int64_t C, void *stream);
+                      double *out, int64_t E, int64_t C, void *workspace, int64_t workspace_bytes, void *stream);
 int dig_element_stats_host(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
                            const double *pi_sum, const double *pi_indel, int pi_indel_per_cohort,
                            const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel,
@@ -129,19 +134,37 @@ int dig_element_stats_host(const double *mu, const double *sigma, const double *
  *   substitution order ("XYZ>XaZ"); strand_minus u8 [E]; d_pr f64 [C, 192] = FREQ re-indexed by
  *   sorted substitution string (genic_driver_tools.py:321-325).
  * Outputs (device): MU, SIGMA f64 [E, C]; R_OBS, FLAG i32 [E, C]; P f64 [E, n_class, C];
- *   R_SIZE, ELT_SIZE i32 [E]; P_INDEL f64 [E]. */
+ *   R_SIZE, ELT_SIZE i32 [E]; P_INDEL f64 [E].
+ * workspace: device scratch of at least dig_accumulate_workspace(E, C) bytes, 256-byte aligned
+ *   (strand-permuted context counts per element + transposed parameter tables).  With
+ *   workspace == NULL a slower single-kernel LDS variant runs.  The function never allocates. */
+int64_t dig_accumulate_workspace(int64_t E, int64_t C);
 int dig_accumulate_elements(const double *bin_mu, const double *bin_std, const int32_t *bin_y,
                             const uint8_t *bin_flag, const int32_t *bin_ctx, const int64_t *ov_ptr,
                             const int32_t *ov_idx, const int32_t *L, int n_class, const uint8_t *strand_minus,
                             const int32_t *gene_length, const double *d_pr, double *MU, double *SIGMA,
                             int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
-                            double *P_INDEL, int64_t N, int64_t E, int64_t C, void *stream);
+                            double *P_INDEL, int64_t N, int64_t E, int64_t C, void *workspace,
+                            int64_t workspace_bytes, void *stream);
 int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, const int32_t *bin_y,
                                  const uint8_t *bin_flag, const int32_t *bin_ctx, const int64_t *ov_ptr,
                                  const int32_t *ov_idx, const int32_t *L, int n_class, const uint8_t *strand_minus,
                                  const int32_t *gene_length, const double *d_pr, double *MU, double *SIGMA,
                                  int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
                                  double *P_INDEL, int64_t N, int64_t E, int64_t C, int device);
+
+/* ---- per-cohort sufficient statistics for the scale factors --------------------------- *
+ * calc_scale_factor_efficient, genome mode (driver_model/transfer_tools.py:148-156):
+ *   out_sum[c] = sum over bins with FLAG == 0 of Y_PRED[bin, c]   (N_SNV_EXP per cohort);
+ *   cj = N_SNV_OBS / out_sum, cj_indel = N_IND_OBS / out_sum are formed by the caller (after the
+ *   all-gather of the per-shard sums when bins are sharded over GPUs).
+ * bin_mu f64 [N, C], bin_flag u8 [N, C]; fixed summation order (bit-reproducible).
+ * workspace: at least dig_scale_suffstats_workspace(N, C) bytes, 8-byte aligned. */
+int64_t dig_scale_suffstats_workspace(int64_t N, int64_t C);
+int dig_scale_suffstats(const double *bin_mu, const uint8_t *bin_flag, int64_t N, int64_t C, double *out_sum,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+int dig_scale_suffstats_host(const double *bin_mu, const uint8_t *bin_flag, int64_t N, int64_t C, double *out_sum,
+                             int device);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins

@@ -127,6 +127,14 @@ def test_element_stats_vs_oracle_random_cohorts(torch_dev):
     want = O.element_stats(mu, sigma, pi, pii[:, None], k1, k2, k3, cj[None, :], cji[None, :], mu_indel=mui, sigma_indel=sgi)
     for name in engine.ES_PLANES:
         rel_close(got[name], want[name], RTOL)
+    # worklist (two-pass) and inline (single-pass) modes give identical bits
+    import torch
+    dev = torch.device("cuda:0")
+    tt = lambda v: torch.as_tensor(v, device=dev)
+    a = engine.element_stats(tt(mu), tt(sigma), tt(pi), tt(pii), tt(k1), tt(k2), tt(k3), tt(cj), tt(cji))
+    b = engine.element_stats(tt(mu), tt(sigma), tt(pi), tt(pii), tt(k1), tt(k2), tt(k3), tt(cj), tt(cji), use_workspace=False)
+    for name in engine.ES_PLANES:
+        assert torch.equal(a[name], b[name]) or np.array_equal(a[name].cpu().numpy(), b[name].cpu().numpy(), equal_nan=True), name
     # empty problem is a no-op
     r = engine.element_stats(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros((0, 3), np.int32),
                              np.zeros((0, 3), np.int32), np.zeros((0, 3), np.int32), np.ones(3), np.ones(3))
@@ -221,11 +229,35 @@ def test_accumulate_vs_oracle_multi_cohort(torch_dev, C):
     rel_close(got["P_INDEL"].cpu().numpy(), want["P_INDEL"], 1e-15)
     for name in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
         assert np.array_equal(got[name].cpu().numpy(), want[name]), name
+    # the no-workspace (single-kernel LDS) variant agrees with the workspace (two-kernel) variant
+    v1 = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], use_workspace=False)
+    for name in ("MU", "SIGMA", "P", "P_INDEL"):
+        rel_close(v1[name].cpu().numpy(), got[name].cpu().numpy(), 1e-12)
+    for name in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
+        assert torch.equal(v1[name], got[name]), name
     # host twin == device path bit for bit
     host = engine.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"],
                                       w["ov_idx"], w["L"], w["strand_minus"], w["d_pr"])
     for name in got:
         assert np.array_equal(host[name], got[name].cpu().numpy(), equal_nan=True), name
+
+
+def test_scale_suffstats(torch_dev):
+    import torch
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(2)
+    for N, C in [(1, 1), (1000, 37), (4097, 64), (300, 300), (70000, 3)]:
+        mu = rng.gamma(9.0, 3.0, (N, C))
+        flag = (rng.uniform(size=(N, C)) < 0.1).astype(np.uint8)
+        got = engine.scale_suffstats(mu, flag)
+        want = np.array([O.scale_factor_genome(mu[:, c], flag[:, c], 1.0, 1.0)[0] for c in range(C)])
+        np.testing.assert_allclose(1.0 / got, want, rtol=1e-12)
+        dev = engine.scale_suffstats(torch.as_tensor(mu, device=torch_dev), torch.as_tensor(flag, device=torch_dev))
+        assert np.array_equal(dev.cpu().numpy(), got)                    # deterministic order
+        again = engine.scale_suffstats(torch.as_tensor(mu, device=torch_dev), torch.as_tensor(flag, device=torch_dev))
+        assert torch.equal(dev, again)
 
 
 # ---------------------------------------------------------------------------------------
@@ -273,7 +305,7 @@ def test_tiled_nb_test_vs_oracle(torch_dev):
         assert np.array_equal(ex[c], we)
     pt3 = np.stack([pt, pt * 0.5, pt * 0.25])
     pval3, _ = engine.tiled_nb_test(pt3, k, mu, sigma)
-    assert np.array_equal(pval3[0], pval[0])
+    assert np.array_equal(pval3[0], pval[0], equal_nan=True)
 
 
 # ---------------------------------------------------------------------------------------
