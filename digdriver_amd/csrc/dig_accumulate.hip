@@ -350,30 +350,34 @@ __global__ void acc_dot_kernel(const int32_t* __restrict__ rcp, const int32_t* _
 // (the grid is only E/64 workgroups) at the price of one int->f64 convert per CT FMAs.
 static int acc_pick_ct(int64_t E, int64_t C, int* nchunk)
 {
+    // Cohorts per wave (CT accumulators in VGPRs; one chunk-wave per CT cohorts).  Measured on MI355X
+    // at C = 37, E = 120 k: CT = 20 (2 chunk-waves, 8 % padded slots) beats 8/10/13/16 -- fewer
+    // int->f64 converts and scalar loads per FMA matter more than extra waves.  Pick the largest
+    // instantiated CT whose padding stays within 10 %, else the least-padded one.
+    (void)E;
     static const int cts[] = {4, 8, 10, 13, 16, 20};
-    int forced = 0;
-    if (const char* env = getenv("DIG_ACC_CT")) forced = atoi(env);
-    const int64_t groups = (E + 63) / 64;
-    const int64_t want_waves = (int64_t)cu_count() * 4 * 4;          // >= 4 waves per SIMD
-    int best = 20;
-    for (int i = 5; i >= 0; --i) {                                    // largest CT that still fills the chip
-        const int ct = cts[i];
-        const int64_t nch = (C + ct - 1) / ct;
-        best = ct;
-        if (groups * nch >= want_waves) break;
-    }
-    if (best > C) {                                                   // do not pad far beyond C
-        for (int i = 0; i < 6; ++i)
-            if (cts[i] >= C) { best = cts[i]; break; }
-    }
-    if (forced)
+    if (const char* env = getenv("DIG_ACC_CT")) {
+        const int forced = atoi(env);
         for (int ct : cts)
-            if (ct == forced) best = ct;
-    *nchunk = (int)((C + best - 1) / best);
-    if (*nchunk > 16) {                                               // blockDim.y <= 16 waves
-        best = 20;
-        *nchunk = (int)((C + 19) / 20);
+            if (ct == forced) {
+                *nchunk = (int)((C + ct - 1) / ct);
+                return ct;
+            }
     }
+    int best = 0;
+    int64_t best_slots = 0;
+    for (int ct : cts) {
+        const int64_t nch = (C + ct - 1) / ct;
+        const int64_t slots = nch * ct;
+        if (slots * 10 <= C * 11) { best = ct; best_slots = slots; }
+    }
+    if (!best) {
+        for (int ct : cts) {
+            const int64_t slots = ((C + ct - 1) / ct) * ct;
+            if (!best || slots < best_slots) { best = ct; best_slots = slots; }
+        }
+    }
+    *nchunk = (int)((C + best - 1) / best);
     return best;
 }
 

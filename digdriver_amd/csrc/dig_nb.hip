@@ -92,55 +92,89 @@ struct ElementStatsArgs {
 
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
 
+struct PairRaw {
+    double mu, sigma, pi_s, pi_i, mu_i, sigma_i, cj, cji;
+    int k_snv, k_smp, k_ind;
+};
+
 struct PairInputs {
     double alpha, theta, p, exp_snv, alpha_i, theta_i, p_i, exp_ind, k_snv, k_smp, k_ind;
 };
 
-// Input preparation for one (element, cohort) pair, bit-identical to the reference's numpy
-// expressions (no FMA contraction): transfer_tools.py:17-19,46-48,300,343-344,476-481,737-745.
-__device__ __forceinline__ PairInputs load_pair(const ElementStatsArgs& a, int64_t i)
+__device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i)
 {
     const int64_t e = a.use_fastdiv ? fastdiv(i, a.divC) : i;   // use_fastdiv == 0 only when C == 1
     const int64_t c = i - e * a.C;
-    const double mu = a.mu[i], sigma = a.sigma[i];
-    const double pi_s = a.pi_sum[i];
-    const double pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
-    PairInputs r;
-    r.k_snv = (double)a.obs_snv[i];
-    r.k_smp = (double)a.obs_samples[i];
-    r.k_ind = (double)a.obs_indel[i];
-    const GammaParams g = normal_params_to_gamma(mu, sigma);
-    r.alpha = g.alpha;
-    r.theta = mul_rn(g.theta, a.cj[c]);
-    r.exp_snv = mul_rn(mul_rn(g.alpha, r.theta), pi_s);
-    r.p = nb_success_prob(r.theta, pi_s);
-    GammaParams gi = g;
-    if (a.mu_indel) gi = normal_params_to_gamma(a.mu_indel[i], a.sigma_indel[i]);
-    r.alpha_i = gi.alpha;
-    r.theta_i = mul_rn(gi.theta, a.cj_indel[c]);
-    r.exp_ind = mul_rn(mul_rn(gi.alpha, r.theta_i), pi_i);
-    r.p_i = nb_success_prob(r.theta_i, pi_i);
+    PairRaw r;
+    r.mu = a.mu[i];
+    r.sigma = a.sigma[i];
+    r.pi_s = a.pi_sum[i];
+    r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
+    r.k_snv = a.obs_snv[i];
+    r.k_smp = a.obs_samples[i];
+    r.k_ind = a.obs_indel[i];
+    r.cj = a.cj[c];
+    r.cji = a.cj_indel[c];
+    r.mu_i = a.mu_indel ? a.mu_indel[i] : r.mu;
+    r.sigma_i = a.mu_indel ? a.sigma_indel[i] : r.sigma;
     return r;
 }
 
+// Input preparation for one (element, cohort) pair, bit-identical to the reference's numpy
+// expressions (no FMA contraction): transfer_tools.py:17-19,46-48,300,343-344,476-481,737-745.
+__device__ __forceinline__ PairInputs prepare_pair(const PairRaw& w, bool has_indel_params)
+{
+    PairInputs r;
+    r.k_snv = (double)w.k_snv;
+    r.k_smp = (double)w.k_smp;
+    r.k_ind = (double)w.k_ind;
+    const GammaParams g = normal_params_to_gamma(w.mu, w.sigma);
+    r.alpha = g.alpha;
+    r.theta = mul_rn(g.theta, w.cj);
+    r.exp_snv = mul_rn(mul_rn(g.alpha, r.theta), w.pi_s);
+    r.p = nb_success_prob(r.theta, w.pi_s);
+    GammaParams gi = g;
+    if (has_indel_params) gi = normal_params_to_gamma(w.mu_i, w.sigma_i);
+    r.alpha_i = gi.alpha;
+    r.theta_i = mul_rn(gi.theta, w.cji);
+    r.exp_ind = mul_rn(mul_rn(gi.alpha, r.theta_i), w.pi_i);
+    r.p_i = nb_success_prob(r.theta_i, w.pi_i);
+    return r;
+}
+
+__device__ __forceinline__ PairInputs load_pair(const ElementStatsArgs& a, int64_t i)
+{
+    return prepare_pair(load_raw(a, i), a.mu_indel != nullptr);
+}
+
 // Pass 1: every pair through the division-free pmf recurrence (SNV and SAMPLE counts share one
-// pass).  Pairs with an unresolved test (large k, or a p-value < 1e-3 where 1 - CDF cancels) are
-// appended to the worklist with one wave-aggregated atomic and finished by pass 2.
+// pass).  WORKLIST = true: pairs with an unresolved test (large k, or a p-value < kDirectMin where
+// 1 - CDF cancels) are appended to the worklist with one wave-aggregated atomic and finished by
+// pass 2; the expensive path is not even compiled into this kernel (fewer VGPRs, more waves).
+// WORKLIST = false: unresolved tests are finished inline.
+// The raw inputs of the wave's NEXT item are loaded before the current one is computed.
+template <bool WORKLIST>
 __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStatsArgs a)
 {
     const int64_t n = a.E * a.C;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
+    const bool has_ip = a.mu_indel != nullptr;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    PairRaw nxt = load_raw(a, i < n ? i : n - 1);
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
+        i = i0 + threadIdx.x;
+        const PairRaw cur = nxt;
+        const int64_t inext = i + stride;
+        nxt = load_raw(a, inext < n ? inext : n - 1);     // prefetch
         bool slow = false;
         if (i < n) {
-            const PairInputs q = load_pair(a, i);
+            const PairInputs q = prepare_pair(cur, has_ip);
             double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
             const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
             const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
             slow = (d1 != 3u) || (d2 != 1u);
-            if (slow && !a.worklist) {   // single-pass mode: finish inline
+            if (!WORKLIST && slow) {   // single-pass mode: finish inline
                 if (!(d1 & 1u)) pv_snv = nb_midp_upper(q.k_snv, q.alpha, q.p);
                 if (!(d1 & 2u)) pv_smp = nb_midp_upper(q.k_smp, q.alpha, q.p);
                 if (!(d2 & 1u)) pv_ind = nb_midp_upper(q.k_ind, q.alpha_i, q.p_i);
@@ -156,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStats
                 a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
             }
         }
-        if (a.worklist) {
+        if (WORKLIST) {
             const unsigned long long m = __ballot(slow);
             if (m) {
                 unsigned base = 0;
@@ -375,7 +409,10 @@ int dig_element_stats(const double* mu, const double* sigma, const double* mu_in
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd};
     if (wl) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
-    hipLaunchKernelGGL(element_stats_fast_kernel, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, s, a);
+    if (wl)
+        hipLaunchKernelGGL(element_stats_fast_kernel<true>, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(element_stats_fast_kernel<false>, dim3(grid_for(E * C, kBlock)), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
     if (wl) {
         hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 16 + 1, kBlock, 4)), dim3(kBlock), 0, s, a);

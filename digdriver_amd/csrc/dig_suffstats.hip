@@ -11,7 +11,7 @@
 //            rows r0 + t / C, r0 + t / C + rpp, ... so a pass over rpp rows is one contiguous,
 //            fully coalesced run of rpp * C doubles; per-thread sums are combined through LDS in
 //            row-group order and written to partial[workgroup][C];
-//   stage 2: one workgroup adds the partials in workgroup order.
+//   stage 2: one workgroup per column adds the partials with a fixed-shape tree.
 #include "dig_common.hpp"
 
 namespace dig {
@@ -67,14 +67,22 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_stage1(const double* __res
     }
 }
 
+// stage 2: one workgroup per cohort column; thread t adds partial[t], partial[t + 256], ... (independent
+// loads), then a fixed-shape LDS tree combines the 256 thread sums -> deterministic.
 __global__ __launch_bounds__(kSsBlock) void suffstats_stage2(const double* __restrict__ partial, int nblocks, int64_t C,
                                                              double* __restrict__ out)
 {
-    for (int64_t c = threadIdx.x; c < C; c += kSsBlock) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * C + c];
-        out[c] = s;
+    __shared__ double red[kSsBlock];
+    const int64_t c = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kSsBlock) s += partial[(int64_t)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kSsBlock / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[c] = red[0];
 }
 
 static int ss_blocks(int64_t N)
@@ -114,7 +122,7 @@ int dig_scale_suffstats(const double* bin_mu, const uint8_t* bin_flag, int64_t N
     const int64_t rpb = (N + g - 1) / g;
     hipLaunchKernelGGL(suffstats_stage1, dim3(g), dim3(kSsBlock), 0, s, bin_mu, bin_flag, N, C, rpb, (double*)workspace);
     DIG_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(suffstats_stage2, dim3(1), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum);
+    hipLaunchKernelGGL(suffstats_stage2, dim3((unsigned)C), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }
