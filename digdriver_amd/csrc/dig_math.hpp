@@ -140,36 +140,39 @@ __device__ inline double nb_upper_tail_from_pmf(double k, double alpha, double p
     return 1.0 - pmfk * ((k + alpha) * x / alpha) * betacf(b, a, p);
 }
 
+__device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, unsigned want, double alpha, double p,
+                                                        double& r1, double& r2);
+
+// The expensive tail of nb_midp_upper: integer k >= 0, 0 < p < 1, finite alpha > 0, and either
+// k > kSmallK, p^alpha underflows, or the p-value is < kDirectMin (1 - CDF would cancel).
+__device__ inline double nb_midp_upper_slow(double k, double alpha, double p)
+{
+    const double x = 1.0 - p;
+    const double pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
+    return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);
+}
+
+// For a test nb_midp_upper_fast2 left unresolved (its argument checks already passed: finite alpha > 0,
+// 0 < p < 1, k not NaN): counts outside the support keep scipy's semantics, the rest take the slow tail.
+__device__ inline double nb_midp_upper_unresolved(double k, double alpha, double p)
+{
+    if (k < 0.0 || floor(k) != k || isinf(k)) return betainc(k + 1.0, alpha, 1.0 - p);   // pmf = 0 off the support
+    return nb_midp_upper_slow(k, alpha, p);
+}
+
 // nb_model.py:271-278:  0.5 * nbinom.pmf(k, alpha, p) + betainc(k + 1, alpha, 1 - p)
 __device__ inline double nb_midp_upper(double k, double alpha, double p)
 {
     if (isnan(k) || isnan(alpha) || isnan(p)) return dnan();
     if (!(alpha > 0.0) || !(p > 0.0) || !(p <= 1.0) || isinf(alpha)) return dnan();
-    const double x = 1.0 - p;
-    const bool kint = (floor(k) == k);
-    if (k < 0.0 || !kint || isinf(k)) {
+    if (k < 0.0 || floor(k) != k || isinf(k)) {
         // never produced by the live callers (counts); keep scipy's semantics
-        const double pmf = (k >= 0.0 && kint) ? nbinom_pmf(k, alpha, p) : 0.0;
-        return 0.5 * pmf + betainc(k + 1.0, alpha, x);
+        const double pmf = 0.0;   // negative or non-integer k is outside the support
+        return 0.5 * pmf + betainc(k + 1.0, alpha, 1.0 - p);
     }
-    if (p == 1.0) return k == 0.0 ? 0.5 : 0.0;
-    const double lp0 = alpha * log(p);   // log t_0
-    double pmfk;
-    if (k <= (double)kSmallK && lp0 > -690.0) {
-        double t = exp(lp0), S = 0.0;
-        const int ki = (int)k;
-        for (int j = 0; j < ki; ++j) {
-            S += t;
-            t *= (alpha + (double)j) * x / (double)(j + 1);
-        }
-        const double r = 1.0 - S - 0.5 * t;
-        if (r >= kDirectMin) return r;
-        pmfk = t;
-        if (!(pmfk > 1e-290)) pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
-    } else {
-        pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
-    }
-    return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);
+    double r = 0.0, dummy = 0.0;
+    if (nb_midp_upper_fast2(k, 0.0, 1u, alpha, p, r, dummy) & 1u) return r;   // same bits as the fused kernels
+    return nb_midp_upper_slow(k, alpha, p);
 }
 
 // ---- fast mid-p evaluation for small integer counts sharing (alpha, p) ----------------

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void fisher_kernel(const double* __restrict
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-        out[i] = fisher_combine(p1[i], p2[i]);
+        out[i] = fisher_combine_fast(p1[i], p2[i]);   // same code path as the fused statistics kernels
 }
 
 __global__ __launch_bounds__(kBlock) void gamma_kernel(const double* __restrict__ mu, const double* __restrict__ sigma,
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStats
             const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
             slow = (d1 != 3u) || (d2 != 1u);
             if (!WORKLIST && slow) {   // single-pass mode: finish inline
-                if (!(d1 & 1u)) pv_snv = nb_midp_upper(q.k_snv, q.alpha, q.p);
-                if (!(d1 & 2u)) pv_smp = nb_midp_upper(q.k_smp, q.alpha, q.p);
-                if (!(d2 & 1u)) pv_ind = nb_midp_upper(q.k_ind, q.alpha_i, q.p_i);
+                if (!(d1 & 1u)) pv_snv = nb_midp_upper_unresolved(q.k_snv, q.alpha, q.p);
+                if (!(d1 & 2u)) pv_smp = nb_midp_upper_unresolved(q.k_smp, q.alpha, q.p);
+                if (!(d2 & 1u)) pv_ind = nb_midp_upper_unresolved(q.k_ind, q.alpha_i, q.p_i);
                 slow = false;
             }
             a.out[0 * n + i] = q.exp_snv;
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(kBlock) void element_stats_slow_kernel(ElementStats
         double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
         const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
-        if (!(d1 & 1u)) pv_snv = nb_midp_upper(q.k_snv, q.alpha, q.p);
-        if (!(d1 & 2u)) pv_smp = (q.k_smp == q.k_snv) ? pv_snv : nb_midp_upper(q.k_smp, q.alpha, q.p);
-        if (!(d2 & 1u)) pv_ind = nb_midp_upper(q.k_ind, q.alpha_i, q.p_i);
+        if (!(d1 & 1u)) pv_snv = nb_midp_upper_unresolved(q.k_snv, q.alpha, q.p);
+        if (!(d1 & 2u)) pv_smp = (q.k_smp == q.k_snv) ? pv_snv : nb_midp_upper_unresolved(q.k_smp, q.alpha, q.p);
+        if (!(d2 & 1u)) pv_ind = nb_midp_upper_unresolved(q.k_ind, q.alpha_i, q.p_i);
         a.out[1 * n + i] = pv_snv;
         a.out[2 * n + i] = pv_smp;
         a.out[5 * n + i] = pv_ind;

@@ -1,0 +1,279 @@
+"""Mutation-file handling and integer observed-count tabulation.
+
+Host mirror of DIGDriver/data_tools/mutation_tools.py.  Same function names, arguments and output
+frames; the reference shells out to ``bedtools intersect`` through pybedtools, here the interval
+join is a sort + binary-search in numpy (half-open ``[START, END)`` overlap, exactly bedtools'
+default: two intervals overlap when ``a.start < b.end and b.start < a.end``; zero-length features
+are treated like bedtools does, as overlapping when ``b.start <= a.start < b.end``... see
+``_overlap_pairs``).  All outputs of this module are integer counts and must be bit-exact.
+"""
+import csv
+import gzip
+
+import numpy as np
+import pandas as pd
+
+_MUT_COLS = {
+    5: ['CHROM', 'POS', 'REF', 'ALT', 'SAMPLE'],
+    6: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE'],
+    7: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'ANNOT'],
+    8: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT'],
+    9: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'ANNOT', 'MUT_TYPE', 'CONTEXT'],
+    10: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT', 'MUT_TYPE', 'CONTEXT'],
+    11: ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT', 'MUT_TYPE', 'CONTEXT', 'STRAND'],
+}
+_INT_COLS = ('POS', 'START', 'END')
+_AUTOSOMES = [str(i) for i in range(1, 23)]
+
+
+def read_mutation_file(path, drop_sex=True, drop_duplicates=False, unique_indels=True):
+    """mutation_tools.py:45-104: header-less TSV, schema chosen by the column count of the first
+    row; plain or gzip."""
+    try:
+        with open(path) as f:
+            first_row = next(csv.reader(f, delimiter='\t', skipinitialspace=True))
+    except UnicodeDecodeError:  # gzip
+        with gzip.open(path, 'rt') as f:
+            first_row = next(csv.reader(f, delimiter='\t', skipinitialspace=True))
+    cols = _MUT_COLS[len(first_row)]
+    dtype = {c: (int if c in _INT_COLS else str) for c in cols}
+    df = pd.read_csv(path, sep="\t", low_memory=False, names=cols, dtype=dtype)
+    if drop_sex:
+        if set(df.CHROM.unique()) - set(_AUTOSOMES):
+            print('Restricting to autosomes')
+            df = df[df.CHROM.isin(_AUTOSOMES)]
+        df['CHROM'] = df.CHROM.astype(int)
+    if drop_duplicates:
+        df = drop_duplicate_mutations(df)
+    if unique_indels:
+        df = get_unique_indels(df)
+    return df
+
+
+def drop_duplicate_mutations(df_mut):
+    """mutation_tools.py:107-109"""
+    return df_mut.drop_duplicates(['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE'])
+
+
+def get_unique_indels(df_mut):
+    """mutation_tools.py:111-117: indels de-duplicated on (CHROM, START, END, REF, ALT, GENE); SNVs first."""
+    df_indel = df_mut[df_mut.ANNOT == 'INDEL']
+    df_snv = df_mut[df_mut.ANNOT != 'INDEL']
+    df_indel = df_indel.drop_duplicates(subset=['CHROM', 'START', 'END', 'REF', 'ALT', 'GENE'])
+    return pd.concat([df_snv, df_indel])
+
+
+def filter_hypermut_samples(df_mut, max_muts_per_sample, return_blacklist=False):
+    """mutation_tools.py:293-304"""
+    sample_cnt = df_mut.SAMPLE.value_counts()
+    samples_blacklist = sample_cnt[sample_cnt > max_muts_per_sample].index.to_list()
+    df_whitelist = df_mut[~df_mut.SAMPLE.isin(samples_blacklist)]
+    if return_blacklist:
+        return df_whitelist, samples_blacklist
+    return df_whitelist
+
+
+def mutations_per_gene(df_mut_cds, max_muts_per_gene_per_sample=3e9):
+    """mutation_tools.py:329-361: per (GENE, SAMPLE, ANNOT) counts, capped, summed per gene; integer frame
+    with columns renamed to OBS_MIS / OBS_NONS / OBS_SYN / OBS_SPL / OBS_INDEL."""
+    df_group = df_mut_cds.groupby(['GENE', 'SAMPLE', 'ANNOT']).size().reset_index(name='COUNT')
+    df_group.loc[df_group.COUNT > max_muts_per_gene_per_sample, 'COUNT'] = max_muts_per_gene_per_sample
+    df_pivot = df_group.pivot_table(index=['GENE', 'ANNOT'], values='COUNT', aggfunc="sum").reset_index()
+    df_counts = df_pivot.pivot(index='GENE', columns='ANNOT', values='COUNT')
+    df_counts = df_counts.fillna(0).astype(int)
+    df_counts.columns = df_counts.columns.to_list()
+    for col in ("Missense", "Nonsense", "Synonymous", "Essential_Splice", "INDEL"):
+        if col not in df_counts.columns:
+            df_counts[col] = 0
+    df_counts.rename({'Missense': 'OBS_MIS', 'Nonsense': 'OBS_NONS', 'Synonymous': 'OBS_SYN',
+                      'Essential_Splice': 'OBS_SPL', 'INDEL': 'OBS_INDEL'}, axis=1, inplace=True)
+    return df_counts
+
+
+def bed12_boundaries(f_bed):
+    """mutation_tools.py:383-414: bed12 -> frame (CHROM int, ELT, STRAND, BLOCK_STARTS, BLOCK_ENDS), autosomes only.
+    As in the reference the 'chr' prefix is stripped only when the FIRST row carries it."""
+    names = ['CHROM', 'START', 'END', "ELT", "SCORE", "STRAND", 'thickStart', 'thickEnd', 'rgb', 'blockCount',
+             'blockSizes', 'blockStarts']
+    df = pd.read_table(f_bed, names=names, low_memory=False)
+    df.CHROM = df.CHROM.astype(str)
+    df.blockSizes = df.blockSizes.astype(str)
+    df.blockStarts = df.blockStarts.astype(str)
+    if 'chr' in str(df['CHROM'][0]):
+        df['CHROM'] = df['CHROM'].map(lambda x: x.lstrip('chr'))
+    df = df[df.CHROM.isin(_AUTOSOMES)].copy()
+    df.CHROM = df.CHROM.astype(int)
+
+    def _ints(s):
+        return [int(x) for x in s.rstrip(',').split(',')]
+
+    starts = [[x + st for x in _ints(bs)] for bs, st in zip(df.blockStarts, df.START)]
+    ends = [[s + z for s, z in zip(ss, _ints(bz))] for ss, bz in zip(starts, df.blockSizes)]
+    df['BLOCK_STARTS'] = starts
+    df['BLOCK_ENDS'] = ends
+    return df[['CHROM', 'ELT', 'STRAND', 'BLOCK_STARTS', 'BLOCK_ENDS']]
+
+
+# ---------------------------------------------------------------------------------------------
+# interval join (replaces `bedtools intersect -wa -wb` on mutations x bed6 blocks)
+# ---------------------------------------------------------------------------------------------
+def _chrom_key(chrom):
+    """Chromosome labels compare as strings in bedtools; normalise 'chr' prefixes like pybedtools callers do."""
+    s = np.asarray(chrom).astype(str)
+    return np.char.lstrip(s, 'chr') if len(s) and s.dtype.kind in 'US' else s
+
+
+def _overlap_pairs(m_chrom, m_start, m_end, b_chrom, b_start, b_end):
+    """All (mutation row, block row) pairs with bedtools-intersect semantics:
+    overlap iff  m.start < b.end  and  b.start < m.end  (half-open).  A zero-length mutation
+    (start == end, bedtools >= 2.27) overlaps block b iff  b.start <= m.start < b.end ... bedtools treats
+    it as the 1-bp feature [start, start+1) for the test; the same is done for zero-length blocks.
+    Output order: mutation-major (file order of the mutation file), blocks in bed order."""
+    m_chrom, b_chrom = _chrom_key(m_chrom), _chrom_key(b_chrom)
+    m_start = np.asarray(m_start, np.int64)
+    m_end = np.asarray(m_end, np.int64)
+    b_start = np.asarray(b_start, np.int64)
+    b_end = np.asarray(b_end, np.int64)
+    m_end_eff = np.where(m_end == m_start, m_start + 1, m_end)
+    b_end_eff = np.where(b_end == b_start, b_start + 1, b_end)
+    mi_all, bi_all = [], []
+    for ch in np.unique(b_chrom):
+        bsel = np.nonzero(b_chrom == ch)[0]
+        msel = np.nonzero(m_chrom == ch)[0]
+        if len(bsel) == 0 or len(msel) == 0:
+            continue
+        order = np.argsort(b_start[bsel], kind="stable")
+        bs, be, bidx = b_start[bsel][order], b_end_eff[bsel][order], bsel[order]
+        # blocks may overlap/nest: candidates are all blocks with start < m.end; filter by end > m.start.
+        # running max of block ends bounds the scan from the left
+        run_max = np.maximum.accumulate(be)
+        hi = np.searchsorted(bs, m_end_eff[msel], side="left")        # blocks [0, hi) have start < m.end
+        lo = np.searchsorted(run_max, m_start[msel], side="right")     # first block whose running max end > m.start
+        cnt = np.maximum(hi - lo, 0)
+        tot = int(cnt.sum())
+        if tot == 0:
+            continue
+        rep_m = np.repeat(np.arange(len(msel)), cnt)
+        offs = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        cand = np.repeat(lo, cnt) + offs
+        keep = be[cand] > m_start[msel][rep_m]
+        mi_all.append(msel[rep_m[keep]])
+        bi_all.append(bidx[cand[keep]])
+    if not mi_all:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    mi = np.concatenate(mi_all)
+    bi = np.concatenate(bi_all)
+    order = np.lexsort((bi, mi))
+    return mi[order], bi[order]
+
+
+def _bed12_to_bed6(df_bed12):
+    """bedtools bed12tobed6: one row per block, keeping the parent's name and strand."""
+    rows = []
+    for chrom, start, name, strand, bsz, bst in zip(df_bed12[0], df_bed12[1], df_bed12[3], df_bed12[5], df_bed12[10],
+                                                    df_bed12[11]):
+        sizes = [int(x) for x in str(bsz).rstrip(',').split(',')]
+        starts = [int(x) for x in str(bst).rstrip(',').split(',')]
+        for s, z in zip(starts, sizes):
+            rows.append((chrom, start + s, start + s + z, name, strand))
+    return pd.DataFrame(rows, columns=['CHROM', 'START', 'END', 'ELT', 'STRAND'])
+
+
+def tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=False, drop_duplicates=False, unique_indels=True):
+    """mutation_tools.py:191-230: mutations x element blocks -> per (ELT, SAMPLE) integer counts
+    OBS_SNV / OBS_INDEL / OBS_MUT.  The raw file rows are joined (no autosome filter), duplicates on
+    (chrom, start, end, ref, alt, sample, elt) dropped when asked (:208), SNV vs INDEL by ANNOT (:211-213)."""
+    df_mut = pd.read_csv(f_mut, sep="\t", header=None, low_memory=False, dtype={0: str})
+    df_bed = pd.read_csv(f_elt_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
+    blocks = _bed12_to_bed6(df_bed) if bed12 else df_bed.rename(columns={0: 'CHROM', 1: 'START', 2: 'END', 3: 'ELT'})
+    mi, bi = _overlap_pairs(df_mut[0].values, df_mut[1].values, df_mut[2].values,
+                            blocks.CHROM.values, blocks.START.values, blocks.END.values)
+    empty = pd.DataFrame({'ELT': [], 'SAMPLE': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'OBS_MUT': []})
+    if len(mi) == 0:
+        return empty
+    inter = df_mut.iloc[mi, :8].reset_index(drop=True)
+    inter.columns = range(inter.shape[1])
+    inter[13] = blocks.ELT.values[bi]
+    if drop_duplicates:
+        inter = inter.drop_duplicates([0, 1, 2, 3, 4, 5, 13])
+    is_indel = inter[7] == 'INDEL'
+    cnt_snv = inter[~is_indel].groupby([13, 5]).size().reset_index(name='OBS_SNV')
+    cnt_ind = inter[is_indel].groupby([13, 5]).size().reset_index(name='OBS_INDEL')
+    df_cnt = cnt_snv.merge(cnt_ind, how='outer')
+    df_cnt['OBS_SNV'] = df_cnt.OBS_SNV.fillna(0)
+    df_cnt['OBS_INDEL'] = df_cnt.OBS_INDEL.fillna(0)
+    df_cnt['OBS_MUT'] = df_cnt.OBS_SNV + df_cnt.OBS_INDEL
+    df_cnt = df_cnt[[13, 5, 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']]
+    df_cnt.columns = ['ELT', 'SAMPLE', 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']
+    return df_cnt
+
+
+def tabulate_mutations_in_element(f_mut, f_elt_bed, bed12=False, drop_duplicates=False, all_elements=False,
+                                  max_muts_per_sample=1e9, max_muts_per_elt_per_sample=3e9, return_blacklist=False):
+    """mutation_tools.py:155-189: hypermutator blacklist, per-(element, sample) cap, then per-element
+    OBS_SAMPLES (= number of distinct samples), OBS_SNV, OBS_INDEL."""
+    df_cnt = tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=bed12, drop_duplicates=drop_duplicates)
+    df_cnt = df_cnt.rename({'SAMPLE': 'OBS_SAMPLES'}, axis=1)
+    if len(df_cnt) > 0:
+        per_sample = df_cnt.groupby('OBS_SAMPLES').OBS_MUT.sum()
+        blacklist = per_sample[per_sample > max_muts_per_sample].index
+        df_cnt = df_cnt[~df_cnt.OBS_SAMPLES.isin(blacklist)].copy()
+    else:
+        blacklist = []
+    df_cnt.loc[df_cnt.OBS_SNV > max_muts_per_elt_per_sample, 'OBS_SNV'] = max_muts_per_elt_per_sample
+    df_cnt.loc[df_cnt.OBS_INDEL > max_muts_per_elt_per_sample, 'OBS_INDEL'] = max_muts_per_elt_per_sample
+    if len(df_cnt) == 0:
+        df_summary = pd.DataFrame({'OBS_SAMPLES': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'ELT': []}).set_index('ELT')
+    else:
+        df_summary = df_cnt.groupby('ELT').agg(OBS_INDEL=('OBS_INDEL', 'sum'), OBS_SAMPLES=('OBS_SAMPLES', len),
+                                               OBS_SNV=('OBS_SNV', 'sum'))
+    if all_elements:
+        df_bed = pd.read_csv(f_elt_bed, sep="\t", header=None).set_index(3)
+        df_bed.index.rename('ELT', inplace=True)
+        df_summary = df_bed.merge(df_summary, left_index=True, right_index=True, how='left')
+        for c in ('OBS_SNV', 'OBS_INDEL', 'OBS_SAMPLES'):
+            df_summary[c] = df_summary[c].fillna(0)
+    out = df_summary[['OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL']]
+    if return_blacklist:
+        return out, blacklist
+    return out
+
+
+def restrict_mutations_by_bed_efficient(f_mut, f_bed, bed12=False, drop_duplicates=False, drop_sex=False,
+                                        replace_cols=False):
+    """mutation_tools.py:32-43: `bedtools intersect -wa`: one output row per (mutation, overlapped block) pair."""
+    import os
+    import tempfile
+    df_raw = pd.read_csv(f_mut, sep="\t", header=None, low_memory=False, dtype=str)
+    df_bed = pd.read_csv(f_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
+    blocks = _bed12_to_bed6(df_bed) if bed12 else df_bed.rename(columns={0: 'CHROM', 1: 'START', 2: 'END'})
+    mi, _ = _overlap_pairs(df_raw[0].values, df_raw[1].astype(np.int64).values, df_raw[2].astype(np.int64).values,
+                           blocks.CHROM.values, blocks.START.values, blocks.END.values)
+    fd, tmp = tempfile.mkstemp(suffix=".tsv")
+    os.close(fd)
+    try:
+        df_raw.iloc[mi].to_csv(tmp, sep="\t", header=False, index=False)
+        if len(mi) == 0:
+            cols = _MUT_COLS[df_raw.shape[1]]
+            return pd.DataFrame({c: [] for c in cols})
+        return read_mutation_file(tmp, drop_duplicates=drop_duplicates, drop_sex=drop_sex)
+    finally:
+        os.remove(tmp)
+
+
+def restrict_mutations_by_bed(df_mut, df_bed, unique=True, remove_X=True, replace_cols=False):
+    """mutation_tools.py:8-30 (frame-level `bedtools intersect`, reports the overlapping part of each mutation:
+    for 1-bp SNVs inside a block that is the mutation itself)."""
+    if remove_X:
+        df_mut = df_mut[df_mut.iloc[:, 0] != "X"]
+        df_bed = df_bed[df_bed.iloc[:, 0] != "X"]
+    mi, bi = _overlap_pairs(df_mut.iloc[:, 0].values, df_mut.iloc[:, 1].values, df_mut.iloc[:, 2].values,
+                            df_bed.iloc[:, 0].values, df_bed.iloc[:, 1].values, df_bed.iloc[:, 2].values)
+    inter = df_mut.iloc[mi].copy()
+    s = np.maximum(df_mut.iloc[mi, 1].values, df_bed.iloc[bi, 1].values)
+    e = np.minimum(df_mut.iloc[mi, 2].values, df_bed.iloc[bi, 2].values)
+    inter.iloc[:, 1] = s
+    inter.iloc[:, 2] = np.maximum(e, s)
+    if unique:
+        inter = inter.drop_duplicates()
+    return inter

@@ -1,0 +1,256 @@
+"""Per-element / per-gene / per-tile pretraining: accumulate region parameters and Pi for every element.
+
+Host mirror of DIGDriver/sequence_model/genic_driver_tools.py.  The reference walks the elements in a
+pure-Python loop inside a multiprocessing pool (three h5 reads per element); here the whole element set
+-- and any number of cohorts -- is one dig_accumulate_elements launch.
+
+Element data container (f_nonc_data / f_genic), mirror layout (see digdriver_amd/io/mapfile.py):
+    window_{w}/full_window_si_values   int  [N, 64]   64 context counts per genome bin
+    window_{w}/full_window_si_index    int  [N, 3]    (chrom, start, end) of those bins
+    window_{w}/{save_key}/names, chrom, strand, blk_ptr, blk_start, blk_end, L [E, n_class, 192]
+(the reference's per-element HDF5 groups window_{w}/{save_key}/{elt}/{L_counts,region_counts}+overlaps,
+sequence_tools.py:639-641, hold the same information one element at a time; region_counts and overlaps are
+recomputed here from the bin table, which is how preprocess_nonc produced them, sequence_tools.py:628-634).
+"""
+import numpy as np
+import pandas as pd
+
+from .. import engine
+from ..io import mapfile
+
+
+# ---------------------------------------------------------------------------------------------
+# small reference helpers
+# ---------------------------------------------------------------------------------------------
+def trip_to_str(trip):
+    """genic_driver_tools.py:286-287"""
+    return 'chr{}:{}-{}'.format(trip[0], trip[1], trip[2])
+
+
+def _index_transform(s):
+    """genic_driver_tools.py:721-725"""
+    chrom = int(s.split(":")[0].lstrip("chr"))
+    start = int(s.split(":")[-1].split('-')[0])
+    end = int(s.split(":")[-1].split('-')[1])
+    return "region_{}_{}_{}".format(chrom, start, end)
+
+
+def get_ideal_overlaps(chrom, intervals, window):
+    """genic_driver_tools.py:275-283: the bins touched by the blocks of one element, as (chrom, start, end)
+    triples.  The reference returns them in set order; here they are sorted by start."""
+    intervals = np.asarray(intervals)
+    starts, ends = intervals[0].astype(np.int64), intervals[1].astype(np.int64)
+    hi = int(max(ends.max(), starts.max()) // window + 2) if len(starts) else 1
+    bin_start = np.arange(0, hi * window, window, dtype=np.int64)
+    _, idx = engine.ideal_overlaps([0], [0, len(starts)], starts, ends, window, np.zeros(len(bin_start), np.int32), bin_start)
+    return [(chrom, int(bin_start[i]), int(bin_start[i]) + int(window)) for i in idx]
+
+
+def get_elt_ideal_overlaps(chrom, start, end, window):
+    """genic_driver_tools.py:289-297"""
+    return [(int(c), s, e) for c, s, e in get_ideal_overlaps(chrom, np.array([[start], [end]]), window)]
+
+
+# ---------------------------------------------------------------------------------------------
+# cohort tables
+# ---------------------------------------------------------------------------------------------
+class RegionTables:
+    """region_params of one or more cohorts as dense [N, C] tables on a common, (chrom, start)-sorted bin grid."""
+
+    def __init__(self, frames):
+        base = frames[0].sort_values(['CHROM', 'START'])
+        self.chrom = base.CHROM.values.astype(np.int32)
+        self.start = base.START.values.astype(np.int64)
+        self.window = int(base.END.values[0] - base.START.values[0])     # genic_driver_tools.py:308
+        cols = {k: [] for k in ('Y_PRED', 'STD', 'Y_TRUE', 'FLAG')}
+        for f in frames:
+            f = f.sort_values(['CHROM', 'START'])
+            if not (np.array_equal(f.CHROM.values, base.CHROM.values) and np.array_equal(f.START.values, base.START.values)):
+                raise ValueError("all cohorts must share one bin grid")
+            for k in cols:
+                cols[k].append(f[k].values)
+        self.mu = np.ascontiguousarray(np.stack(cols['Y_PRED'], axis=1), np.float64)
+        self.std = np.ascontiguousarray(np.stack(cols['STD'], axis=1), np.float64)
+        self.y = np.ascontiguousarray(np.stack(cols['Y_TRUE'], axis=1), np.int32)
+        self.flag = np.ascontiguousarray(np.stack(cols['FLAG'], axis=1).astype(bool), np.uint8)
+
+    def aligned_context(self, si_index, si_values):
+        """Rows of full_window_si_values re-ordered to this bin grid (a bin without context row is an error)."""
+        key = {(int(c), int(s)): i for i, (c, s) in enumerate(zip(si_index[:, 0], si_index[:, 1]))}
+        try:
+            rows = [key[(int(c), int(s))] for c, s in zip(self.chrom, self.start)]
+        except KeyError as exc:
+            raise KeyError("bin chr%s:%s of region_params has no context counts" % exc.args[0]) from exc
+        return np.ascontiguousarray(si_values[rows], np.int32)
+
+
+def sorted_d_pr(df_seq):
+    """FREQ re-indexed by the sorted 'XYZ>XaZ' string (genic_driver_tools.py:321-325)."""
+    names = [c + '>' + c[0] + m[2] + c[2] for m, c in zip(df_seq.MUT_TYPE, df_seq.CONTEXT)]
+    order = np.argsort(np.array(names), kind="stable")
+    return np.asarray(df_seq.FREQ.values, np.float64)[order]
+
+
+def _load_cohorts(f_pretrained, key='region_params'):
+    files = [f_pretrained] if isinstance(f_pretrained, (str, bytes)) or hasattr(f_pretrained, "__fspath__") else list(f_pretrained)
+    tables = RegionTables([mapfile.read_frame(f, key) for f in files])
+    d_pr = np.stack([sorted_d_pr(mapfile.read_frame(f, 'sequence_model_192')) for f in files])
+    return files, tables, d_pr
+
+
+def _element_set(f_data, window, save_key, names=None):
+    base = 'window_{}/{}/'.format(window, save_key)
+    all_names = mapfile.read_array(f_data, base + 'names').astype(str)
+    sel = np.arange(len(all_names))
+    if names is not None:
+        pos = {n: i for i, n in enumerate(all_names)}
+        sel = np.array([pos[n] for n in names], dtype=np.int64)
+    blk_ptr = mapfile.read_array(f_data, base + 'blk_ptr').astype(np.int64)
+    bs = mapfile.read_array(f_data, base + 'blk_start').astype(np.int64)
+    be = mapfile.read_array(f_data, base + 'blk_end').astype(np.int64)
+    cnt = (blk_ptr[1:] - blk_ptr[:-1])[sel]
+    new_ptr = np.concatenate([[0], np.cumsum(cnt)])
+    take = np.concatenate([np.arange(blk_ptr[i], blk_ptr[i + 1]) for i in sel]) if len(sel) else np.zeros(0, np.int64)
+    strand = mapfile.read_array(f_data, base + 'strand').astype(str)[sel]
+    L = mapfile.read_array(f_data, base + 'L')[sel]
+    if L.ndim == 2:
+        L = L[:, None, :]
+    return dict(names=all_names[sel], chrom=mapfile.read_array(f_data, base + 'chrom')[sel].astype(np.int32),
+                strand_minus=np.isin(strand, ['-', '-1']).astype(np.uint8), blk_ptr=new_ptr, blk_start=bs[take],
+                blk_end=be[take], L=np.ascontiguousarray(L, np.int32))
+
+
+def _accumulate(tables, d_pr, f_data, elts, gene_length=None):
+    w = tables.window
+    si_index = mapfile.read_array(f_data, 'window_{}/full_window_si_index'.format(w))
+    si_values = mapfile.read_array(f_data, 'window_{}/full_window_si_values'.format(w))
+    ctx = tables.aligned_context(si_index, si_values)
+    ov_ptr, ov_idx = engine.ideal_overlaps(elts['chrom'], elts['blk_ptr'], elts['blk_start'], elts['blk_end'], w,
+                                           tables.chrom, tables.start)
+    return engine.accumulate_elements(tables.mu, tables.std, tables.y, tables.flag, ctx, ov_ptr, ov_idx, elts['L'],
+                                      elts['strand_minus'], d_pr, gene_length=gene_length)
+
+
+def _nonc_frame(names, acc, c, acc_indel=None):
+    ind = acc if acc_indel is None else acc_indel
+    return pd.DataFrame({
+        'ELT': names, 'ELT_SIZE': acc['ELT_SIZE'], 'FLAG': acc['FLAG'][:, c].astype(bool), 'R_SIZE': acc['R_SIZE'],
+        'R_OBS': acc['R_OBS'][:, c], 'R_INDEL': ind['R_OBS'][:, c], 'MU': acc['MU'][:, c], 'SIGMA': acc['SIGMA'][:, c],
+        'MU_INDEL': ind['MU'][:, c], 'SIGMA_INDEL': ind['SIGMA'][:, c], 'P_SUM': acc['P'][:, 0, c],
+        'P_INDEL': acc['P_INDEL']})
+
+
+# ---------------------------------------------------------------------------------------------
+# nonc / tiled / genic models
+# ---------------------------------------------------------------------------------------------
+def nonc_model(elt_lst, f_pretrained, f_nonc_data, save_key, indels_direct):
+    """genic_driver_tools.py:300-431.  `f_pretrained` may be one map or a list of maps (cohorts): one frame is
+    returned for a single map, a list of frames (one per cohort, one launch for all of them) for a list."""
+    files, tables, d_pr = _load_cohorts(f_pretrained)
+    elts = _element_set(f_nonc_data, tables.window, save_key, names=list(elt_lst))
+    acc = _accumulate(tables, d_pr, f_nonc_data, elts)
+    acc_ind = None
+    if indels_direct:
+        _, t_ind, _ = _load_cohorts(f_pretrained, key='region_params_indels')
+        acc_ind = _accumulate(t_ind, d_pr, f_nonc_data, elts)
+    frames = [_nonc_frame(elts['names'], acc, c, acc_ind) for c in range(len(files))]
+    return frames[0] if isinstance(f_pretrained, (str, bytes)) or hasattr(f_pretrained, "__fspath__") else frames
+
+
+def nonc_model_parallel(f_pretrained, f_nonc_data, nonc_L_key, N_procs, indels_direct=False):
+    """genic_driver_tools.py:434-463.  N_procs is accepted for interface compatibility; the GPU needs no pool."""
+    first = f_pretrained if isinstance(f_pretrained, (str, bytes)) else list(f_pretrained)[0]
+    idx = mapfile.read_array(first, 'idx')
+    window = int(idx[0, 2] - idx[0, 1])
+    names = mapfile.read_array(f_nonc_data, 'window_{}/{}/names'.format(window, nonc_L_key)).astype(str)
+    return nonc_model(list(names), f_pretrained, f_nonc_data, nonc_L_key, indels_direct)
+
+
+def tiled_nonc_model(elt_lst, f_pretrained, f_nonc_data, save_key):
+    """genic_driver_tools.py:599-690: one-bin-per-element tiles named 'chr{c}:{s}-{e}'; L comes from the table
+    '{save_key}/L_counts' (rows = tiles).  Returned ELT names are 'region_{c}_{s}_{e}' (:666)."""
+    files, tables, d_pr = _load_cohorts(f_pretrained)
+    w = tables.window
+    L_table = mapfile.read_frame(f_nonc_data, "{}/L_counts".format(save_key))
+    elt_lst = list(elt_lst)
+    L = np.ascontiguousarray(L_table.loc[elt_lst].values, np.int32)[:, None, :]
+    chrom = np.array([int(e.split(":")[0].lstrip("chr")) for e in elt_lst], np.int32)
+    start = np.array([int(e.split(":")[1].split("-")[0]) for e in elt_lst], np.int64)
+    region_start = (start // 10000) * 10000                   # hard-coded 10 kb in the reference (:634)
+    n = len(elt_lst)
+    elts = dict(names=np.array(elt_lst), chrom=chrom, strand_minus=np.zeros(n, np.uint8), blk_ptr=np.arange(n + 1),
+                blk_start=region_start, blk_end=region_start + w, L=L)
+    acc = _accumulate(tables, d_pr, f_nonc_data, elts)
+    out_names = [_index_transform(e) for e in elt_lst]
+    frames = [_nonc_frame(out_names, acc, c) for c in range(len(files))]
+    return frames[0] if isinstance(f_pretrained, (str, bytes)) else frames
+
+
+def tiled_model_parallel(f_pretrained, f_nonc_data, save_key, N_procs):
+    """genic_driver_tools.py:692-719"""
+    elt_table = mapfile.read_frame(f_nonc_data, "{}/L_counts".format(save_key))
+    return tiled_nonc_model(list(elt_table.index), f_pretrained, f_nonc_data, save_key)
+
+
+def genic_model(genes_lst, f_pretrained_str, f_genic_str, counts_key, indels_direct):
+    """genic_driver_tools.py:31-203: four mutation classes per gene (L_data rows: silent, missense, nonsense,
+    splice).  Genes on X/Y are skipped (:90-92).  The gene container holds, under window_{w}/genes/, the same
+    arrays as an element set with L of shape [G, 4, 192]; GENE_LENGTH = sum(end - start + 1) over CDS blocks (:158).
+    `counts_key` is accepted for interface compatibility: the per-gene region counts it names in the reference
+    are the sum of the overlapped bins' context rows, which is what the kernel recomputes."""
+    files, tables, d_pr = _load_cohorts(f_pretrained_str)
+    w = tables.window
+    base = 'window_{}/genes/'.format(w)
+    chrom_str = mapfile.read_array(f_genic_str, base + 'chrom_str').astype(str)
+    all_names = mapfile.read_array(f_genic_str, base + 'names').astype(str)
+    pos = {n: i for i, n in enumerate(all_names)}
+    keep = [g for g in genes_lst if chrom_str[pos[g]] not in ('X', 'Y')]
+    elts = _element_set(f_genic_str, w, 'genes', names=keep)
+    nblk = np.diff(elts['blk_ptr'])
+    owner = np.repeat(np.arange(len(keep)), nblk)
+    glen = np.zeros(len(keep), np.int64)
+    np.add.at(glen, owner, elts['blk_end'] - elts['blk_start'] + 1)
+    acc = _accumulate(tables, d_pr, f_genic_str, elts, gene_length=glen.astype(np.int32))
+    acc_ind = None
+    if indels_direct:
+        _, t_ind, _ = _load_cohorts(f_pretrained_str, key='region_params_indels')
+        acc_ind = _accumulate(t_ind, d_pr, f_genic_str, elts, gene_length=glen.astype(np.int32))
+    frames = []
+    for c in range(len(files)):
+        ind = acc if acc_ind is None else acc_ind
+        P = acc['P'][:, :, c]
+        frames.append(pd.DataFrame({
+            'CHROM': [chrom_str[pos[g]] for g in keep], 'GENE': keep, 'GENE_LENGTH': glen, 'R_SIZE': acc['R_SIZE'],
+            'R_OBS': acc['R_OBS'][:, c], 'R_INDEL': ind['R_OBS'][:, c], 'MU': acc['MU'][:, c], 'SIGMA': acc['SIGMA'][:, c],
+            'MU_INDEL': ind['MU'][:, c], 'SIGMA_INDEL': ind['SIGMA'][:, c], 'FLAG': acc['FLAG'][:, c].astype(bool),
+            'P_MIS': P[:, 1], 'P_NONS': P[:, 2], 'P_SILENT': P[:, 0], 'P_SPLICE': P[:, 3], 'P_TRUNC': P[:, 2] + P[:, 3],
+            'P_INDEL': acc['P_INDEL']}))
+    return frames[0] if isinstance(f_pretrained_str, (str, bytes)) else frames
+
+
+def genic_model_parallel(f_pretrained_str, f_genic_str, N_procs, counts_key="window_10kb/counts", indels_direct=False):
+    """genic_driver_tools.py:206-227"""
+    first = f_pretrained_str if isinstance(f_pretrained_str, (str, bytes)) else list(f_pretrained_str)[0]
+    idx = mapfile.read_array(first, 'idx')
+    window = int(idx[0, 2] - idx[0, 1])
+    names = mapfile.read_array(f_genic_str, 'window_{}/genes/names'.format(window)).astype(str)
+    return genic_model(list(names), f_pretrained_str, f_genic_str, counts_key, indels_direct)
+
+
+def get_region_params_direct(df, overlaps, window):
+    """genic_driver_tools.py:258-272 for one element on a region_params frame (host convenience; the batched
+    path is dig_accumulate_elements)."""
+    rows = [trip_to_str(r) for r in overlaps]
+    sub = df.loc[rows]
+    mu, var, robs, flag = 0, 0, 0, False
+    for yp, sd, yt, fl in zip(sub.Y_PRED.values, sub.STD.values, sub.Y_TRUE.values, sub.FLAG.values):
+        mu += yp
+        var += sd ** 2
+        robs += yt
+        flag = bool(flag) | bool(fl)
+    return mu, np.sqrt(var), robs, flag
+
+
+def get_region_params(df, chrom, intervals, window):
+    """genic_driver_tools.py:235-251"""
+    return get_region_params_direct(df, get_ideal_overlaps(chrom, intervals, window), window)

@@ -316,8 +316,8 @@ def gen_gene_stats():
              frame_chrom=frame.CHROM.values.astype(str),
              max_muts_per_sample=np.int64(170), max_muts_per_gene_per_sample=np.int64(3),
              cj=np.float64(cj), t_indel=np.float64(t_indel), null_excluded=np.array(["G1", "G2", "G3"]),
-             cnt_index=np.array(df_cnt.index), cnt_cols=np.array(df_cnt.columns), cnt_vals=df_cnt.values.astype(np.int64),
-             out_index=np.array(df.index), out_cols=np.array(num_cols), out_vals=df[num_cols].values.astype(float))
+             cnt_index=np.array(df_cnt.index).astype(str), cnt_cols=np.array(df_cnt.columns).astype(str), cnt_vals=df_cnt.values.astype(np.int64),
+             out_index=np.array(df.index).astype(str), out_cols=np.array(num_cols).astype(str), out_vals=df[num_cols].values.astype(float))
 
 
 # ----------------------------------------------------------------------------

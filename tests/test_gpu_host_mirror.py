@@ -1,0 +1,183 @@
+"""GPU tests of the host-side mirror of the reference's function-level API (transfer_tools,
+genic_driver_tools) against goldens produced by the reference's own functions."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def _gpu():
+    from digdriver_amd import _lib
+    _lib.require_device()
+
+
+def _build_maps(tmp_path):
+    """Mirror containers equivalent to the in-memory stand-ins make_golden.py fed to the reference."""
+    from digdriver_amd.io import mapfile
+    d = np.load(os.path.join(GOLDEN, "accumulate_golden.npz"))
+    pre = str(tmp_path / "pretrained.map")
+    dat = str(tmp_path / "element_data.map")
+    idx = d["bin_idx"]
+    df_reg = pd.DataFrame(dict(CHROM=idx[:, 0], START=idx[:, 1], END=idx[:, 2], Y_TRUE=d["bin_y_true"],
+                               Y_PRED=d["bin_y_pred"], STD=d["bin_std"], FLAG=d["bin_flag"]),
+                          index=['chr{}:{}-{}'.format(*r) for r in idx])
+    # shuffle rows: the loader must sort the grid itself
+    df_reg = df_reg.sample(frac=1.0, random_state=0)
+    mapfile.write_frame(pre, "region_params", df_reg)
+    mapfile.write_frame(pre, "sequence_model_192", pd.DataFrame(dict(MUT_TYPE=d["seq_mut_type"], CONTEXT=d["seq_context"],
+                                                                      FREQ=d["seq_freq"])))
+    mapfile.write_array(pre, "idx", idx.astype(np.int32))
+    w = int(d["window"])
+    mapfile.write_array(dat, "window_%d/full_window_si_values" % w, d["bin_ctx"])
+    mapfile.write_array(dat, "window_%d/full_window_si_index" % w, idx)
+    bs, be = d["block_starts"], d["block_ends"]
+    nblk = (bs >= 0).sum(axis=1)
+    base = "window_%d/elts/" % w
+    mapfile.write_array(dat, base + "names", d["elt_names"])
+    mapfile.write_array(dat, base + "chrom", d["elt_chrom"])
+    mapfile.write_array(dat, base + "strand", d["elt_strand"])
+    mapfile.write_array(dat, base + "blk_ptr", np.concatenate([[0], np.cumsum(nblk)]))
+    mapfile.write_array(dat, base + "blk_start", bs[bs >= 0])
+    mapfile.write_array(dat, base + "blk_end", be[be >= 0])
+    mapfile.write_array(dat, base + "L", d["elt_L"].astype(np.int32))
+    mapfile.write_frame(dat, "tiles/L_counts", pd.DataFrame(d["tile_L"].astype(np.int32), index=d["tile_names"]))
+    g = np.load(os.path.join(GOLDEN, "genic_golden.npz"))
+    gs, ge = g["cds_starts"], g["cds_ends"]
+    gn = (gs >= 0).sum(axis=1)
+    base = "window_%d/genes/" % w
+    names = np.concatenate([g["gene_names"], ["GENEX"]])
+    mapfile.write_array(dat, base + "names", names)
+    mapfile.write_array(dat, base + "chrom", np.concatenate([g["gene_chrom"], [1]]))
+    mapfile.write_array(dat, base + "chrom_str", np.concatenate([g["gene_chrom"].astype(str), ["X"]]))
+    mapfile.write_array(dat, base + "strand", np.array(["+"] * len(names)))
+    mapfile.write_array(dat, base + "blk_ptr", np.concatenate([[0], np.cumsum(np.concatenate([gn, [1]]))]))
+    mapfile.write_array(dat, base + "blk_start", np.concatenate([gs[gs >= 0], [100]]))
+    mapfile.write_array(dat, base + "blk_end", np.concatenate([ge[ge >= 0], [400]]))
+    mapfile.write_array(dat, base + "L", np.concatenate([g["L_data"], np.zeros((1, 4, 192))]).astype(np.int32))
+    return pre, dat, d, g
+
+
+def _cmp_frame(df, cols, vals, skip=()):
+    for i, c in enumerate(cols):
+        if c in skip:
+            continue
+        got = df[c].values.astype(float)
+        if c in ("ELT_SIZE", "FLAG", "R_SIZE", "R_OBS", "R_INDEL", "GENE_LENGTH"):
+            assert np.array_equal(got, vals[:, i]), c
+        else:
+            rel_close(got, vals[:, i], 1e-11)
+
+
+def test_nonc_tiled_genic_models_match_reference_loops(_gpu, tmp_path):
+    from digdriver_amd.sequence_model import genic_driver_tools as gdt
+    pre, dat, d, g = _build_maps(tmp_path)
+    df = gdt.nonc_model(list(d["elt_names"]), pre, dat, "elts", False)
+    assert list(df.columns) == ['ELT', 'ELT_SIZE', 'FLAG', 'R_SIZE', 'R_OBS', 'R_INDEL', 'MU', 'SIGMA', 'MU_INDEL',
+                                'SIGMA_INDEL', 'P_SUM', 'P_INDEL']      # genic_driver_tools.py:404-417
+    assert list(df.ELT) == list(d["elt_names"])
+    _cmp_frame(df, list(d["out_cols"]), d["out_vals"])
+    # subset + order is respected, parallel wrapper == all elements
+    sub = list(d["elt_names"][[5, 3, 77]])
+    assert list(gdt.nonc_model(sub, pre, dat, "elts", False).ELT) == sub
+    allf = gdt.nonc_model_parallel(pre, dat, "elts", 4)
+    assert allf.equals(df)
+    # two cohorts in one launch == two single launches
+    two = gdt.nonc_model(list(d["elt_names"]), [pre, pre], dat, "elts", False)
+    assert len(two) == 2 and two[0].equals(df) and two[1].equals(df)
+
+    tl = gdt.tiled_nonc_model(list(d["tile_names"]), pre, dat, "tiles")
+    assert list(tl.ELT) == list(d["tile_out_names"])
+    _cmp_frame(tl, list(d["out_cols"]), d["tile_out_vals"])
+
+    gm = gdt.genic_model(list(g["gene_names"]) + ["GENEX"], pre, dat, "window_10kb/counts", False)
+    assert list(gm.GENE) == list(g["out_genes"])                # the X gene is skipped
+    assert list(gm.CHROM) == list(g["out_chrom"])
+    _cmp_frame(gm, list(g["out_cols"]), g["out_vals"])
+
+    ov = gdt.get_ideal_overlaps(4, np.array([[5, 25000, 99990], [500, 31000, 100010]]), 10000)
+    assert ov == [(4, 0, 10000), (4, 20000, 30000), (4, 30000, 40000), (4, 90000, 100000), (4, 100000, 110000)]
+
+
+def test_run_gene_model_matches_reference(_gpu, tmp_path):
+    from digdriver_amd.driver_model import transfer_tools as tt
+    from digdriver_amd.io import mapfile
+    g = np.load(os.path.join(GOLDEN, "gene_stats_golden.npz"))
+    frame = pd.DataFrame(g["frame_vals"], columns=list(g["frame_cols"]))
+    for c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+        frame[c] = frame[c].astype(np.int64)
+    frame.insert(0, "GENE", g["genes"])
+    frame.insert(0, "CHROM", g["frame_chrom"])
+    path = str(tmp_path / "genes.map")
+    mapfile.write_frame(path, "genic_model", frame)
+    df = tt.run_gene_model(os.path.join(GOLDEN, "gene_mutations.tsv"), path,
+                           max_muts_per_sample=int(g["max_muts_per_sample"]),
+                           max_muts_per_gene_per_sample=int(g["max_muts_per_gene_per_sample"]),
+                           all_cosmic=list(g["null_excluded"]))
+    assert list(df.index) == list(g["out_index"])
+    cols = list(g["out_cols"])
+    assert [c for c in df.columns if c != "CHROM"] == cols          # same columns, same order as the reference
+    vals = g["out_vals"]
+    for i, c in enumerate(cols):
+        got = df[c].values.astype(float)
+        if c.startswith(("OBS_", "N_SAMP_")) or c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+            assert np.array_equal(got, vals[:, i]), c                # integer columns: bit-exact
+        else:
+            rel_close(got, vals[:, i], 1e-6)
+
+
+def test_run_element_region_model_end_to_end(_gpu, tmp_path):
+    """DigDriver.py elementDriver path on a synthetic cohort: TSV + bed12 + map -> results frame; fused and
+    column-by-column routes agree bit for bit and match the oracle on the tabulated counts."""
+    from bench import make_workload
+    from digdriver_amd.driver_model import transfer_tools as tt
+    from digdriver_amd.io import mapfile
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(4)
+    E = 300
+    names = ["elt%03d" % i for i in range(E)]
+    starts = np.sort(rng.integers(1000, 900000, E))
+    sizes = rng.integers(200, 1500, E)
+    chrom = rng.integers(1, 5, E)
+    bed = tmp_path / "e.bed"
+    with open(bed, "w") as f:
+        for n, c, s, z in zip(names, chrom, starts, sizes):
+            f.write("%d\t%d\t%d\t%s\t0\t+\t%d\t%d\t.\t1\t%d,\t0,\n" % (c, s, s + z, n, s, s, z))
+    mu = rng.gamma(9.0, 3.0, E)
+    sigma = rng.gamma(4.0, 1.0, E)
+    pi = sizes / 10000.0
+    frame = pd.DataFrame(dict(ELT=names, ELT_SIZE=sizes, FLAG=rng.integers(0, 2, E).astype(bool), R_SIZE=10000,
+                              R_OBS=rng.poisson(mu), R_INDEL=rng.poisson(mu), MU=mu, SIGMA=sigma, MU_INDEL=mu,
+                              SIGMA_INDEL=sigma, P_SUM=pi, P_INDEL=pi))
+    path = str(tmp_path / "cohort.map")
+    mapfile.write_frame(path, "my_elts", frame)
+    rows = []
+    for n, c, s, z, m in zip(names, chrom, starts, sizes, mu * pi * 1.3):
+        for _ in range(rng.poisson(m)):
+            p = int(s + rng.integers(0, z))
+            rows.append((str(c), p, p + 1, "A", "T", "S%d" % rng.integers(0, 40), ".", "Noncoding", "A>T", "CAG"))
+        for _ in range(rng.poisson(m * 0.1)):
+            p = int(s + rng.integers(0, z))
+            rows.append((str(c), p, p + 3, "AGG", "A", "S%d" % rng.integers(0, 40), ".", "INDEL", "DEL", "."))
+    mut = tmp_path / "m.tsv"
+    pd.DataFrame(rows).to_csv(mut, sep="\t", header=False, index=False)
+    a = tt.run_element_region_model(str(mut), str(bed), path, "my_elts", scale_factor=1.3, scale_factor_indel=0.13,
+                                    scale_by_expectation=False)
+    b = tt.run_element_region_model(str(mut), str(bed), path, "my_elts", scale_factor=1.3, scale_factor_indel=0.13,
+                                    scale_by_expectation=False, fused=True)
+    assert list(a.columns) == list(b.columns)
+    for c in a.columns:
+        assert np.array_equal(a[c].values, b[c].values, equal_nan=True), c
+    # THETA_INDEL is updated in place; the appended columns and their order are the reference's
+    assert list(a.columns)[-9:] == ['OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL', 'EXP_SNV', 'PVAL_SNV_BURDEN',
+                                   'PVAL_SAMPLE_BURDEN', 'EXP_INDEL', 'PVAL_INDEL_BURDEN', 'PVAL_MUT_BURDEN']
+    want = O.element_stats(mu, sigma, pi, pi, a.OBS_SNV.values, a.OBS_SAMPLES.values, a.OBS_INDEL.values, 1.3, 0.13)
+    for c in ('EXP_SNV', 'PVAL_SNV_BURDEN', 'PVAL_SAMPLE_BURDEN', 'THETA_INDEL', 'EXP_INDEL', 'PVAL_INDEL_BURDEN',
+              'PVAL_MUT_BURDEN'):
+        rel_close(a[c].values, want[c], 1e-6)
+    assert a.OBS_SNV.sum() > 0 and a.OBS_INDEL.sum() > 0 and (a.OBS_SAMPLES <= a.OBS_SNV + a.OBS_INDEL).all()

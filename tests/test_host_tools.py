@@ -1,0 +1,124 @@
+"""CPU-only tests of the host-side mirror: mutation-file reader, integer tabulation (the interval join that
+replaces `bedtools intersect`), the map-file container.  Integer outputs must be bit-exact against the
+goldens produced by the reference (tests/golden/mutation_tools_golden.json)."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+from digdriver_amd.data_tools import mutation_tools as mt
+from digdriver_amd.io import mapfile
+
+
+def test_read_mutation_file_and_counts_match_reference():
+    g = json.load(open(os.path.join(GOLDEN, "mutation_tools_golden.json")))
+    path = os.path.join(GOLDEN, "mutations_small.tsv")
+    rd = mt.read_mutation_file(path, drop_sex=True, drop_duplicates=True, unique_indels=True)
+    rd2 = mt.read_mutation_file(path, drop_sex=True, drop_duplicates=False, unique_indels=True)
+    assert len(rd) == g["n_read_dedup"] and len(rd2) == g["n_read_nodedup"]
+    assert rd.astype(str).values.tolist()[:50] == g["read_dedup_rows"]
+    chk = int(pd.util.hash_pandas_object(rd.reset_index(drop=True).astype(str), index=False).sum() % (2 ** 61))
+    assert chk == g["read_dedup_checksum"]
+    filt, black = mt.filter_hypermut_samples(rd2, 95, return_blacklist=True)
+    assert sorted(black) == g["blacklist"] and len(filt) == g["n_filtered"]
+    cnt = mt.mutations_per_gene(rd2[rd2.GENE != '.'], max_muts_per_gene_per_sample=2)
+    assert list(cnt.index) == g["cnt_index"]
+    assert sorted(cnt.columns) == sorted(g["cnt_cols"])
+    assert np.array_equal(cnt[g["cnt_cols"]].values, np.array(g["cnt_vals"]))
+
+
+def test_bed12_boundaries_matches_reference():
+    g = json.load(open(os.path.join(GOLDEN, "mutation_tools_golden.json")))["bed12"]
+    bb = mt.bed12_boundaries(os.path.join(GOLDEN, "elements_small.bed"))
+    assert [int(c) for c in bb.CHROM] == g["CHROM"] and list(bb.ELT) == g["ELT"] and list(bb.STRAND) == g["STRAND"]
+    assert [list(map(int, x)) for x in bb.BLOCK_STARTS] == g["BLOCK_STARTS"]
+    assert [list(map(int, x)) for x in bb.BLOCK_ENDS] == g["BLOCK_ENDS"]
+
+
+def _brute_pairs(mc, ms, me, bc, bs, be):
+    out = []
+    for i in range(len(mc)):
+        for j in range(len(bc)):
+            if str(mc[i]) == str(bc[j]) and ms[i] < be[j] and bs[j] < me[i]:
+                out.append((i, j))
+    return out
+
+
+def test_interval_join_against_brute_force():
+    rng = np.random.default_rng(1)
+    for trial in range(5):
+        nb, nm = 60, 400
+        bc = rng.integers(1, 4, nb).astype(str)
+        bs = rng.integers(0, 5000, nb)
+        be = bs + rng.integers(1, 800, nb)          # overlapping and nested blocks included
+        mc = rng.integers(1, 5, nm).astype(str)
+        ms = rng.integers(0, 6000, nm)
+        me = ms + rng.integers(1, 4, nm)
+        mi, bi = mt._overlap_pairs(mc, ms, me, bc, bs, be)
+        assert sorted(zip(mi.tolist(), bi.tolist())) == sorted(_brute_pairs(mc, ms, me, bc, bs, be))
+    # boundaries: half-open on both sides
+    mi, bi = mt._overlap_pairs(["1"] * 4, [99, 100, 199, 200], [100, 101, 200, 201], ["1"], [100], [200])
+    assert mi.tolist() == [1, 2]
+
+
+def test_tabulation_integer_semantics(tmp_path):
+    # two elements; E1 has two blocks; S1 hits E1 three times (one a duplicated annotation row), S2 once + an indel
+    bed = tmp_path / "e.bed"
+    bed.write_text("1\t100\t400\tE1\t0\t+\t100\t100\t.\t2\t50,100,\t0,200,\n"
+                   "2\t1000\t1100\tE2\t0\t-\t1000\t1000\t.\t1\t100,\t0,\n")
+    rows = [
+        ("1", 110, 111, "A", "T", "S1", "G1", "Noncoding", "A>T", "CAG"),
+        ("1", 110, 111, "A", "T", "S1", "G2", "Noncoding", "A>T", "CAG"),     # same mutation, second gene annotation
+        ("1", 320, 321, "C", "G", "S1", "G1", "Noncoding", "C>G", "ACT"),
+        ("1", 160, 161, "C", "G", "S1", "G1", "Noncoding", "C>G", "ACT"),     # between the blocks: no hit
+        ("1", 399, 400, "C", "G", "S2", "G1", "Noncoding", "C>G", "ACT"),
+        ("1", 300, 305, "CAAAA", "C", "S2", "G1", "INDEL", "DEL", "."),
+        ("2", 1099, 1100, "G", "A", "S3", ".", "Noncoding", "G>A", "AGT"),
+        ("2", 1100, 1101, "G", "A", "S3", ".", "Noncoding", "G>A", "AGT"),     # END of block is exclusive
+        ("X", 5, 6, "G", "A", "S3", ".", "Noncoding", "G>A", "AGT"),
+    ]
+    mut = tmp_path / "m.tsv"
+    pd.DataFrame(rows).to_csv(mut, sep="\t", header=False, index=False)
+    tab, black = mt.tabulate_mutations_in_element(str(mut), str(bed), bed12=True, drop_duplicates=True,
+                                                  return_blacklist=True)
+    assert tab.loc["E1"].tolist() == [2, 3, 1]      # OBS_SAMPLES, OBS_SNV, OBS_INDEL
+    assert tab.loc["E2"].tolist() == [1, 1, 0]
+    assert len(black) == 0
+    # without de-duplication the doubly annotated SNV counts twice
+    tab2 = mt.tabulate_mutations_in_element(str(mut), str(bed), bed12=True, drop_duplicates=False)
+    assert tab2.loc["E1", "OBS_SNV"] == 4
+    # hypermutator blacklist and per-element cap
+    tab3, black3 = mt.tabulate_mutations_in_element(str(mut), str(bed), bed12=True, drop_duplicates=True,
+                                                    max_muts_per_sample=1, max_muts_per_elt_per_sample=1,
+                                                    return_blacklist=True)
+    assert sorted(black3) == ["S1", "S2"] and "E1" not in tab3.index and tab3.loc["E2", "OBS_SNV"] == 1
+    # all_elements adds zero rows
+    tab4 = mt.tabulate_mutations_in_element(str(mut), str(bed), bed12=True, drop_duplicates=True, all_elements=True,
+                                            max_muts_per_sample=1)
+    assert tab4.loc["E1"].tolist() == [0, 0, 0]
+    # empty intersection
+    mut2 = tmp_path / "m2.tsv"
+    pd.DataFrame(rows[-1:]).to_csv(mut2, sep="\t", header=False, index=False)
+    tab5 = mt.tabulate_mutations_in_element(str(mut2), str(bed), bed12=True)
+    assert len(tab5) == 0 and list(tab5.columns) == ['OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL']
+
+
+def test_mapfile_directory_roundtrip(tmp_path):
+    path = str(tmp_path / "cohort.map")
+    df = pd.DataFrame({"CHROM": [1, 1, 2], "START": [0, 10000, 0], "END": [10000, 20000, 10000],
+                       "Y_PRED": [1.5, 2.5, 3.5], "FLAG": [False, True, False], "NAME": ["a", "b", "c"]},
+                      index=["chr1:0-10000", "chr1:10000-20000", "chr2:0-10000"])
+    mapfile.write_frame(path, "region_params", df)
+    mapfile.write_array(path, "idx", df[["CHROM", "START", "END"]].values.astype(np.int32))
+    mapfile.write_attrs(path, cohort_name="X", N_SAMPLES=np.int64(12))
+    back = mapfile.read_frame(path, "region_params")
+    assert list(back.columns) == list(df.columns) and list(back.index) == list(df.index)
+    assert back.FLAG.dtype == bool and np.array_equal(back.Y_PRED.values, df.Y_PRED.values)
+    assert mapfile.read_array(path, "idx").dtype == np.int32
+    assert mapfile.read_attrs(path) == {"cohort_name": "X", "N_SAMPLES": 12}
+    assert mapfile.has_key(path, "region_params") and not mapfile.has_key(path, "nope")
+    with pytest.raises(KeyError):
+        mapfile.read_frame(path, "nope")
