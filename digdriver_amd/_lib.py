@@ -72,6 +72,13 @@ def load():
         raise DigHipError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C digdriver_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; if ours were the first HIP runtime in the process, torch
+    # could no longer initialise its device layer (torch.cuda.is_available() -> False).  Import torch first
+    # so both use the runtime torch was built against.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:
