@@ -162,7 +162,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from digdriver_amd import _lib, engine
+    from digdriver_amd import _lib, engine, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,21 +185,16 @@ def main():
     td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
-    part_buf = torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous()
+    exp_sum = torch.zeros_like(td["n_snv_obs"])
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     k_acc, k_stat = [], []
 
     def step(timed):
-        # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156)
-        engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part_buf[0])
-        part = part_buf                                                                             # [3, C]
-        if world > 1:
-            gathered = [torch.empty_like(part) for _ in range(world)]
-            dist.all_gather(gathered, part)          # RCCL over xGMI; 3*C doubles per rank
-            part = torch.stack(gathered).sum(dim=0)  # fixed rank order -> bit-reproducible
-        cj = part[1] / part[0]     # cj = N_SNV_OBS / sum(Y_PRED[~FLAG])
-        cji = part[2] / part[0]    # cj_indel = N_IND_OBS / sum(Y_PRED[~FLAG])
+        # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
+        #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors
+        engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=exp_sum)
+        cj, cji = parallel.scale_factors(exp_sum, td["n_snv_obs"], td["n_ind_obs"])
         e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
         if timed:
             e0.record()

@@ -1,0 +1,82 @@
+"""Bin selection for the region model: mappability / count-quantile filters and k-fold splits.
+
+Mirror of the index logic in DIGDriver/region_model/data_aux/dataset_generator.py (BaseDatasetGenerator
+:16-50, KFoldDatasetGenerator :189-273) and of the per-bin gather of mut_dataset.py:76-81.  The reference
+re-opens the HDF5 file for every sample inside 16 DataLoader workers; here the whole bin x position x track
+matrix is resident in HBM (fp32 or int16: values are round(x, 2) * 100, DataExtractor.py:220) and a batch is
+one dig_gather_bins launch that also emits the channels-first layout conv1d consumes.
+"""
+import re
+
+import numpy as np
+
+from ... import engine
+
+
+def rank_quantiles(labels):
+    """stats.mstats.rankdata(labels) / len(labels) (dataset_generator.py:27): average ranks for ties."""
+    labels = np.asarray(labels)
+    order = np.argsort(labels, kind="mergesort")
+    ranks = np.empty(len(labels), float)
+    sorted_l = labels[order]
+    # average rank over runs of equal values
+    boundaries = np.flatnonzero(np.concatenate([[True], sorted_l[1:] != sorted_l[:-1], [True]]))
+    for a, b in zip(boundaries[:-1], boundaries[1:]):
+        ranks[order[a:b]] = 0.5 * (a + 1 + b)
+    return ranks / len(labels)
+
+
+def select_bins(mappability, labels, mapp_thresh, count_quantile):
+    """dataset_generator.py:28-42: keep bins with mappability >= threshold and count <= quantile(cq).
+    Returns (idxs, below_mapp) exactly as the reference defines them."""
+    mappability, labels = np.asarray(mappability), np.asarray(labels)
+    low_map = mappability < mapp_thresh
+    high_count = labels > np.quantile(labels, count_quantile)
+    return np.where(~low_map & ~high_count)[0], np.where(low_map | high_count)[0]
+
+
+def load_track_selection(lines):
+    """Track-selection grammar of dataset_generator.py:57-80: one integer or a half-open range 'a:b' per line;
+    blank lines and '#' comments are skipped; anything else is an error."""
+    tracks = []
+    for i, raw in enumerate(lines):
+        if raw.startswith(('\n', '#')) or raw == "":
+            continue
+        tok = raw.rstrip()
+        if re.search(r'[^:0-9]', tok):
+            raise ValueError('Expected track selection lines to contain only digits and colons. Found: {} in line #{}.'.format(tok, i))
+        parts = tok.split(':')
+        if len(parts) > 2 or not all(p.isdigit() for p in parts):
+            raise ValueError('Expected one integer or one "a:b" pair. Found: {} in line #{}.'.format(tok, i))
+        if len(parts) == 1:
+            tracks.append(int(parts[0]))
+        else:
+            a, b = int(parts[0]), int(parts[1])
+            if not a < b:
+                raise ValueError('Expected x < y in pair x:y. Found: {} in line #{}.'.format(tok, i))
+            tracks.extend(range(a, b))
+    return tracks
+
+
+def split_folds(idxs, k, seed=None):
+    """dataset_generator.py:208-213: shuffle, then k contiguous folds.  The reference's shuffle is unseeded
+    (fold membership is not reproducible there); here the seed is explicit."""
+    idxs = np.array(idxs)
+    np.random.default_rng(seed).shuffle(idxs)
+    return np.array_split(idxs, k)
+
+
+class BinTrackStore:
+    """x_data [N, L, T] resident on the GPU (torch tensor, fp32 / fp64 / int16) + batch gather."""
+
+    def __init__(self, x_data, selected_tracks=None):
+        self.x = x_data
+        self.n_bins, self.length, self.n_tracks_total = x_data.shape
+        self.tracks = np.arange(self.n_tracks_total) if selected_tracks is None else np.asarray(selected_tracks)
+
+    def shape(self, n):
+        return (n, self.length, len(self.tracks))
+
+    def batch(self, bin_rows, channels_first=True, out_dtype="f32"):
+        """x_data[bin_rows, :, tracks] (mut_dataset.py:76-81) for a batch, optionally as [B, T, L]."""
+        return engine.gather_bins(self.x, bin_rows, self.tracks, out_dtype=out_dtype, transpose=channels_first)

@@ -1,0 +1,122 @@
+"""1-D ResNet regressor over (positions x epigenomic tracks) bins -- the region model's CNN.
+
+Mirror of SimpleMultiTaskResNet (DIGDriver/region_model/nets/cnn_predictors.py:77-171): same layer
+names, shapes and registration order (so a reference ``state_dict`` loads unchanged and seeded
+initialisation reproduces the reference's weights), same ``forward`` contract
+
+    model(x[B, L, T]) -> (outputs: list of C tensors [B], feature_vecs: list of C tensors [B, 16], None)
+
+The dense conv1d / linear layers stay in PyTorch-ROCm (MIOpen / hipBLASLt on the MFMA units), per the
+north star.  MI355X-first additions:
+  * ``forward_channels_first`` takes the [B, T, L] layout produced directly by dig_gather_bins
+    (transpose fused into the gather, no extra pass over the batch);
+  * ``fold_batchnorm()`` returns an inference copy with every BatchNorm folded into the preceding
+    convolution (eval-mode BN is an affine map), halving the elementwise traffic between convs;
+  * the C task heads are evaluated as three batched matmuls instead of 3*C small linears.
+"""
+import copy
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+# (name, in_channels or None = input tracks, out_channels, kernel, padding, stride)
+_CONV_SPEC = [
+    ("11", None, 128, 5, 1, 1), ("12", 128, 256, 3, 1, 2),
+    ("21", 256, 256, 3, 1, 1), ("22", 256, 256, 3, 1, 1),
+    ("3", 256, 512, 3, 1, 2),
+    ("41", 512, 512, 3, 1, 1), ("42", 512, 512, 3, 1, 1),
+    ("5", 512, 1024, 3, 1, 2),
+    ("61", 1024, 1024, 3, 1, 1), ("62", 1024, 1024, 3, 1, 1),
+]
+_FLAT = 1024 * 13          # cnn_predictors.py:126,160: L = 100 -> 98 -> 49 -> 25 -> 13 positions
+
+
+class SimpleMultiTaskResNet(nn.Module):
+    def __init__(self, shape, task_num, get_attention_maps=False):
+        super().__init__()
+        self.get_attention_maps = get_attention_maps
+        self.inp_len, self.inp_size, self.task_num = shape[1], shape[2], task_num
+        self.hidden_dim, self.fc2_dim, self.fc3_dim = 128, 128, 16
+        if get_attention_maps:   # cnn_predictors.py:90-94
+            self.att_conv1 = nn.Conv1d(self.inp_size, self.inp_size, kernel_size=5, padding=2, stride=1)
+            self.att_conv2 = nn.Conv1d(self.inp_size, self.inp_size, kernel_size=3, padding=1, stride=1)
+        for name, cin, cout, k, pad, stride in _CONV_SPEC:
+            setattr(self, "conv" + name, nn.Conv1d(cin or self.inp_size, cout, kernel_size=k, padding=pad, stride=stride))
+            setattr(self, "bn" + name, nn.BatchNorm1d(cout))
+        self.fc1_lst, self.fc2_lst, self.fc3_lst = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(task_num):
+            self.fc1_lst.append(nn.Linear(_FLAT, self.fc2_dim))
+            self.fc2_lst.append(nn.Linear(self.fc2_dim, self.fc3_dim))
+            self.fc3_lst.append(nn.Linear(self.fc3_dim, 1))
+        self._folded = False
+
+    # ---- trunk ------------------------------------------------------------------------------
+    def _block(self, x, name):
+        x = getattr(self, "conv" + name)(x)
+        if not self._folded:
+            x = getattr(self, "bn" + name)(x)
+        return F.relu(x)
+
+    def trunk(self, x):
+        """x: [B, T, L] channels-first -> [B, 13312] (cnn_predictors.py:143-160)."""
+        att = None
+        if self.get_attention_maps:
+            att = F.softmax(F.relu(self.att_conv2(F.relu(self.att_conv1(x)))), dim=2)
+            x = x * att
+        x = self._block(self._block(x, "11"), "12")
+        x = self._block(self._block(x, "21"), "22") + x
+        x = self._block(x, "3")
+        x = self._block(self._block(x, "41"), "42") + x
+        x = self._block(x, "5")
+        x = self._block(self._block(x, "61"), "62") + x
+        return x.reshape(-1, _FLAT), att
+
+    # ---- heads ------------------------------------------------------------------------------
+    def heads(self, flat):
+        """All task heads as batched matmuls: [B, 13312] -> outputs [C, B], features [C, B, 16]."""
+        W1 = torch.stack([m.weight for m in self.fc1_lst])          # [C, 128, 13312]
+        b1 = torch.stack([m.bias for m in self.fc1_lst])
+        W2 = torch.stack([m.weight for m in self.fc2_lst])          # [C, 16, 128]
+        b2 = torch.stack([m.bias for m in self.fc2_lst])
+        W3 = torch.stack([m.weight for m in self.fc3_lst])          # [C, 1, 16]
+        b3 = torch.stack([m.bias for m in self.fc3_lst])
+        h1 = F.relu(torch.einsum("bk,cok->cbo", flat, W1) + b1[:, None, :])
+        h2 = F.relu(torch.bmm(h1, W2.transpose(1, 2)) + b2[:, None, :])
+        out = (torch.bmm(h2, W3.transpose(1, 2)) + b3[:, None, :]).squeeze(-1)
+        return out, h2
+
+    def forward_channels_first(self, x):
+        flat, att = self.trunk(x)
+        out, feats = self.heads(flat)
+        outputs = [out[i] for i in range(self.task_num)]
+        feature_vecs = [feats[i] for i in range(self.task_num)]
+        return outputs, feature_vecs, att
+
+    def forward(self, x):
+        """x: [B, L, T] as stored (cnn_predictors.py:130-131 transposes first)."""
+        return self.forward_channels_first(x.transpose(1, 2))
+
+    # ---- inference copy ---------------------------------------------------------------------
+    @torch.no_grad()
+    def fold_batchnorm(self):
+        """Eval-mode copy with BN folded: w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta."""
+        m = copy.deepcopy(self).eval()
+        for name, *_ in _CONV_SPEC:
+            conv, bn = getattr(m, "conv" + name), getattr(m, "bn" + name)
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight.mul_(scale[:, None, None])
+            conv.bias.copy_((conv.bias - bn.running_mean) * scale + bn.bias)
+            setattr(m, "bn" + name, nn.Identity())
+        m._folded = True
+        return m
+
+
+def flops_per_bin(n_tracks, task_num, length=100):
+    """Multiply-add count of one forward pass (x2 for FLOP): used for the MFMA roofline of the CNN."""
+    pos = [98, 49, 49, 49, 25, 25, 25, 13, 13, 13]
+    macs = 0
+    for (name, cin, cout, k, pad, stride), p in zip(_CONV_SPEC, pos):
+        macs += p * (cin or n_tracks) * cout * k
+    macs += task_num * (_FLAT * 128 + 128 * 16 + 16)
+    return 2 * macs

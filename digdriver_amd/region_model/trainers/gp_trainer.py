@@ -1,0 +1,192 @@
+"""Sparse Gaussian-process calibration of the CNN's 16-d features: mean AND standard deviation per bin.
+
+Mirror of GPTrainer / SparseGP (DIGDriver/region_model/trainers/gp_trainer.py:28-204).  The reference builds
+the model from gpytorch (ExactGP + InducingPointKernel(ScaleKernel(RBFKernel)) + GaussianLikelihood) --
+a third-party dependency that is neither vendored nor version-pinned, so there are no golden vectors for
+this row ("parity unpinned").  What is restated here is the published algorithm those classes implement:
+Titsias' SGPR collapsed bound with a constant mean, one shared RBF lengthscale, an output scale, Gaussian
+noise (softplus-parametrised, noise >= 1e-4) and m inducing points initialised to the first m training
+rows and optimised together with the hyper-parameters by Adam(lr = 0.8) for n_iter steps on
+-bound / n; prediction returns the latent mean and standard deviation, de-standardised as
+mean * y_std + y_mean and std * y_std (gp_trainer.py:190-192).
+
+Everything runs in torch on the GPU (float64: the O(n m^2) work is tiny next to the CNN).
+"""
+import math
+
+import numpy as np
+import torch
+
+from ..predict import r2_score
+
+_JITTER = 1e-6
+
+
+def _softplus_inv(v):
+    return math.log(math.expm1(v))
+
+
+class SparseGP(torch.nn.Module):
+    """SGPR with learnable inducing locations."""
+
+    def __init__(self, train_x, train_y, n_inducing=2000):
+        super().__init__()
+        self.train_x, self.train_y = train_x, train_y
+        self.raw_lengthscale = torch.nn.Parameter(torch.zeros((), dtype=train_x.dtype, device=train_x.device))
+        self.raw_outputscale = torch.nn.Parameter(torch.zeros((), dtype=train_x.dtype, device=train_x.device))
+        self.raw_noise = torch.nn.Parameter(torch.zeros((), dtype=train_x.dtype, device=train_x.device))
+        self.mean_const = torch.nn.Parameter(torch.zeros((), dtype=train_x.dtype, device=train_x.device))
+        self.inducing_points = torch.nn.Parameter(train_x[:n_inducing, :].clone())   # gp_trainer.py:39
+
+    lengthscale = property(lambda self: torch.nn.functional.softplus(self.raw_lengthscale))
+    outputscale = property(lambda self: torch.nn.functional.softplus(self.raw_outputscale))
+    noise = property(lambda self: torch.nn.functional.softplus(self.raw_noise) + 1e-4)
+
+    def kernel(self, a, b):
+        d2 = (a * a).sum(-1, keepdim=True) - 2.0 * a @ b.T + (b * b).sum(-1)[None, :]
+        return self.outputscale * torch.exp(-0.5 * d2.clamp_min(0.0) / self.lengthscale ** 2)
+
+    def _factor(self):
+        Z, X = self.inducing_points, self.train_x
+        m = Z.shape[0]
+        Kmm = self.kernel(Z, Z) + _JITTER * self.outputscale.detach() * torch.eye(m, dtype=Z.dtype, device=Z.device)
+        L = torch.linalg.cholesky(Kmm)
+        sig = torch.sqrt(self.noise)
+        A = torch.linalg.solve_triangular(L, self.kernel(Z, X), upper=False) / sig        # [m, n]
+        B = torch.eye(m, dtype=Z.dtype, device=Z.device) + A @ A.T
+        LB = torch.linalg.cholesky(B)
+        r = self.train_y - self.mean_const
+        c = torch.linalg.solve_triangular(LB, (A @ r)[:, None], upper=False)[:, 0] / sig
+        return L, A, LB, r, c
+
+    def neg_bound_per_point(self):
+        """-(collapsed SGPR bound) / n  == the reference's  -mll(model(X), y)  in train mode."""
+        L, A, LB, r, c = self._factor()
+        n = self.train_x.shape[0]
+        s2 = self.noise
+        bound = (-0.5 * n * math.log(2 * math.pi) - torch.log(torch.diagonal(LB)).sum() - 0.5 * n * torch.log(s2)
+                 - 0.5 * (r @ r) / s2 + 0.5 * (c @ c)
+                 - 0.5 * n * self.outputscale / s2 + 0.5 * (A * A).sum())
+        return -bound / n
+
+    @torch.no_grad()
+    def predict(self, x, chunk=65536):
+        L, A, LB, r, c = self._factor()
+        means, stds = [], []
+        for s in range(0, x.shape[0], chunk):
+            xs = x[s:s + chunk]
+            t1 = torch.linalg.solve_triangular(L, self.kernel(self.inducing_points, xs), upper=False)
+            t2 = torch.linalg.solve_triangular(LB, t1, upper=False)
+            means.append(self.mean_const + t2.T @ c)
+            var = self.outputscale - (t1 * t1).sum(0) + (t2 * t2).sum(0)
+            stds.append(torch.sqrt(var.clamp_min(0.0)))
+        return torch.cat(means), torch.cat(stds)
+
+
+class GPTrainer:
+    samp_bound = int(1.5e5)      # gp_trainer.py:55: training-set cap
+
+    def __init__(self, device, train_tup, val_tup, heldout_tup=None, n_iter=50, n_inducing=500, seed=None,
+                 dtype=torch.float64):
+        self.device, self.n_iter, self.n_inducing, self.dtype = device, n_iter, n_inducing, dtype
+        self.org_train_x, self.org_train_y = train_tup[0], train_tup[1]
+        self.org_val_x, self.org_val_y = val_tup[0], val_tup[1]
+        self.train_meta, self.val_meta = train_tup[2:], val_tup[2:]
+        self.train_x, self.train_y, self.scaler, self.y_mean, self.y_std = self.standardize(train_tup[0], train_tup[1])
+        self.val_x, self.val_y, _, _, _ = self.standardize(val_tup[0], val_tup[1], self.scaler, self.y_mean, self.y_std)
+        self.idx_feat = np.where(np.abs(self.train_x).mean(axis=0) > 0)[0]       # gp_trainer.py:79
+        n = self.train_x.shape[0]
+        if n > self.samp_bound:                                                  # :81-86
+            pick = np.random.default_rng(seed).choice(n, size=self.samp_bound, replace=False)
+            self.train_x, self.train_y = self.train_x[pick], self.train_y[pick]
+            print('Reduced train set size from {} to {}, to stay within memory limits'.format(n, self.samp_bound))
+        self.train_x = self.train_x[:, self.idx_feat]
+        self.val_x = self.val_x[:, self.idx_feat]
+        print('After zero features reduction feature vectors are now of size: {}'.format(self.train_x.shape[1]))
+        self.held_x = self.held_y = None
+        if heldout_tup is not None:
+            self.org_ho_x, self.org_ho_y, self.ho_meta = heldout_tup[0], heldout_tup[1], heldout_tup[2:]
+            self.held_x, self.held_y, _, _, _ = self.standardize(heldout_tup[0], heldout_tup[1], self.scaler,
+                                                                 self.y_mean, self.y_std)
+            self.held_x = self.held_x[:, self.idx_feat]
+
+    @staticmethod
+    def standardize(X, Y, scaler=None, y_mean=None, y_std=None):
+        """gp_trainer.py:107-120 (sklearn StandardScaler: population std, zero-variance columns left unscaled)."""
+        X, Y = np.asarray(X, float), np.asarray(Y, float)
+        if scaler is None:
+            mean, std = X.mean(axis=0), X.std(axis=0)
+            std = np.where(std == 0, 1.0, std)
+            scaler = (mean, std)
+        if not y_mean:
+            y_mean, y_std = Y.mean(), Y.std()
+        return (X - scaler[0]) / scaler[1], (Y - y_mean) / y_std, scaler, y_mean, y_std
+
+    def _t(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=self.dtype, device=self.device)
+
+    def train_model(self):
+        model = SparseGP(self._t(self.train_x), self._t(self.train_y), n_inducing=self.n_inducing)
+        opt = torch.optim.Adam(model.parameters(), lr=0.8)                       # gp_trainer.py:129
+        for _ in range(self.n_iter):
+            opt.zero_grad()
+            loss = model.neg_bound_per_point()
+            loss.backward()
+            opt.step()
+        return model
+
+    def predict(self, model, x, y):
+        mean, std = model.predict(self._t(x))
+        y_t = self._t(y)
+        var = std ** 2 + model.noise.detach()
+        nll = 0.5 * (torch.log(2 * math.pi * var) + (y_t - mean) ** 2 / var).mean()
+        return mean.cpu().numpy(), std.cpu().numpy(), float(nll)
+
+    @staticmethod
+    def get_results_dict(mean, std, r2, loss, params):
+        return {'gp_mean': mean, 'gp_std': std, 'r2': r2, 'loss': loss, 'params': params}
+
+    def run(self):
+        """gp_trainer.py:173-204 -> (val_res, hld_res) dicts with keys gp_mean, gp_std, r2, loss, params."""
+        model = self.train_model()
+        params = np.array([model.lengthscale.item(), model.outputscale.item(), model.noise.item()])
+        v_mean, v_std, v_loss = self.predict(model, self.val_x, self.val_y)
+        v_r2 = r2_score(self.val_y, v_mean)
+        print('Validation set R2: {}'.format(v_r2))
+        val_res = self.get_results_dict(v_mean * self.y_std + self.y_mean, v_std * self.y_std, v_r2, v_loss, params)
+        if self.held_x is None:
+            return val_res, None
+        h_mean, h_std, h_loss = self.predict(model, self.held_x, self.held_y)
+        h_r2 = r2_score(self.held_y, h_mean)
+        print('Held-out set R2: {}'.format(h_r2))
+        return val_res, self.get_results_dict(h_mean * self.y_std + self.y_mean, h_std * self.y_std, h_r2, h_loss, params)
+
+
+def run_gp(device, train_tup, val_tup, heldout_tup, n_runs=5, n_iter=50, n_inducing=400, gp_reruns=3, gp_delta=0.03,
+           nn_r2=None, seed=0):
+    """Retry ladder of OutputGenerator.run_gp / run_gp_iteration (mutations_main.py:174-247): `n_runs` GP fits;
+    each fit is retried up to `gp_reruns` times on a numerical failure or when the GP's R^2 falls more than
+    `gp_delta` below the CNN's; after exhausting the retries the number of inducing points drops by 100.
+    Returns (list of held-out result dicts, mean over runs of gp_mean, mean over runs of gp_std)."""
+    results = []
+    for run in range(n_runs):
+        m, attempt, done = n_inducing, 0, None
+        while done is None and m > 0:
+            try:
+                tr = GPTrainer(device, train_tup, val_tup, heldout_tup, n_iter=n_iter, n_inducing=m,
+                               seed=seed + 1000 * run + attempt)
+                _, hld = tr.run()
+                if nn_r2 is not None and hld['r2'] - nn_r2 < -gp_delta:
+                    raise RuntimeError("GP R2 %.4f fell below CNN R2 %.4f" % (hld['r2'], nn_r2))
+                done = hld
+            except (RuntimeError, torch.linalg.LinAlgError) as exc:
+                print('GP attempt failed: {}'.format(exc))
+                attempt += 1
+                if attempt >= gp_reruns:
+                    attempt, m = 0, m - 100
+        if done is None:
+            raise AssertionError("GP failed for every inducing-point count")      # kfold_mutations_main.py:228
+        results.append(done)
+    means = np.mean([r['gp_mean'] for r in results], axis=0)                      # gp_trainer.py:247-261
+    stds = np.mean([r['gp_std'] for r in results], axis=0)
+    return results, means, stds

@@ -1,0 +1,95 @@
+"""GPU tests of the region-model inference pipeline (HBM-resident track matrix -> dig_gather_bins -> CNN on
+PyTorch-ROCm) and of the command-line shims end to end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_plus_cnn_predict_matches_cpu_reference():
+    import torch
+    from digdriver_amd import _lib
+    from digdriver_amd.region_model.data_aux.dataset_generator import BinTrackStore
+    from digdriver_amd.region_model.predict import predict
+    from test_region_and_sequence_models import _golden_net
+    _lib.require_device()
+    dev = torch.device("cuda:0")
+    net, d = _golden_net()
+    rng = np.random.default_rng(0)
+    N, L, T = 300, 100, 40
+    x = (np.round(rng.uniform(0, 1, (N, L, T)), 2) * 100).astype(np.float32)
+    tracks = np.arange(4, 36)                       # the golden net has 32 input tracks
+    rows = rng.permutation(N)[:170]
+    labels = [rng.poisson(20, N).astype(float) for _ in range(3)]
+    with torch.no_grad():
+        want_o, want_f, _ = net(torch.tensor(x[rows][:, :, tracks]))
+    store = BinTrackStore(torch.as_tensor(x, device=dev), tracks)
+    preds, feats, r2 = predict(net.to(dev), store, rows, labels=labels, batch_size=64)
+    np.testing.assert_allclose(preds, torch.stack(want_o).numpy(), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(feats, torch.stack(want_f).numpy(), rtol=2e-3, atol=1e-4)
+    assert preds.shape == (3, 170) and feats.shape == (3, 170, 16) and r2.shape == (3,)
+    # int16 storage of the same matrix (values are integers <= 100) gives identical results
+    store16 = BinTrackStore(torch.as_tensor(x.astype(np.int16), device=dev), tracks)
+    assert torch.equal(store16.batch(rows), store.batch(rows))             # the gathered batch is bit-identical
+    preds16, _, _ = predict(net, store16, rows, batch_size=64)
+    np.testing.assert_allclose(preds16, preds, rtol=1e-4, atol=1e-5)       # MIOpen may pick another conv algorithm
+
+
+def test_cli_pretrain_then_driver(tmp_path):
+    from test_gpu_host_mirror import _build_maps
+    from digdriver_amd.io import mapfile
+    pre, dat, d, g = _build_maps(tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    # DigPretrain.py elementModel: writes the frame under save_key into the map
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "DigPretrain.py"), "elementModel", pre, dat, "elts"],
+                          env=env)
+    frame = mapfile.read_frame(pre, "elts")
+    col = {c: i for i, c in enumerate(d["out_cols"])}
+    np.testing.assert_allclose(frame.P_SUM.values, d["out_vals"][:, col["P_SUM"]], rtol=1e-11)
+    assert list(frame.ELT) == list(d["elt_names"])
+    # a bed12 + mutation file for those elements, then DigDriver.py elementDriver
+    bs, be = d["block_starts"], d["block_ends"]
+    bed = tmp_path / "elts.bed"
+    rng = np.random.default_rng(3)
+    rows = []
+    with open(bed, "w") as f:
+        for name, c, st, s_, e_ in zip(d["elt_names"], d["elt_chrom"], d["elt_strand"], bs, be):
+            s_, e_ = s_[s_ >= 0], e_[e_ >= 0]
+            f.write("%d\t%d\t%d\t%s\t0\t%s\t%d\t%d\t.\t%d\t%s\t%s\n" % (
+                c, s_[0], e_[-1], name, st, s_[0], s_[0], len(s_), ",".join(map(str, e_ - s_)) + ",",
+                ",".join(map(str, s_ - s_[0])) + ","))
+            for _ in range(rng.poisson(3)):
+                b = rng.integers(0, len(s_))
+                p = int(rng.integers(s_[b], e_[b]))
+                rows.append((str(c), p, p + 1, "A", "T", "S%d" % rng.integers(0, 30), ".", "Noncoding", "A>T", "CAG"))
+            if rng.uniform() < 0.3:
+                p = int(s_[0])
+                rows.append((str(c), p, p + 2, "AG", "A", "S%d" % rng.integers(0, 30), ".", "INDEL", "DEL", "."))
+    mut = tmp_path / "cohort.tsv"
+    pd.DataFrame(rows).to_csv(mut, sep="\t", header=False, index=False)
+    out = tmp_path / "out"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver", str(mut), pre,
+                           "elts", "--f-bed", str(bed), "--scale-factor-manual", "0.002", "--scale-factor-indel-manual",
+                           "0.0002", "--outdir", str(out), "--outpfx", "run1"], env=env)
+    res = pd.read_csv(out / "run1.results.txt", sep="\t", index_col=0)
+    assert res.index.name == "ELT" and len(res) == len(d["elt_names"])
+    for c in ("OBS_SAMPLES", "OBS_SNV", "OBS_INDEL"):
+        assert res[c].dtype.kind == "i"                                   # integer columns in the TSV
+    assert {"EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "EXP_INDEL", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN"} <= set(res.columns)
+    from digdriver_amd.driver_model import transfer_tools as tt
+    same = tt.run_element_region_model(str(mut), str(bed), pre, "elts", scale_factor=0.002, scale_factor_indel=0.0002,
+                                       scale_by_expectation=False, fused=True)
+    np.testing.assert_allclose(res.PVAL_MUT_BURDEN.values, same.PVAL_MUT_BURDEN.values, rtol=1e-12)
+    assert res.PVAL_SNV_BURDEN.between(0, 1).all()
+    # argument coupling of the reference CLI (DigDriver.py:68,78-80)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver", str(mut), pre, "elts",
+                          "--f-bed", str(bed), "--scale-factor-manual", "1.0", "--outdir", str(out), "--outpfx", "x"],
+                         env=env, capture_output=True, text=True)
+    assert bad.returncode != 0 and "both" in (bad.stderr + bad.stdout)
