@@ -108,6 +108,19 @@ def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, wind
                 n_ind_obs=n_ind_obs, window=window)
 
 
+def committed_traffic(kernel_prefixes):
+    """HBM bytes per launch of the dominant operation from the committed rocprofv3 PMC summary of this same
+    command (profiles/rNN_traffic.json, made by tools/make_profile_summary.py: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, KiB units, FETCH_SIZE x2 on gfx950).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    tot = sum(v["hbm_bytes"] for k, v in d["kernels"].items() if any(p in k for p in kernel_prefixes))
+    return (tot or None), os.path.basename(files[-1])
+
+
 def algorithmic_bytes(E, C, nbar_ov):
     """SURVEY 8d definitions (unfused)."""
     acc = E * (784 + 260 * nbar_ov) + E * C * (21 * nbar_ov + 32)
@@ -238,6 +251,10 @@ def main():
         dominant = "dig_element_stats" if ms_stat >= ms_acc else "dig_accumulate_elements"
         d_bytes, d_ms = (b_stat, ms_stat) if ms_stat >= ms_acc else (b_acc, ms_acc)
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
+        prefixes = ["element_stats_fast", "element_stats_slow"] if dominant == "dig_element_stats" else \
+            ["acc_region", "acc_dot", "acc_prep"]
+        default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
+        traffic, traffic_src = committed_traffic(prefixes) if default_shape else (None, None)
         res = {
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
@@ -247,8 +264,9 @@ def main():
                                    "per GPU, K=192 substitution types, mean %.2f bins/element" % (N, C, E, nbar),
                        "bins": N, "cohorts": C, "elements_per_gpu": E, "parallelism": "elements sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
-                         "algorithmic_bytes_per_launch": d_bytes, "avg_launch_ms": d_ms},
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": d_bytes,
+                         "avg_launch_ms": d_ms},
             "kernels": {"dig_accumulate_elements": {"avg_ms": ms_acc, "algorithmic_GBps": b_acc / (ms_acc * 1e-3) / 1e9},
                         "dig_element_stats": {"avg_ms": ms_stat, "algorithmic_GBps": b_stat / (ms_stat * 1e-3) / 1e9}},
             "finite_pvalues": ok, "slow_pair_fraction": slow_frac,
