@@ -50,6 +50,7 @@ class SimpleMultiTaskResNet(nn.Module):
             self.fc2_lst.append(nn.Linear(self.fc2_dim, self.fc3_dim))
             self.fc3_lst.append(nn.Linear(self.fc3_dim, 1))
         self._folded = False
+        self._gw = None
 
     # ---- trunk ------------------------------------------------------------------------------
     def _block(self, x, name):
@@ -97,6 +98,74 @@ class SimpleMultiTaskResNet(nn.Module):
         """x: [B, L, T] as stored (cnn_predictors.py:130-131 transposes first)."""
         return self.forward_channels_first(x.transpose(1, 2))
 
+    # ---- GEMM formulation (inference) -------------------------------------------------------
+    def _gemm_weights(self):
+        """Conv weights as [k*Cin, Cout] matrices for channels-last windows, head weights with the flatten order
+        of a channels-last trunk; cached on the (folded) module."""
+        ref = self.conv11.weight
+        if getattr(self, "_gw", None) is None or self._gw["W1"].dtype != ref.dtype or self._gw["W1"].device != ref.device:
+            gw = {}
+            for name, cin, cout, k, pad, stride in _CONV_SPEC:
+                conv = getattr(self, "conv" + name)
+                gw[name] = (conv.weight.permute(2, 1, 0).contiguous(), conv.bias, k, pad, stride)   # [k, Cin, Cout]
+            # reference flatten index = c * 13 + l  ->  channels-last flatten index = l * 1024 + c
+            W1 = torch.stack([m.weight.view(self.fc2_dim, 1024, 13).permute(0, 2, 1).reshape(self.fc2_dim, _FLAT)
+                              for m in self.fc1_lst])                                  # [C, 128, 13312]
+            gw["W1"] = W1.reshape(-1, _FLAT).t().contiguous()                            # [13312, C*128]
+            gw["b1"] = torch.cat([m.bias for m in self.fc1_lst])
+            gw["W2"] = torch.stack([m.weight for m in self.fc2_lst]).transpose(1, 2).contiguous()   # [C, 128, 16]
+            gw["b2"] = torch.stack([m.bias for m in self.fc2_lst])
+            gw["W3"] = torch.stack([m.weight for m in self.fc3_lst]).transpose(1, 2).contiguous()   # [C, 16, 1]
+            gw["b3"] = torch.stack([m.bias for m in self.fc3_lst])
+            self._gw = gw
+        return self._gw
+
+    @staticmethod
+    def _conv_gemm(x, w, b, k, pad, stride):
+        """conv1d on channels-last activations x [B, L, C] as k accumulated GEMMs, one per filter tap, WITHOUT an
+        im2col copy: the zero-padded batch is viewed as one [B*Lp, C] matrix; the rows `tap, tap+s, tap+2s, ...` of
+        that matrix are exactly the tap-th inputs of all output positions of all batch elements (plus a few rows
+        that straddle two batch elements, which land in discarded output rows), so
+
+            out_full = bias + sum_tap  flat[tap::s] @ W_tap          (hipBLASLt, MFMA)
+
+        and the valid outputs are out_full.view(B, Lp/s, Cout)[:, :Lout].  w: [k, C, Cout]."""
+        B, L, C = x.shape
+        Lout = (L + 2 * pad - k) // stride + 1
+        extra = (-(L + 2 * pad)) % stride                     # make Lp a multiple of the stride
+        xp = F.pad(x, (0, 0, pad, pad + extra))
+        Lp = L + 2 * pad + extra
+        flat = xp.view(B * Lp, C)
+        rows_out = B * Lp // stride
+        out_full = torch.empty((rows_out, w.shape[2]), dtype=x.dtype, device=x.device)
+        m = (B * Lp - (k - 1) + stride - 1) // stride         # output rows that have all k taps inside `flat`
+        head = out_full[:m]
+        torch.addmm(b, flat[0:(m - 1) * stride + 1:stride], w[0], out=head)
+        for tap in range(1, k):
+            head.addmm_(flat[tap:tap + (m - 1) * stride + 1:stride], w[tap])
+        if m < rows_out:
+            out_full[m:].zero_()
+        return torch.relu_(out_full).view(B, Lp // stride, -1)[:, :Lout]
+
+    def forward_gemm(self, x):
+        """Inference on x [B, L, T] (the row-major batch dig_gather_bins produces): BN must be folded.  Same
+        (outputs, feature_vecs, None) contract as forward()."""
+        assert self._folded and not self.get_attention_maps, "forward_gemm needs fold_batchnorm() and no attention branch"
+        gw = self._gemm_weights()
+        cv = lambda t, n: self._conv_gemm(t, *gw[n])
+        x = cv(cv(x, "11"), "12")
+        x = cv(cv(x, "21"), "22") + x
+        x = cv(x, "3")
+        x = cv(cv(x, "41"), "42") + x
+        x = cv(x, "5")
+        x = cv(cv(x, "61"), "62") + x
+        flat = x.reshape(x.shape[0], _FLAT)
+        C = self.task_num
+        h1 = F.relu(torch.addmm(gw["b1"], flat, gw["W1"])).view(-1, C, self.fc2_dim).transpose(0, 1)   # [C, B, 128]
+        h2 = F.relu(torch.baddbmm(gw["b2"][:, None, :], h1, gw["W2"]))                                  # [C, B, 16]
+        out = torch.baddbmm(gw["b3"][:, None, :], h2, gw["W3"]).squeeze(-1)                             # [C, B]
+        return [out[i] for i in range(C)], [h2[i] for i in range(C)], None
+
     # ---- inference copy ---------------------------------------------------------------------
     @torch.no_grad()
     def fold_batchnorm(self):
@@ -109,6 +178,7 @@ class SimpleMultiTaskResNet(nn.Module):
             conv.bias.copy_((conv.bias - bn.running_mean) * scale + bn.bias)
             setattr(m, "bn" + name, nn.Identity())
         m._folded = True
+        m._gw = None
         return m
 
 

@@ -26,11 +26,13 @@ def predict(model, store, bin_rows, labels=None, batch_size=2048, fold_bn=True, 
     dev = next(net.parameters()).device
     bin_rows = np.asarray(bin_rows)
     preds, feats = [], []
+    use_gemm = getattr(net, "_folded", False) and not net.get_attention_maps
     for s in range(0, len(bin_rows), batch_size):
-        xb = store.batch(bin_rows[s:s + batch_size], channels_first=True)
+        # GEMM path consumes the row-major (channels-last) batch directly; the conv path wants channels-first
+        xb = store.batch(bin_rows[s:s + batch_size], channels_first=not use_gemm)
         if xb.device != dev:
             xb = xb.to(dev)
-        out, fv, _ = net.forward_channels_first(xb.to(dtype))
+        out, fv, _ = net.forward_gemm(xb.to(dtype)) if use_gemm else net.forward_channels_first(xb.to(dtype))
         preds.append(torch.stack(out).float())
         feats.append(torch.stack(fv).float())
     preds = torch.cat(preds, dim=1).cpu().numpy()
