@@ -1,0 +1,143 @@
+"""Observed-count tabulation on the GPU for many cohorts at once: mutations x element blocks -> OBS_SNV,
+OBS_SAMPLES, OBS_INDEL as [E, C] int32 tensors, ready for dig_element_stats.
+
+Same integer semantics as mutation_tools.tabulate_mutations_in_element (reference mutation_tools.py:155-230):
+interval join -> drop duplicates on (chrom, start, end, ref, alt, sample, element) -> SNV / INDEL counts per
+(element, sample) -> drop samples whose total count exceeds max_muts_per_sample -> cap the per-(element, sample)
+counts -> per element: number of distinct samples, sum of SNVs, sum of indels.  The join runs in the HIP kernels
+dig_overlap_join_{count,fill}; de-duplication and the segmented counts are sort/unique calls on the device
+(PyTorch as plumbing).  Results are bit-identical to the host path (tests/test_gpu_tabulate.py).
+"""
+import numpy as np
+
+from .. import _lib
+from . import mutation_tools
+
+
+class ElementBlocks:
+    """bed6 blocks of an element set, sorted by (chrom, start), as device tensors with composite keys."""
+
+    def __init__(self, chrom, start, end, elt_id, n_elements, device):
+        import torch
+        chrom = np.asarray(chrom, np.int64)
+        start = np.asarray(start, np.int64)
+        end = np.asarray(end, np.int64)
+        end_eff = np.where(end == start, start + 1, end)
+        order = np.lexsort((start, chrom))
+        chrom, start, end_eff, elt_id = chrom[order], start[order], end_eff[order], np.asarray(elt_id, np.int64)[order]
+        runmax = np.empty_like(end_eff)
+        for c in np.unique(chrom):
+            sel = chrom == c
+            runmax[sel] = np.maximum.accumulate(end_eff[sel])
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
+        self.start_key, self.runmax_key, self.end = t((chrom << 40) | start), t((chrom << 40) | runmax), t(end_eff)
+        self.elt = t(elt_id)
+        self.n_blocks, self.n_elements, self.device = len(start), int(n_elements), device
+
+    @classmethod
+    def from_bed12(cls, f_bed, device, names=None):
+        """bed12 file -> blocks; element ids follow `names` (default: first appearance in the file).
+        Chromosome labels are normalised to integers (autosomes 1..22; others are dropped like bedtools would
+        never match them against integer-labelled autosomal mutations)."""
+        import pandas as pd
+        df = pd.read_csv(f_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
+        blocks = mutation_tools._bed12_to_bed6(df)
+        ch = blocks.CHROM.astype(str).str.replace("chr", "", regex=False)
+        keep = ch.isin([str(i) for i in range(1, 23)])
+        blocks, ch = blocks[keep], ch[keep].astype(int)
+        if names is None:
+            names = list(dict.fromkeys(df[3].tolist()))
+        pos = {n: i for i, n in enumerate(names)}
+        return cls(ch.values, blocks.START.values, blocks.END.values, blocks.ELT.map(pos).values, len(names), device), names
+
+
+def overlap_pairs(blocks, m_chrom, m_start, m_end):
+    """(mutation row, block row) pairs on the device: int32 tensors, mutation-major, blocks ascending."""
+    import torch
+    dev = blocks.device
+    n = m_chrom.numel()
+    counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    args = [_lib.dev_ptr(blocks.start_key), _lib.dev_ptr(blocks.runmax_key), _lib.dev_ptr(blocks.end), blocks.n_blocks,
+            _lib.dev_ptr(m_chrom), _lib.dev_ptr(m_start), _lib.dev_ptr(m_end), n]
+    with torch.cuda.device(dev):
+        _lib.call("dig_overlap_join_count", *args, _lib.dev_ptr(counts), _lib.stream_ptr())
+        incl = torch.cumsum(counts, 0, dtype=torch.int64)
+        total = int(incl[-1].item()) if n else 0
+        offsets = (incl - counts).contiguous()
+        pm = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        pb = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        if total:
+            _lib.call("dig_overlap_join_fill", *args, _lib.dev_ptr(offsets), _lib.dev_ptr(pm), _lib.dev_ptr(pb),
+                      _lib.stream_ptr())
+    return pm[:total], pb[:total]
+
+
+def encode_mutations(df_mut, device, cohort_id=0):
+    """Mutation frame (reference column names) -> device tensors.  Strings become dense integer ids on the host:
+    `uid` identifies (CHROM, START, END, REF, ALT) and `sample` the sample label, both exactly (no hashing)."""
+    import pandas as pd
+    import torch
+    ch = df_mut.CHROM.astype(str).str.replace("chr", "", regex=False)
+    keep = ch.isin([str(i) for i in range(1, 23)])
+    df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
+    uid = pd.factorize(pd.MultiIndex.from_arrays([ch.values, df_mut.START.values, df_mut.END.values,
+                                                  df_mut.REF.astype(str).values, df_mut.ALT.astype(str).values]))[0]
+    samp, sample_names = pd.factorize(df_mut.SAMPLE.astype(str).values)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=device)
+    return dict(chrom=t(ch.values, np.int64), start=t(df_mut.START.values, np.int64), end=t(df_mut.END.values, np.int64),
+                uid=t(uid, np.int64), sample=t(samp, np.int64), indel=t((df_mut.ANNOT == 'INDEL').values, np.int64),
+                cohort=torch.full((len(df_mut),), int(cohort_id), dtype=torch.int64, device=device),
+                sample_names=list(sample_names))
+
+
+def tabulate_cohorts(blocks, cohorts, drop_duplicates=True, max_muts_per_sample=1e9, max_muts_per_elt_per_sample=3e9):
+    """`cohorts`: list of encode_mutations() dicts (one per cohort).  Returns (OBS_SNV, OBS_SAMPLES, OBS_INDEL) int32
+    [E, C] device tensors and the per-cohort lists of blacklisted sample names."""
+    import torch
+    dev = blocks.device
+    C, E = len(cohorts), blocks.n_elements
+    cat = lambda k: torch.cat([c[k] for c in cohorts])
+    # sample ids are per cohort: make them globally distinct with an offset
+    offs = np.concatenate([[0], np.cumsum([len(c["sample_names"]) for c in cohorts])])
+    sample = torch.cat([c["sample"] + int(o) for c, o in zip(cohorts, offs[:-1])])
+    uid_off = np.concatenate([[0], np.cumsum([int(c["uid"].max().item()) + 1 if c["uid"].numel() else 0 for c in cohorts])])
+    uid = torch.cat([c["uid"] + int(o) for c, o in zip(cohorts, uid_off[:-1])])
+    chrom, start, end, indel, cohort = cat("chrom"), cat("start"), cat("end"), cat("indel"), cat("cohort")
+    pm, pb = overlap_pairs(blocks, chrom, start, end)
+    pm = pm.long()
+    elt = blocks.elt[pb.long()]
+    rec = torch.stack([cohort[pm], elt, sample[pm], uid[pm], indel[pm]], dim=1)        # [n_pairs, 5]
+    if drop_duplicates and rec.shape[0]:
+        # duplicates on (chrom, start, end, ref, alt, sample, element): ANNOT is a function of the mutation here
+        rec = _unique_rows_keep_flag(rec)
+    # per (cohort, element, sample): SNV and INDEL counts
+    key3, inv = torch.unique(rec[:, :3], dim=0, return_inverse=True)
+    n3 = key3.shape[0]
+    snv = torch.zeros(n3, dtype=torch.int64, device=dev).index_add_(0, inv, 1 - rec[:, 4])
+    ind = torch.zeros(n3, dtype=torch.int64, device=dev).index_add_(0, inv, rec[:, 4])
+    # hypermutator blacklist per (cohort, sample): total over elements of OBS_MUT
+    n_samp_tot = int(offs[-1])
+    tot = torch.zeros(max(n_samp_tot, 1), dtype=torch.int64, device=dev).index_add_(0, key3[:, 2], snv + ind)
+    black = tot > max_muts_per_sample
+    keep = ~black[key3[:, 2]]
+    key3, snv, ind = key3[keep], snv[keep], ind[keep]
+    cap = int(min(max_muts_per_elt_per_sample, 2 ** 62))
+    snv, ind = snv.clamp(max=cap), ind.clamp(max=cap)
+    flat = key3[:, 1] * C + key3[:, 0]                                                  # [E, C] layout
+    z = lambda: torch.zeros(E * C, dtype=torch.int64, device=dev)
+    obs_snv = z().index_add_(0, flat, snv).view(E, C).to(torch.int32)
+    obs_ind = z().index_add_(0, flat, ind).view(E, C).to(torch.int32)
+    obs_smp = z().index_add_(0, flat, torch.ones_like(snv)).view(E, C).to(torch.int32)
+    black_np = black.cpu().numpy()
+    blacklists = [[n for j, n in enumerate(c["sample_names"]) if black_np[int(o) + j]] for c, o in zip(cohorts, offs[:-1])]
+    return obs_snv, obs_smp, obs_ind, blacklists
+
+
+def _unique_rows_keep_flag(rec):
+    """Unique on the first four columns (cohort, element, sample, mutation uid), keeping the indel flag of the
+    first occurrence (identical for all occurrences: the flag is a property of the mutation)."""
+    import torch
+    key, inv = torch.unique(rec[:, :4], dim=0, return_inverse=True)
+    flag = torch.zeros(key.shape[0], dtype=rec.dtype, device=rec.device)
+    flag.scatter_reduce_(0, inv, rec[:, 4], reduce="amax", include_self=True)
+    return torch.cat([key, flag[:, None]], dim=1)

@@ -176,6 +176,23 @@ int dig_ideal_overlaps_host(const int32_t *elt_chrom, const int64_t *blk_ptr, co
                             const int64_t *blk_end, int64_t E, int64_t window, const int32_t *bin_chrom,
                             const int64_t *bin_start, int64_t N, int64_t *ov_ptr, int32_t *ov_idx);
 
+/* ---- mutation x element-block interval join (data_tools/mutation_tools.py:191-230) ----------- *
+ * Replaces `bedtools intersect -wa -wb` of the mutation file with the bed6 blocks of the elements: half-open
+ * overlap  m.start < b.end && b.start < m.end  on the same chromosome (a zero-length mutation is tested as
+ * [start, start+1)).  Blocks are sorted by (chrom, start) and given as composite keys:
+ *   blk_start_key[i] = chrom << 40 | start,  blk_runmax_key[i] = chrom << 40 | running max of end within the chrom,
+ *   blk_end[i] = end.   Mutations: mut_chrom, mut_start, mut_end (int64, any order).
+ * Two-call protocol: dig_overlap_join_count fills counts[n_mut] (overlapped blocks per mutation); the caller
+ * forms the exclusive prefix sum `offsets`; dig_overlap_join_fill writes the pairs (mutation row, block row) at
+ * offsets[m] ..., mutation-major with blocks ascending -- the order bedtools reports them in.  The integer
+ * bookkeeping after the join (de-duplication, per-sample caps, blacklist; :208-226, :155-189) is sort/unique work. */
+int dig_overlap_join_count(const int64_t *blk_start_key, const int64_t *blk_runmax_key, const int64_t *blk_end,
+                           int64_t n_blk, const int64_t *mut_chrom, const int64_t *mut_start, const int64_t *mut_end,
+                           int64_t n_mut, int32_t *counts, void *stream);
+int dig_overlap_join_fill(const int64_t *blk_start_key, const int64_t *blk_runmax_key, const int64_t *blk_end,
+                          int64_t n_blk, const int64_t *mut_chrom, const int64_t *mut_start, const int64_t *mut_end,
+                          int64_t n_mut, const int64_t *offsets, int32_t *pair_mut, int32_t *pair_blk, void *stream);
+
 /* ---- per-bin epigenomic-track gather (region_model/data_aux/mut_dataset.py:76-81) ---- *
  * out[b, l, t] = (float) x_data[bin_rows[b], l, tracks[t]]      (transpose_out == 0)
  * out[b, t, l] = ...                                            (transpose_out != 0: the
