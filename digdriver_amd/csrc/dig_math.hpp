@@ -67,6 +67,16 @@ __device__ __forceinline__ double mul_rn(double a, double b)
     return a * b;
 }
 
+// 1 / v to full precision from the hardware reciprocal estimate + two Newton steps (5 FP64 ops instead of the
+// ~12 of an IEEE division; used only where the last-bit rounding of the quotient does not matter).
+__device__ __forceinline__ double recip_nr(double v)
+{
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
 // ---- natural logarithm, < 1 ulp, ~1/3 of the instructions of the library log ---------------
 // Classical reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = f / (2 + f), f = m - 1,
 // with the degree-14 minimax polynomial in s^2 (the coefficients are the standard ones of this scheme).
@@ -82,7 +92,7 @@ __device__ __forceinline__ double fast_log(double x)
     k += i >> 20;
     const long long mbits = ((long long)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffll);
     const double f = __longlong_as_double(mbits) - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = f * recip_nr(2.0 + f);
     const double z = s * s, w = z * z;
     const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
     const double t2 = z * (6.666666666666735130e-01 +
@@ -121,16 +131,6 @@ __device__ inline double betacf(double a, double b, double x)
         if (fabs(del - 1.0) <= kCfEps) break;
     }
     return h;
-}
-
-// 1 / v to full precision from the hardware reciprocal estimate + two Newton steps (5 FP64 ops instead of the
-// ~12 of an IEEE division; used only where the last-bit rounding of the quotient does not matter).
-__device__ __forceinline__ double recip_nr(double v)
-{
-    double r = __builtin_amdgcn_rcp(v);
-    r = fma(fma(-v, r, 1.0), r, r);
-    r = fma(fma(-v, r, 1.0), r, r);
-    return r;
 }
 
 // The same continued fraction evaluated with the forward (A_n, B_n) recurrence, renormalised every double step:
@@ -268,14 +268,27 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
 
 // ---- fast mid-p evaluation for small integer counts sharing (alpha, p) ----------------
 // 1 - S_k - t_k / 2 from the scaled state (A_k, N_k, D_k = k!, k):  t_k = t_0 N_k / D_k,  S_k = t_0 A_k k / D_k.
-// noinline-free but single definition: both counts of a pair and every entry point go through these exact operations.
+// Single definition: both counts of a pair and every entry point go through these exact operations.
 __device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0)
 {
 #pragma clang fp contract(off)
-    const double rD = t0 / D;
+    const double rD = t0 * recip_nr(D);
     const double S = (A * k) * rD;
     const double t = N * rD;
     return (1.0 - S) - 0.5 * t;
+}
+
+// One step of the scaled recurrence.  The accumulator update A <- A * j + N is issued as the three-address
+// v_fma_f64 (the compiler's v_fmac form needs three register copies per step to keep N alive).
+__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x)
+{
+    double An;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(An) : "v"(A), "v"(jj), "v"(N));
+    A = An;                 // A_{j+1} = A_j * j + N_j
+    N *= u;                 // N_{j+1}
+    u += x;
+    jj += 1.0;
+    D *= jj;                // D_{j+1} = (j+1)!
 }
 
 // Resolve 0.5 pmf(k) + P(X > k) for up to two counts (k1, k2) that share (alpha, p) with ONE
@@ -305,35 +318,23 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     const double lp0 = alpha * fast_log(p);
     if (!(lp0 > -400.0)) return done & want;     // keeps the scaled sums below (N_k <= k!/t_0) far from overflow
     const double x = 1.0 - p;
-    const int k1i = e1 ? (int)k1 : -1, k2i = e2 ? (int)k2 : -1;
+    const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
     // the lane's loop ends at the larger count; only the smaller one needs recording on the way
-    const int kmax = k1i > k2i ? k1i : k2i;
-    const int kmin = k1i > k2i ? k2i : k1i;
+    const double kmax = fmax(k1d, k2d), kmin = fmin(k1d, k2d);
     // Division- and table-free form of  t_{j+1} = t_j (alpha + j) x / (j + 1),  S_j = sum_{i<j} t_i :
     //   N_j = prod_{i<j} (alpha + i) x,  D_j = j!,  A_j = S_j D_{j-1} / t_0   (A_{j+1} = A_j * j + N_j)
     // so one step is 5 full-rate FP64 ops with no memory access; t_k = t_0 N_k / D_k, S_k = t_0 A_k k / D_k.
+    // The trip count is tested on the FP64 counter itself (one v_cmp, no integer shadow counter).
     const double t0 = exp(lp0);
     double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
     // two exec-masked loops instead of one loop with a per-step snapshot: 0 .. kmin, snapshot, kmin .. kmax
-    int j = 0;
-    for (; j < kmin; ++j) {
-        A = fma(A, jj, N);      // A_{j+1} = A_j * j + N_j
-        N *= u;                 // N_{j+1}
-        u += x;
-        jj += 1.0;
-        D *= jj;                // D_{j+1} = (j+1)!
-    }
+    while (jj < kmin) pmf_scaled_step(A, N, D, u, jj, x);
     const double r_min = midp_from_state(A, N, D, jj, t0);
-    for (; j < kmax; ++j) {
-        A = fma(A, jj, N);
-        N *= u;
-        u += x;
-        jj += 1.0;
-        D *= jj;
-    }
+    while (jj < kmax) pmf_scaled_step(A, N, D, u, jj, x);
     const double r_max = midp_from_state(A, N, D, jj, t0);
-    const double ra = (k1i >= k2i) ? r_max : r_min;   // result for k1
-    const double rb = (k1i >= k2i) ? r_min : r_max;   // result for k2
+    const bool k1_is_max = k1d >= k2d;
+    const double ra = k1_is_max ? r_max : r_min;   // result for k1
+    const double rb = k1_is_max ? r_min : r_max;   // result for k2
     if (e1 && ra >= kDirectMin) { r1 = ra; done |= 1u; }
     if (e2 && rb >= kDirectMin) { r2 = rb; done |= 2u; }
     return done & want;

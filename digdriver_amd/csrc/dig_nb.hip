@@ -12,6 +12,7 @@
 // (512 B per wave-instruction per operand), grid capped at 8 blocks/CU.  The arithmetic per
 // item is the FP64 recurrence / continued fraction in dig_math.hpp.
 #include <algorithm>
+#include <cstdlib>
 
 #include "dig_common.hpp"
 #include "dig_math.hpp"
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStats
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     bool slow = false;
+    PairInputs q{};
+    double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
     if (i < n) {
-        const PairInputs q = load_pair(a, i);
-        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        q = load_pair(a, i);
         const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
         slow = (d1 != 3u) || (d2 != 1u);
@@ -174,6 +176,26 @@ __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStats
             if (!(d2 & 1u)) pv_ind = nb_midp_upper_unresolved(q.k_ind, q.alpha_i, q.p_i);
             slow = false;
         }
+    }
+    // The worklist slot is requested and consumed BEFORE the result stores are issued: the vector-memory counter
+    // retires in order, so an atomic issued after the seven stores would make its wave wait for all of them to
+    // reach memory.  The Fisher combination sits between request and use to cover part of the round trip.
+    unsigned base = 0;
+    unsigned long long m = 0;
+    int leader = 0;
+    if (WORKLIST) {
+        m = __ballot(slow);
+        if (m) {
+            leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(a.worklist, (unsigned)__popcll(m));
+        }
+    }
+    const double pv_mut = slow ? 0.0 : fisher_combine_fast(pv_snv, pv_ind);   // overlaps the atomic's round trip
+    if (WORKLIST && m) {
+        const unsigned slot = kWorkHeader + __shfl(base, leader, 64) + __popcll(m & ((1ull << lane) - 1ull));
+        if (slow) a.worklist[slot] = (unsigned)i;
+    }
+    if (i < n) {
         a.out[0 * n + i] = q.exp_snv;
         a.out[3 * n + i] = q.theta_i;
         a.out[4 * n + i] = q.exp_ind;
@@ -181,19 +203,69 @@ __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStats
             a.out[1 * n + i] = pv_snv;
             a.out[2 * n + i] = pv_smp;
             a.out[5 * n + i] = pv_ind;
-            a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
+            a.out[6 * n + i] = pv_mut;
         }
     }
-    if (WORKLIST) {
+}
+
+// Pass 1, streaming form (used whenever a worklist is available): a persistent grid of 8 waves per SIMD, each wave
+// walking 64-pair tiles with stride n_waves.  Profiling the one-shot form showed its waves spending two thirds of
+// their life in s_waitcnt (input loads at the start, the worklist atomic's round trip at the end) with 5.3 of 8
+// wave slots filled on average, i.e. a latency problem, not an arithmetic one.  Here
+//   * the raw inputs of the NEXT tile are requested before the current tile's arithmetic starts,
+//   * slow pairs are parked in a per-wave LDS buffer and handed to the global worklist with one atomic per
+//     kParkCap pairs (normally one per wave lifetime) instead of one round trip per tile,
+//   * every vector-memory operation of the loop body is unconditional (lanes past the end replay pair n-1, pass 2
+//     overwrites the p-value planes of its pairs), so the in-order memory counter can be waited on exactly:
+//     the loop waits for the prefetched loads only, never for its stores.
+constexpr int kParkCap = 256;   // per-wave parking buffer (entries); flushed when fewer than 64 slots are free
+
+__device__ __forceinline__ unsigned park_flush(unsigned* worklist, const unsigned* park, unsigned count, int lane)
+{
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(worklist, count);
+    base = __shfl(base, 0, 64);
+    for (unsigned j = lane; j < count; j += 64) worklist[kWorkHeader + base + j] = park[j];
+    return 0;
+}
+
+template <bool HAS_INDEL_PARAMS>
+__global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementStatsArgs a)
+{
+    __shared__ unsigned park_all[kBlock / 64][kParkCap];
+    unsigned* park = park_all[threadIdx.x >> 6];
+    const int64_t n = a.E * a.C;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    int64_t tile = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (tile >= n_tiles) return;
+    PairRaw nxt = load_raw(a, min(tile * 64 + lane, n - 1));
+    unsigned parked = 0;   // wave-uniform
+    for (; tile < n_tiles; tile += n_waves) {
+        if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
+        const int64_t i_raw = tile * 64 + lane;
+        const int64_t i = min(i_raw, n - 1);
+        const PairRaw cur = nxt;
+        nxt = load_raw(a, min((tile + n_waves) * 64 + lane, n - 1));
+        const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
+        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
+        const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
+        const bool slow = ((d1 != 3u) || (d2 != 1u)) && i_raw < n;
         const unsigned long long m = __ballot(slow);
-        if (m) {
-            unsigned base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(a.worklist, (unsigned)__popcll(m));
-            base = __shfl(base, leader, 64);
-            if (slow) a.worklist[kWorkHeader + base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
-        }
+        if (slow) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
+        parked += (unsigned)__popcll(m);
+        a.out[0 * n + i] = q.exp_snv;
+        a.out[1 * n + i] = pv_snv;
+        a.out[2 * n + i] = pv_smp;
+        a.out[3 * n + i] = q.theta_i;
+        a.out[4 * n + i] = q.exp_ind;
+        a.out[5 * n + i] = pv_ind;
+        a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
     }
+    if (parked) park_flush(a.worklist, park, parked, lane);
 }
 
 // Pass 2: the compacted slow pairs.  The pass is latency-bound (few items, long dependent FP64 chains), so the
@@ -418,9 +490,26 @@ int dig_element_stats(const double* mu, const double* sigma, const double* mu_in
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
     DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
     const int grid = (int)want_blocks;
-    if (wl)
-        hipLaunchKernelGGL(element_stats_fast_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
-    else
+    if (wl) {
+        // persistent grid: exactly as many blocks as are resident at once
+        static int resident[2] = {0, 0};
+        const int which = mu_indel ? 1 : 0;
+        if (!resident[which]) {
+            int per_cu = 0;
+            if (which)
+                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<true>, kBlock, 0));
+            else
+                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false>, kBlock, 0));
+            resident[which] = per_cu > 0 ? per_cu : 4;
+        }
+        int blocks_per_cu = resident[which];
+        if (const char* e = getenv("DIG_ES_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));   // tuning knob
+        const int sgrid = grid_for(E * C, kBlock, blocks_per_cu);
+        if (which)
+            hipLaunchKernelGGL(element_stats_stream_kernel<true>, dim3(sgrid), dim3(kBlock), 0, s, a);
+        else
+            hipLaunchKernelGGL(element_stats_stream_kernel<false>, dim3(sgrid), dim3(kBlock), 0, s, a);
+    } else
         hipLaunchKernelGGL(element_stats_fast_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
     if (wl) {
