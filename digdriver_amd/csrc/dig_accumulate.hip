@@ -222,25 +222,33 @@ static int launch_acc_v1(const AccArgs& a, hipStream_t stream)
 // =======================================================================================
 constexpr int kRegionBlock = 256;
 
+// acc_region_kernel: persistent grid, two independent phases per wave (no barriers, no LDS).
+//   phase A (rates)    the (element, cohort) pairs are flattened to g = e * C + c and walked in 64-pair tiles:
+//                      every lane is busy whatever C is, consecutive lanes read C*8 contiguous bytes of the [N, C]
+//                      bin tables and the four outputs are written as fully coalesced rows of g.  The per-pair sums run
+//                      over the element's bins in CSR order (the order of genic_driver_tools.py:262-268).
+//   phase B (contexts) 16 lanes per element, one 16-byte slice of the 256-byte context row each: four elements per
+//                      wave step, so the dependent ov_ptr -> ov_idx -> row chain is paid once per four elements.
+//                      The strand permutation (sequence_tools.py:633-634) is applied on the store.
 __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
     const double* __restrict__ bin_mu, const double* __restrict__ bin_std, const int32_t* __restrict__ bin_y,
     const uint8_t* __restrict__ bin_flag, const int32_t* __restrict__ bin_ctx, const int64_t* __restrict__ ov_ptr,
     const int32_t* __restrict__ ov_idx, const uint8_t* __restrict__ strand_minus, double* __restrict__ MU,
     double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS, int32_t* __restrict__ FLAG, int32_t* __restrict__ R_SIZE,
-    int32_t* __restrict__ rcp, int64_t E, int64_t C)
+    int32_t* __restrict__ rcp, int64_t E, int64_t C, FastDiv divC, int use_fastdiv)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * kRegionBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kRegionBlock) >> 6;
-    for (int64_t e = wave0; e < E; e += nwaves) {
-        const int64_t q0 = ov_ptr[e], q1 = ov_ptr[e + 1];
-        int rc = 0;
-        for (int64_t q = q0; q < q1; ++q) rc += bin_ctx[(int64_t)ov_idx[q] * 64 + lane];
-        const int rsize = wave_sum_i32(rc);
-        const int dst = strand_minus[e] ? revcomp_ctx(lane) : lane;   // sequence_tools.py:633-634
-        rcp[e * 64 + dst] = rc;
-        if (lane == 0) R_SIZE[e] = rsize;                             // genic_driver_tools.py:375
-        for (int64_t c = lane; c < C; c += 64) {
+
+    const int64_t n = E * C;
+    const int64_t n_tiles = (n + 63) >> 6;
+    for (int64_t tile = wave0; tile < n_tiles; tile += nwaves) {
+        const int64_t g = tile * 64 + lane;
+        if (g < n) {
+            const int64_t e = use_fastdiv ? fastdiv(g, divC) : g;
+            const int64_t c = g - e * C;
+            const int64_t q0 = ov_ptr[e], q1 = ov_ptr[e + 1];
             double mu = 0.0, var = 0.0;
             int robs = 0, flag = 0;
             for (int64_t q = q0; q < q1; ++q) {
@@ -251,11 +259,41 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
                 robs += bin_y[o];                // :267
                 flag |= (bin_flag[o] != 0);      // :268 (numpy bool '+' is a logical OR)
             }
-            const int64_t o = e * C + c;
-            MU[o] = mu;
-            SIGMA[o] = sqrt(var);                // :271
-            R_OBS[o] = robs;
-            FLAG[o] = flag;
+            MU[g] = mu;
+            SIGMA[g] = sqrt(var);                // :271
+            R_OBS[g] = robs;
+            FLAG[g] = flag;
+        }
+    }
+
+    const int sub = lane >> 4, l16 = lane & 15;
+    const int4* ctx4 = reinterpret_cast<const int4*>(bin_ctx);
+    const int64_t n_quads = (E + 3) >> 2;
+    for (int64_t t = wave0; t < n_quads; t += nwaves) {
+        const int64_t e = t * 4 + sub;
+        if (e < E) {   // uniform within each 16-lane group
+            const int64_t q0 = ov_ptr[e], q1 = ov_ptr[e + 1];
+            int minus = strand_minus[e];           // requested with the CSR bounds, consumed after the bin loop
+            asm volatile("" : "+v"(minus));        // (keeps the compiler from sinking the load below the loop)
+            int4 acc = make_int4(0, 0, 0, 0);
+            for (int64_t q = q0; q < q1; ++q) {
+                const int4 v = ctx4[(int64_t)ov_idx[q] * 16 + l16];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            int s = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (l16 == 0) R_SIZE[e] = s;                              // genic_driver_tools.py:375
+            if (!minus) {
+                reinterpret_cast<int4*>(rcp)[e * 16 + l16] = acc;
+            } else {                                                  // sequence_tools.py:633-634
+                int32_t* row = rcp + e * 64;
+                const int c0 = 4 * l16;
+                row[revcomp_ctx(c0 + 0)] = acc.x;
+                row[revcomp_ctx(c0 + 1)] = acc.y;
+                row[revcomp_ctx(c0 + 2)] = acc.z;
+                row[revcomp_ctx(c0 + 3)] = acc.w;
+            }
         }
     }
 }
@@ -476,11 +514,10 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
     hipLaunchKernelGGL(acc_prep_kernel, dim3(16), dim3(256), 0, s, d_pr, w.dT, w.d64T, (int)C, w.CPAD);
     DIG_HIP_TRY(hipGetLastError());
     {
-        const int64_t want = (E + (kRegionBlock / 64) - 1) / (kRegionBlock / 64);
-        const int64_t cap = (int64_t)cu_count() * 8;
-        const int grid = (int)std::max<int64_t>(1, std::min(want, cap));
+        const int grid = grid_for(E * C, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
-                           bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C);
+                           bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C,
+                           make_fastdiv(C), (int)(C >= 2));
         DIG_HIP_TRY(hipGetLastError());
     }
     return (n_class == 1) ? launch_dot<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)

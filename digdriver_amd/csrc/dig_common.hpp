@@ -44,6 +44,23 @@ struct DevBuf {
     }
 };
 
+// i / C with a host-computed magic multiplier: e = hi64(i * ceil(2^64 / C)), exact while
+// i * C < 2^64 (the per-pair int64 division the flat [E, C] index would otherwise need costs
+// more than a whole recurrence step).
+struct FastDiv {
+    uint64_t magic;   // ceil(2^64 / d), d >= 2
+};
+inline FastDiv make_fastdiv(int64_t d)
+{
+    FastDiv f;
+    f.magic = (d >= 2) ? (~(uint64_t)0 / (uint64_t)d) + 1 : 0;
+    return f;
+}
+__device__ __forceinline__ int64_t fastdiv(int64_t i, const FastDiv& f)
+{
+    return (int64_t)__umul64hi((uint64_t)i, f.magic);
+}
+
 inline int grid_for(int64_t n, int block, int max_blocks_per_cu = 8)
 {
     int64_t want = (n + block - 1) / block;

@@ -214,30 +214,38 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
 
 // The expensive tail of nb_midp_upper: integer k >= 0, 0 < p < 1, finite alpha > 0, and either
 // k > kSmallK, p^alpha underflows, or the p-value is < kDirectMin (1 - CDF would cancel).
-constexpr int kRecurK = 2048;   // direct summation limit of the slow pass (k iterations of ~10 FP64 ops)
+constexpr int kRecurK = 2048;   // direct summation limit of the slow pass
+
+__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x);
+__device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0);
 
 // Slow-pass evaluation for integer k >= 0, 0 < p < 1, finite alpha > 0.  Most items get here only because
-// k > kSmallK while sitting near their mean: the multiplicative recurrence t_{j+1} = t_j u_j / (j+1) (no factorial,
-// so no overflow) gives S_k and t_k in k steps and 1 - S_k - t_k/2 is accepted under the same >= kDirectMin rule
-// (absolute error grows like k ulp: 2048 * 1.1e-16 / 1e-6 = 2e-7 worst case, inside the 1e-6 contract).  Only a
-// genuinely small tail, p^alpha underflow or a huge k goes on to lgamma + continued fraction.
+// k > kSmallK while sitting near their mean: the same scaled recurrence as the fast pass (5 FP64 ops per step, no
+// division), with (A, N, D) rescaled by the exact power of two 2^-exponent(D) every 16 steps so that D = j! never
+// overflows, gives S_k and t_k in k steps; 1 - S_k - t_k/2 is accepted under the same >= kDirectMin rule (absolute
+// error grows like k ulp: 2048 * 1.1e-16 / 1e-4 = 2e-9 worst case).  Range: after rescaling N/D = t_j/t_0 <= 1/t_0
+// and one block of 16 steps multiplies by at most 2048^16 = 1e53, so p^alpha >= e^-500 keeps everything finite.
+// Only a genuinely small tail, a smaller p^alpha or a huge k goes on to lgamma + continued fraction.
 __device__ inline double nb_midp_upper_slow(double k, double alpha, double p)
 {
     const double x = 1.0 - p;
     const double lp0 = alpha * fast_log(p);
     double pmfk = -1.0;
-    if (k <= (double)kRecurK && lp0 > -690.0) {
-        double t = exp(lp0), S = 0.0, u = alpha * x, jj = 1.0;
-        const int ki = (int)k;
-        for (int j = 0; j < ki; ++j) {
-            S += t;
-            t *= u * recip_nr(jj);
-            u += x;
-            jj += 1.0;
+    if (k <= (double)kRecurK && lp0 > -500.0) {
+        const double t0 = exp(lp0);
+        double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
+        while (jj < k) {
+            const double stop = fmin(k, jj + 16.0);
+            while (jj < stop) pmf_scaled_step(A, N, D, u, jj, x);
+            const int e = -__builtin_amdgcn_frexp_exp(D);
+            D = ldexp(D, e);
+            N = ldexp(N, e);
+            A = ldexp(A, e);
         }
-        const double r = (1.0 - S) - 0.5 * t;
+        const double r = midp_from_state(A, N, D, jj, t0);
         if (r >= (k <= 256.0 ? kDirectMin : 1e-4)) return r;      // long sums: keep a wider safety margin
-        if (t > 1e-290) pmfk = t;
+        const double t = N * (t0 * recip_nr(D));
+        if (t > 1e-290 && t < 1.0) pmfk = t;
     }
     if (pmfk < 0.0) pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
     return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);

@@ -64,23 +64,6 @@ __global__ __launch_bounds__(kBlock) void gamma_kernel(const double* __restrict_
     }
 }
 
-// i / C with a host-computed magic multiplier: e = hi64(i * ceil(2^64 / C)), exact while
-// i * C < 2^64 (the per-pair int64 division the flat [E, C] index would otherwise need costs
-// more than a whole recurrence step).
-struct FastDiv {
-    uint64_t magic;   // ceil(2^64 / d), d >= 2
-};
-static FastDiv make_fastdiv(int64_t d)
-{
-    FastDiv f;
-    f.magic = (d >= 2) ? (~(uint64_t)0 / (uint64_t)d) + 1 : 0;
-    return f;
-}
-__device__ __forceinline__ int64_t fastdiv(int64_t i, const FastDiv& f)
-{
-    return (int64_t)__umul64hi((uint64_t)i, f.magic);
-}
-
 struct ElementStatsArgs {
     const double *mu, *sigma, *mu_indel, *sigma_indel, *pi_sum, *pi_indel;
     const int32_t *obs_snv, *obs_samples, *obs_indel;
