@@ -4,21 +4,21 @@
 //   genic_driver_tools.py:300-431 nonc_model, :31-203 genic_model, :599-690 tiled_nonc_model,
 //   driver_model/onthefly_tools.py:109-164 (loop body of DIG_onthefly).
 //
-// Mapping onto CDNA4
+// Mapping onto CDNA4 (workspace path, the one every caller of the package uses; kernels further down)
+//   * acc_region_kernel     HBM-bound bin-table sums: (element, cohort) pairs flattened to 64-pair tiles for the
+//                           [N, C] rate tables, 16 lanes x 16 bytes per element for the 256-byte context rows;
+//   * acc_dot_mfma_kernel   the [E x 256] x [256 x C] FP64 product on the matrix cores (v_mfma_f64_16x16x4_f64),
+//                           parameter table pre-swizzled in LDS, quotient + element sizes in registers.
+// Without a workspace (NULL) a single LDS kernel does everything (accumulate_kernel below, ~3.5x slower):
 //   * one 64-lane wave per element; a workgroup of W waves (W = 16 / 8 / 4 by LDS budget) walks
 //     groups of W consecutive elements, one workgroup per CU, persistent grid;
 //   * phase 1, lanes = the 64 trinucleotide contexts: the wave sums the 256-B context rows of the
-//     element's overlapped bins (one coalesced dword load per bin) and stages the reverse-
-//     complement-permuted counts and the 192 L counts of the element as doubles in LDS;
-//     in the same bin loop, lanes = cohorts read the [N, C] rate tables (C*8 contiguous bytes
-//     per bin) and accumulate MU / VAR / R_OBS / FLAG;
-//   * phase 2, lanes = cohorts: the per-cohort trinucleotide parameters d_pr[C,192] live in LDS
-//     transposed ([192][C], conflict-free 8-byte reads) next to their per-context sums
-//     ([64][C]); each lane runs the 64-term denominator and the 192-term numerator dot products
-//     against LDS-broadcast element counts -- no cross-lane reduction in the hot loop;
-//   * blockIdx -> element-group mapping is XCD-aware: workgroups that share an XCD (b % 8)
-//     walk one contiguous eighth of the genome-ordered element list, so the bin rows that
-//     neighbouring elements share stay in that XCD's L2.
+//     element's overlapped bins and stages the reverse-complement-permuted counts and the 192 L counts of the
+//     element as doubles in LDS; lanes = cohorts accumulate MU / VAR / R_OBS / FLAG in the same bin loop;
+//   * phase 2, lanes = cohorts: d_pr[C,192] lives in LDS transposed ([192][C], conflict-free 8-byte reads) next
+//     to its per-context sums; each lane runs the 64-term and 192-term dot products against LDS-broadcast counts;
+//   * blockIdx -> element-group mapping is XCD-aware: workgroups that share an XCD (b % 8) walk one contiguous
+//     eighth of the genome-ordered element list, so shared bin rows stay in that XCD's L2.
 #include <algorithm>
 #include <vector>
 
@@ -204,21 +204,11 @@ static int launch_acc_v1(const AccArgs& a, hipStream_t stream)
 }
 
 // =======================================================================================
-// v2: two kernels, no LDS in the FMA loop.
+// Workspace path: two kernels.
 //
-//   acc_region_kernel   one wave per element.  lanes = 64 contexts sum the bins' context rows
-//                       (256-B coalesced loads) and write the strand-permuted counts to a
-//                       workspace row; lanes = cohorts sum Y_PRED / STD^2 / Y_TRUE / FLAG over the
-//                       element's bins ([N, C] tables: C*8 contiguous bytes per bin).  No LDS, no
-//                       barriers: waves run independently, so the dependent ov_ptr -> ov_idx ->
-//                       bin-row loads of different elements overlap.
-//   acc_dot_kernel      one LANE per element, 64 consecutive elements per wave.  The per-cohort
-//                       trinucleotide parameters are wave-uniform, so they are read with SCALAR
-//                       loads (transposed, padded table in the workspace; served by the scalar
-//                       cache / L2) and enter v_fma_f64 as SGPR operands: the 64 + 192-term dot
-//                       products need neither LDS traffic nor cross-lane reductions, all 64 lanes
-//                       are busy whatever C is, and each int32 count is converted to FP64 once per
-//                       CT cohorts.  Cohorts are processed CT at a time (CT accumulators in VGPRs).
+//   acc_region_kernel    bin-table sums (HBM-bound; flattened (element, cohort) pairs + 16-lane context slices),
+//                        writes MU / SIGMA / R_OBS / FLAG / R_SIZE and the strand-permuted context counts (workspace);
+//   acc_dot_mfma_kernel  the [E x 256] x [256 x C] FP64 product on the matrix cores, quotient and element sizes.
 // =======================================================================================
 constexpr int kRegionBlock = 256;
 
@@ -298,175 +288,226 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
     }
 }
 
-// transposed, zero-padded parameter tables: dT[j][CPAD] (j < 192) and d64T[ctx][CPAD] (ctx < 64)
-__global__ void acc_prep_kernel(const double* __restrict__ d_pr, double* __restrict__ dT, double* __restrict__ d64T,
-                                int C, int CPAD)
+// =======================================================================================
+// v3 dot stage on the FP64 matrix cores.
+//
+// P[e, c] = sum_j L[e, j] d_pr[c, j] / sum_ctx rc[e, ctx] d64[c, ctx] is a [E x 256] x [256 x C] product in FP64 --
+// the one GEMM-shaped step of the accumulation.  v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950, but
+// each operand register feeds 16 FMAs, which removes the one-parameter-fetch-per-FMA limit of the scalar-operand
+// form tried first (one lane per element, parameters as SGPR operands: 94 us, bound by scalar-cache misses on the
+// 80 KB parameter table; this kernel: 65 us).
+//
+//   * operand layout (probed on the device, tools/probe/mfma_f64_layout.hip): A[i][k] in lane 16 k + i, B[k][j] in
+//     lane 16 k + j, D[i][j] in lane 16 (i % 4) + j, register i / 4;
+//   * a wave owns 16 consecutive elements (one A tile) and up to 48 cohorts (NT 16-column B tiles), 16 waves per
+//     workgroup (4 per SIMD): lane (i, k) reads its element's count rows 16 bytes at a time (ints 16 t + 4 k .. + 3),
+//     converts each int once and uses it for NT MFMAs; the K order inside a 16-int group is permuted accordingly
+//     (a sum, so free); loads run one group of four slices (48 MFMAs) ahead;
+//   * the parameter table is staged once per workgroup in LDS, pre-swizzled by acc_prep_mfma_kernel into the exact
+//     per-lane order of the B operand (tab[step][nt][lane]): every ds_read_b64 is 512 contiguous bytes;
+//   * denominators (64 context rows) and numerators (192 substitution rows) use separate accumulators; the quotient
+//     and the integer element sizes are formed in registers and written once.
+// =======================================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int kMfmaWaves = 8;                 // waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS)
+constexpr int kMfmaSteps = 64;                // 256 K rows / 4
+constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
+
+// tab[chunk][step = 4 t + u][nt][lane] = T[kappa = 16 t + 4 (lane / 16) + u][chunk * 48 + nt * 16 + lane % 16],
+// T = per-context sums (kappa < 64, d_pr[c][3 ctx .. 3 ctx + 2] summed as (a + b) + c) then d_pr[c][kappa - 64].
+__global__ void acc_prep_mfma_kernel(const double* __restrict__ d_pr, double* __restrict__ tab, int C, int nchunk)
 {
-    const int n = 192 * CPAD;
+    const int n = nchunk * kMfmaSteps * 3 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        const int j = idx / CPAD, c = idx - j * CPAD;
-        dT[idx] = (c < C) ? d_pr[(int64_t)c * 192 + j] : 0.0;
-    }
-    const int n64 = 64 * CPAD;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n64; idx += gridDim.x * blockDim.x) {
-        const int ctx = idx / CPAD, c = idx - ctx * CPAD;
-        const double* d = d_pr + (int64_t)c * 192 + 3 * ctx;
-        d64T[idx] = (c < C) ? (d[0] + d[1]) + d[2] : 0.0;
+        const int lane = idx & 63, nt = (idx >> 6) % 3, step = (idx / 192) % kMfmaSteps, chunk = idx / (192 * kMfmaSteps);
+        const int kappa = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3);
+        const int c = chunk * kMfmaChunk + nt * 16 + (lane & 15);
+        double v = 0.0;
+        if (c < C) {
+            const double* d = d_pr + (int64_t)c * 192;
+            v = (kappa < 64) ? (d[3 * kappa] + d[3 * kappa + 1]) + d[3 * kappa + 2] : d[kappa - 64];
+        }
+        tab[idx] = v;
     }
 }
 
-// acc_dot_kernel: blockDim = (64 lanes = 64 consecutive elements, nchunk waves = cohort chunks).
-// The waves of a workgroup read the same rcp / L rows (L1/L2 hits) and each keeps CT accumulators.
-template <int NCLASS, int CT>
-__global__ void acc_dot_kernel(const int32_t* __restrict__ rcp, const int32_t* __restrict__ L,
-                               const double* __restrict__ dT, const double* __restrict__ d64T,
-                               const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length,
-                               double* __restrict__ P, int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL,
-                               int64_t E, int C, int CPAD, int chunk0)
+template <int NT>
+__device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __restrict__ tab, int step0, int lane,
+                                           double4_t (&acc)[NT], int& isum)
 {
-    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int chunk = chunk0 + __builtin_amdgcn_readfirstlane(threadIdx.y);   // wave-uniform
-    const bool live = e < E;
-    const int64_t ec = live ? e : E - 1;
-    const int cbase = chunk * CT;
-    const int4* rcrow = reinterpret_cast<const int4*>(rcp + ec * 64);
-    int lsum = 0;
-
-    double den[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) den[c] = 0.0;
+    for (int t = 0; t < 4; ++t) {
+        const int v[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+        isum += (a[t].x + a[t].y) + (a[t].z + a[t].w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double A = (double)v[u];
+            const double* b = tab + ((step0 + 4 * t + u) * NT) * 64 + lane;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, b[nt * 64], acc[nt], 0, 0, 0);
+        }
+    }
+}
+
+template <int NCLASS, int NT>
+__global__ __launch_bounds__(kMfmaWaves * 64) void acc_dot_mfma_kernel(
+    const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
+    const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
+    int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
+{
+    extern __shared__ double tab[];           // [kMfmaSteps][NT][64]
     {
-        int4 cur = rcrow[0];
-        for (int m = 0; m < 16; ++m) {            // sum(region_counts * d_pr), genic_driver_tools.py:361
-            const int4 nxt = rcrow[m < 15 ? m + 1 : 15];   // prefetch the next 16 B of the lane's row
-            const int rv[4] = {cur.x, cur.y, cur.z, cur.w};
+        // stage this chunk's NT tiles of the pre-swizzled table (global layout: 3 tiles per step); all loads of a
+        // thread are issued before its first LDS write
+        constexpr int kPer = (kMfmaSteps * NT * 64) / (kMfmaWaves * 64);   // 4 * NT doubles per thread
+        double v[kPer];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double v = (double)rv[u];
-                const double* row = d64T + (int64_t)(4 * m + u) * CPAD + cbase;   // wave-uniform -> scalar loads
-#pragma unroll
-                for (int c = 0; c < CT; ++c) den[c] = fma(v, row[c], den[c]);
-            }
-            cur = nxt;
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = threadIdx.x + k * kMfmaWaves * 64;
+            const int lane_ = idx & 63, nt = (idx >> 6) % NT, step = idx / (NT * 64);
+            v[k] = tab_g[(step * 3 + nt) * 64 + lane_];
         }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) tab[threadIdx.x + k * kMfmaWaves * 64] = v[k];
     }
-#pragma unroll 1
-    for (int q = 0; q < NCLASS; ++q) {
-        double num[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) num[c] = 0.0;
-        const int4* Lrow = reinterpret_cast<const int4*>(L + (ec * NCLASS + q) * 192);
-        int4 cur = Lrow[0];
-        for (int m = 0; m < 48; ++m) {            // sum(t_pi * L), :364-366
-            const int4 nxt = Lrow[m < 47 ? m + 1 : 47];
-            const int rv[4] = {cur.x, cur.y, cur.z, cur.w};
-            lsum += (cur.x + cur.y) + (cur.z + cur.w);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double v = (double)rv[u];
-                const double* row = dT + (int64_t)(4 * m + u) * CPAD + cbase;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) num[c] = fma(v, row[c], num[c]);
-            }
-            cur = nxt;
-        }
-        if (live) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-                if (cbase + c < C) P[(e * NCLASS + q) * C + cbase + c] = num[c] / den[c];
-        }
-    }
-    if (live && chunk == 0) {
-        const int esize = lsum / 3;                                        // :380
-        ELT_SIZE[e] = esize;
-        const double numer = gene_length ? (double)gene_length[e] : (double)esize;
-        P_INDEL[e] = numer / (double)R_SIZE[e];                            // :381 / :159
-    }
-}
+    __syncthreads();
 
-// Cohorts per wave (CT) and number of chunk-waves per workgroup.  Smaller CT = more waves in flight
-// (the grid is only E/64 workgroups) at the price of one int->f64 convert per CT FMAs.
-static int acc_pick_ct(int64_t E, int64_t C, int* nchunk)
-{
-    // Cohorts per wave (CT accumulators in VGPRs; one chunk-wave per CT cohorts).  Measured on MI355X
-    // at C = 37, E = 120 k: CT = 20 (2 chunk-waves, 8 % padded slots) beats 8/10/13/16 -- fewer
-    // int->f64 converts and scalar loads per FMA matter more than extra waves.  Pick the largest
-    // instantiated CT whose padding stays within 10 %, else the least-padded one.
-    (void)E;
-    static const int cts[] = {4, 8, 10, 13, 16, 20};
-    if (const char* env = getenv("DIG_ACC_CT")) {
-        const int forced = atoi(env);
-        for (int ct : cts)
-            if (ct == forced) {
-                *nchunk = (int)((C + ct - 1) / ct);
-                return ct;
-            }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int64_t n_tiles = (E + 15) >> 4;
+    const int64_t n_waves = (int64_t)gridDim.x * kMfmaWaves;
+    constexpr int G = 1 + 3 * NCLASS;         // 16-row groups per tile: contexts, then 3 per mutation class
+
+    // slice t of group gi of a tile (rows past the end replay row E-1 and are never stored)
+    auto slice_ptr = [&](int64_t tile_, int gi) -> const int4* {
+        const int64_t row = min(tile_ * 16 + i, E - 1);
+        return gi == 0 ? reinterpret_cast<const int4*>(rcp + row * 64) + kq
+                       : reinterpret_cast<const int4*>(L + row * NCLASS * 192) + (gi - 1) * 16 + kq;
+    };
+    // round r of wave w takes tile r * n_waves + (w's rank with workgroups interleaved), so a partial last round is
+    // spread over all CUs instead of filling the first workgroups only
+    const int64_t rank = (int64_t)wave * gridDim.x + blockIdx.x;
+    int64_t tile = rank;
+    if (tile >= n_tiles) return;
+    int4 cur[4], nxt[4];
+    {
+        const int4* p0 = slice_ptr(tile, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nxt[t] = p0[4 * t];
     }
-    int best = 0;
-    int64_t best_slots = 0;
-    for (int ct : cts) {
-        const int64_t nch = (C + ct - 1) / ct;
-        const int64_t slots = nch * ct;
-        if (slots * 10 <= C * 11) { best = ct; best_slots = slots; }
-    }
-    if (!best) {
-        for (int ct : cts) {
-            const int64_t slots = ((C + ct - 1) / ct) * ct;
-            if (!best || slots < best_slots) { best = ct; best_slots = slots; }
+    while (tile < n_tiles) {
+        // The table reads are invariant across tiles; without this opaque zero the compiler hoists all 192 of them out
+        // of the persistent loop and spills.
+        int opaque_zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+        const double* tabw = tab + opaque_zero;
+        const int64_t e0 = tile * 16;
+        const int64_t tile_next = tile + n_waves;
+        double4_t den[NT];
+        int rsum = 0, lsum = 0;
+        // group 0: the 64 context rows -> denominators
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+        {
+            const int4* pn = slice_ptr(tile, 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nxt[t] = pn[4 * t];
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) den[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+        mfma_group<NT>(cur, tabw, 0, lane, den, rsum);                  // sum(region_counts * d_pr), genic_driver_tools.py:361
+#pragma unroll 1
+        for (int q = 0; q < NCLASS; ++q) {
+            int opaque_zero_q;                                           // (same hoisting guard, per class)
+            asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero_q));
+            const double* tabq = tabw + opaque_zero_q;
+            double4_t num[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) num[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {                                // sum(t_pi * L), :364-366
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+                {   // request the next group of the stream (first group of the next tile after the last one)
+                    const int gi_next = 2 + 3 * q + g;
+                    const int4* pn = (gi_next < G) ? slice_ptr(tile, gi_next) : slice_ptr(min(tile_next, n_tiles - 1), 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nxt[t] = pn[4 * t];
+                }
+                mfma_group<NT>(cur, tabq, 16 + 16 * g, lane, num, lsum);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t e = e0 + 4 * r + kq;                      // D[i][j]: lane 16 (i % 4) + j, register i / 4
+                if (e < E) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int c = c0 + nt * 16 + i;
+                        if (c < C) P[(e * NCLASS + q) * C + c] = num[nt][r] / den[nt][r];
+                    }
+                }
+            }
+        }
+        if (write_sizes) {
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            const int64_t e = e0 + i;
+            if (kq == 0 && e < E) {
+                const int esize = lsum / 3;                                          // :380
+                ELT_SIZE[e] = esize;
+                const double numer = gene_length ? (double)gene_length[e] : (double)esize;
+                P_INDEL[e] = numer / (double)R_SIZE[e];                              // :381 / :159
+            }
+        }
+        tile = tile_next;
     }
-    *nchunk = (int)((C + best - 1) / best);
-    return best;
 }
 
 struct AccWorkspace {
-    int32_t* rcp;
-    double *dT, *d64T;
-    int CT, nchunk, CPAD;
+    int32_t* rcp;    // strand-permuted context counts of the elements, [E][64]
+    double* tab;     // pre-swizzled MFMA parameter table, [n48][64 steps][3][64]
+    int n48;         // cohort chunks of 48 for the dot stage
     int64_t bytes;
 };
 
 static AccWorkspace acc_workspace_layout(void* base, int64_t E, int64_t C)
 {
     AccWorkspace w{};
-    w.CT = acc_pick_ct(E, C, &w.nchunk);
-    w.CPAD = ((w.CT * w.nchunk + 7) / 8) * 8;
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
     const int64_t o_rc = 0;
-    const int64_t o_dT = up(o_rc + E * 64 * (int64_t)sizeof(int32_t));
-    const int64_t o_d64 = up(o_dT + 192 * (int64_t)w.CPAD * (int64_t)sizeof(double));
-    w.bytes = up(o_d64 + 64 * (int64_t)w.CPAD * (int64_t)sizeof(double));
+    const int64_t o_tab = up(o_rc + E * 64 * (int64_t)sizeof(int32_t));
+    w.n48 = (int)((C + kMfmaChunk - 1) / kMfmaChunk);
+    w.bytes = up(o_tab + (int64_t)w.n48 * kMfmaSteps * 3 * 64 * (int64_t)sizeof(double));
     char* b = (char*)base;
     w.rcp = (int32_t*)(b + o_rc);
-    w.dT = (double*)(b + o_dT);
-    w.d64T = (double*)(b + o_d64);
+    w.tab = (double*)(b + o_tab);
     return w;
 }
 
 template <int NCLASS>
-static int launch_dot(const AccWorkspace& w, const int32_t* L, const int32_t* R_SIZE, const int32_t* gene_length,
-                      double* P, int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, hipStream_t stream)
+static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_t* R_SIZE, const int32_t* gene_length,
+                           double* P, int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, hipStream_t stream)
 {
-    // more than 16 chunk-waves do not fit one workgroup: split the cohort range over several launches
-    for (int ch0 = 0; ch0 < w.nchunk; ch0 += 16) {
-        const int nch = std::min(16, w.nchunk - ch0);
-        const dim3 grid((unsigned)((E + 63) / 64)), block(64, nch);
-#define DIG_DOT(CTV)                                                                                               \
-    case CTV:                                                                                                      \
-        hipLaunchKernelGGL((acc_dot_kernel<NCLASS, CTV>), grid, block, 0, stream, w.rcp, L, w.dT, w.d64T, R_SIZE,  \
-                           gene_length, P, ELT_SIZE, P_INDEL, E, (int)C, w.CPAD, ch0);                             \
-        break;
-        switch (w.CT) {
-            DIG_DOT(4)
-            DIG_DOT(8)
-            DIG_DOT(10)
-            DIG_DOT(13)
-            DIG_DOT(16)
-            DIG_DOT(20)
-            default: return set_error(DIG_EINVAL, "accumulate: no kernel for CT=%d", w.CT);
-        }
-#undef DIG_DOT
-        DIG_HIP_TRY(hipGetLastError());
+    const int64_t n_tiles = (E + 15) / 16;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cu_count(), (n_tiles + kMfmaWaves - 1) / kMfmaWaves));
+    for (int ch = 0; ch < w.n48; ++ch) {
+        const int c0 = ch * kMfmaChunk;
+        const int nt = (int)std::min<int64_t>(3, (C - c0 + 15) / 16);
+        const size_t lds = (size_t)kMfmaSteps * nt * 64 * sizeof(double);
+        const double* tab = w.tab + (int64_t)ch * kMfmaSteps * 3 * 64;
+        auto go = [&](auto kern) -> int {
+            DIG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaWaves * 64), lds, stream, w.rcp, L, tab, R_SIZE, gene_length, P,
+                               ELT_SIZE, P_INDEL, E, (int)C, c0, (int)(ch == 0));
+            DIG_HIP_TRY(hipGetLastError());
+            return DIG_OK;
+        };
+        int rc;
+        if (nt == 3) rc = go(acc_dot_mfma_kernel<NCLASS, 3>);
+        else if (nt == 2) rc = go(acc_dot_mfma_kernel<NCLASS, 2>);
+        else rc = go(acc_dot_mfma_kernel<NCLASS, 1>);
+        if (rc) return rc;
     }
     return DIG_OK;
 }
@@ -511,8 +552,6 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
     DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
     const AccWorkspace w = acc_workspace_layout(workspace, E, C);
     DIG_REQUIRE(workspace_bytes >= w.bytes, "workspace smaller than dig_accumulate_workspace(E, C)");
-    hipLaunchKernelGGL(acc_prep_kernel, dim3(16), dim3(256), 0, s, d_pr, w.dT, w.d64T, (int)C, w.CPAD);
-    DIG_HIP_TRY(hipGetLastError());
     {
         const int grid = grid_for(E * C, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
@@ -520,8 +559,10 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
                            make_fastdiv(C), (int)(C >= 2));
         DIG_HIP_TRY(hipGetLastError());
     }
-    return (n_class == 1) ? launch_dot<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
-                          : launch_dot<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
+    hipLaunchKernelGGL(acc_prep_mfma_kernel, dim3(32), dim3(256), 0, s, d_pr, w.tab, (int)C, w.n48);
+    DIG_HIP_TRY(hipGetLastError());
+    return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
+                          : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
 }
 
 int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,

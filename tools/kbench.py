@@ -46,14 +46,8 @@ def main():
                              td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"], out=out_st, use_workspace=ws)
 
     acc()
-    for ct in os.environ.get("KB_CTS", "0,4,8,10,13,16,20").split(","):
-        if ct != "0":
-            os.environ["DIG_ACC_CT"] = ct
-        else:
-            os.environ.pop("DIG_ACC_CT", None)
-        us = timeit(acc)
-        print("accumulate CT=%-3s %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (ct, us, b_acc / us / 1e3, b_acc / us / 1e3 / 80))
-    os.environ.pop("DIG_ACC_CT", None)
+    us = timeit(acc)
+    print("accumulate %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (us, b_acc / us / 1e3, b_acc / us / 1e3 / 80))
     for ws in (True, False):
         us = timeit(lambda: stats(ws))
         print("element_stats workspace=%-5s %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (ws, us, b_stat / us / 1e3, b_stat / us / 1e3 / 80))
