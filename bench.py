@@ -251,7 +251,7 @@ def main():
         dominant = "dig_element_stats" if ms_stat >= ms_acc else "dig_accumulate_elements"
         d_bytes, d_ms = (b_stat, ms_stat) if ms_stat >= ms_acc else (b_acc, ms_acc)
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
-        prefixes = ["element_stats_fast", "element_stats_slow"] if dominant == "dig_element_stats" else \
+        prefixes = ["element_stats_"] if dominant == "dig_element_stats" else \
             ["acc_region", "acc_dot", "acc_prep"]
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
         traffic, traffic_src = committed_traffic(prefixes) if default_shape else (None, None)
