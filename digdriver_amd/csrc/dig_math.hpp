@@ -219,36 +219,100 @@ constexpr int kRecurK = 2048;   // direct summation limit of the slow pass
 __device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x);
 __device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0);
 
-// Slow-pass evaluation for integer k >= 0, 0 < p < 1, finite alpha > 0.  Most items get here only because
-// k > kSmallK while sitting near their mean: the same scaled recurrence as the fast pass (5 FP64 ops per step, no
-// division), with (A, N, D) rescaled by the exact power of two 2^-exponent(D) every 16 steps so that D = j! never
-// overflows, gives S_k and t_k in k steps; 1 - S_k - t_k/2 is accepted under the same >= kDirectMin rule (absolute
-// error grows like k ulp: 2048 * 1.1e-16 / 1e-4 = 2e-9 worst case).  Range: after rescaling N/D = t_j/t_0 <= 1/t_0
-// and one block of 16 steps multiplies by at most 2048^16 = 1e53, so p^alpha >= e^-500 keeps everything finite.
-// Only a genuinely small tail, a smaller p^alpha or a huge k goes on to lgamma + continued fraction.
-__device__ inline double nb_midp_upper_slow(double k, double alpha, double p)
+// Slow-pass evaluation for integer k >= 0, 0 < p < 1, finite alpha > 0.
+//  (1) Most items get here only because k > kSmallK while sitting near their mean: the same scaled recurrence as
+//      the fast pass (5 FP64 ops per step, no division), with (A, N, D) rescaled by the exact power of two
+//      2^-exponent(D) every 16 steps so that D = j! never overflows, gives S_k and t_k in k steps; 1 - S_k - t_k/2
+//      is accepted under the same >= kDirectMin rule (absolute error grows like k ulp: 2048 * 1.1e-16 / 1e-4 = 2e-9
+//      worst case).  Range: after rescaling N/D = t_j/t_0 <= 1/t_0 and one block of 16 steps multiplies by at most
+//      (2 * 2048)^16 = 1e58, so p^alpha >= e^-500 keeps everything finite.
+//  (2) A small tail (1 - S_k cancels) is summed directly instead: the recurrence simply continues past k with a
+//      fresh accumulator, B_{J+1} = B_J (J+1) + N_{J+1}, so that sum_{k<j<=J} t_j = t_0 B_J / D_J -- all terms
+//      positive, no cancellation, relative error ~ (number of terms) ulp -- until the last term is below 2^-56 of
+//      the sum (the terms fall geometrically this far above the mean; the test runs every 8 steps).
+//  (3) Only a smaller p^alpha, k > kRecurK or a series that has not converged after kTailMax terms goes on to
+//      lgamma + the continued fraction.
+constexpr int kTailMax = 4096;
+
+// Two counts sharing (alpha, p) in ONE pass of the recurrence (the SNV and SAMPLE tests of a pair): the state is
+// evaluated at the smaller count on the way to the larger one.  `want` selects the requested counts (bit 0: k1,
+// bit 1: k2); both must be integers >= 0.  All rescalings are exact powers of two, so the result for a count does
+// not depend on whether it was computed alone or together with another one.
+__device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, double alpha, double p, double& r1,
+                                           double& r2)
 {
     const double x = 1.0 - p;
     const double lp0 = alpha * fast_log(p);
-    double pmfk = -1.0;
-    if (k <= (double)kRecurK && lp0 > -500.0) {
+    unsigned todo = want;
+    if (lp0 > -500.0) {
         const double t0 = exp(lp0);
+        const bool el1 = (want & 1u) && k1 <= (double)kRecurK, el2 = (want & 2u) && k2 <= (double)kRecurK;
+        // targets in ascending order; a single eligible count is visited once
+        const double klo = (el1 && el2) ? fmin(k1, k2) : (el1 ? k1 : k2);
+        const double khi = (el1 && el2) ? fmax(k1, k2) : klo;
+        const int n_phase = (el1 || el2) ? ((el1 && el2 && k1 != k2) ? 2 : 1) : 0;
         double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
-        while (jj < k) {
-            const double stop = fmin(k, jj + 16.0);
-            while (jj < stop) pmf_scaled_step(A, N, D, u, jj, x);
-            const int e = -__builtin_amdgcn_frexp_exp(D);
-            D = ldexp(D, e);
-            N = ldexp(N, e);
-            A = ldexp(A, e);
+        for (int phase = 0; phase < n_phase; ++phase) {
+            const double k = phase == 0 ? klo : khi;
+            while (jj < k) {
+                const double stop = fmin(k, jj + 16.0);
+                while (jj < stop) pmf_scaled_step(A, N, D, u, jj, x);
+                const int e = -__builtin_amdgcn_frexp_exp(D);
+                D = ldexp(D, e);
+                N = ldexp(N, e);
+                A = ldexp(A, e);
+            }
+            double res = midp_from_state(A, N, D, jj, t0);
+            bool ok = res >= (k <= 256.0 ? kDirectMin : 1e-4);     // long sums: keep a wider safety margin
+            if (!ok) {
+                // (2) tail series from a copy of the state at k:  0.5 t_k + sum_{j>k} t_j
+                double Nt = N, Dt = D, ut = u, jt = jj, B = 0.0, H = 0.5 * N;
+                const double jend = k + (double)kTailMax;
+                bool converged = false;
+                while (jt < jend) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        Nt *= ut;                // N_{j+1}
+                        ut += x;
+                        jt += 1.0;
+                        Dt *= jt;                // D_{j+1}
+                        B = fma(B, jt, Nt);      // B_{j+1} = B_j (j+1) + N_{j+1}
+                        H *= jt;                 // keeps 0.5 t_k on the same scale
+                    }
+                    if (Nt <= B * 0x1p-56) { converged = true; break; }
+                    const int e = -__builtin_amdgcn_frexp_exp(Dt);
+                    Dt = ldexp(Dt, e);
+                    Nt = ldexp(Nt, e);
+                    B = ldexp(B, e);
+                    H = ldexp(H, e);
+                }
+                if (converged) {
+                    const double v = (B + H) * (t0 * recip_nr(Dt));
+                    if (v > 1e-290) { res = v; ok = true; }        // below that the scaled terms may have underflowed
+                }
+            }
+            if (ok) {
+                if (el1 && k1 == k && (todo & 1u)) { r1 = res; todo &= ~1u; }
+                if (el2 && k2 == k && (todo & 2u)) { r2 = res; todo &= ~2u; }
+            }
         }
-        const double r = midp_from_state(A, N, D, jj, t0);
-        if (r >= (k <= 256.0 ? kDirectMin : 1e-4)) return r;      // long sums: keep a wider safety margin
-        const double t = N * (t0 * recip_nr(D));
-        if (t > 1e-290 && t < 1.0) pmfk = t;
     }
-    if (pmfk < 0.0) pmfk = exp(nbinom_logpmf_unchecked(k, alpha, p));
-    return 0.5 * pmfk + nb_upper_tail_from_pmf(k, alpha, p, x, pmfk);
+    // (3) lgamma + continued fraction for whatever is left
+    if (todo & 1u) {
+        const double pmfk = exp(nbinom_logpmf_unchecked(k1, alpha, p));
+        r1 = 0.5 * pmfk + nb_upper_tail_from_pmf(k1, alpha, p, x, pmfk);
+    }
+    if (todo & 2u) {
+        const double pmfk = exp(nbinom_logpmf_unchecked(k2, alpha, p));
+        r2 = 0.5 * pmfk + nb_upper_tail_from_pmf(k2, alpha, p, x, pmfk);
+    }
+}
+
+__device__ inline double nb_midp_upper_slow(double k, double alpha, double p)
+{
+    double r = 0.0, dummy = 0.0;
+    nb_midp_upper_slow2(k, 0.0, 1u, alpha, p, r, dummy);
+    return r;
 }
 
 // For a test nb_midp_upper_fast2 left unresolved (its argument checks already passed: finite alpha > 0,
