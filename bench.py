@@ -198,7 +198,10 @@ def main():
     td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
-    exp_sum = torch.zeros_like(td["n_snv_obs"])
+    # the shard's statistics for the scale factors as one [3, C] tensor: row 0 is filled by dig_scale_suffstats each
+    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs)
+    part = torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous()
+    cj_out = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     k_acc, k_stat = [], []
@@ -206,8 +209,8 @@ def main():
     def step(timed):
         # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
         #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors
-        engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=exp_sum)
-        cj, cji = parallel.scale_factors(exp_sum, td["n_snv_obs"], td["n_ind_obs"])
+        engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part[0])
+        cj, cji = parallel.scale_factors_from_part(part, out=cj_out)
         e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
         if timed:
             e0.record()

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "dig_accumulate_elements_host": [_vp] * 8 + [_int] + [_vp] * 11 + [_i64, _i64, _i64, _int],
     "dig_scale_suffstats": [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp],
     "dig_scale_suffstats_host": [_vp, _vp, _i64, _i64, _vp, _int],
+    "dig_scale_factors": [_vp, _int, _i64, _vp, _vp, _vp],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_overlap_join_fill": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dig_ideal_overlaps_host": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp],

@@ -210,6 +210,32 @@ static int launch_acc_v1(const AccArgs& a, hipStream_t stream)
 //                        writes MU / SIGMA / R_OBS / FLAG / R_SIZE and the strand-permuted context counts (workspace);
 //   acc_dot_mfma_kernel  the [E x 256] x [256 x C] FP64 product on the matrix cores, quotient and element sizes.
 // =======================================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int kMfmaWaves = 8;                 // waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS)
+constexpr int kMfmaSteps = 64;                // 256 K rows / 4
+constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
+
+// tab[chunk][step = 4 t + u][nt][lane] = T[kappa = 16 t + 4 (lane / 16) + u][chunk * 48 + nt * 16 + lane % 16],
+// T = per-context sums (kappa < 64, d_pr[c][3 ctx .. 3 ctx + 2] summed as (a + b) + c) then d_pr[c][kappa - 64].
+// (written by the first phase of acc_region_kernel, which precedes the dot kernel on the stream)
+__device__ __forceinline__ void acc_write_mfma_table(const double* __restrict__ d_pr, double* __restrict__ tab, int C,
+                                                     int nchunk, int64_t first, int64_t step_)
+{
+    const int n = nchunk * kMfmaSteps * 3 * 64;
+    for (int64_t idx64 = first; idx64 < n; idx64 += step_) {
+        const int idx = (int)idx64;
+        const int lane = idx & 63, nt = (idx >> 6) % 3, step = (idx / 192) % kMfmaSteps, chunk = idx / (192 * kMfmaSteps);
+        const int kappa = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3);
+        const int c = chunk * kMfmaChunk + nt * 16 + (lane & 15);
+        double v = 0.0;
+        if (c < C) {
+            const double* d = d_pr + (int64_t)c * 192;
+            v = (kappa < 64) ? (d[3 * kappa] + d[3 * kappa + 1]) + d[3 * kappa + 2] : d[kappa - 64];
+        }
+        tab[idx] = v;
+    }
+}
+
 constexpr int kRegionBlock = 256;
 
 // acc_region_kernel: persistent grid, two independent phases per wave (no barriers, no LDS).
@@ -225,11 +251,16 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
     const uint8_t* __restrict__ bin_flag, const int32_t* __restrict__ bin_ctx, const int64_t* __restrict__ ov_ptr,
     const int32_t* __restrict__ ov_idx, const uint8_t* __restrict__ strand_minus, double* __restrict__ MU,
     double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS, int32_t* __restrict__ FLAG, int32_t* __restrict__ R_SIZE,
-    int32_t* __restrict__ rcp, int64_t E, int64_t C, FastDiv divC, int use_fastdiv)
+    int32_t* __restrict__ rcp, int64_t E, int64_t C, FastDiv divC, int use_fastdiv, const double* __restrict__ d_pr,
+    double* __restrict__ tab, int n48)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * kRegionBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kRegionBlock) >> 6;
+
+    // phase 0: the pre-swizzled parameter table of the dot stage (a few hundred KB, once per call)
+    acc_write_mfma_table(d_pr, tab, (int)C, n48, (int64_t)blockIdx.x * kRegionBlock + threadIdx.x,
+                         (int64_t)gridDim.x * kRegionBlock);
 
     const int64_t n = E * C;
     const int64_t n_tiles = (n + 63) >> 6;
@@ -303,34 +334,11 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
 //     workgroup (4 per SIMD): lane (i, k) reads its element's count rows 16 bytes at a time (ints 16 t + 4 k .. + 3),
 //     converts each int once and uses it for NT MFMAs; the K order inside a 16-int group is permuted accordingly
 //     (a sum, so free); loads run one group of four slices (48 MFMAs) ahead;
-//   * the parameter table is staged once per workgroup in LDS, pre-swizzled by acc_prep_mfma_kernel into the exact
+//   * the parameter table is staged once per workgroup in LDS, pre-swizzled (acc_write_mfma_table) into the exact
 //     per-lane order of the B operand (tab[step][nt][lane]): every ds_read_b64 is 512 contiguous bytes;
 //   * denominators (64 context rows) and numerators (192 substitution rows) use separate accumulators; the quotient
 //     and the integer element sizes are formed in registers and written once.
 // =======================================================================================
-typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int kMfmaWaves = 8;                 // waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS)
-constexpr int kMfmaSteps = 64;                // 256 K rows / 4
-constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
-
-// tab[chunk][step = 4 t + u][nt][lane] = T[kappa = 16 t + 4 (lane / 16) + u][chunk * 48 + nt * 16 + lane % 16],
-// T = per-context sums (kappa < 64, d_pr[c][3 ctx .. 3 ctx + 2] summed as (a + b) + c) then d_pr[c][kappa - 64].
-__global__ void acc_prep_mfma_kernel(const double* __restrict__ d_pr, double* __restrict__ tab, int C, int nchunk)
-{
-    const int n = nchunk * kMfmaSteps * 3 * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, nt = (idx >> 6) % 3, step = (idx / 192) % kMfmaSteps, chunk = idx / (192 * kMfmaSteps);
-        const int kappa = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3);
-        const int c = chunk * kMfmaChunk + nt * 16 + (lane & 15);
-        double v = 0.0;
-        if (c < C) {
-            const double* d = d_pr + (int64_t)c * 192;
-            v = (kappa < 64) ? (d[3 * kappa] + d[3 * kappa + 1]) + d[3 * kappa + 2] : d[kappa - 64];
-        }
-        tab[idx] = v;
-    }
-}
-
 template <int NT>
 __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __restrict__ tab, int step0, int lane,
                                            double4_t (&acc)[NT], int& isum)
@@ -556,11 +564,9 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
         const int grid = grid_for(E * C, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
                            bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C,
-                           make_fastdiv(C), (int)(C >= 2));
+                           make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48);
         DIG_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(acc_prep_mfma_kernel, dim3(32), dim3(256), 0, s, d_pr, w.tab, (int)C, w.n48);
-    DIG_HIP_TRY(hipGetLastError());
     return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
                           : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
 }

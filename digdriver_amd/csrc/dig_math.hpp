@@ -77,6 +77,42 @@ __device__ __forceinline__ double recip_nr(double v)
     return r;
 }
 
+// a * b + c with the wave-uniform constant c held in scalar registers: the compiler's own choice for a Horner step
+// with a literal is v_mov_b32 x2 + v_fmac_f64 (three vector instructions); this is one, the constant costs two
+// scalar moves that issue beside the vector pipe.
+__device__ __forceinline__ double fma_sconst(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
+// ---- exponential for arguments in [-745, 0] (p^alpha = exp(alpha log p)), < 1 ulp ----------------
+// x = n ln2 + r, |r| <= ln2 / 2;  e^r from the degree-13 Taylor polynomial (remainder r^14 / 14! < 5e-18), scaled by
+// 2^n with ldexp.  Anything outside (-745, 0] or NaN goes to the library exp.
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    if (!(x <= 0.0 && x > -745.0)) return exp(x);
+    const double n = rint(x * 1.4426950408889634);                       // log2(e)
+    double r = fma(n, -6.93147180369123816490e-01, x);                   // ln2 split: high part has 32 zero low bits
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double q = 1.6059043836821613e-10;                                   // 1/13!
+    q = fma_sconst(q, r, 2.08767569878681e-09);                          // 1/12!
+    q = fma_sconst(q, r, 2.505210838544172e-08);                         // 1/11!
+    q = fma_sconst(q, r, 2.755731922398589e-07);                         // 1/10!
+    q = fma_sconst(q, r, 2.7557319223985893e-06);                        // 1/9!
+    q = fma_sconst(q, r, 2.48015873015873e-05);                          // 1/8!
+    q = fma_sconst(q, r, 1.984126984126984e-04);                         // 1/7!
+    q = fma_sconst(q, r, 1.3888888888888889e-03);                        // 1/6!
+    q = fma_sconst(q, r, 8.333333333333333e-03);                         // 1/5!
+    q = fma_sconst(q, r, 4.1666666666666664e-02);                        // 1/4!
+    q = fma_sconst(q, r, 1.6666666666666666e-01);                        // 1/3!
+    q = fma_sconst(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)n);
+}
+
 // ---- natural logarithm, < 1 ulp, ~1/3 of the instructions of the library log ---------------
 // Classical reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = f / (2 + f), f = m - 1,
 // with the degree-14 minimax polynomial in s^2 (the coefficients are the standard ones of this scheme).
@@ -94,9 +130,15 @@ __device__ __forceinline__ double fast_log(double x)
     const double f = __longlong_as_double(mbits) - 1.0;
     const double s = f * recip_nr(2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-    const double t2 = z * (6.666666666666735130e-01 +
-                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    double t1 = 1.531383769920937332e-01;
+    t1 = fma_sconst(t1, w, 2.222219843214978396e-01);
+    t1 = fma_sconst(t1, w, 3.999999999940941908e-01);
+    t1 *= w;
+    double t2 = 1.479819860511658591e-01;
+    t2 = fma_sconst(t2, w, 1.818357216161805012e-01);
+    t2 = fma_sconst(t2, w, 2.857142874366239149e-01);
+    t2 = fma_sconst(t2, w, 6.666666666666735130e-01);
+    t2 *= z;
     const double R = t1 + t2;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
@@ -245,7 +287,7 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
     const double lp0 = alpha * fast_log(p);
     unsigned todo = want;
     if (lp0 > -500.0) {
-        const double t0 = exp(lp0);
+        const double t0 = fast_exp_neg(lp0);
         const bool el1 = (want & 1u) && k1 <= (double)kRecurK, el2 = (want & 2u) && k2 <= (double)kRecurK;
         // targets in ascending order; a single eligible count is visited once
         const double klo = (el1 && el2) ? fmin(k1, k2) : (el1 ? k1 : k2);
@@ -397,7 +439,7 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     //   N_j = prod_{i<j} (alpha + i) x,  D_j = j!,  A_j = S_j D_{j-1} / t_0   (A_{j+1} = A_j * j + N_j)
     // so one step is 5 full-rate FP64 ops with no memory access; t_k = t_0 N_k / D_k, S_k = t_0 A_k k / D_k.
     // The trip count is tested on the FP64 counter itself (one v_cmp, no integer shadow counter).
-    const double t0 = exp(lp0);
+    const double t0 = fast_exp_neg(lp0);
     double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
     // two exec-masked loops instead of one loop with a per-step snapshot: 0 .. kmin, snapshot, kmin .. kmax
     while (jj < kmin) pmf_scaled_step(A, N, D, u, jj, x);

@@ -33,15 +33,19 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_stage1(const double* __res
         double acc = 0.0;
         if (rg < rpp) {
             int64_t r = r_begin + rg;
-            // 4 independent loads in flight per thread
-            for (; r + 3 * rpp < r_end; r += 4 * rpp) {
-                const int64_t o0 = r * C + col, o1 = o0 + rpp * C, o2 = o1 + rpp * C, o3 = o2 + rpp * C;
-                const double v0 = bin_mu[o0], v1 = bin_mu[o1], v2 = bin_mu[o2], v3 = bin_mu[o3];
-                const uint8_t f0 = bin_flag[o0], f1 = bin_flag[o1], f2 = bin_flag[o2], f3 = bin_flag[o3];
-                acc += f0 ? 0.0 : v0;
-                acc += f1 ? 0.0 : v1;
-                acc += f2 ? 0.0 : v2;
-                acc += f3 ? 0.0 : v3;
+            // 8 independent row loads in flight per thread (the pass is pure streaming: what limits it is bytes in
+            // flight per CU, not arithmetic)
+            for (; r + 7 * rpp < r_end; r += 8 * rpp) {
+                double v[8];
+                uint8_t f[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t o = (r + (int64_t)q * rpp) * C + col;
+                    v[q] = bin_mu[o];
+                    f[q] = bin_flag[o];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += f[q] ? 0.0 : v[q];
             }
             for (; r < r_end; r += rpp) {
                 const int64_t o = r * C + col;
@@ -85,9 +89,28 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_stage2(const double* __res
     if (threadIdx.x == 0) out[c] = red[0];
 }
 
+// scale factors from the all-gathered per-rank statistics: parts[r][0][c] = sum(Y_PRED[~FLAG]) of rank r's bins,
+// parts[r][1][c] = its observed SNVs, parts[r][2][c] = its observed indels.  Summed in rank order on every rank
+// (bit-reproducible, independent of the collective's reduction order), then cj = obs / expected.
+__global__ void scale_factors_kernel(const double* __restrict__ parts, int world, int C, double* __restrict__ cj,
+                                     double* __restrict__ cj_indel)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double e = 0.0, s = 0.0, d = 0.0;
+        for (int r = 0; r < world; ++r) {
+            const double* q = parts + (int64_t)r * 3 * C;
+            e += q[c];
+            s += q[C + c];
+            d += q[2 * C + c];
+        }
+        cj[c] = s / e;            // transfer_tools.py:153
+        cj_indel[c] = d / e;      // :154
+    }
+}
+
 static int ss_blocks(int64_t N)
 {
-    int64_t g = (int64_t)cu_count() * 4;
+    int64_t g = (int64_t)cu_count() * 8;
     if (g > (N + 63) / 64) g = (N + 63) / 64;
     return (int)(g < 1 ? 1 : g);
 }
@@ -123,6 +146,18 @@ int dig_scale_suffstats(const double* bin_mu, const uint8_t* bin_flag, int64_t N
     hipLaunchKernelGGL(suffstats_stage1, dim3(g), dim3(kSsBlock), 0, s, bin_mu, bin_flag, N, C, rpb, (double*)workspace);
     DIG_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(suffstats_stage2, dim3((unsigned)C), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_scale_factors(const double* parts, int world, int64_t C, double* cj, double* cj_indel, void* stream)
+{
+    DIG_REQUIRE(world >= 1 && C >= 0, "world >= 1, C >= 0");
+    if (C == 0) return DIG_OK;
+    DIG_REQUIRE(parts && cj && cj_indel, "non-null pointers");
+    DIG_REQUIRE(C <= 0x7fffffff, "C fits in 32 bits");
+    hipLaunchKernelGGL(scale_factors_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
+                       world, (int)C, cj, cj_indel);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

@@ -129,6 +129,22 @@ def scale_suffstats(bin_mu, bin_flag, device=0, out=None):
     return res
 
 
+def scale_factors_from_parts(parts, out=None):
+    """cj, cj_indel from the all-gathered per-shard statistics `parts` f64 [world, 3, C] on the device
+    (rank-ordered sums + division in one kernel; transfer_tools.py:153-154)."""
+    import torch
+    dev = parts.device
+    parts = _t(parts, torch.float64, dev)
+    world, three, C = parts.shape
+    assert three == 3
+    if out is None:
+        out = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
+    with torch.cuda.device(dev):
+        _lib.call("dig_scale_factors", _lib.dev_ptr(parts), world, C, _lib.dev_ptr(out[0]), _lib.dev_ptr(out[1]),
+                  _lib.stream_ptr())
+    return out
+
+
 # ---------------------------------------------------------------------------
 def ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bin_start):
     """CSR of overlapped bin rows per element (genic_driver_tools.py:275-283), ascending rows.

@@ -74,7 +74,30 @@ def scale_factors(local_exp_sum, local_n_snv, local_n_indel, group=None):
     cj = sum_r N_SNV_OBS_r / sum_r sum(Y_PRED[~FLAG])_r, cj_indel likewise.  One exchange of a [3, C] tensor."""
     import torch
     part = torch.stack([local_exp_sum, local_n_snv.to(local_exp_sum.dtype), local_n_indel.to(local_exp_sum.dtype)])
-    tot = rank_ordered_sum(part, group)
+    return scale_factors_from_part(part, group)
+
+
+def scale_factors_from_part(part, group=None, out=None):
+    """Same, from the shard's statistics already laid out as one [3, C] f64 tensor (row 0 = sum(Y_PRED[~FLAG]),
+    rows 1-2 = observed SNV / indel totals): all-gather, then -- on the device -- one kernel that adds the shards in
+    rank order and divides (dig_scale_factors); host tensors (the gloo tests) use the same arithmetic in torch."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        parts = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
+        if part.is_cuda:
+            dist.all_gather_into_tensor(parts, part.contiguous(), group=group)
+        else:
+            dist.all_gather(list(parts.unbind(0)), part.contiguous(), group=group)
+    else:
+        parts = part.unsqueeze(0)
+    if parts.is_cuda:
+        from . import engine
+        return engine.scale_factors_from_parts(parts, out=out)
+    tot = parts[0].clone()
+    for r in range(1, parts.shape[0]):      # rank order
+        tot += parts[r]
     return tot[1] / tot[0], tot[2] / tot[0]
 
 

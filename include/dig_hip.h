@@ -166,6 +166,12 @@ int dig_scale_suffstats(const double *bin_mu, const uint8_t *bin_flag, int64_t N
 int dig_scale_suffstats_host(const double *bin_mu, const uint8_t *bin_flag, int64_t N, int64_t C, double *out_sum,
                              int device);
 
+/* Scale factors from the (all-gathered) per-shard statistics, transfer_tools.py:153-154:
+ *   parts f64 [world, 3, C]: row 0 = sum(Y_PRED[~FLAG]) of the shard, row 1 = its N_SNV_OBS, row 2 = its N_IND_OBS;
+ *   cj[c] = sum_r parts[r][1][c] / sum_r parts[r][0][c],  cj_indel[c] = sum_r parts[r][2][c] / sum_r parts[r][0][c],
+ *   both sums taken in rank order r = 0 .. world-1 (bit-reproducible on every rank).  world = 1: a plain division. */
+int dig_scale_factors(const double *parts, int world, int64_t C, double *cj, double *cj_indel, void *stream);
+
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins
  * floor(start/w)*w ... ceil(end/w)*w; duplicates removed; rows are looked up in the sorted bin

@@ -93,3 +93,19 @@ def test_cli_pretrain_then_driver(tmp_path):
                           "--f-bed", str(bed), "--scale-factor-manual", "1.0", "--outdir", str(out), "--outpfx", "x"],
                          env=env, capture_output=True, text=True)
     assert bad.returncode != 0 and "both" in (bad.stderr + bad.stdout)
+
+
+def test_scale_factors_kernel_rank_ordered_sum():
+    """dig_scale_factors: shards added in rank order, then the two divisions of transfer_tools.py:153-154 (bit-exact
+    against the same sequence of IEEE operations in numpy)."""
+    import torch
+    from digdriver_amd import engine
+    rng = np.random.default_rng(11)
+    for world, C in ((1, 37), (3, 5), (8, 300)):
+        parts = rng.gamma(3.0, 1e5, (world, 3, C))
+        cj, cji = engine.scale_factors_from_parts(torch.as_tensor(parts, device="cuda:0"))
+        tot = parts[0].copy()
+        for r in range(1, world):
+            tot += parts[r]
+        assert np.array_equal(cj.cpu().numpy(), tot[1] / tot[0])
+        assert np.array_equal(cji.cpu().numpy(), tot[2] / tot[0])
