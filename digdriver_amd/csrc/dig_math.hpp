@@ -251,6 +251,10 @@ __device__ inline double nb_upper_tail_from_pmf(double k, double alpha, double p
     return 1.0 - pmfk * ((k + alpha) * x / alpha) * betacf_fast(b, a, p);
 }
 
+// The recurrences below evaluate  1 - S_k - (W2 / 2) t_k  (S_k = sum_{j<k} t_j):  W2 = 1 is the mid-p statistic
+// 0.5 pmf(k) + P(X > k);  W2 = 0 is P(X >= k) = betainc(k, alpha, 1 - p), the upper tail of nb_pvalue_exact and
+// nb_pvalue_greater.
+template <int W2 = 1>
 __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, unsigned want, double alpha, double p,
                                                         double& r1, double& r2);
 
@@ -259,6 +263,7 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
 constexpr int kRecurK = 2048;   // direct summation limit of the slow pass
 
 __device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x);
+template <int W2 = 1>
 __device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0);
 
 // Slow-pass evaluation for integer k >= 0, 0 < p < 1, finite alpha > 0.
@@ -280,6 +285,7 @@ constexpr int kTailMax = 4096;
 // evaluated at the smaller count on the way to the larger one.  `want` selects the requested counts (bit 0: k1,
 // bit 1: k2); both must be integers >= 0.  All rescalings are exact powers of two, so the result for a count does
 // not depend on whether it was computed alone or together with another one.
+template <int W2 = 1>
 __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, double alpha, double p, double& r1,
                                            double& r2)
 {
@@ -304,11 +310,11 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
                 N = ldexp(N, e);
                 A = ldexp(A, e);
             }
-            double res = midp_from_state(A, N, D, jj, t0);
+            double res = midp_from_state<W2>(A, N, D, jj, t0);
             bool ok = res >= (k <= 256.0 ? kDirectMin : 1e-4);     // long sums: keep a wider safety margin
             if (!ok) {
-                // (2) tail series from a copy of the state at k:  0.5 t_k + sum_{j>k} t_j
-                double Nt = N, Dt = D, ut = u, jt = jj, B = 0.0, H = 0.5 * N;
+                // (2) tail series from a copy of the state at k:  (1 - W2/2) t_k + sum_{j>k} t_j
+                double Nt = N, Dt = D, ut = u, jt = jj, B = 0.0, H = (1.0 - 0.5 * W2) * N;
                 const double jend = k + (double)kTailMax;
                 bool converged = false;
                 while (jt < jend) {
@@ -342,11 +348,11 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
     // (3) lgamma + continued fraction for whatever is left
     if (todo & 1u) {
         const double pmfk = exp(nbinom_logpmf_unchecked(k1, alpha, p));
-        r1 = 0.5 * pmfk + nb_upper_tail_from_pmf(k1, alpha, p, x, pmfk);
+        r1 = (1.0 - 0.5 * W2) * pmfk + nb_upper_tail_from_pmf(k1, alpha, p, x, pmfk);
     }
     if (todo & 2u) {
         const double pmfk = exp(nbinom_logpmf_unchecked(k2, alpha, p));
-        r2 = 0.5 * pmfk + nb_upper_tail_from_pmf(k2, alpha, p, x, pmfk);
+        r2 = (1.0 - 0.5 * W2) * pmfk + nb_upper_tail_from_pmf(k2, alpha, p, x, pmfk);
     }
 }
 
@@ -383,11 +389,13 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
 // ---- fast mid-p evaluation for small integer counts sharing (alpha, p) ----------------
 // 1 - S_k - t_k / 2 from the scaled state (A_k, N_k, D_k = k!, k):  t_k = t_0 N_k / D_k,  S_k = t_0 A_k k / D_k.
 // Single definition: both counts of a pair and every entry point go through these exact operations.
+template <int W2>
 __device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0)
 {
 #pragma clang fp contract(off)
     const double rD = t0 * recip_nr(D);
     const double S = (A * k) * rD;
+    if (W2 == 0) return 1.0 - S;
     const double t = N * rD;
     return (1.0 - S) - 0.5 * t;
 }
@@ -410,6 +418,7 @@ __device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D,
 // (bit 0: k1, bit 1: k2); unresolved ones (k > kSmallK, non-integer, p^alpha underflow, or a
 // result < kDirectMin where 1 - S cancels) must go through nb_midp_upper().
 // `want` selects which of the two counts are requested.
+template <int W2>
 __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, unsigned want, double alpha, double p,
                                                         double& r1, double& r2)
 {
@@ -422,8 +431,8 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     if (isnan(k1)) { r1 = dnan(); done |= 1u; }
     if (isnan(k2)) { r2 = dnan(); done |= 2u; }
     if (p == 1.0) {
-        if ((want & 1u) && k1 >= 0.0 && floor(k1) == k1) { r1 = (k1 == 0.0) ? 0.5 : 0.0; done |= 1u; }
-        if ((want & 2u) && k2 >= 0.0 && floor(k2) == k2) { r2 = (k2 == 0.0) ? 0.5 : 0.0; done |= 2u; }
+        if ((want & 1u) && k1 >= 0.0 && floor(k1) == k1) { r1 = (k1 == 0.0) ? (W2 ? 0.5 : 1.0) : 0.0; done |= 1u; }
+        if ((want & 2u) && k2 >= 0.0 && floor(k2) == k2) { r2 = (k2 == 0.0) ? (W2 ? 0.5 : 1.0) : 0.0; done |= 2u; }
         return done & want;
     }
     const bool e1 = (want & 1u) && !(done & 1u) && k1 >= 0.0 && k1 <= (double)kSmallK && floor(k1) == k1;
@@ -443,9 +452,9 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
     // two exec-masked loops instead of one loop with a per-step snapshot: 0 .. kmin, snapshot, kmin .. kmax
     while (jj < kmin) pmf_scaled_step(A, N, D, u, jj, x);
-    const double r_min = midp_from_state(A, N, D, jj, t0);
+    const double r_min = midp_from_state<W2>(A, N, D, jj, t0);
     while (jj < kmax) pmf_scaled_step(A, N, D, u, jj, x);
-    const double r_max = midp_from_state(A, N, D, jj, t0);
+    const double r_max = midp_from_state<W2>(A, N, D, jj, t0);
     const bool k1_is_max = k1d >= k2d;
     const double ra = k1_is_max ? r_max : r_min;   // result for k1
     const double rb = k1_is_max ? r_min : r_max;   // result for k2
@@ -458,11 +467,24 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
 // is subnormal/zero or an argument is out of (0, 1].
 __device__ __forceinline__ double fisher_combine_fast(double p1, double p2);
 
+// betainc(k, alpha, 1 - p) = P(X >= k) for an integer count k >= 1 and valid (alpha, p) from the same recurrences as
+// the mid-p statistic (weight 0 on pmf(k) in 1 - S_k - w t_k); anything else takes the general incomplete beta.
+__device__ inline double nb_upper_incl(double k, double alpha, double p)
+{
+    if (!(k >= 1.0) || floor(k) != k || isinf(k) || isnan(alpha) || isnan(p) || !(alpha > 0.0) || !(p > 0.0) ||
+        !(p < 1.0) || isinf(alpha))
+        return betainc(k, alpha, 1.0 - p);
+    double r = 0.0, dummy = 0.0;
+    if (nb_midp_upper_fast2<0>(k, 0.0, 1u, alpha, p, r, dummy) & 1u) return r;
+    nb_midp_upper_slow2<0>(k, 0.0, 1u, alpha, p, r, dummy);
+    return r;
+}
+
 // nb_model.py:243-256
 __device__ inline double nb_greater(double k, double alpha, double p)
 {
     if (k == 0.0) return 1.0;
-    double pv = betainc(k, alpha, 1.0 - p);
+    double pv = nb_upper_incl(k, alpha, p);
     if (pv == 0.0) pv = nbinom_pmf(k, alpha, p);
     return pv;
 }
@@ -473,14 +495,15 @@ __device__ __forceinline__ bool nb_lower_cdf_small(double k, double alpha, doubl
 {
     if (!(alpha > 0.0) || !(p > 0.0) || !(p < 1.0) || isinf(alpha)) return false;
     if (!(k >= 0.0) || k > (double)kSmallK || floor(k) != k) return false;
-    const double lp0 = alpha * log(p);
+    const double lp0 = alpha * fast_log(p);
     if (!(lp0 > -690.0)) return false;
     const double x = 1.0 - p;
-    double t = exp(lp0), S = t;
-    const int ki = (int)k;
-    for (int j = 0; j < ki; ++j) {
-        t *= (alpha + (double)j) * x / (double)(j + 1);
+    double t = fast_exp_neg(lp0), S = t, u = alpha * x, jj = 1.0;
+    while (jj <= k) {
+        t *= u * recip_nr(jj);
         S += t;
+        u += x;
+        jj += 1.0;
     }
     *out = S;
     return true;
@@ -495,7 +518,7 @@ __device__ inline double nb_exact(double k, double alpha, double p)
         if (nb_lower_cdf_small(k, alpha, p, &s)) return s;
         return betainc(alpha, k + 1.0, p);
     }
-    double pv = betainc(k, alpha, 1.0 - p);
+    double pv = nb_upper_incl(k, alpha, p);
     if (pv == 0.0) pv = nbinom_pmf(k, alpha, p);
     return pv;
 }

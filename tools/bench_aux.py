@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Roofline measurements for the two remaining HBM-bound rows of the scope table that bench.py's step does not
+contain: the per-bin track gather (a1, dig_gather_bins) and the per-base tiled NB test (a18, dig_tiled_nb_test).
+Synthetic inputs per SURVEY 8d; prints one JSON object (committed as profiles/rNN_aux.json).  Developer tool."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from digdriver_amd import engine                     # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e-3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {"gather_bins": [], "tiled_nb_test": []}
+    g = torch.Generator(device=dev).manual_seed(2)
+    # ---- a1: gather of B bins x 100 positions x 735 tracks from an HBM-resident matrix -------------------------
+    N, L, T, B = 20000, 100, 735, 4096
+    x16 = torch.randint(0, 10000, (N, L, T), dtype=torch.int16, device=dev, generator=g)   # round(x, 2) * 100 values
+    rows = torch.randint(0, N, (B,), dtype=torch.int64, device=dev, generator=g)
+    sel = torch.arange(T, dtype=torch.int32, device=dev)
+    for name, x in (("i16", x16), ("f32", x16[: N // 2].float())):
+        for odt in ("bf16", "f32"):
+            for tr in (False, True):
+                r = rows % x.shape[0]
+                dt = timeit(lambda: engine.gather_bins(x, r, sel, out_dtype=odt, transpose=tr))
+                by = B * L * T * (x.element_size() + (2 if odt == "bf16" else 4))
+                out["gather_bins"].append({"in": name, "out": odt, "channels_first": tr, "bins": B, "L": L, "T": T,
+                                           "ms": dt * 1e3, "bins_per_s": B / dt, "algorithmic_GBps": by / dt / 1e9,
+                                           "frac_hbm_peak": by / dt / HBM_PEAK})
+        del x
+    del x16
+    torch.cuda.empty_cache()
+    # ---- a18: per-base tiles, 50-bp tiles of 10-kb bins (200 tiles per bin), C cohorts ------------------------------
+    C, nb, nt = 37, 8000, 200
+    rng = np.random.default_rng(5)
+    mu = torch.as_tensor(rng.gamma(9.0, 3.0, (C, nb)), device=dev)
+    sigma = torch.as_tensor(rng.gamma(4.0, 1.0, (C, nb)), device=dev)
+    pt_np = rng.dirichlet(np.ones(nt), size=nb)                       # per-tile share of the bin's rate
+    pt = torch.as_tensor(pt_np, device=dev)
+    k = torch.poisson(mu[:, :, None] * pt[None, :, :]).to(torch.int32)
+    dt = timeit(lambda: engine.tiled_nb_test(pt, k, mu, sigma), n=5, warm=1)
+    units = C * nb * nt
+    by = 28.0 * units + 16.0 * C * nb
+    pv, ex = engine.tiled_nb_test(pt, k, mu, sigma)
+    out["tiled_nb_test"].append({"cohorts": C, "bins": nb, "tiles_per_bin": nt, "tile_cohort_tests": units, "ms": dt * 1e3,
+                                 "tests_per_s": units / dt, "algorithmic_GBps": by / dt / 1e9,
+                                 "frac_hbm_peak": by / dt / HBM_PEAK, "finite": bool(torch.isfinite(pv).all().item()),
+                                 "whole_genome_x37_seconds": 288000 * nt * C / (units / dt)})
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
