@@ -161,6 +161,68 @@ def cpu_baseline(w, sample_elements, want_seconds=15.0):
     return out
 
 
+_POOL_W = None   # workload shared with forked workers (copy-on-write)
+
+
+def _oracle_slice(bounds):
+    """One oracle pass over elements [a, b) of the shared workload (worker of cpu_baseline_all_cores)."""
+    from oracle import dig_oracle as O
+    a, b = bounds
+    w = _POOL_W
+    if b <= a:
+        return 0
+    q0, q1 = int(w["ov_ptr"][a]), int(w["ov_ptr"][b])
+    ptr = w["ov_ptr"][a: b + 1] - q0
+    idx = w["ov_idx"][q0:q1]
+    acc = O.accumulate_elements_fast(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], ptr, idx,
+                                     w["L"][a:b], w["strand_minus"][a:b].astype(bool), w["d_pr"])
+    O.element_stats(acc["MU"], acc["SIGMA"], acc["P"][:, 0, :], acc["P_INDEL"][:, None], w["obs_snv"][a:b],
+                    w["obs_samples"][a:b], w["obs_indel"][a:b], w["cj"][None, :], w["cj_indel"][None, :])
+    return b - a
+
+
+def _usable_cores():
+    """Processes for the multi-process baseline: the reference's own default P = min(max(1, ncpu - 2), 20)
+    (auxilaries/utils.py:3-8), with ncpu taken from the affinity mask and capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("BENCH_CPU_PROCS"):
+        return max(1, int(os.environ["BENCH_CPU_PROCS"]))
+    return min(max(1, n - 2), 20)
+
+
+def cpu_baseline_all_cores(w, want_seconds=8.0):
+    """The same oracle in P processes over contiguous element slices -- how the reference itself parallelises
+    (multiprocessing.Pool over chunks, genic_driver_tools.py:447-457; P = its default, see _usable_cores).  Must run before the
+    process touches the GPU (workers are forked).  Test infrastructure, never the product."""
+    global _POOL_W
+    import multiprocessing as mp
+    cores = _usable_cores()
+    E, C = w["L"].shape[0], w["d_pr"].shape[0]
+    _POOL_W = w
+    edges = np.linspace(0, E, cores + 1).astype(int)
+    chunks = list(zip(edges[:-1], edges[1:]))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_slice, [(0, min(64, E))] * cores)            # start the workers, import the oracle
+        total, reps = 0.0, 0
+        while total < want_seconds and reps < 20:
+            t0 = time.perf_counter()
+            done = sum(pool.map(_oracle_slice, chunks, chunksize=1))
+            total += time.perf_counter() - t0
+            reps += 1
+            assert done == E
+    _POOL_W = None
+    return {"value": E * C * reps / total, "unit": "element-cohort tests/s", "cores": cores, "kind": "port",
+            "sample": "all %d elements x %d cohorts, %d pass(es), oracle/dig_oracle.py in %d forked processes "
+                      "(one contiguous element slice each)" % (E, C, reps, cores)}
+
+
 # --------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -182,6 +244,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    # CPU baselines first: the all-core one forks workers, which must happen before this process touches the GPU
+    w, cpu_res = None, (None, None)
+    if world == 1:
+        w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
+        if args.cpu_sample > 0:
+            cpu_res = (cpu_baseline(w, args.cpu_sample), cpu_baseline_all_cores(w))
     _lib.require_device()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -191,7 +259,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
+    if w is None:
+        w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
     E, C = w["L"].shape[0], w["d_pr"].shape[0]
     N = w["bin_mu"].shape[0]
     nbar = float(len(w["ov_idx"])) / E
@@ -275,7 +344,7 @@ def main():
             "finite_pvalues": ok, "slow_pair_fraction": slow_frac,
         }
         if args.cpu_sample > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
+            res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
