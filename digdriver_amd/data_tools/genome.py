@@ -1,0 +1,98 @@
+"""Packed reference genome for the context-counting kernel (dig_count_contexts).
+
+The reference reads sequence through pysam.FastaFile per region (sequence_tools.py:21-29, onthefly_tools.py:120).
+Here the FASTA is parsed once into the 4-bit layout of include/dig_hip.h (A=0 C=1 G=2 T=3, anything else 4; eight
+bases per 32-bit word, base 0 in the low nibble; chromosomes word-aligned; one all-N pad word at either end), cached
+as an .npz next to the FASTA if the directory is writable, and uploaded to HBM once (hg19: 1.55 GB).
+"""
+import gzip
+import os
+
+import numpy as np
+
+_CODE = np.full(256, 4, np.uint8)
+for _i, _ch in enumerate("ACGT"):
+    _CODE[ord(_ch)] = _i
+    _CODE[ord(_ch.lower())] = _i
+
+
+class PackedGenome:
+    def __init__(self, names, offsets, lengths, words):
+        self.names = list(names)
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.offsets = np.asarray(offsets, np.int64)     # in bases, counted from word 1, multiples of 8
+        self.lengths = np.asarray(lengths, np.int64)
+        self.words = np.ascontiguousarray(words, np.uint32)
+        self._dev = {}
+
+    # ---- construction ----------------------------------------------------------------------
+    @classmethod
+    def from_sequences(cls, seqs):
+        """seqs: dict name -> str/bytes (any case)."""
+        names, offsets, lengths, total = [], [], [], 0
+        for n, s in seqs.items():
+            names.append(n)
+            offsets.append(total)
+            lengths.append(len(s))
+            total += (len(s) + 7) // 8 * 8
+        nib = np.full(total + 16, 4, np.uint8)            # + one pad word (8 nibbles) at either end
+        for n, o in zip(names, offsets):
+            s = seqs[n]
+            b = np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8)
+            nib[8 + o: 8 + o + len(b)] = _CODE[b]
+        n8 = nib.reshape(-1, 8).astype(np.uint32)
+        words = np.zeros(n8.shape[0], np.uint32)
+        for k in range(8):
+            words |= n8[:, k] << np.uint32(4 * k)
+        return cls(names, offsets, lengths, words)
+
+    @classmethod
+    def from_fasta(cls, f_fasta, cache=True):
+        f_cache = f_fasta + ".dig4.npz"
+        if cache and os.path.exists(f_cache) and os.path.getmtime(f_cache) >= os.path.getmtime(f_fasta):
+            d = np.load(f_cache, allow_pickle=False)
+            return cls([str(n) for n in d["names"]], d["offsets"], d["lengths"], d["words"])
+        seqs, name, parts = {}, None, []
+        opener = gzip.open if f_fasta.endswith(".gz") else open
+        with opener(f_fasta, "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if name is not None:
+                        seqs[name] = b"".join(parts)
+                    name, parts = line[1:].split()[0].decode(), []
+                else:
+                    parts.append(line.strip())
+        if name is not None:
+            seqs[name] = b"".join(parts)
+        g = cls.from_sequences(seqs)
+        if cache:
+            try:
+                np.savez(f_cache, names=np.array(g.names), offsets=g.offsets, lengths=g.lengths, words=g.words)
+            except OSError:
+                pass
+        return g
+
+    # ---- lookup ------------------------------------------------------------------------------
+    def chrom_index(self, chroms):
+        """Chromosome labels -> indices; accepts '1' or 'chr1' whichever the FASTA uses."""
+        out = np.empty(len(chroms), np.int32)
+        for i, c in enumerate(chroms):
+            c = str(c)
+            if c in self.index:
+                out[i] = self.index[c]
+            elif "chr" + c in self.index:
+                out[i] = self.index["chr" + c]
+            elif c.startswith("chr") and c[3:] in self.index:
+                out[i] = self.index[c[3:]]
+            else:
+                raise KeyError("chromosome %r is not in the genome" % c)
+        return out
+
+    def on_device(self, device):
+        import torch
+        dev = torch.device(device)
+        key = (dev.type, dev.index)
+        if key not in self._dev:
+            self._dev[key] = (torch.as_tensor(self.words.view(np.int32), device=dev),
+                              torch.as_tensor(self.offsets, device=dev), torch.as_tensor(self.lengths, device=dev))
+        return self._dev[key]

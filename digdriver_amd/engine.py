@@ -277,6 +277,36 @@ def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False,
     return out
 
 
+def count_contexts(genome, chroms, starts, ends, minus=None, device=0, on_device=True):
+    """Trinucleotide context counts [R, 64] of regions of a PackedGenome (sequence_tools.py:65-99,527-566).
+    on_device=True keeps the genome resident in HBM (uploaded on first use) and returns a device tensor; False goes
+    through the host twin (uploads the genome for this call; small genomes / tests)."""
+    ci = genome.chrom_index(chroms)
+    R = len(ci)
+    st, en = _lib.as_host(starts, np.int64).ravel(), _lib.as_host(ends, np.int64).ravel()
+    mi = np.zeros(R, np.uint8) if minus is None else _lib.as_host(np.asarray(minus).astype(np.uint8), np.uint8).ravel()
+    assert len(st) == len(en) == len(mi) == R
+    if (st < 0).any() or (en < 0).any():
+        raise ValueError("negative region coordinates")
+    if on_device:
+        import torch
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        words, off, ln = genome.on_device(dev)
+        t = lambda a: torch.as_tensor(a, device=dev)
+        out = torch.empty((R, 64), dtype=torch.int32, device=dev)
+        rc, rs, re_, rm = t(ci), t(st), t(en), t(mi)
+        with torch.cuda.device(dev):
+            _lib.call("dig_count_contexts", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln),
+                      len(genome.names), _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), _lib.dev_ptr(rm), R,
+                      _lib.dev_ptr(out), _lib.stream_ptr())
+        return out
+    out = np.empty((R, 64), np.int32)
+    _lib.call("dig_count_contexts_host", _lib.host_ptr(genome.words), genome.words.size, _lib.host_ptr(genome.offsets),
+              _lib.host_ptr(genome.lengths), len(genome.names), _lib.host_ptr(ci), _lib.host_ptr(st), _lib.host_ptr(en),
+              _lib.host_ptr(mi), R, _lib.host_ptr(out), device if isinstance(device, int) else 0)
+    return out
+
+
 def tiled_nb_test(pt, k, mu, sigma, device=0):
     """Per-tile exact NB test (nb_model.py:141-178).  pt f64 [n_bins, n_tiles] or [C, n_bins, n_tiles];
     k i32 [C, n_bins, n_tiles]; mu, sigma f64 [C, n_bins].  Returns (pval, exp) [C, n_bins, n_tiles]."""

@@ -172,6 +172,24 @@ int dig_scale_suffstats_host(const double *bin_mu, const uint8_t *bin_flag, int6
  *   both sums taken in rank order r = 0 .. world-1 (bit-reproducible on every rank).  world = 1: a plain division. */
 int dig_scale_factors(const double *parts, int world, int64_t C, double *cj, double *cj_indel, void *stream);
 
+/* ---- trinucleotide context counting from sequence ---------------------------------------- *
+ * count_sequence_context over fetch_sequence (sequence_model/sequence_tools.py:21-29,42-55,65-80), for a batch of
+ * regions: count_contexts_by_regions (:82-99), nonc_elt_context_count (:527-566), DIG_onthefly
+ * (driver_model/onthefly_tools.py:70-71,120).
+ *   genome_words u32 [n_words]: 4 bits per base (A=0 C=1 G=2 T=3, anything else 4), 8 bases per word, base 0 in the
+ *       low nibble; word 0 and word n_words-1 are all-N pad words; chromosome c occupies bases
+ *       chrom_off[c] .. chrom_off[c] + chrom_len[c] - 1 counted from word 1, chrom_off[c] % 8 == 0.
+ *   region r: centre positions max(start, 1) .. min(end, chrom_len - 1) - 1 of chromosome reg_chrom[r] (the fetch is
+ *       widened by one base, START == 0 becomes 1, truncated at the chromosome end); a triplet holding a non-ACGT
+ *       base is skipped; reg_minus[r] != 0 counts the reverse-complemented sequence ('-' strand elements).
+ *   out i32 [R, 64], context index 16 b0 + 4 b1 + b2 (= itertools.product('ACGT', repeat=3) order).  Bit-exact. */
+int dig_count_contexts(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
+                       const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                       const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, void *stream);
+int dig_count_contexts_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
+                            const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                            const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, int device);
+
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins
  * floor(start/w)*w ... ceil(end/w)*w; duplicates removed; rows are looked up in the sorted bin

@@ -359,3 +359,45 @@ def scale_factor_genome(bin_y_pred, bin_flag, n_snv_obs, n_indel_obs):
     """cj = N_SNV_OBS / sum(Y_PRED[~FLAG]); cj_indel = N_IND_OBS / same (transfer_tools.py:148-156)"""
     n_exp = bin_y_pred[~bin_flag.astype(bool)].sum()
     return n_snv_obs / n_exp, n_indel_obs / n_exp
+
+
+# --------------------------------------------------------------------------
+# trinucleotide context counting from sequence (sequence_tools.py:21-29,42-55,65-94,527-566)
+# --------------------------------------------------------------------------
+def count_contexts_region(chrom_seq, start, end):
+    """64 trinucleotide counts of the centre positions of [start, end) on one chromosome string.
+    fetch_sequence (:21-29): the region is widened by one base on either side, START == 0 becomes 1, the fetch is
+    truncated at the chromosome end and upper-cased; count_sequence_context (:65-80) then counts every window of
+    three that holds no 'N' (seq_to_context :48-49).  Any other non-ACGT letter would raise KeyError in the
+    reference; it is skipped here like 'N'."""
+    if start == 0:
+        start = 1
+    seq = chrom_seq[start - 1:end + 1].upper()
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    out = np.zeros(64, np.int64)
+    for i in range(1, len(seq) - 1):
+        tri = seq[i - 1:i + 2]
+        if all(ch in code for ch in tri):
+            out[16 * code[tri[0]] + 4 * code[tri[1]] + code[tri[2]]] += 1
+    return out
+
+
+def count_contexts_regions(genome, chroms, starts, ends, minus=None):
+    """[R, 64] counts (columns in context64() order).  minus[r] = True counts the reverse-complemented sequence
+    (nonc_elt_context_count, :551-553), i.e. out[ctx] = plus[revcomp(ctx)]."""
+    rho = minus_strand_gather64()
+    out = np.zeros((len(chroms), 64), np.int64)
+    for r, (c, s, e) in enumerate(zip(chroms, starts, ends)):
+        cnt = count_contexts_region(genome[c], int(s), int(e))
+        out[r] = cnt[rho] if (minus is not None and minus[r]) else cnt
+    return out
+
+
+def expand_contexts_192(counts64):
+    """64 context counts -> the 192 columns of sorted "XYZ>XaZ" keys (nonc_elt_context_count :558-564): every
+    substitution column takes the count of its context."""
+    keys = subst_idx192()
+    ctx = context64()
+    pos = {c: i for i, c in enumerate(ctx)}
+    cols = np.array([pos[k.split(">")[0]] for k in keys])
+    return np.asarray(counts64)[..., cols], keys

@@ -666,7 +666,62 @@ def gen_cnn():
              first_conv_w_sum=np.float64(net.conv11.weight.double().sum().item()))
 
 
+class _FakeFasta:
+    """pysam.FastaFile look-alike over an in-memory genome: fetch(chrom, start, end) returns the stored text
+    (case preserved), truncated at the end of the chromosome like pysam does."""
+    genomes = {}
+
+    def __init__(self, path):
+        self._g = _FakeFasta.genomes[path]
+
+    def fetch(self, chrom, start, end):
+        assert start >= 0
+        return self._g[chrom][start:end]
+
+
+def gen_contexts():
+    """Trinucleotide context counting (sequence_tools.py:21-29,65-94,527-566) on a small random genome with N runs
+    and soft-masked stretches: 64-column counts per region and the 192-column strand-aware element counts."""
+    rng = np.random.default_rng(64)
+    genome = {}
+    for chrom, n in (("chr1", 3000), ("chr2", 2111), ("chr3", 517)):
+        seq = rng.choice(list("ACGT"), n)
+        for _ in range(4):                                    # N runs
+            a = int(rng.integers(0, n - 40))
+            seq[a:a + int(rng.integers(1, 40))] = "N"
+        for _ in range(3):                                    # soft-masked (lower-case) stretches
+            a = int(rng.integers(0, n - 100))
+            b = a + int(rng.integers(1, 100))
+            seq[a:b] = np.char.lower(seq[a:b])
+        genome[chrom] = "".join(seq)
+    _FakeFasta.genomes["mem://genome"] = genome
+    sys.modules["pysam"].FastaFile = _FakeFasta
+    regions = [("chr1", 0, 100), ("chr1", 1, 100), ("chr1", 100, 100), ("chr1", 2900, 3000), ("chr1", 2950, 3100),
+               ("chr2", 5, 6), ("chr2", 0, 2111), ("chr3", 0, 517), ("chr3", 500, 600)]
+    for _ in range(40):
+        chrom = ["chr1", "chr2", "chr3"][int(rng.integers(0, 3))]
+        n = len(genome[chrom])
+        a = int(rng.integers(0, n - 2))
+        regions.append((chrom, a, a + int(rng.integers(1, 700))))
+    chroms, starts, ends = zip(*regions)
+    df64 = ref_seq.count_contexts_by_regions("mem://genome", list(chroms), list(starts), list(ends), n_up=1, n_down=1)
+    strands = [["+", "-", -1, "+"][int(rng.integers(0, 4))] for _ in regions]
+    trans_idx = ref_seq.mk_trans_idx(n_up=1, n_down=1, collapse=False)
+    regs = [(c[3:], s, e, st) for (c, s, e), st in zip(regions, strands)]
+    df192 = ref_seq.nonc_elt_context_count(regs, trans_idx, "mem://genome")
+    out = dict(genome=genome, regions=[[c, int(s), int(e)] for c, s, e in regions],
+               strands=[str(st) for st in strands], columns64=list(df64.columns), index64=list(df64.index),
+               counts64=df64.values.astype(int).tolist(), columns192=list(df192.columns), index192=list(df192.index),
+               counts192=df192.values.astype(int).tolist())
+    with open(os.path.join(HERE, "contexts_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote contexts_golden.json", df64.shape, df192.shape)
+
+
 def main():
+    if "--only-contexts" in sys.argv:
+        gen_contexts()
+        return
     gen_nb_midp()
     gen_nb_exact()
     gen_element_stats()
@@ -677,6 +732,7 @@ def main():
     gen_mutation_tools()
     gen_sequence_model(df_empty)
     gen_cnn()
+    gen_contexts()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

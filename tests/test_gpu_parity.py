@@ -359,3 +359,43 @@ def test_properties_at_baseline_size(torch_dev):
     lower = k_s < mean
     assert torch.allclose(torch.where(lower & (k_s > 0), two + m0, torch.ones_like(m0)), torch.ones_like(m0), rtol=1e-9)
     assert torch.allclose(two[~lower], m0[~lower], rtol=1e-12)
+
+
+def test_context_counting_matches_reference_golden_and_oracle():
+    """dig_count_contexts (device-resident and host twin) against the reference's own counts on the golden genome and
+    against the oracle on a larger random genome (bit-exact)."""
+    import json
+    import torch
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from oracle import dig_oracle as O
+    g = json.load(open(os.path.join(GOLDEN, "contexts_golden.json")))
+    genome = PackedGenome.from_sequences(g["genome"])
+    chroms, starts, ends = zip(*g["regions"])
+    got = engine.count_contexts(genome, chroms, starts, ends, device=0)
+    assert np.array_equal(got.cpu().numpy(), np.array(g["counts64"]))
+    minus = [s in ("-", "-1") for s in g["strands"]]
+    got_m = engine.count_contexts(genome, [c[3:] for c in chroms], starts, ends, minus, on_device=False)
+    want192 = np.array(g["counts192"])
+    got192, keys = O.expand_contexts_192(got_m)
+    assert keys == g["columns192"] and np.array_equal(got192, want192)
+    # larger random genome: 10-kb windows and short blocks, N runs across word boundaries
+    rng = np.random.default_rng(9)
+    seqs = {}
+    for name, n in (("1", 250_003), ("2", 99_999)):
+        s = rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), n, p=[.24, .24, .24, .24, .005, .005, .005, .005, .02])
+        a = int(rng.integers(0, n - 5000))
+        s[a:a + 3000] = ord("N")
+        seqs[name] = s.tobytes().decode()
+    genome = PackedGenome.from_sequences(seqs)
+    regs = [("1", 10000 * i, 10000 * (i + 1)) for i in range(26)] + [("2", 10000 * i, 10000 * (i + 1)) for i in range(10)]
+    for _ in range(300):
+        c = "12"[int(rng.integers(0, 2))]
+        a = int(rng.integers(0, len(seqs[c])))
+        regs.append((c, a, a + int(rng.integers(0, 3000))))
+    chroms, starts, ends = zip(*regs)
+    minus = rng.uniform(size=len(regs)) < 0.5
+    got = engine.count_contexts(genome, chroms, starts, ends, minus, device=0).cpu().numpy()
+    want = O.count_contexts_regions(seqs, chroms, starts, ends, minus)
+    assert np.array_equal(got, want)
+    assert got.sum() > 0

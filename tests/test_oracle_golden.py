@@ -275,3 +275,20 @@ def test_py_oracle_sequence_model():
     assert np.array_equal(freq, d["out_freq"])
     assert ctx64 == list(d["out64_context"])
     np.testing.assert_allclose(freq64, d["out64_freq"], rtol=1e-15)
+
+
+def test_context_counting_oracle_matches_reference():
+    """oracle.count_contexts_* against the reference's count_contexts_by_regions / nonc_elt_context_count run on a
+    small random genome with N runs, lower-case stretches, START == 0 and regions past the chromosome end."""
+    import json
+    from oracle import dig_oracle as O
+    g = json.load(open(os.path.join(GOLDEN, "contexts_golden.json")))
+    assert g["columns64"] == O.context64()
+    chroms, starts, ends = zip(*g["regions"])
+    got = O.count_contexts_regions(g["genome"], chroms, starts, ends)
+    assert np.array_equal(got, np.array(g["counts64"]))
+    assert g["index64"] == ["%s:%d-%d" % r for r in zip(chroms, starts, ends)]
+    minus = [s in ("-", "-1") for s in g["strands"]]
+    got192, keys = O.expand_contexts_192(O.count_contexts_regions(g["genome"], chroms, starts, ends, minus))
+    assert keys == g["columns192"]
+    assert np.array_equal(got192, np.array(g["counts192"]))
