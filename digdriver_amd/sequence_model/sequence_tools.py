@@ -119,3 +119,75 @@ def train_sequence_model(regions, df_mut, genome_counts, n_up=1, n_down=1, key_p
     df_freq_mut = mutation_freq_conditional(df_ct, genome_counts)
     df_freq_context = df_freq_mut.pivot_table('FREQ', index=['CONTEXT'], aggfunc="sum")
     return df_freq_mut, df_freq_context
+
+
+# ---------------------------------------------------------------------------------------------
+# context counting from sequence on the GPU (reference: pysam fetch + Python loop per region)
+# ---------------------------------------------------------------------------------------------
+_GENOMES = {}
+
+
+def load_genome(f_fasta):
+    """FASTA -> PackedGenome (4 bits per base, cached in memory per path and as <fasta>.dig4.npz on disk)."""
+    from ..data_tools.genome import PackedGenome
+    if f_fasta not in _GENOMES:
+        _GENOMES[f_fasta] = f_fasta if isinstance(f_fasta, PackedGenome) else PackedGenome.from_fasta(f_fasta)
+    return _GENOMES[f_fasta]
+
+
+def _require_trinuc(n_up, n_down, collapse):
+    if (n_up, n_down, bool(collapse)) != (1, 1, False):
+        raise NotImplementedError("the GPU context counter handles trinucleotides (n_up = n_down = 1, collapse=False), the "
+                                  "only configuration the driver path uses (onthefly_tools.py:70-71,120)")
+
+
+def count_contexts_by_regions(f_fasta, chrom_lst, start_lst, end_lst, n_up=2, n_down=2, collapse=False):
+    """sequence_tools.py:82-99: frame [regions x 64 contexts] (columns in mk_context_sequences order, index
+    "{CHROM}:{START}-{END}") -- one dig_count_contexts launch for all regions.  `f_fasta`: path or PackedGenome."""
+    from .. import engine
+    _require_trinuc(n_up, n_down, collapse)
+    genome = f_fasta if hasattr(f_fasta, "words") else load_genome(f_fasta)
+    cnt = engine.count_contexts(genome, list(chrom_lst), np.asarray(start_lst, np.int64), np.asarray(end_lst, np.int64))
+    idx = ["{}:{}-{}".format(c, s, e) for c, s, e in zip(chrom_lst, start_lst, end_lst)]
+    return pd.DataFrame(cnt.cpu().numpy().astype(np.int64), index=idx, columns=list(mk_context_sequences(1, 1).keys()))
+
+
+def nonc_elt_context_count(regions, trans_idx, f_fasta, n_up=1, n_down=1):
+    """sequence_tools.py:527-566: `regions` = (chrom, start, end, strand) tuples; '-' / -1 strand regions count the
+    reverse-complemented sequence; result [regions x 192] with the sorted substitution keys as columns, every
+    substitution column holding the count of its context; index "chr{chrom}:{start}-{end}"."""
+    from .. import engine
+    _require_trinuc(n_up, n_down, False)
+    genome = f_fasta if hasattr(f_fasta, "words") else load_genome(f_fasta)
+    chroms = ['chr' + str(r[0]) for r in regions]
+    starts = np.array([r[1] for r in regions], np.int64)
+    ends = np.array([r[2] for r in regions], np.int64)
+    minus = np.array([(r[3] == '-' or r[3] == -1) for r in regions], bool)
+    cnt = engine.count_contexts(genome, chroms, starts, ends, minus).cpu().numpy().astype(np.float64)
+    keys = sorted(set(trans_idx))
+    ctx = list(mk_context_sequences(1, 1).keys())
+    pos = {c: i for i, c in enumerate(ctx)}
+    cols = np.array([pos[k.split('>')[0]] for k in keys])
+    idx = ["{}:{}-{}".format(c, s, e) for c, s, e in zip(chroms, starts, ends)]
+    return pd.DataFrame(cnt[:, cols], index=idx, columns=keys)
+
+
+def precount_region_contexts_parallel(f_nonc_bed, f_fasta, n_procs, window, sub_elts=True, n_up=1, n_down=1):
+    """sequence_tools.py:481-525: context counts of every block of a bed12 (sub_elts) or of every bed row, rows with a
+    repeated index removed.  n_procs is accepted for compatibility (one launch does all regions)."""
+    from ..data_tools import mutation_tools
+    trans_idx = mk_trans_idx(n_up=1, n_down=1, collapse=False)
+    df = pd.read_csv(f_nonc_bed, sep='\t', header=None, names=None, low_memory=False, dtype={0: str})
+    if sub_elts:
+        df6 = mutation_tools._bed12_to_bed6(df)
+        chrom = df6.CHROM.astype(str)
+        if 'chr' in str(chrom.iloc[0]):
+            chrom = chrom.map(lambda x: x.lstrip('chr'))
+        regions = list(zip(chrom, df6.START, df6.END, df6.STRAND))
+    else:
+        chrom = df[0].astype(str)
+        if 'chr' in str(chrom.iloc[0]):
+            chrom = chrom.map(lambda x: x.lstrip('chr'))
+        regions = list(zip(chrom, df[1], df[2], df[5]))
+    results = nonc_elt_context_count(regions, trans_idx, f_fasta, n_up=n_up, n_down=n_down)
+    return results.loc[~results.index.duplicated()]

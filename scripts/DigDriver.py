@@ -76,9 +76,21 @@ def cmd_element(args):
 
 
 def cmd_quick(args):
-    raise SystemExit("quickDriver is not available in this build: it needs trinucleotide counting from a FASTA "
-                     "(reference sequence_tools.py:65-94), which is a 'next' item of the scope table; use "
-                     "elementDriver with a pretrained element key.")
+    if not (args.f_elts_bed or args.region_str):
+        raise SystemExit("ERROR: you must provide --f_elts_bed or --region_str.")
+    from digdriver_amd.driver_model import onthefly_tools
+    print('Running user-defined element driver detection')
+    _scale_mode(args)
+    res = onthefly_tools.DIG_onthefly(
+        args.model, args.fmut, args.f_fasta, f_elts_bed=args.f_elts_bed, region_str=args.region_str,
+        scale_factor=args.scale_factor_manual, scale_factor_indel=args.scale_factor_indel_manual,
+        scale_type=args.scale_type, max_muts_per_sample=args.max_muts_per_sample,
+        max_muts_per_elt_per_sample=args.max_muts_per_elt_per_sample, scale_by_expectation=args.scale_by_expectation,
+        skip_pvals=args.skip_pvals)
+    for col in ('OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL'):
+        if col in res.columns:
+            res[col] = res[col].astype(int)
+    write_results(res, args)
 
 
 def _common(p, element_caps):

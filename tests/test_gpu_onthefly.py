@@ -1,0 +1,162 @@
+"""quickDriver (DIG_onthefly) end to end on a synthetic genome, against an expectation assembled from the oracle the
+way the reference's per-element loop does it (onthefly_tools.py:109-164): sequence -> window / block context counts
+-> per-element sums -> NB mid-p tests -> Fisher.  Integers bit-exact, p-values within the tolerance contract."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import ROOT, rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_case(tmp_path, rng):
+    from digdriver_amd.io import mapfile
+    from oracle import dig_oracle as O
+    window, nbins = 1000, {"1": 40, "2": 25}
+    seqs = {}
+    for c, n in nbins.items():
+        s = rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), n * window, p=[.24, .24, .24, .24, .005, .005, .005, .005, .02])
+        seqs["chr" + c] = s.tobytes().decode()
+    fa = tmp_path / "genome.fa"
+    with open(fa, "w") as f:
+        for name, s in seqs.items():
+            f.write(">%s some description\n" % name)
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+    # region_params on the 1-kb grid + a sequence model
+    rows = []
+    for c, n in nbins.items():
+        for b in range(n):
+            mu = float(rng.gamma(9.0, 3.0))
+            rows.append((int(c), b * window, (b + 1) * window, int(rng.poisson(mu)), mu, float(rng.gamma(4.0, 1.0)), 1.0, 0.5,
+                         bool(rng.uniform() < 0.15)))
+    rp = pd.DataFrame(rows, columns=["CHROM", "START", "END", "Y_TRUE", "Y_PRED", "STD", "MAPP", "QUANT", "FLAG"])
+    rp.index = ["chr{}:{}-{}".format(c, s, e) for c, s, e in zip(rp.CHROM, rp.START, rp.END)]
+    seq_rows = O.model_rows192()
+    freq = rng.dirichlet(np.ones(192)) * 1e-3
+    sm = pd.DataFrame({"MUT_TYPE": [m for m, _ in seq_rows], "CONTEXT": [c for _, c in seq_rows],
+                       "COUNT": rng.integers(1, 1000, 192), "FREQ": freq})
+    pre = str(tmp_path / "cohort.map")
+    mapfile.write_frame(pre, "region_params", rp)
+    mapfile.write_frame(pre, "sequence_model_192", sm)
+    # elements: 1-3 blocks, both strands, one crossing a window edge exactly, one at the chromosome start
+    elts, lines = [], []
+    specs = [("1", 0, [(0, 300)], "+"), ("1", 2000, [(0, 1000)], "-"), ("2", 5100, [(0, 200), (700, 150), (1900, 400)], "-")]
+    for i in range(25):
+        c = "12"[int(rng.integers(0, 2))]
+        st = int(rng.integers(0, nbins[c] * window - 4000))
+        nb = int(rng.integers(1, 4))
+        blocks, off = [], 0
+        for _ in range(nb):
+            z = int(rng.integers(50, 900))
+            blocks.append((off, z))
+            off += z + int(rng.integers(10, 600))
+        specs.append((c, st, blocks, "+-"[int(rng.integers(0, 2))]))
+    for i, (c, st, blocks, strand) in enumerate(specs):
+        name = "E%02d" % i
+        end = st + blocks[-1][0] + blocks[-1][1]
+        lines.append("%s\t%d\t%d\t%s\t0\t%s\t%d\t%d\t.\t%d\t%s,\t%s,\n" % (
+            c, st, end, name, strand, st, st, len(blocks), ",".join(str(z) for _, z in blocks), ",".join(str(o) for o, _ in blocks)))
+        elts.append((name, c, strand, [(st + o, st + o + z) for o, z in blocks]))
+    bed = tmp_path / "elts.bed"
+    bed.write_text("".join(lines))
+    muts = []
+    for name, c, strand, blocks in elts:
+        for _ in range(int(rng.poisson(4))):
+            s, e = blocks[int(rng.integers(0, len(blocks)))]
+            p = int(rng.integers(s, e))
+            muts.append((c, p, p + 1, "A", "T", "S%d" % rng.integers(0, 12), ".", "Noncoding", "A>T", "CAG"))
+        if rng.uniform() < 0.4:
+            p = blocks[0][0]
+            muts.append((c, p, p + 3, "AGG", "A", "S%d" % rng.integers(0, 12), ".", "INDEL", "DEL", "."))
+    mut = tmp_path / "cohort.tsv"
+    pd.DataFrame(muts).to_csv(mut, sep="\t", header=False, index=False)
+    return dict(pre=pre, fa=str(fa), bed=str(bed), mut=str(mut), seqs=seqs, rp=rp, sm=sm, elts=elts, window=window)
+
+
+def _expected(case, cj, cj_indel, tab):
+    """The reference's per-element loop restated with oracle functions."""
+    from oracle import dig_oracle as O
+    rp, window, seqs = case["rp"], case["window"], case["seqs"]
+    names = [m + "|" + c for m, c in zip(case["sm"].MUT_TYPE, case["sm"].CONTEXT)]
+    subst = [c + ">" + c[0] + m[2] + c[2] for m, c in zip(case["sm"].MUT_TYPE, case["sm"].CONTEXT)]
+    order = np.argsort(np.array(subst), kind="stable")
+    d_pr = case["sm"].FREQ.values[order]
+    keys = sorted(subst)
+    rho192 = O.minus_strand_gather192()
+    out = {}
+    for name, c, strand, blocks in case["elts"]:
+        starts = sorted({x for s, e in blocks for x in range(s // window * window, -(-e // window) * window, window)})
+        rc = np.zeros(64, np.int64)
+        mu = var = 0.0
+        robs = 0
+        for x in starts:
+            rc += O.count_contexts_region(seqs["chr" + c], x, x + window)
+            row = rp.loc["chr{}:{}-{}".format(c, x, x + window)]
+            mu += row.Y_PRED
+            var += row.STD ** 2
+            robs += row.Y_TRUE
+        region_counts = np.repeat(rc, 3).astype(float)
+        if strand == "-":
+            region_counts = region_counts[rho192]
+        L = np.zeros(192)
+        for s, e in blocks:
+            cnt = O.count_contexts_region(seqs["chr" + c], s, e)
+            if strand == "-":
+                cnt = cnt[O.minus_strand_gather64()]
+            L += np.repeat(cnt, 3)
+        p_mut = ((d_pr / (region_counts * d_pr).sum()) * L).sum()
+        sigma = np.sqrt(var)
+        alpha, theta = mu ** 2 / sigma ** 2, sigma ** 2 / mu
+        r_size, e_size = int(region_counts.sum() / 3), int(L.sum() / 3)
+        out[name] = dict(MU=mu, SIGMA=sigma, R_OBS=robs, R_SIZE=r_size, ELT_SIZE=e_size, Pi_SUM=p_mut, Pi_INDEL=e_size / r_size,
+                         ALPHA=alpha, THETA=theta * cj, THETA_INDEL=theta * cj_indel * cj_indel)
+    df = pd.DataFrame(out).T
+    df = tab.merge(df, left_index=True, right_index=True)
+    a = df.ALPHA.values.astype(float)
+    p = 1.0 / (df.THETA.values.astype(float) * df.Pi_SUM.values.astype(float) + 1.0)
+    df["EXP_SNV"] = a * df.THETA.values.astype(float) * df.Pi_SUM.values.astype(float)
+    df["PVAL_SNV_BURDEN"] = O.nb_pvalue_greater_midp(df.OBS_SNV.values.astype(float), a, p)
+    df["PVAL_SAMPLE_BURDEN"] = O.nb_pvalue_greater_midp(df.OBS_SAMPLES.values.astype(float), a, p)
+    pi = 1.0 / (df.THETA_INDEL.values.astype(float) * df.Pi_INDEL.values.astype(float) + 1.0)
+    df["EXP_INDEL"] = a * df.THETA_INDEL.values.astype(float) * df.Pi_INDEL.values.astype(float)
+    df["PVAL_INDEL_BURDEN"] = O.nb_pvalue_greater_midp(df.OBS_INDEL.values.astype(float), a, pi)
+    df["PVAL_MUT_BURDEN"] = O.fisher_combine(df.PVAL_SNV_BURDEN.values, df.PVAL_INDEL_BURDEN.values)
+    return df
+
+
+def test_quickdriver_matches_oracle_loop(tmp_path):
+    from digdriver_amd.data_tools import mutation_tools
+    from digdriver_amd.driver_model import onthefly_tools
+    rng = np.random.default_rng(17)
+    case = _make_case(tmp_path, rng)
+    cj, cj_indel = 0.004, 0.0007
+    got = onthefly_tools.DIG_onthefly(case["pre"], case["mut"], case["fa"], f_elts_bed=case["bed"], scale_factor=cj,
+                                      scale_factor_indel=cj_indel, scale_by_expectation=False)
+    tab = mutation_tools.tabulate_mutations_in_element(case["mut"], case["bed"], bed12=True, drop_duplicates=True,
+                                                       all_elements=True)
+    want = _expected(case, cj, cj_indel, tab)
+    got = got.loc[want.index]
+    for col in ("OBS_SNV", "OBS_SAMPLES", "OBS_INDEL", "R_OBS", "R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(got[col].values.astype(np.int64), want[col].values.astype(np.int64)), col
+    for col in ("MU", "SIGMA", "Pi_SUM", "Pi_INDEL", "ALPHA", "THETA", "THETA_INDEL", "EXP_SNV", "EXP_INDEL",
+                "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN"):
+        rel_close(got[col].values.astype(float), want[col].values.astype(float), rtol=1e-6)
+    assert (got.OBS_SNV.values > 0).any() and (got.OBS_INDEL.values > 0).any()
+    # region string form: one element named UserELT, '+' strand
+    one = onthefly_tools.DIG_onthefly(case["pre"], case["mut"], case["fa"], region_str="chr1:2000-3000", scale_factor=cj,
+                                      scale_factor_indel=cj_indel, scale_by_expectation=False)
+    assert list(one.index) == ["UserELT"] and int(one.ELT_SIZE.iloc[0]) <= 1000
+    # the command line writes the same table
+    out = tmp_path / "out"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "DigDriver.py"), "quickDriver", case["mut"],
+                           case["pre"], case["fa"], "--f_elts_bed", case["bed"], "--scale-factor-manual", str(cj),
+                           "--scale-factor-indel-manual", str(cj_indel), "--outdir", str(out), "--outpfx", "q"],
+                          env=dict(os.environ, PYTHONPATH=ROOT))
+    res = pd.read_csv(out / "q.results.txt", sep="\t", index_col=0)
+    rel_close(res.loc[want.index].PVAL_MUT_BURDEN.values, want.PVAL_MUT_BURDEN.values.astype(float), rtol=1e-6)
