@@ -133,7 +133,7 @@ def parse_args(text=None):
 
     for name, func, extra in (('elementDriver', cmd_element, 'element'), ('quickDriver', cmd_quick, 'quick')):
         e = _common(sub.add_parser(name, help='test user-defined elements' if extra == 'element'
-                                   else 'test ad-hoc elements or a region string'), True)
+                                   else 'test ad-hoc elements or a region string (no pretrained element model)'), True)
         if extra == 'element':
             e.add_argument('pretrain_key', type=str, help='key of the pretrained element model inside the map')
             e.add_argument('--f-bed', type=str, default="", help='bed12 file the element model was pretrained on')

@@ -66,6 +66,37 @@ def main():
                                  "tests_per_s": units / dt, "algorithmic_GBps": by / dt / 1e9,
                                  "frac_hbm_peak": by / dt / HBM_PEAK, "finite": bool(torch.isfinite(pv).all().item()),
                                  "whole_genome_x37_seconds": 288000 * nt * C / (units / dt)})
+    # ---- f3: trinucleotide contexts of all 10-kb windows of a genome-sized packed sequence --------------------------
+    del pt, k, mu, sigma, pv, ex
+    torch.cuda.empty_cache()
+    from digdriver_amd.data_tools.genome import PackedGenome
+    nwin, window = 288000, 10000
+    nbases = nwin * window
+    words = (torch.randint(0, 2 ** 31 - 1, (nbases // 8 + 2,), dtype=torch.int32, device=dev, generator=g) & 0x33333333)
+    words[0] = 0x44444444
+    words[-1] = 0x44444444
+    genome = PackedGenome(["chr1"], [0], [nbases], np.zeros(2, np.uint32))          # host copy not needed: device-resident
+    genome._dev[(dev.type, dev.index)] = (words, torch.zeros(1, dtype=torch.int64, device=dev),
+                                          torch.full((1,), nbases, dtype=torch.int64, device=dev))
+    starts = np.arange(nwin, dtype=np.int64) * window
+    chroms = ["chr1"] * nwin
+    ci = genome.chrom_index(chroms[:1])
+    from digdriver_amd import _lib
+    rc = torch.zeros(nwin, dtype=torch.int32, device=dev)
+    rs, re_ = torch.as_tensor(starts, device=dev), torch.as_tensor(starts + window, device=dev)
+    rm = torch.zeros(nwin, dtype=torch.uint8, device=dev)
+    res = torch.empty((nwin, 64), dtype=torch.int32, device=dev)
+    off, ln = genome._dev[(dev.type, dev.index)][1:]
+
+    def run():
+        _lib.call("dig_count_contexts", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln), 1,
+                  _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), _lib.dev_ptr(rm), nwin, _lib.dev_ptr(res),
+                  _lib.stream_ptr())
+    dt = timeit(run, n=5, warm=1)
+    by = nbases * 0.5 + nwin * 256.0
+    out["count_contexts"] = [{"windows": nwin, "window_bp": window, "bases": nbases, "ms": dt * 1e3,
+                              "bases_per_s": nbases / dt, "algorithmic_GBps": by / dt / 1e9,
+                              "frac_hbm_peak": by / dt / HBM_PEAK, "total_counted": int(res.sum(dtype=torch.int64).item())}]
     print(json.dumps(out))
 
 
