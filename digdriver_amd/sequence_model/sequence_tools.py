@@ -191,3 +191,54 @@ def precount_region_contexts_parallel(f_nonc_bed, f_fasta, n_procs, window, sub_
         regions = list(zip(chrom, df[1], df[2], df[5]))
     results = nonc_elt_context_count(regions, trans_idx, f_fasta, n_up=n_up, n_down=n_down)
     return results.loc[~results.index.duplicated()]
+
+
+def count_contexts_in_bed(f_fasta, df_bed, n_up=1, n_down=1, N_proc=1, N_chunk=10, collapse=False):
+    """sequence_tools.py:101-137: context counts of every row of a bed-like frame (columns 0-2 = chrom, start, end;
+    'chr' is prepended to the chromosome label).  One launch; N_proc / N_chunk accepted for compatibility."""
+    chrom_lst = ['chr{}'.format(val) for val in df_bed.iloc[:, 0].values]
+    return count_contexts_by_regions(f_fasta, chrom_lst, df_bed.iloc[:, 1].values, df_bed.iloc[:, 2].values, n_up=n_up,
+                                     n_down=n_down, collapse=collapse)
+
+
+def initialize_nonc_data(f_nonc_data, f_genome_counts, window, n_up=1, n_down=1):
+    """sequence_tools.py:451-478: start an element-data container from the genome-wide window counts: the sorted
+    substitution index and window_{w}/full_window_si_{index,values}."""
+    from ..io import mapfile
+    key = 'window_{}'.format(window)
+    if not mapfile.has_key(f_nonc_data, 'substitution_idx'):
+        mapfile.write_array(f_nonc_data, 'substitution_idx', np.array(mk_trans_idx(n_up=n_up, n_down=n_down, collapse=False)))
+    if not (mapfile.has_key(f_nonc_data, key + '/full_window_si_index') and
+            mapfile.has_key(f_nonc_data, key + '/full_window_si_values')):
+        idx = mapfile.read_array(f_genome_counts, 'idx')
+        genome_df = mapfile.read_frame(f_genome_counts, 'all_window_genome_counts')
+        assert int(str(genome_df.index[0]).split('-')[-1]) == window      # the counts must be on this window size (:476)
+        mapfile.write_array(f_nonc_data, key + '/full_window_si_values', genome_df.values.astype(np.int64))
+        mapfile.write_array(f_nonc_data, key + '/full_window_si_index', idx)
+
+
+def preprocess_nonc(f_nonc_bed, f_nonc_data, f_pretrained, L_contexts, save_key, window):
+    """sequence_tools.py:596-641: per-element L counts (sum of the block rows of L_contexts) and geometry under
+    window_{w}/{save_key}.  The reference stores one h5 group per element plus its overlapped-window counts; the
+    overlaps and region counts are recomputed on the GPU at model time here (dig_ideal_overlaps_host +
+    dig_accumulate_elements), so the container holds flat arrays: names, chrom, strand, blk_ptr, blk_start, blk_end, L."""
+    from ..data_tools import mutation_tools
+    from ..io import mapfile
+    df_elts = mutation_tools.bed12_boundaries(f_nonc_bed)
+    E = len(df_elts)
+    blk_ptr = np.concatenate([[0], np.cumsum([len(b) for b in df_elts.BLOCK_STARTS])]).astype(np.int64)
+    blk_start = np.array([s for b in df_elts.BLOCK_STARTS for s in b], np.int64)
+    blk_end = np.array([e for b in df_elts.BLOCK_ENDS for e in b], np.int64)
+    chrom = df_elts.CHROM.values.astype(np.int32)
+    owner = np.repeat(np.arange(E), np.diff(blk_ptr))
+    keys = ['chr{}:{}-{}'.format(c, s, e) for c, s, e in zip(chrom[owner], blk_start, blk_end)]
+    L = np.zeros((E, 192))
+    np.add.at(L, owner, L_contexts.loc[keys].values)
+    base = 'window_{}/{}/'.format(window, save_key)
+    mapfile.write_array(f_nonc_data, base + 'names', df_elts.ELT.values.astype(str))
+    mapfile.write_array(f_nonc_data, base + 'chrom', chrom)
+    mapfile.write_array(f_nonc_data, base + 'strand', df_elts.STRAND.astype(str).values)
+    mapfile.write_array(f_nonc_data, base + 'blk_ptr', blk_ptr)
+    mapfile.write_array(f_nonc_data, base + 'blk_start', blk_start)
+    mapfile.write_array(f_nonc_data, base + 'blk_end', blk_end)
+    mapfile.write_array(f_nonc_data, base + 'L', np.rint(L).astype(np.int32))

@@ -44,6 +44,7 @@ def _make_case(tmp_path, rng):
     pre = str(tmp_path / "cohort.map")
     mapfile.write_frame(pre, "region_params", rp)
     mapfile.write_frame(pre, "sequence_model_192", sm)
+    mapfile.write_array(pre, "idx", rp[["CHROM", "START", "END"]].values.astype(np.int32))
     # elements: 1-3 blocks, both strands, one crossing a window edge exactly, one at the chromosome start
     elts, lines = [], []
     specs = [("1", 0, [(0, 300)], "+"), ("1", 2000, [(0, 1000)], "-"), ("2", 5100, [(0, 200), (700, 150), (1900, 400)], "-")]
@@ -160,3 +161,40 @@ def test_quickdriver_matches_oracle_loop(tmp_path):
                           env=dict(os.environ, PYTHONPATH=ROOT))
     res = pd.read_csv(out / "q.results.txt", sep="\t", index_col=0)
     rel_close(res.loc[want.index].PVAL_MUT_BURDEN.values, want.PVAL_MUT_BURDEN.values.astype(float), rtol=1e-6)
+
+
+def test_preprocess_pretrain_driver_chain_equals_quickdriver(tmp_path):
+    """DigPreprocess (window counts -> element data) -> DigPretrain elementModel -> DigDriver elementDriver gives the
+    same table as quickDriver on the same inputs: both routes compute the element parameters from the same sequence,
+    one through stored counts, one on the fly.  (The indel columns differ by the reference's double scaling in the
+    on-the-fly route, so strict_reference=False is used for the comparison.)"""
+    from digdriver_amd.driver_model import onthefly_tools
+    from digdriver_amd.io import mapfile
+    rng = np.random.default_rng(23)
+    case = _make_case(tmp_path, rng)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda *a: subprocess.check_call([sys.executable] + [str(x) for x in a], env=env)
+    # windows bed = the region_params grid
+    wbed = tmp_path / "windows.bed"
+    case["rp"][["CHROM", "START", "END"]].to_csv(wbed, sep="\t", header=False, index=False)
+    gc, ed = str(tmp_path / "genome_counts.map"), str(tmp_path / "element_data.map")
+    pp = os.path.join(ROOT, "scripts", "DigPreprocess.py")
+    run(pp, "countGenomeContext", case["fa"], gc, "--bed", wbed)
+    run(pp, "initialize_f_data", ed, gc)
+    run(pp, "preprocess_element_model", ed, case["pre"], case["fa"], "myelts", "--f-bed", case["bed"], "--window", case["window"])
+    run(os.path.join(ROOT, "scripts", "DigPretrain.py"), "elementModel", case["pre"], ed, "myelts")
+    out = tmp_path / "o"
+    cj, cji = 0.004, 0.0007
+    run(os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver", case["mut"], case["pre"], "myelts", "--f-bed", case["bed"],
+        "--scale-factor-manual", cj, "--scale-factor-indel-manual", cji, "--outdir", out, "--outpfx", "e")
+    res = pd.read_csv(out / "e.results.txt", sep="\t", index_col=0)
+    quick = onthefly_tools.DIG_onthefly(case["pre"], case["mut"], case["fa"], f_elts_bed=case["bed"], scale_factor=cj,
+                                        scale_factor_indel=cji, scale_by_expectation=False, strict_reference=False)
+    common = [i for i in res.index if i in quick.index]
+    assert len(common) == len(res) > 5
+    for col in ("OBS_SNV", "OBS_SAMPLES", "OBS_INDEL", "R_OBS", "R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(res.loc[common, col].values.astype(np.int64), quick.loc[common, col].values.astype(np.int64)), col
+    for col in ("MU", "SIGMA", "Pi_SUM", "Pi_INDEL", "EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "PVAL_INDEL_BURDEN",
+                "PVAL_MUT_BURDEN"):
+        rel_close(res.loc[common, col].values.astype(float), quick.loc[common, col].values.astype(float), rtol=1e-9)
+    assert int(mapfile.read_frame(gc, "genome_counts").COUNT.sum()) > 0
