@@ -119,3 +119,24 @@ def gather_to_rank0(t, group=None):
     if rank != 0:
         return None
     return torch.cat([b[: int(s.item())] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def average_gradients(params, group=None):
+    """Data-parallel gradient exchange for the CNN (replaces nn.DataParallel, kfold_mutations_main.py:143): all
+    gradients are packed into ONE flat buffer, summed with a single all-reduce (RCCL ring over xGMI: one large
+    message instead of ~60 small ones) and divided by the world size.  No-op without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

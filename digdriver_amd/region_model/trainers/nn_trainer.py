@@ -1,0 +1,105 @@
+"""CNN training / evaluation epochs over an HBM-resident track matrix.
+
+Mirror of NNTrainer (DIGDriver/region_model/trainers/nn_trainer.py:17-141): Adam + summed per-task MSE, per-batch
+squared-Pearson "accuracy", and -- as in the reference -- the features handed to the GP are the activations captured
+DURING the training epoch (train-mode BatchNorm, :64), not a clean re-forward.  Differences that are MI355X-first
+rather than behavioural: batches come from dig_gather_bins (channels-first, no DataLoader workers, no host copies);
+the shuffle is seeded; with a process group every rank trains on its slice of each batch and the gradients are
+averaged with one flat all-reduce (parallel.average_gradients) instead of nn.DataParallel.
+"""
+import numpy as np
+import torch
+
+from .. import predict as _predict
+from ... import parallel
+
+
+class NNTrainer:
+    def __init__(self, model, optimizer, loss_fn, bs, label_ids, store, train_rows, test_rows, labels, device, seed=0,
+                 group=None):
+        self.device = device
+        self.model = model.to(device)
+        self.optimizer, self.loss_fn, self.bs, self.label_ids = optimizer, loss_fn, int(bs), list(label_ids)
+        self.store = store
+        self.train_rows, self.test_rows = np.asarray(train_rows), np.asarray(test_rows)
+        self.labels = [torch.as_tensor(np.asarray(l), dtype=torch.float32, device=device) for l in labels]   # [C][N]
+        self.rng = np.random.default_rng(seed)
+        self.group = group
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+    def _forward(self, rows):
+        x = self.store.batch(rows, channels_first=True)
+        if x.device != self.device:
+            x = x.to(self.device)
+        return self.model.forward_channels_first(x.float())
+
+    def train(self, epoch, run=0, print_interval=10):
+        """nn_trainer.py:40-91 -> (losses [C], accs [C], features [C][n,16], preds [C][n], true [C][n]) over the
+        rows this rank saw, in visiting order."""
+        self.model.train()
+        C = len(self.label_ids)
+        order = self.rng.permutation(self.train_rows)
+        n_batches = (len(order) + self.bs - 1) // self.bs
+        loss_sums, acc_sums = np.zeros(C), np.zeros(C)
+        feats, preds, true = [[] for _ in range(C)], [[] for _ in range(C)], [[] for _ in range(C)]
+        seen = []
+        print('Training epoch {}'.format(epoch))
+        for j in range(n_batches):
+            rows = order[j * self.bs:(j + 1) * self.bs][self.rank::self.world]
+            if len(rows) == 0:
+                continue
+            seen.append(rows)
+            y_lst, fv_lst, _ = self._forward(rows)
+            r = torch.as_tensor(rows, device=self.device)
+            losses = []
+            for i in range(C):
+                t = self.labels[i][r]
+                losses.append(self.loss_fn(y_lst[i], t))
+                feats[i].append(fv_lst[i].detach())
+                preds[i].append(y_lst[i].detach())
+                true[i].append(t)
+            loss = torch.sum(torch.stack(losses))
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            parallel.average_gradients(list(self.model.parameters()), self.group)
+            self.optimizer.step()
+            lv = torch.stack(losses).detach().cpu().numpy()
+            loss_sums += lv
+            for i in range(C):
+                acc_sums[i] += _predict.r2_score(true[i][-1].cpu().numpy(), preds[i][-1].cpu().numpy())
+            if n_batches >= 10 and j % max(1, int(n_batches * print_interval / 100)) == 0 and j > 0:
+                print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {}'.format(epoch, j, n_batches, 100. * j / n_batches,
+                                                                          loss_sums / (j + 1)))
+        cat = lambda lst: [torch.cat(v).cpu().numpy() for v in lst]
+        losses, accs = loss_sums / n_batches, acc_sums / n_batches
+        self.last_train_rows = np.concatenate(seen) if seen else np.zeros(0, np.int64)   # visiting order of the features
+        print('====> Epoch: {}, Average loss: {}, Average accuracy: {}'.format(epoch, losses, accs))
+        return losses, accs, cat(feats), cat(preds), cat(true)
+
+    @torch.no_grad()
+    def test(self, epoch, run=0):
+        """nn_trainer.py:93-141 on the validation rows: eval mode, (losses, accs, features, preds, true, None)."""
+        self.model.eval()
+        C = len(self.label_ids)
+        n_batches = max(1, (len(self.test_rows) + self.bs - 1) // self.bs)
+        loss_sums, acc_sums = np.zeros(C), np.zeros(C)
+        feats, preds, true = [[] for _ in range(C)], [[] for _ in range(C)], [[] for _ in range(C)]
+        for j in range(n_batches):
+            rows = self.test_rows[j * self.bs:(j + 1) * self.bs]
+            if len(rows) == 0:
+                continue
+            y_lst, fv_lst, _ = self._forward(rows)
+            r = torch.as_tensor(rows, device=self.device)
+            for i in range(C):
+                t = self.labels[i][r]
+                loss_sums[i] += float(self.loss_fn(y_lst[i], t))
+                acc_sums[i] += _predict.r2_score(t.cpu().numpy(), y_lst[i].cpu().numpy())
+                feats[i].append(fv_lst[i])
+                preds[i].append(y_lst[i])
+                true[i].append(t)
+        cat = lambda lst: [torch.cat(v).cpu().numpy() for v in lst]
+        losses, accs = loss_sums / n_batches, acc_sums / n_batches
+        print('====> Test set loss: {}, accuracy: {}'.format(losses, accs))
+        return losses, accs, cat(feats), cat(preds), cat(true), None

@@ -88,3 +88,32 @@ def test_two_rank_exchange_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok.npy")
+
+
+def _grad_worker(rank, world, port, tmp):
+    """Data-parallel CNN step semantics: each rank's mean-loss gradient on its half of a batch, averaged with the flat
+    all-reduce, equals the single-process gradient of the mean loss over the whole batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1)).double()
+        x, y = torch.randn(8, 6, dtype=torch.float64), torch.randn(8, 1, dtype=torch.float64)
+        full = torch.nn.functional.mse_loss(net(x), y)
+        want = torch.autograd.grad(full, list(net.parameters()))
+        net.zero_grad()
+        torch.nn.functional.mse_loss(net(x[rank::world]), y[rank::world]).backward()
+        parallel.average_gradients(list(net.parameters()))
+        for p, w_ in zip(net.parameters(), want):
+            assert torch.allclose(p.grad, w_, rtol=1e-12, atol=1e-14)
+        if rank == 0:
+            np.save(os.path.join(tmp, "grad_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_average_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "grad_ok.npy")

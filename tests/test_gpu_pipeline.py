@@ -109,3 +109,31 @@ def test_scale_factors_kernel_rank_ordered_sum():
             tot += parts[r]
         assert np.array_equal(cj.cpu().numpy(), tot[1] / tot[0])
         assert np.array_equal(cji.cpu().numpy(), tot[2] / tot[0])
+
+
+def test_kfold_training_writes_results_regionmodel_reads(tmp_path):
+    """f4: CNN training + SGPR calibration end to end on a tiny synthetic track matrix whose labels are a smooth
+    function of the tracks: the loss falls, every fold writes its results, and `kfold_results` assembles a
+    region_params frame whose predictions correlate with the labels."""
+    import torch
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.region_model import kfold_mutations_main as kf, region_model_tools
+    rng = np.random.default_rng(4)
+    N, L, T = 900, 100, 6
+    base = rng.uniform(0, 1, (N, 1, T))
+    x = np.round(np.clip(base + 0.15 * rng.normal(size=(N, L, T)), 0, 1), 2) * 100
+    y = np.rint(40 * base[:, 0, 0] + 25 * base[:, 0, 1] ** 2 + rng.normal(0, 1.0, N) + 5).clip(0)
+    data = str(tmp_path / "train.map")
+    mapfile.write_array(data, "x_data", x.astype(np.float32))
+    mapfile.write_array(data, "idx", np.stack([np.ones(N, int), np.arange(N) * 10000, (np.arange(N) + 1) * 10000], 1))
+    mapfile.write_array(data, "mappability", rng.uniform(0.3, 1.0, N))
+    mapfile.write_array(data, "COHORT_A", y)
+    args = kf.get_cmd_arguments("-c COHORT_A -d %s -o %s -k 2 -e 4 -b 64 -gp 2 -nd 100 -nt 30 -gd 0.5 -u --seed 1" % (data, tmp_path))
+    out_dir = kf.main(args)
+    assert os.path.isdir(out_dir)
+    df = region_model_tools.kfold_results(out_dir, "COHORT_A")
+    assert len(df) == N and {"Y_TRUE", "Y_PRED", "STD", "FLAG"} <= set(df.columns)
+    ok = ~df.FLAG.values.astype(bool)
+    r = np.corrcoef(df.Y_TRUE.values[ok], df.Y_PRED.values[ok])[0, 1]
+    assert np.isfinite(df.Y_PRED.values).all() and (df.STD.values > 0).all()
+    assert r > 0.5, r
