@@ -400,9 +400,53 @@ __device__ __forceinline__ double midp_from_state(double A, double N, double D, 
     return (1.0 - S) - 0.5 * t;
 }
 
-// One step of the scaled recurrence.  The accumulator update A <- A * j + N is issued as the three-address
-// v_fma_f64 (the compiler's v_fmac form needs three register copies per step to keep N alive).
-__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x)
+// 1 / k! for k = 0 .. kSmallK, correctly rounded (generated from exact rationals).  The fast recurrence reads it from
+// LDS (one ds_read per evaluated count; LDS waits are independent of the in-order vector-memory counter), which
+// removes the running factorial from the loop and the reciprocal from the evaluation.  Every kernel that reaches
+// nb_midp_upper_fast2 calls nb_tables_init() first.
+static __device__ __constant__ const double kInvFactorialRom[kSmallK + 1] = {
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p-1, 0x1.5555555555555p-3,
+    0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13,
+    0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26,
+    0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33, 0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-41,
+    0x1.ae7f3e733b81fp-45, 0x1.952c77030ad4ap-49, 0x1.6827863b97d97p-53, 0x1.2f49b46814157p-57,
+    0x1.e542ba4020225p-62, 0x1.71b8ef6dcf572p-66, 0x1.0ce396db7f853p-70, 0x1.761b41316381ap-75,
+    0x1.f2cf01972f578p-80, 0x1.3f3ccdd165fa9p-84, 0x1.88e85fc6a4e5ap-89, 0x1.d1ab1c2dccea3p-94,
+    0x1.0a18a2635085dp-98, 0x1.259f98b4358adp-103, 0x1.3932c5047d60ep-108, 0x1.434d2e783f5bcp-113,
+    0x1.434d2e783f5bcp-118, 0x1.3981254dd0d52p-123, 0x1.2710231c0fd7ap-128, 0x1.0dc59c716d91fp-133,
+    0x1.df983290c2ca9p-139, 0x1.9ec8d1c94e85bp-144, 0x1.5d4acb9c0c3abp-149, 0x1.1e99449a4bacep-154,
+    0x1.ca8ed42a12ae3p-160, 0x1.65e61c39d0241p-165, 0x1.10af527530de8p-170, 0x1.95db45257e512p-176,
+    0x1.272b1b03fec6ap-181, 0x1.a3cb872220648p-187, 0x1.240804f659510p-192, 0x1.8da8e0a127ebap-198,
+    0x1.091b406b6ff26p-203, 0x1.5a42f0dfeb086p-209, 0x1.bb36f6e12cd78p-215, 0x1.161872bf7b823p-220,
+    0x1.56457989358c9p-226, 0x1.9d4f1058674dfp-232, 0x1.e9d8f6ed83eaap-238, 0x1.1d008faac5c50p-243,
+    0x1.45b77f9e98e12p-249, 0x1.6db793c887b97p-255, 0x1.938cc661b03f6p-261, 0x1.b5bfc17fa97d3p-267,
+    0x1.d2eeac43e7fcfp-273, 0x1.e9e56d649f768p-279, 0x1.f9b3059128bc7p-285, 0x1.00dcf6a320e1cp-290,
+    0x1.00dcf6a320e1cp-296,
+};
+__shared__ double g_inv_factorial[kSmallK + 1];
+
+__device__ __forceinline__ void nb_tables_init()
+{
+    const unsigned t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    if (t <= (unsigned)kSmallK) g_inv_factorial[t] = kInvFactorialRom[t];
+    __syncthreads();
+}
+
+// 1 - S_k - (W2/2) t_k from the scaled state (A_k, N_k) with 1/k! from the table:  t_k = t_0 N_k / k!,
+// S_k = t_0 A_k k / k!.
+template <int W2>
+__device__ __forceinline__ double tail_from_state_tab(double A, double N, double k, double t0)
+{
+#pragma clang fp contract(off)
+    const double rD = t0 * g_inv_factorial[(int)k];
+    const double S = (A * k) * rD;
+    if (W2 == 0) return 1.0 - S;
+    const double t = N * rD;
+    return (1.0 - S) - 0.5 * t;
+}
+
+// One step of the scaled recurrence without the factorial (fast pass): 4 FP64 operations.
+__device__ __forceinline__ void pmf_scaled_step_nofact(double& A, double& N, double& u, double& jj, double x)
 {
     double An;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(An) : "v"(A), "v"(jj), "v"(N));
@@ -410,14 +454,49 @@ __device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D,
     N *= u;                 // N_{j+1}
     u += x;
     jj += 1.0;
-    D *= jj;                // D_{j+1} = (j+1)!
 }
 
-// Resolve 0.5 pmf(k) + P(X > k) for up to two counts (k1, k2) that share (alpha, p) with ONE
-// pass of the pmf recurrence.  Returns a bit mask of the counts that were resolved
-// (bit 0: k1, bit 1: k2); unresolved ones (k > kSmallK, non-integer, p^alpha underflow, or a
-// result < kDirectMin where 1 - S cancels) must go through nb_midp_upper().
-// `want` selects which of the two counts are requested.
+// The recurrence itself for eligible counts (integers 0 .. kSmallK; -1 = not requested), valid (alpha, p) and
+// lp0 = alpha log p > -400 (keeps N_k <= k! / t_0 far from overflow).  TWO = false skips the intermediate evaluation.
+//   N_j = prod_{i<j} (alpha + i) x,  A_j = S_j (j-1)! / t_0  (A_{j+1} = A_j * j + N_j):  one step is 4 full-rate FP64
+//   operations with no memory access and no division; the trip count is tested on the FP64 counter itself.
+template <int W2, bool TWO>
+__device__ __forceinline__ void nb_fast_recurrence(double kmin, double kmax, double alpha, double x, double lp0,
+                                                   double& r_min, double& r_max)
+{
+    const double t0 = fast_exp_neg(lp0);
+    double N = 1.0, A = 0.0, u = alpha * x, jj = 0.0;
+    if (TWO) {
+        while (jj < kmin) pmf_scaled_step_nofact(A, N, u, jj, x);
+        r_min = tail_from_state_tab<W2>(A, N, jj, t0);
+    }
+    while (jj < kmax) pmf_scaled_step_nofact(A, N, u, jj, x);
+    r_max = tail_from_state_tab<W2>(A, N, jj, t0);
+}
+
+// Shared tail of the two front ends below: e1 / e2 say which counts are eligible for the fast recurrence.
+template <int W2>
+__device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, bool e2, bool two, double alpha, double p,
+                                                 double& r1, double& r2)
+{
+    const double lp0 = alpha * fast_log(p);
+    if (!(lp0 > -400.0)) return 0u;
+    const double x = 1.0 - p;
+    const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
+    // the lane's loop ends at the larger count; only the smaller one needs recording on the way
+    const double kmax = fmax(k1d, k2d), kmin = fmin(k1d, k2d);
+    double r_min = 0.0, r_max = 0.0;
+    if (two) nb_fast_recurrence<W2, true>(kmin, kmax, alpha, x, lp0, r_min, r_max);
+    else nb_fast_recurrence<W2, false>(kmin, kmax, alpha, x, lp0, r_min, r_max);
+    const bool k1_is_max = !two || k1d >= k2d;
+    const double ra = k1_is_max ? r_max : r_min;   // result for k1
+    const double rb = k1_is_max ? r_min : r_max;   // result for k2
+    unsigned done = 0;
+    if (e1 && ra >= kDirectMin) { r1 = ra; done |= 1u; }
+    if (e2 && rb >= kDirectMin) { r2 = rb; done |= 2u; }
+    return done;
+}
+
 template <int W2>
 __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, unsigned want, double alpha, double p,
                                                         double& r1, double& r2)
@@ -438,29 +517,21 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     const bool e1 = (want & 1u) && !(done & 1u) && k1 >= 0.0 && k1 <= (double)kSmallK && floor(k1) == k1;
     const bool e2 = (want & 2u) && !(done & 2u) && k2 >= 0.0 && k2 <= (double)kSmallK && floor(k2) == k2;
     if (!(e1 || e2)) return done & want;
-    const double lp0 = alpha * fast_log(p);
-    if (!(lp0 > -400.0)) return done & want;     // keeps the scaled sums below (N_k <= k!/t_0) far from overflow
-    const double x = 1.0 - p;
-    const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
-    // the lane's loop ends at the larger count; only the smaller one needs recording on the way
-    const double kmax = fmax(k1d, k2d), kmin = fmin(k1d, k2d);
-    // Division- and table-free form of  t_{j+1} = t_j (alpha + j) x / (j + 1),  S_j = sum_{i<j} t_i :
-    //   N_j = prod_{i<j} (alpha + i) x,  D_j = j!,  A_j = S_j D_{j-1} / t_0   (A_{j+1} = A_j * j + N_j)
-    // so one step is 5 full-rate FP64 ops with no memory access; t_k = t_0 N_k / D_k, S_k = t_0 A_k k / D_k.
-    // The trip count is tested on the FP64 counter itself (one v_cmp, no integer shadow counter).
-    const double t0 = fast_exp_neg(lp0);
-    double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
-    // two exec-masked loops instead of one loop with a per-step snapshot: 0 .. kmin, snapshot, kmin .. kmax
-    while (jj < kmin) pmf_scaled_step(A, N, D, u, jj, x);
-    const double r_min = midp_from_state<W2>(A, N, D, jj, t0);
-    while (jj < kmax) pmf_scaled_step(A, N, D, u, jj, x);
-    const double r_max = midp_from_state<W2>(A, N, D, jj, t0);
-    const bool k1_is_max = k1d >= k2d;
-    const double ra = k1_is_max ? r_max : r_min;   // result for k1
-    const double rb = k1_is_max ? r_min : r_max;   // result for k2
-    if (e1 && ra >= kDirectMin) { r1 = ra; done |= 1u; }
-    if (e2 && rb >= kDirectMin) { r2 = rb; done |= 2u; }
+    done |= nb_fast2_run<W2>(k1, k2, e1, e2, (want & 2u) != 0u, alpha, p, r1, r2);
     return done & want;
+}
+
+// Front end for integer counts (the fused statistics kernels): anything unusual -- alpha or p not a finite number in
+// the open range, p == 1, a negative count -- is simply left unresolved; the compacted pass takes those pairs through
+// nb_midp_upper with the full scipy semantics.  Same recurrence, same bits as nb_midp_upper_fast2 on valid inputs.
+template <int W2>
+__device__ __forceinline__ unsigned nb_fast2_counts(int k1, int k2, bool two, double alpha, double p, double& r1,
+                                                    double& r2)
+{
+    if (!(alpha > 0.0 && alpha < __longlong_as_double(0x7ff0000000000000LL) && p > 0.0 && p < 1.0)) return 0u;
+    const bool e1 = k1 >= 0 && k1 <= kSmallK, e2 = two && k2 >= 0 && k2 <= kSmallK;
+    if (!(e1 || e2)) return 0u;
+    return nb_fast2_run<W2>((double)k1, (double)k2, e1, e2, two, alpha, p, r1, r2);
 }
 
 // Fisher via q = p1 p2:  chi2.sf(-2 ln q, 4) = q (1 - ln q); falls back to the log form when q

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(kBlock) void nb3_kernel(const double* __restrict__ 
                                                      const double* __restrict__ p, double* __restrict__ out,
                                                      int64_t n)
 {
+    nb_tables_init();
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
         out[i] = Op::apply(k[i], alpha[i], p[i]);
@@ -142,6 +143,7 @@ __device__ __forceinline__ PairInputs load_pair(const ElementStatsArgs& a, int64
 template <bool WORKLIST>
 __global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStatsArgs a)
 {
+    nb_tables_init();
     const int64_t n = a.E * a.C;
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -216,6 +218,7 @@ template <bool HAS_INDEL_PARAMS>
 __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementStatsArgs a)
 {
     __shared__ unsigned park_all[kBlock / 64][kParkCap];
+    nb_tables_init();
     unsigned* park = park_all[threadIdx.x >> 6];
     const int64_t n = a.E * a.C;
     const int lane = threadIdx.x & 63;
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
         nxt = load_raw(a, min((tile + n_waves) * 64 + lane, n - 1));
         const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
         double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
-        const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
-        const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
+        const unsigned d1 = nb_fast2_counts<1>(cur.k_snv, cur.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
+        const unsigned d2 = nb_fast2_counts<1>(cur.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
         const bool slow = ((d1 != 3u) || (d2 != 1u)) && i_raw < n;
         const unsigned long long m = __ballot(slow);
         if (slow) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
 // lane 0 combines them; a wave finishes 16 pairs at a time.
 __global__ __launch_bounds__(kBlock) void element_stats_slow_kernel(ElementStatsArgs a)
 {
+    nb_tables_init();
     const int64_t n = a.E * a.C;
     const unsigned count = a.worklist[0];
     const unsigned quads_per_pass = gridDim.x * (kBlock / 4);
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restri
                                                           double* __restrict__ exp_out, int64_t C, int64_t n_bins,
                                                           int64_t n_tiles)
 {
+    nb_tables_init();
     const int64_t per_cohort = n_bins * n_tiles;
     const int64_t n = C * per_cohort;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
