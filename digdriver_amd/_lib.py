@@ -46,6 +46,7 @@ _SIGNATURES = {
     "dig_scale_suffstats": [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp],
     "dig_scale_suffstats_host": [_vp, _vp, _i64, _i64, _vp, _int],
     "dig_scale_factors": [_vp, _int, _i64, _vp, _vp, _vp],
+    "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _vp, _i64, _vp],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -62,6 +63,7 @@ _SIZE_QUERIES = {
     "dig_element_stats_workspace": [_i64, _i64],
     "dig_accumulate_workspace": [_i64, _i64],
     "dig_scale_suffstats_workspace": [_i64, _i64],
+    "dig_element_pipeline_workspace": [_i64, _i64],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
@@ -119,7 +121,7 @@ def workspace_bytes(kind, E, C):
     """Scratch bytes needed by dig_element_stats ("element_stats") / dig_accumulate_elements ("accumulate")."""
     lib = load()
     fn = {"element_stats": lib.dig_element_stats_workspace, "accumulate": lib.dig_accumulate_workspace,
-          "suffstats": lib.dig_scale_suffstats_workspace}[kind]
+          "suffstats": lib.dig_scale_suffstats_workspace, "pipeline": lib.dig_element_pipeline_workspace}[kind]
     return int(fn(int(E), int(C)))
 
 

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
     const int32_t* __restrict__ ov_idx, const uint8_t* __restrict__ strand_minus, double* __restrict__ MU,
     double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS, int32_t* __restrict__ FLAG, int32_t* __restrict__ R_SIZE,
     int32_t* __restrict__ rcp, int64_t E, int64_t C, FastDiv divC, int use_fastdiv, const double* __restrict__ d_pr,
-    double* __restrict__ tab, int n48)
+    double* __restrict__ tab, int n48, int do_rates)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * kRegionBlock + threadIdx.x) >> 6;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
                          (int64_t)gridDim.x * kRegionBlock);
 
     const int64_t n = E * C;
-    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t n_tiles = do_rates ? (n + 63) >> 6 : 0;   // dig_element_pipeline forms the rate sums in its statistics kernel
     for (int64_t tile = wave0; tile < n_tiles; tile += nwaves) {
         const int64_t g = tile * 64 + lane;
         if (g < n) {
@@ -532,12 +532,18 @@ int64_t dig_accumulate_workspace(int64_t E, int64_t C)
     return acc_workspace_layout(nullptr, E, C).bytes;
 }
 
-int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
-                            const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
-                            int n_class, const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
-                            double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE,
-                            int32_t* ELT_SIZE, double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace,
-                            int64_t workspace_bytes, void* stream)
+}  // extern "C"
+
+namespace dig {
+
+// Shared by dig_accumulate_elements and dig_element_pipeline (do_rates = 0: MU / SIGMA / R_OBS / FLAG are left to the
+// caller's statistics kernel; needs the workspace path).
+int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                      const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L, int n_class,
+                      const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
+                      double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
+                      double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
+                      void* stream, int do_rates)
 {
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
@@ -547,6 +553,7 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
     DIG_REQUIRE(MU && SIGMA && R_OBS && FLAG && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
     hipStream_t s = (hipStream_t)stream;
     if (!workspace) {
+        DIG_REQUIRE(do_rates, "the fused pipeline needs a workspace");
         // no scratch: single-kernel LDS variant (slower; kept for callers that cannot provide a workspace)
         for (int64_t c0 = 0; c0 < C; c0 += 64) {
             AccArgs a{bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
@@ -561,14 +568,30 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
     const AccWorkspace w = acc_workspace_layout(workspace, E, C);
     DIG_REQUIRE(workspace_bytes >= w.bytes, "workspace smaller than dig_accumulate_workspace(E, C)");
     {
-        const int grid = grid_for(E * C, kRegionBlock, 8);
+        const int grid = grid_for(do_rates ? E * C : E * 16, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
                            bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C,
-                           make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48);
+                           make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48, do_rates);
         DIG_HIP_TRY(hipGetLastError());
     }
     return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
                           : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
+}
+
+}  // namespace dig
+
+extern "C" {
+
+int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                            const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
+                            int n_class, const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
+                            double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE,
+                            int32_t* ELT_SIZE, double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace,
+                            int64_t workspace_bytes, void* stream)
+{
+    return accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, n_class, strand_minus,
+                             gene_length, d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace,
+                             workspace_bytes, stream, 1);
 }
 
 int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,

@@ -445,6 +445,20 @@ __device__ __forceinline__ double tail_from_state_tab(double A, double N, double
     return (1.0 - S) - 0.5 * t;
 }
 
+// One step of the scaled recurrence with the running factorial (compacted pass, where D is rescaled on the way).  The
+// accumulator update A <- A * j + N is issued as the three-address v_fma_f64 (the compiler's v_fmac form needs three
+// register copies per step to keep N alive).
+__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x)
+{
+    double An;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(An) : "v"(A), "v"(jj), "v"(N));
+    A = An;                 // A_{j+1} = A_j * j + N_j
+    N *= u;                 // N_{j+1}
+    u += x;
+    jj += 1.0;
+    D *= jj;                // D_{j+1} = (j+1)!
+}
+
 // One step of the scaled recurrence without the factorial (fast pass): 4 FP64 operations.
 __device__ __forceinline__ void pmf_scaled_step_nofact(double& A, double& N, double& u, double& jj, double x)
 {

@@ -75,6 +75,15 @@ struct ElementStatsArgs {
     unsigned* worklist;   // [0] = count, entries from [kWorkHeader]; NULL -> slow lanes are resolved inline
     FastDiv divC;
     int use_fastdiv;
+    // fused pipeline only (dig_element_pipeline): the rate sums of the accumulation are formed here from the bin
+    // tables and written to mu_w / sigma_w / r_obs / flag (mu, sigma above alias mu_w, sigma_w for the compacted pass)
+    const double *bin_mu, *bin_std;
+    const int32_t* bin_y;
+    const uint8_t* bin_flag;
+    const int64_t* ov_ptr;
+    const int32_t* ov_idx;
+    double *mu_w, *sigma_w;
+    int32_t *r_obs, *flag;
 };
 
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
@@ -82,19 +91,28 @@ constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (c
 struct PairRaw {
     double mu, sigma, pi_s, pi_i, mu_i, sigma_i, cj, cji;
     int k_snv, k_smp, k_ind;
+    int64_t q0, q1;   // fused pipeline: CSR range of the pair's element (instead of mu, sigma)
 };
 
 struct PairInputs {
     double alpha, theta, p, exp_snv, alpha_i, theta_i, p_i, exp_ind, k_snv, k_smp, k_ind;
 };
 
+template <bool FUSED_RATES = false>
 __device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i)
 {
     const int64_t e = a.use_fastdiv ? fastdiv(i, a.divC) : i;   // use_fastdiv == 0 only when C == 1
     const int64_t c = i - e * a.C;
     PairRaw r;
-    r.mu = a.mu[i];
-    r.sigma = a.sigma[i];
+    if (FUSED_RATES) {
+        r.q0 = a.ov_ptr[e];
+        r.q1 = a.ov_ptr[e + 1];
+        r.mu = r.sigma = 0.0;
+    } else {
+        r.mu = a.mu[i];
+        r.sigma = a.sigma[i];
+        r.q0 = r.q1 = 0;
+    }
     r.pi_s = a.pi_sum[i];
     r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[i] : a.pi_indel[e];
     r.k_snv = a.obs_snv[i];
@@ -214,7 +232,10 @@ __device__ __forceinline__ unsigned park_flush(unsigned* worklist, const unsigne
     return 0;
 }
 
-template <bool HAS_INDEL_PARAMS>
+// FUSED_RATES (dig_element_pipeline): MU = sum Y_PRED, SIGMA = sqrt(sum STD^2), R_OBS, FLAG of the pair are summed
+// here over the element's bins (same CSR order and IEEE operations as acc_region_kernel, genic_driver_tools.py:262-271)
+// and written out, instead of being read back from a previous kernel: 24 B per pair less HBM traffic each way.
+template <bool HAS_INDEL_PARAMS, bool FUSED_RATES = false>
 __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementStatsArgs a)
 {
     __shared__ unsigned park_all[kBlock / 64][kParkCap];
@@ -227,14 +248,33 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
     int64_t tile = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (tile >= n_tiles) return;
-    PairRaw nxt = load_raw(a, min(tile * 64 + lane, n - 1));
+    PairRaw nxt = load_raw<FUSED_RATES>(a, min(tile * 64 + lane, n - 1));
     unsigned parked = 0;   // wave-uniform
     for (; tile < n_tiles; tile += n_waves) {
         if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
         const int64_t i_raw = tile * 64 + lane;
         const int64_t i = min(i_raw, n - 1);
-        const PairRaw cur = nxt;
-        nxt = load_raw(a, min((tile + n_waves) * 64 + lane, n - 1));
+        PairRaw cur = nxt;
+        nxt = load_raw<FUSED_RATES>(a, min((tile + n_waves) * 64 + lane, n - 1));
+        if (FUSED_RATES) {
+            const int64_t c = i - (a.use_fastdiv ? fastdiv(i, a.divC) : i) * a.C;
+            double mu = 0.0, var = 0.0;
+            int robs = 0, flag = 0;
+            for (int64_t qq = cur.q0; qq < cur.q1; ++qq) {
+                const int64_t o = (int64_t)a.ov_idx[qq] * a.C + c;
+                const double sd = a.bin_std[o];
+                mu += a.bin_mu[o];
+                var = fma(sd, sd, var);
+                robs += a.bin_y[o];
+                flag |= (a.bin_flag[o] != 0);
+            }
+            cur.mu = mu;
+            cur.sigma = sqrt(var);
+            a.mu_w[i] = cur.mu;
+            a.sigma_w[i] = cur.sigma;
+            a.r_obs[i] = robs;
+            a.flag[i] = flag;
+        }
         const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
         double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
         const unsigned d1 = nb_fast2_counts<1>(cur.k_snv, cur.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
@@ -453,6 +493,87 @@ int64_t dig_element_stats_workspace(int64_t E, int64_t C)
     return (int64_t)sizeof(unsigned) * (kWorkHeader + n);
 }
 
+}  // extern "C"
+
+namespace dig {
+
+// Shared launcher of dig_element_stats and of the statistics stage of dig_element_pipeline (fused != NULL: the rate
+// sums are formed inside the streaming kernel from the bin tables and written to fused->mu_w etc.).
+struct FusedRates {
+    const double *bin_mu, *bin_std;
+    const int32_t* bin_y;
+    const uint8_t* bin_flag;
+    const int64_t* ov_ptr;
+    const int32_t* ov_idx;
+    double *mu_w, *sigma_w;
+    int32_t *r_obs, *flag;
+};
+
+int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
+                         const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
+                         const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
+                         double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream,
+                         const FusedRates* fused)
+{
+    const int64_t need = dig_element_stats_workspace(E, C);
+    unsigned* wl = nullptr;
+    if (workspace && need > 0) {
+        DIG_REQUIRE(workspace_bytes >= need, "workspace smaller than dig_element_stats_workspace(E, C)");
+        DIG_REQUIRE(((uintptr_t)workspace & 3u) == 0, "workspace 4-byte aligned");
+        wl = (unsigned*)workspace;
+    }
+    DIG_REQUIRE(!fused || (wl && !mu_indel), "the fused pipeline needs the worklist workspace and shares the SNV parameters");
+    hipStream_t s = (hipStream_t)stream;
+    const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
+    ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
+                       cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (fused) {
+        a.bin_mu = fused->bin_mu; a.bin_std = fused->bin_std; a.bin_y = fused->bin_y; a.bin_flag = fused->bin_flag;
+        a.ov_ptr = fused->ov_ptr; a.ov_idx = fused->ov_idx;
+        a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
+    }
+    if (wl) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
+    const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
+    DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
+    const int grid = (int)want_blocks;
+    if (wl) {
+        // persistent grid: exactly as many blocks as are resident at once
+        static int resident[3] = {0, 0, 0};
+        const int which = fused ? 2 : (mu_indel ? 1 : 0);
+        if (!resident[which]) {
+            int per_cu = 0;
+            if (which == 2)
+                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false, true>, kBlock, 0));
+            else if (which == 1)
+                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<true, false>, kBlock, 0));
+            else
+                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false, false>, kBlock, 0));
+            resident[which] = per_cu > 0 ? per_cu : 4;
+        }
+        int blocks_per_cu = resident[which];
+        if (const char* e = getenv("DIG_ES_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));   // tuning knob
+        const int sgrid = grid_for(E * C, kBlock, blocks_per_cu);
+        if (which == 2)
+            hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(sgrid), dim3(kBlock), 0, s, a);
+        else if (which == 1)
+            hipLaunchKernelGGL((element_stats_stream_kernel<true, false>), dim3(sgrid), dim3(kBlock), 0, s, a);
+        else
+            hipLaunchKernelGGL((element_stats_stream_kernel<false, false>), dim3(sgrid), dim3(kBlock), 0, s, a);
+    } else
+        hipLaunchKernelGGL(element_stats_fast_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+    DIG_HIP_TRY(hipGetLastError());
+    if (wl) {
+        hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 8 + 1, kBlock, 8)), dim3(kBlock), 0, s, a);
+        DIG_HIP_TRY(hipGetLastError());
+    }
+    return DIG_OK;
+}
+
+}  // namespace dig
+
+extern "C" {
+
 int dig_element_stats(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
                       const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                       const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
@@ -463,48 +584,8 @@ int dig_element_stats(const double* mu, const double* sigma, const double* mu_in
     DIG_REQUIRE(mu && sigma && pi_sum && pi_indel && obs_snv && obs_samples && obs_indel && cj && cj_indel && out,
                 "non-null pointers");
     DIG_REQUIRE((mu_indel == nullptr) == (sigma_indel == nullptr), "mu_indel and sigma_indel both set or both NULL");
-    const int64_t need = dig_element_stats_workspace(E, C);
-    unsigned* wl = nullptr;
-    if (workspace && need > 0) {
-        DIG_REQUIRE(workspace_bytes >= need, "workspace smaller than dig_element_stats_workspace(E, C)");
-        DIG_REQUIRE(((uintptr_t)workspace & 3u) == 0, "workspace 4-byte aligned");
-        wl = (unsigned*)workspace;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
-    ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
-                       cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd};
-    if (wl) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
-    const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
-    DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
-    const int grid = (int)want_blocks;
-    if (wl) {
-        // persistent grid: exactly as many blocks as are resident at once
-        static int resident[2] = {0, 0};
-        const int which = mu_indel ? 1 : 0;
-        if (!resident[which]) {
-            int per_cu = 0;
-            if (which)
-                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<true>, kBlock, 0));
-            else
-                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false>, kBlock, 0));
-            resident[which] = per_cu > 0 ? per_cu : 4;
-        }
-        int blocks_per_cu = resident[which];
-        if (const char* e = getenv("DIG_ES_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));   // tuning knob
-        const int sgrid = grid_for(E * C, kBlock, blocks_per_cu);
-        if (which)
-            hipLaunchKernelGGL(element_stats_stream_kernel<true>, dim3(sgrid), dim3(kBlock), 0, s, a);
-        else
-            hipLaunchKernelGGL(element_stats_stream_kernel<false>, dim3(sgrid), dim3(kBlock), 0, s, a);
-    } else
-        hipLaunchKernelGGL(element_stats_fast_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
-    DIG_HIP_TRY(hipGetLastError());
-    if (wl) {
-        hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 8 + 1, kBlock, 8)), dim3(kBlock), 0, s, a);
-        DIG_HIP_TRY(hipGetLastError());
-    }
-    return DIG_OK;
+    return element_stats_launch(mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, pi_indel_per_cohort, obs_snv,
+                                obs_samples, obs_indel, cj, cj_indel, out, E, C, workspace, workspace_bytes, stream, nullptr);
 }
 
 int dig_element_stats_host(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,

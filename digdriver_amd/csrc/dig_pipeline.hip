@@ -1,0 +1,78 @@
+// dig_pipeline.hip -- accumulation + statistics block as ONE operation (the element / tile driver path).
+//
+// dig_element_pipeline == dig_accumulate_elements (n_class = 1) followed by dig_element_stats on its outputs
+// (genic_driver_tools.py:300-431 then transfer_tools.py:1069-1087), with one fusion across the two: the per-pair rate
+// sums MU / SIGMA / R_OBS / FLAG are formed inside the statistics streaming kernel, which needs them anyway, instead
+// of being written by the region kernel and read back (24 B per (element, cohort) less HBM traffic each way and one
+// HBM-bound pass fewer).  All outputs of both operations are still written; results are bit-identical to the two
+// separate calls (tests/test_gpu_parity.py).  Kernel sequence: acc_region_kernel (contexts + parameter table) ->
+// acc_dot_mfma_kernel -> element_stats_stream_kernel<false, true> -> element_stats_slow_kernel.
+#include "dig_common.hpp"
+
+namespace dig {
+
+struct FusedRates {
+    const double *bin_mu, *bin_std;
+    const int32_t* bin_y;
+    const uint8_t* bin_flag;
+    const int64_t* ov_ptr;
+    const int32_t* ov_idx;
+    double *mu_w, *sigma_w;
+    int32_t *r_obs, *flag;
+};
+
+int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                      const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L, int n_class,
+                      const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
+                      double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
+                      double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
+                      void* stream, int do_rates);
+int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
+                         const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
+                         const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
+                         double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream,
+                         const FusedRates* fused);
+
+}  // namespace dig
+
+using namespace dig;
+
+extern "C" {
+
+int64_t dig_accumulate_workspace(int64_t E, int64_t C);
+int64_t dig_element_stats_workspace(int64_t E, int64_t C);
+
+int64_t dig_element_pipeline_workspace(int64_t E, int64_t C)
+{
+    if (E <= 0 || C <= 0) return 0;
+    const int64_t a = dig_accumulate_workspace(E, C), b = dig_element_stats_workspace(E, C);
+    if (a <= 0 || b <= 0) return 0;
+    return (a + 255) / 256 * 256 + b;
+}
+
+int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                         const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
+                         const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
+                         const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
+                         const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
+                         int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
+                         void* workspace, int64_t workspace_bytes, void* stream)
+{
+    DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(obs_snv && obs_samples && obs_indel && cj && cj_indel && out, "non-null statistics arguments");
+    const int64_t need = dig_element_pipeline_workspace(E, C);
+    DIG_REQUIRE(workspace && need > 0 && workspace_bytes >= need,
+                "workspace of at least dig_element_pipeline_workspace(E, C) bytes (E * C must stay below 2^32 - 1)");
+    DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
+    const int64_t acc_bytes = (dig_accumulate_workspace(E, C) + 255) / 256 * 256;
+    int rc = accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, 1, strand_minus, gene_length,
+                               d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace, acc_bytes,
+                               stream, 0);
+    if (rc) return rc;
+    const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG};
+    return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
+                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f);
+}
+
+}  // extern "C"

@@ -244,6 +244,40 @@ def accumulate_elements(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_id
 _NP_DT = {np.dtype(np.float32): _lib.DIG_F32, np.dtype(np.float64): _lib.DIG_F64, np.dtype(np.int16): _lib.DIG_I16}
 
 
+def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
+                     obs_samples, obs_indel, cj, cj_indel, gene_length=None, out_acc=None, out_stats=None):
+    """accumulate_elements (n_class = 1) + element_stats as one operation on device tensors (dig_element_pipeline):
+    the rate sums are formed inside the statistics kernel.  Returns (accumulate dict, statistics tensor [7, E, C])."""
+    import torch
+    dev = bin_mu.device
+    f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
+    bin_mu, bin_std = _t(bin_mu, f64, dev), _t(bin_std, f64, dev)
+    N, C = bin_mu.shape
+    bin_y, bin_flag, bin_ctx = _t(bin_y, i32, dev), _t(bin_flag, u8, dev), _t(bin_ctx, i32, dev)
+    ov_ptr, ov_idx = _t(ov_ptr, i64, dev), _t(ov_idx, i32, dev)
+    L = _t(L, i32, dev)
+    if L.dim() == 2:
+        L = L[:, None, :]
+    E, n_class, K = L.shape
+    assert n_class == 1 and K == 192 and bin_ctx.shape == (N, 64) and ov_ptr.numel() == E + 1
+    strand_minus, gene_length, d_pr = _t(strand_minus, u8, dev), _t(gene_length, i32, dev), _t(d_pr, f64, dev)
+    obs = [_t(x, i32, dev) for x in (obs_snv, obs_samples, obs_indel)]
+    assert all(x.shape == (E, C) for x in obs)
+    cj, cj_indel = _t(cj, f64, dev), _t(cj_indel, f64, dev)
+    o = out_acc if out_acc is not None else alloc_accumulate_outputs(E, C, 1, dev)
+    st = out_stats if out_stats is not None else torch.empty((len(ES_PLANES), E, C), dtype=f64, device=dev)
+    ws, wsb = _workspace("pipeline", E, C, dev)
+    if ws is None:
+        raise _lib.DigHipError("dig_element_pipeline: problem too large for the fused path (E * C >= 2^32 - 1)")
+    p = _lib.dev_ptr
+    with torch.cuda.device(dev):
+        _lib.call("dig_element_pipeline", p(bin_mu), p(bin_std), p(bin_y), p(bin_flag), p(bin_ctx), p(ov_ptr), p(ov_idx),
+                  p(L), p(strand_minus), p(gene_length), p(d_pr), p(obs[0]), p(obs[1]), p(obs[2]), p(cj), p(cj_indel),
+                  p(o["MU"]), p(o["SIGMA"]), p(o["R_OBS"]), p(o["FLAG"]), p(o["P"]), p(o["R_SIZE"]), p(o["ELT_SIZE"]),
+                  p(o["P_INDEL"]), p(st), N, E, C, p(ws), wsb, _lib.stream_ptr())
+    return o, st
+
+
 def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False, device=0):
     """x_data[bin_rows, :, tracks] as float32 (or bf16) -- mut_dataset.py:76-81 for a batch.
     transpose=True returns channels-first [B, T_sel, L] (cnn_predictors.py:131)."""

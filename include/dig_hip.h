@@ -153,6 +153,22 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
                                  int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
                                  double *P_INDEL, int64_t N, int64_t E, int64_t C, int device);
 
+/* ---- accumulation + statistics block as one operation --------------------------------------- *
+ * dig_element_pipeline == dig_accumulate_elements (n_class = 1) followed by dig_element_stats(MU, SIGMA, NULL, NULL,
+ * P, P_INDEL [E], obs..., cj, cj_indel, out): the elementDriver / tiledModel route from bin tables to p-values
+ * (genic_driver_tools.py:300-431 then transfer_tools.py:1069-1087).  One fusion across the two: MU / SIGMA / R_OBS /
+ * FLAG are summed inside the statistics streaming kernel instead of being written by one kernel and read back by
+ * the next.  All outputs of both operations are written; results are bit-identical to the two separate calls.
+ * workspace: dig_element_pipeline_workspace(E, C) bytes (0 = not available: E * C >= 2^32 - 1), 256-byte aligned. */
+int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
+int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
+                         const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
+                         const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,
+                         const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel, const double *cj,
+                         const double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
+                         int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- per-cohort sufficient statistics for the scale factors --------------------------- *
  * calc_scale_factor_efficient, genome mode (driver_model/transfer_tools.py:148-156):
  *   out_sum[c] = sum over bins with FLAG == 0 of Y_PRED[bin, c]   (N_SNV_EXP per cohort);

@@ -399,3 +399,30 @@ def test_context_counting_matches_reference_golden_and_oracle():
     want = O.count_contexts_regions(seqs, chroms, starts, ends, minus)
     assert np.array_equal(got, want)
     assert got.sum() > 0
+
+
+def test_element_pipeline_equals_separate_calls(torch_dev):
+    """dig_element_pipeline (rate sums fused into the statistics kernel) against dig_accumulate_elements followed by
+    dig_element_stats on the same inputs: every output of both operations bit-identical."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    for (nb, E, C, seed) in ((3000, 2500, 5, 1), (900, 700, 37, 2), (400, 333, 1, 3)):
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        # make a few pairs take the compacted pass and a few be degenerate
+        td["obs_snv"][::97] += 90
+        td["bin_std"][5] = 0.0
+        acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                         td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"])
+        st = engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], td["obs_snv"], td["obs_samples"],
+                                  td["obs_indel"], td["cj"], td["cj_indel"])
+        acc2, st2 = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                            td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"],
+                                            td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"])
+        for k in acc:
+            a, b = acc[k], acc2[k]
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), k
+        for j, name in enumerate(engine.ES_PLANES):
+            a, b = st[name], st2[j]
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name

@@ -51,6 +51,13 @@ def main():
     for ws in (True, False):
         us = timeit(lambda: stats(ws))
         print("element_stats workspace=%-5s %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (ws, us, b_stat / us / 1e3, b_stat / us / 1e3 / 80))
+    pipe_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
+    us = timeit(lambda: engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                                td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
+                                                td["obs_snv"], td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"],
+                                                out_acc=pipe_acc, out_stats=out_st))
+    print("element_pipeline (fused) %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+        us, (b_acc + b_stat) / us / 1e3, (b_acc + b_stat) / us / 1e3 / 80))
     us = timeit(lambda: engine.scale_suffstats(td["bin_mu"], td["bin_flag"]))
     print("scale_suffstats %8.1f us  %7.1f GB/s" % (us, td["bin_mu"].numel() * 9 / us / 1e3))
     us = timeit(lambda: engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
