@@ -90,9 +90,9 @@ __device__ __forceinline__ double fma_sconst(double a, double b, double c)
 // ---- exponential for arguments in [-745, 0] (p^alpha = exp(alpha log p)), < 1 ulp ----------------
 // x = n ln2 + r, |r| <= ln2 / 2;  e^r from the degree-13 Taylor polynomial (remainder r^14 / 14! < 5e-18), scaled by
 // 2^n with ldexp.  Anything outside (-745, 0] or NaN goes to the library exp.
-__device__ __forceinline__ double fast_exp_neg(double x)
+// x in (-745, 0] (no checks).
+__device__ __forceinline__ double fast_exp_neg_core(double x)
 {
-    if (!(x <= 0.0 && x > -745.0)) return exp(x);
     const double n = rint(x * 1.4426950408889634);                       // log2(e)
     double r = fma(n, -6.93147180369123816490e-01, x);                   // ln2 split: high part has 32 zero low bits
     r = fma(n, -1.90821492927058770002e-10, r);
@@ -113,15 +113,21 @@ __device__ __forceinline__ double fast_exp_neg(double x)
     return ldexp(q, (int)n);
 }
 
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    if (!(x <= 0.0 && x > -745.0)) return exp(x);
+    return fast_exp_neg_core(x);
+}
+
 // ---- natural logarithm, < 1 ulp, ~1/3 of the instructions of the library log ---------------
 // Classical reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = f / (2 + f), f = m - 1,
 // with the degree-14 minimax polynomial in s^2 (the coefficients are the standard ones of this scheme).
 // Arguments that are not positive normal numbers go to the library log.
-__device__ __forceinline__ double fast_log(double x)
+// x must be a positive normal number (no checks).
+__device__ __forceinline__ double fast_log_normal(double x)
 {
     const long long bits = __double_as_longlong(x);
     int hx = (int)(bits >> 32);
-    if (hx < 0x00100000 || hx >= 0x7ff00000) return log(x);   // zero, negative, subnormal, inf, nan
     int k = (hx >> 20) - 1023;
     hx &= 0x000fffff;
     const int i = (hx + 0x95f64) & 0x100000;                   // m >= sqrt(2) -> halve it, k += 1
@@ -143,6 +149,13 @@ __device__ __forceinline__ double fast_log(double x)
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+__device__ __forceinline__ double fast_log(double x)
+{
+    const int hx = (int)(__double_as_longlong(x) >> 32);
+    if (hx < 0x00100000 || hx >= 0x7ff00000) return log(x);   // zero, negative, subnormal, inf, nan
+    return fast_log_normal(x);
 }
 
 // ---- continued fraction for I_x(a,b) (fast for x < (a+1)/(a+b+2)) -------------------
@@ -478,13 +491,24 @@ template <int W2, bool TWO>
 __device__ __forceinline__ void nb_fast_recurrence(double kmin, double kmax, double alpha, double x, double lp0,
                                                    double& r_min, double& r_max)
 {
-    const double t0 = fast_exp_neg(lp0);
+    const double t0 = fast_exp_neg_core(lp0);                    // -400 < lp0 <= 0 here
     double N = 1.0, A = 0.0, u = alpha * x, jj = 0.0;
+    // steps are taken two at a time (one trip test per pair), then at most one single step
     if (TWO) {
-        while (jj < kmin) pmf_scaled_step_nofact(A, N, u, jj, x);
+        const double kmin_m1 = kmin - 1.0;
+        while (jj < kmin_m1) {
+            pmf_scaled_step_nofact(A, N, u, jj, x);
+            pmf_scaled_step_nofact(A, N, u, jj, x);
+        }
+        if (jj < kmin) pmf_scaled_step_nofact(A, N, u, jj, x);
         r_min = tail_from_state_tab<W2>(A, N, jj, t0);
     }
-    while (jj < kmax) pmf_scaled_step_nofact(A, N, u, jj, x);
+    const double kmax_m1 = kmax - 1.0;
+    while (jj < kmax_m1) {
+        pmf_scaled_step_nofact(A, N, u, jj, x);
+        pmf_scaled_step_nofact(A, N, u, jj, x);
+    }
+    if (jj < kmax) pmf_scaled_step_nofact(A, N, u, jj, x);
     r_max = tail_from_state_tab<W2>(A, N, jj, t0);
 }
 
@@ -493,7 +517,8 @@ template <int W2>
 __device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, bool e2, bool two, double alpha, double p,
                                                  double& r1, double& r2)
 {
-    const double lp0 = alpha * fast_log(p);
+    if (!(p >= 2.2250738585072014e-308)) return 0u;   // subnormal p: leave it to the general path
+    const double lp0 = alpha * fast_log_normal(p);
     if (!(lp0 > -400.0)) return 0u;
     const double x = 1.0 - p;
     const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
@@ -634,7 +659,7 @@ __device__ __forceinline__ double fisher_combine(double p1, double p2)
 __device__ __forceinline__ double fisher_combine_fast(double p1, double p2)
 {
     const double q = p1 * p2;
-    if (q > 1e-290 && p1 <= 1.0 && p2 <= 1.0) return q * (1.0 - fast_log(q));
+    if (q > 1e-290 && p1 <= 1.0 && p2 <= 1.0) return q * (1.0 - fast_log_normal(q));
     return fisher_combine(p1, p2);
 }
 
