@@ -5,8 +5,9 @@ One "step" = one pass of the burden-test hot path over one batch of synthetic in
 already resident in HBM:
 
     per-cohort sufficient statistics -> (RCCL all-gather when N > 1) -> scale factors cj
-    dig_accumulate_elements  (genic_driver_tools.py:300-431 for all elements x cohorts)
-    dig_element_stats        (transfer_tools.py:272-302,343-344,473-482,594-615,731-747,1086-1087)
+    dig_element_pipeline = dig_accumulate_elements (genic_driver_tools.py:300-431 for all elements x cohorts)
+                         + dig_element_stats (transfer_tools.py:272-302,343-344,473-482,594-615,731-747,1086-1087)
+                           as one operation (rate sums fused into the statistics kernel; every output of both written)
 
 Workload at N=1: BASELINE.json configs[2] ("whole genome, 37 cohorts batched, 1 MI355X"; the
 metric is quoted on whole-genome x 37 cohorts and this fits one GPU): 288 000 10-kb bins,
@@ -273,26 +274,23 @@ def main():
     cj_out = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    k_acc, k_stat = [], []
+    k_pipe = []
 
     def step(timed):
         # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
-        #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors
+        #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors -> (4) accumulation +
+        #     statistics block as one operation (dig_element_pipeline; all outputs of both are written)
         engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part[0])
         cj, cji = parallel.scale_factors_from_part(part, out=cj_out)
-        e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
+        e0, e1 = (ev(), ev()) if timed else (None, None)
         if timed:
             e0.record()
-        acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
-                                         td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], out=out_acc)
+        engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                                td["obs_indel"], cj, cji, out_acc=out_acc, out_stats=out_stats)
         if timed:
             e1.record()
-        engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], td["obs_snv"],
-                             td["obs_samples"], td["obs_indel"], cj, cji, out=out_stats)
-        if timed:
-            e2.record()
-            k_acc.append((e0, e1))
-            k_stat.append((e1, e2))
+            k_pipe.append((e0, e1))
 
     def barrier():
         if world > 1:
@@ -303,7 +301,7 @@ def main():
         step(False)
     barrier()
     t0 = time.perf_counter()
-    # HIP events bracket the two dominant operations on a SAMPLE of the timed steps (every 4th, at least 5): each
+    # HIP events bracket the dominant operation on a SAMPLE of the timed steps (every 4th, at least 5): each
     # event record is a barrier packet in the queue (~6 us), so timing every step would slow the thing being measured
     every = max(1, min(4, args.steps // 5))
     for it in range(args.steps):
@@ -314,20 +312,21 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ms_acc = float(np.mean([a.elapsed_time(b) for a, b in k_acc]))
-    ms_stat = float(np.mean([a.elapsed_time(b) for a, b in k_stat]))
+    ms_pipe = float(np.mean([a.elapsed_time(b) for a, b in k_pipe]))
     ok = bool(torch.isfinite(out_stats[1]).all().item())
-    ws = engine._WS_CACHE.get(("element_stats", dev.index))
-    slow_frac = float(ws[:4].view(torch.int32)[0].item()) / (E * C) if ws is not None else None
+    ws = engine._WS_CACHE.get(("pipeline", dev.index))
+    slow_frac = None
+    if ws is not None:
+        off = (_lib.workspace_bytes("accumulate", E, C) + 255) // 256 * 256
+        slow_frac = float(ws[off:off + 4].view(torch.int32)[0].item()) / (E * C)
 
     if rank == 0:
         units = float(E) * C * world * args.steps
         b_acc, b_stat = algorithmic_bytes(E, C, nbar)
-        dominant = "dig_element_stats" if ms_stat >= ms_acc else "dig_accumulate_elements"
-        d_bytes, d_ms = (b_stat, ms_stat) if ms_stat >= ms_acc else (b_acc, ms_acc)
+        dominant = "dig_element_pipeline"
+        d_bytes, d_ms = b_acc + b_stat, ms_pipe
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
-        prefixes = ["element_stats_"] if dominant == "dig_element_stats" else \
-            ["acc_region", "acc_dot", "acc_prep"]
+        prefixes = ["acc_region", "acc_dot", "element_stats_"]
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
         traffic, traffic_src = committed_traffic(prefixes) if default_shape else (None, None)
         res = {
@@ -342,10 +341,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": d_bytes,
                          "avg_launch_ms": d_ms},
-            "kernels": {"dig_accumulate_elements": {"avg_ms": ms_acc, "algorithmic_GBps": b_acc / (ms_acc * 1e-3) / 1e9},
-                        "dig_element_stats": {"avg_ms": ms_stat, "algorithmic_GBps": b_stat / (ms_stat * 1e-3) / 1e9}},
-            "kernel_timing": "HIP events on torch's current stream around dig_accumulate_elements / dig_element_stats on "
-                             "%d of the %d timed steps" % (len(k_acc), args.steps),
+            "operations": {"dig_element_pipeline": {
+                "avg_ms": ms_pipe, "kernels": "acc_region_kernel (contexts + table), acc_dot_mfma_kernel, "
+                                              "element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
+                "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat}}},
+            "kernel_timing": "HIP events on torch's current stream around dig_element_pipeline on %d of the %d timed "
+                             "steps" % (len(k_pipe), args.steps),
             "finite_pvalues": ok, "slow_pair_fraction": slow_frac,
         }
         if args.cpu_sample > 0 and world == 1:
