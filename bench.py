@@ -280,8 +280,12 @@ def main():
         # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
         #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors -> (4) accumulation +
         #     statistics block as one operation (dig_element_pipeline; all outputs of both are written)
-        engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part[0])
-        cj, cji = parallel.scale_factors_from_part(part, out=cj_out)
+        if world == 1:      # nothing to all-gather: sums and divisions come from one pair of kernels
+            cj, cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"],
+                                                    out=(cj_out[0], cj_out[1], part[0]))
+        else:
+            engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part[0])
+            cj, cji = parallel.scale_factors_from_part(part, out=cj_out)
         e0, e1 = (ev(), ev()) if timed else (None, None)
         if timed:
             e0.record()

@@ -252,11 +252,14 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
     const int32_t* __restrict__ ov_idx, const uint8_t* __restrict__ strand_minus, double* __restrict__ MU,
     double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS, int32_t* __restrict__ FLAG, int32_t* __restrict__ R_SIZE,
     int32_t* __restrict__ rcp, int64_t E, int64_t C, FastDiv divC, int use_fastdiv, const double* __restrict__ d_pr,
-    double* __restrict__ tab, int n48, int do_rates)
+    double* __restrict__ tab, int n48, int do_rates, unsigned* __restrict__ zero_dwords, int n_zero)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * kRegionBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kRegionBlock) >> 6;
+
+    // (pipeline only) clear the worklist header of the statistics stage that follows on the stream
+    if (zero_dwords && blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_dwords[threadIdx.x] = 0u;
 
     // phase 0: the pre-swizzled parameter table of the dot stage (a few hundred KB, once per call)
     acc_write_mfma_table(d_pr, tab, (int)C, n48, (int64_t)blockIdx.x * kRegionBlock + threadIdx.x,
@@ -543,7 +546,7 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
                       const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
                       double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
                       double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
-                      void* stream, int do_rates)
+                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero)
 {
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
@@ -571,7 +574,7 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
         const int grid = grid_for(do_rates ? E * C : E * 16, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
                            bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C,
-                           make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48, do_rates);
+                           make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48, do_rates, zero_dwords, n_zero);
         DIG_HIP_TRY(hipGetLastError());
     }
     return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
@@ -591,7 +594,7 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
 {
     return accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, n_class, strand_minus,
                              gene_length, d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace,
-                             workspace_bytes, stream, 1);
+                             workspace_bytes, stream, 1, nullptr, 0);
 }
 
 int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,

@@ -513,7 +513,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
                          const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                          const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
                          double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream,
-                         const FusedRates* fused)
+                         const FusedRates* fused, int worklist_already_zero)
 {
     const int64_t need = dig_element_stats_workspace(E, C);
     unsigned* wl = nullptr;
@@ -533,7 +533,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.ov_ptr = fused->ov_ptr; a.ov_idx = fused->ov_idx;
         a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
     }
-    if (wl) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
+    if (wl && !worklist_already_zero) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
     DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
     const int grid = (int)want_blocks;
@@ -585,7 +585,7 @@ int dig_element_stats(const double* mu, const double* sigma, const double* mu_in
                 "non-null pointers");
     DIG_REQUIRE((mu_indel == nullptr) == (sigma_indel == nullptr), "mu_indel and sigma_indel both set or both NULL");
     return element_stats_launch(mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, pi_indel_per_cohort, obs_snv,
-                                obs_samples, obs_indel, cj, cj_indel, out, E, C, workspace, workspace_bytes, stream, nullptr);
+                                obs_samples, obs_indel, cj, cj_indel, out, E, C, workspace, workspace_bytes, stream, nullptr, 0);
 }
 
 int dig_element_stats_host(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,

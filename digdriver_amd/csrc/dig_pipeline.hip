@@ -26,12 +26,12 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
                       const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
                       double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
                       double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
-                      void* stream, int do_rates);
+                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero);
 int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
                          const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                          const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
                          double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream,
-                         const FusedRates* fused);
+                         const FusedRates* fused, int worklist_already_zero);
 
 }  // namespace dig
 
@@ -66,13 +66,15 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                 "workspace of at least dig_element_pipeline_workspace(E, C) bytes (E * C must stay below 2^32 - 1)");
     DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
     const int64_t acc_bytes = (dig_accumulate_workspace(E, C) + 255) / 256 * 256;
+    // the first kernel also clears the worklist header of the statistics stage (64 dwords): no separate memset node
+    unsigned* wl = (unsigned*)((char*)workspace + acc_bytes);
     int rc = accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, 1, strand_minus, gene_length,
                                d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace, acc_bytes,
-                               stream, 0);
+                               stream, 0, wl, 64);
     if (rc) return rc;
     const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG};
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
-                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f);
+                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f, 1);
 }
 
 }  // extern "C"

@@ -73,8 +73,12 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_stage1(const double* __res
 
 // stage 2: one workgroup per cohort column; thread t adds partial[t], partial[t + 256], ... (independent
 // loads), then a fixed-shape LDS tree combines the 256 thread sums -> deterministic.
+// n_snv / n_ind != NULL (single-shard form): the scale factors cj = n_snv / sum, cj_indel = n_ind / sum are written
+// as well (transfer_tools.py:153-154), saving the separate division kernel when there is nothing to all-gather.
 __global__ __launch_bounds__(kSsBlock) void suffstats_stage2(const double* __restrict__ partial, int nblocks, int64_t C,
-                                                             double* __restrict__ out)
+                                                             double* __restrict__ out, const double* __restrict__ n_snv,
+                                                             const double* __restrict__ n_ind, double* __restrict__ cj,
+                                                             double* __restrict__ cj_indel)
 {
     __shared__ double red[kSsBlock];
     const int64_t c = blockIdx.x;
@@ -86,7 +90,13 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_stage2(const double* __res
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = red[0];
+    if (threadIdx.x == 0) {
+        out[c] = red[0];
+        if (n_snv) {
+            cj[c] = n_snv[c] / red[0];
+            cj_indel[c] = n_ind[c] / red[0];
+        }
+    }
 }
 
 // scale factors from the all-gathered per-rank statistics: parts[r][0][c] = sum(Y_PRED[~FLAG]) of rank r's bins,
@@ -108,10 +118,21 @@ __global__ void scale_factors_kernel(const double* __restrict__ parts, int world
     }
 }
 
-static int ss_blocks(int64_t N)
+// Rows per workgroup: a multiple of 8 passes (the unrolled inner loop keeps 8 row loads in flight per thread; a
+// ragged remainder would be walked one load at a time), sized for ~8 workgroups per CU.
+static int64_t ss_rows_per_block(int64_t N, int64_t C)
 {
-    int64_t g = (int64_t)cu_count() * 8;
-    if (g > (N + 63) / 64) g = (N + 63) / 64;
+    const int64_t rpp = (C <= kSsBlock) ? kSsBlock / C : 1;
+    const int64_t unit = 8 * rpp;
+    int64_t target = (N + (int64_t)cu_count() * 8 - 1) / ((int64_t)cu_count() * 8);
+    if (target < unit) target = unit;
+    return (target + unit - 1) / unit * unit;
+}
+
+static int ss_blocks(int64_t N, int64_t C)
+{
+    const int64_t rpb = ss_rows_per_block(N, C);
+    const int64_t g = (N + rpb - 1) / rpb;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -124,7 +145,7 @@ extern "C" {
 int64_t dig_scale_suffstats_workspace(int64_t N, int64_t C)
 {
     if (N <= 0 || C <= 0) return 0;
-    return (int64_t)ss_blocks(N) * C * (int64_t)sizeof(double);
+    return (int64_t)ss_blocks(N, C) * C * (int64_t)sizeof(double);
 }
 
 int dig_scale_suffstats(const double* bin_mu, const uint8_t* bin_flag, int64_t N, int64_t C, double* out_sum,
@@ -139,13 +160,33 @@ int dig_scale_suffstats(const double* bin_mu, const uint8_t* bin_flag, int64_t N
         return DIG_OK;
     }
     DIG_REQUIRE(bin_mu && bin_flag && workspace, "non-null inputs and workspace");
-    const int g = ss_blocks(N);
+    const int g = ss_blocks(N, C);
     DIG_REQUIRE(workspace_bytes >= (int64_t)g * C * (int64_t)sizeof(double), "workspace smaller than dig_scale_suffstats_workspace(N, C)");
     DIG_REQUIRE(((uintptr_t)workspace & 7u) == 0, "workspace 8-byte aligned");
-    const int64_t rpb = (N + g - 1) / g;
+    const int64_t rpb = ss_rows_per_block(N, C);
     hipLaunchKernelGGL(suffstats_stage1, dim3(g), dim3(kSsBlock), 0, s, bin_mu, bin_flag, N, C, rpb, (double*)workspace);
     DIG_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(suffstats_stage2, dim3((unsigned)C), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum);
+    hipLaunchKernelGGL(suffstats_stage2, dim3((unsigned)C), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum,
+                       (const double*)nullptr, (const double*)nullptr, (double*)nullptr, (double*)nullptr);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_scale_factors_local(const double* bin_mu, const uint8_t* bin_flag, int64_t N, int64_t C, const double* n_snv_obs,
+                            const double* n_ind_obs, double* out_sum, double* cj, double* cj_indel, void* workspace,
+                            int64_t workspace_bytes, void* stream)
+{
+    DIG_REQUIRE(N > 0 && C > 0, "N, C > 0");
+    DIG_REQUIRE(bin_mu && bin_flag && n_snv_obs && n_ind_obs && out_sum && cj && cj_indel && workspace, "non-null pointers");
+    hipStream_t s = (hipStream_t)stream;
+    const int g = ss_blocks(N, C);
+    DIG_REQUIRE(workspace_bytes >= (int64_t)g * C * (int64_t)sizeof(double), "workspace smaller than dig_scale_suffstats_workspace(N, C)");
+    DIG_REQUIRE(((uintptr_t)workspace & 7u) == 0, "workspace 8-byte aligned");
+    const int64_t rpb = ss_rows_per_block(N, C);
+    hipLaunchKernelGGL(suffstats_stage1, dim3(g), dim3(kSsBlock), 0, s, bin_mu, bin_flag, N, C, rpb, (double*)workspace);
+    DIG_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(suffstats_stage2, dim3((unsigned)C), dim3(kSsBlock), 0, s, (const double*)workspace, g, C, out_sum,
+                       n_snv_obs, n_ind_obs, cj, cj_indel);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

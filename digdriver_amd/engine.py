@@ -129,6 +129,24 @@ def scale_suffstats(bin_mu, bin_flag, device=0, out=None):
     return res
 
 
+def scale_factors_local(bin_mu, bin_flag, n_snv_obs, n_ind_obs, out=None):
+    """Single-shard scale factors (transfer_tools.py:148-156): masked column sums and the two divisions in one pair of
+    kernels (dig_scale_factors_local).  Returns (cj, cj_indel, exp_sum) device tensors."""
+    import torch
+    dev = bin_mu.device
+    bin_mu, bin_flag = _t(bin_mu, torch.float64, dev), _t(bin_flag, torch.uint8, dev)
+    N, C = bin_mu.shape
+    n_snv_obs, n_ind_obs = _t(n_snv_obs, torch.float64, dev), _t(n_ind_obs, torch.float64, dev)
+    if out is None:
+        out = tuple(torch.empty(C, dtype=torch.float64, device=dev) for _ in range(3))
+    ws, wsb = _workspace("suffstats", N, C, dev)
+    with torch.cuda.device(dev):
+        _lib.call("dig_scale_factors_local", _lib.dev_ptr(bin_mu), _lib.dev_ptr(bin_flag), N, C, _lib.dev_ptr(n_snv_obs),
+                  _lib.dev_ptr(n_ind_obs), _lib.dev_ptr(out[2]), _lib.dev_ptr(out[0]), _lib.dev_ptr(out[1]), _lib.dev_ptr(ws),
+                  wsb, _lib.stream_ptr())
+    return out
+
+
 def scale_factors_from_parts(parts, out=None):
     """cj, cj_indel from the all-gathered per-shard statistics `parts` f64 [world, 3, C] on the device
     (rank-ordered sums + division in one kernel; transfer_tools.py:153-154)."""

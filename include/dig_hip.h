@@ -187,6 +187,12 @@ int dig_scale_suffstats_host(const double *bin_mu, const uint8_t *bin_flag, int6
  *   cj[c] = sum_r parts[r][1][c] / sum_r parts[r][0][c],  cj_indel[c] = sum_r parts[r][2][c] / sum_r parts[r][0][c],
  *   both sums taken in rank order r = 0 .. world-1 (bit-reproducible on every rank).  world = 1: a plain division. */
 int dig_scale_factors(const double *parts, int world, int64_t C, double *cj, double *cj_indel, void *stream);
+/* Single-shard form of the two calls above (nothing to all-gather): out_sum as dig_scale_suffstats, and
+ * cj[c] = n_snv_obs[c] / out_sum[c], cj_indel[c] = n_ind_obs[c] / out_sum[c] from the same final reduction kernel.
+ * Same bits as dig_scale_suffstats + dig_scale_factors(world = 1).  Workspace as dig_scale_suffstats. */
+int dig_scale_factors_local(const double *bin_mu, const uint8_t *bin_flag, int64_t N, int64_t C, const double *n_snv_obs,
+                            const double *n_ind_obs, double *out_sum, double *cj, double *cj_indel, void *workspace,
+                            int64_t workspace_bytes, void *stream);
 
 /* ---- trinucleotide context counting from sequence ---------------------------------------- *
  * count_sequence_context over fetch_sequence (sequence_model/sequence_tools.py:21-29,42-55,65-80), for a batch of

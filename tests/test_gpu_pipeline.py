@@ -137,3 +137,19 @@ def test_kfold_training_writes_results_regionmodel_reads(tmp_path):
     r = np.corrcoef(df.Y_TRUE.values[ok], df.Y_PRED.values[ok])[0, 1]
     assert np.isfinite(df.Y_PRED.values).all() and (df.STD.values > 0).all()
     assert r > 0.5, r
+
+
+def test_scale_factors_local_equals_two_step_form():
+    """dig_scale_factors_local == dig_scale_suffstats + dig_scale_factors(world = 1), bit for bit."""
+    import torch
+    from digdriver_amd import engine
+    rng = np.random.default_rng(12)
+    for N, C in ((5000, 37), (777, 3), (64, 300)):
+        mu = torch.as_tensor(rng.gamma(9.0, 3.0, (N, C)), device="cuda:0")
+        fl = torch.as_tensor((rng.uniform(size=(N, C)) < 0.1).astype(np.uint8), device="cuda:0")
+        ns = torch.as_tensor(rng.gamma(3.0, 1e5, C), device="cuda:0")
+        ni = torch.as_tensor(rng.gamma(3.0, 1e4, C), device="cuda:0")
+        cj, cji, tot = engine.scale_factors_local(mu, fl, ns, ni)
+        tot2 = engine.scale_suffstats(mu, fl)
+        cj2, cji2 = engine.scale_factors_from_parts(torch.stack([tot2, ns, ni]).unsqueeze(0).contiguous())
+        assert torch.equal(tot, tot2) and torch.equal(cj, cj2) and torch.equal(cji, cji2)
