@@ -255,9 +255,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, all-gather, barrier, max-reduce) with whatever world
+    # size the environment gives, also 1: a one-GPU check that the RCCL calls of the multi-GPU path work
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     if w is None:
@@ -280,7 +286,7 @@ def main():
         # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
         #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors -> (4) accumulation +
         #     statistics block as one operation (dig_element_pipeline; all outputs of both are written)
-        if world == 1:      # nothing to all-gather: sums and divisions come from one pair of kernels
+        if not use_dist:    # nothing to all-gather: sums and divisions come from one pair of kernels
             cj, cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"],
                                                     out=(cj_out[0], cj_out[1], part[0]))
         else:
@@ -297,7 +303,7 @@ def main():
             k_pipe.append((e0, e1))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -312,7 +318,7 @@ def main():
         step(it % every == 0)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -358,7 +364,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
