@@ -4,13 +4,14 @@
 //   nb3_kernel<Op>          elementwise (k, alpha, p) -> p-value   (nb_model.py:243-337)
 //   fisher_kernel           chi2.sf(-2(ln p1 + ln p2), 4)         (transfer_tools.py:1086-1087)
 //   gamma_kernel            normal_params_to_gamma                (nb_model.py:237-241)
-//   element_stats_kernel    the seven-column statistics block per (element, cohort)
+//   element_stats_stream_kernel / element_stats_slow_kernel (two-pass) and element_stats_single_pass_kernel:
+//                           the seven-column statistics block per (element, cohort)
 //                           (transfer_tools.py:17-19,300,343-344,473-482,594-615,731-747,1086-1087)
 //   tiled_nb_kernel         per-base / per-tile exact test        (nb_model.py:141-178)
 //
-// All of them are one work item per test with a grid-stride loop: 8-byte coalesced loads
-// (512 B per wave-instruction per operand), grid capped at 8 blocks/CU.  The arithmetic per
-// item is the FP64 recurrence / continued fraction in dig_math.hpp.
+// The elementwise kernels are one work item per test with a grid-stride loop (8-byte coalesced loads, grid capped at
+// 8 blocks/CU); the statistics block is a persistent streaming pass plus a compacted pass (see below).  The
+// arithmetic per item is the FP64 recurrence / continued fraction in dig_math.hpp.
 #include <algorithm>
 #include <cstdlib>
 
@@ -152,63 +153,30 @@ __device__ __forceinline__ PairInputs load_pair(const ElementStatsArgs& a, int64
     return prepare_pair(load_raw(a, i), a.mu_indel != nullptr);
 }
 
-// Pass 1: every pair through the division-free pmf recurrence (SNV and SAMPLE counts share one pass).
-// One pair per thread, no grid-stride loop: measured 7 % faster than a persistent grid here (the kernel is
-// FP64-issue bound; the hardware dispatcher balances the uneven per-wave loop counts better than a static split).
-// WORKLIST = true: pairs with an unresolved test (k > kSmallK, or a p-value < kDirectMin where 1 - CDF cancels) are
-// appended to the worklist with one wave-aggregated atomic and finished by pass 2; the expensive path is not even
-// compiled into this kernel (fewer VGPRs, more waves).  WORKLIST = false: unresolved tests are finished inline.
-template <bool WORKLIST>
-__global__ __launch_bounds__(kBlock) void element_stats_fast_kernel(ElementStatsArgs a)
+// Single-pass form, used only when the caller provides no workspace (no worklist): one pair per thread, every pair
+// through the fast recurrence (SNV and SAMPLE counts share one pass) and unresolved tests (k > kSmallK, or a p-value
+// < kDirectMin where 1 - CDF cancels) finished inline.  The rare slow lanes stall their waves here; the two-pass path
+// below exists because of that (measured: 210 us against 170 us).
+__global__ __launch_bounds__(kBlock) void element_stats_single_pass_kernel(ElementStatsArgs a)
 {
     nb_tables_init();
     const int64_t n = a.E * a.C;
-    const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool slow = false;
-    PairInputs q{};
+    if (i >= n) return;
+    const PairInputs q = load_pair(a, i);
     double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
-    if (i < n) {
-        q = load_pair(a, i);
-        const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
-        const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
-        slow = (d1 != 3u) || (d2 != 1u);
-        if (!WORKLIST && slow) {   // single-pass mode: finish inline
-            if (!(d1 & 1u)) pv_snv = nb_midp_upper_unresolved(q.k_snv, q.alpha, q.p);
-            if (!(d1 & 2u)) pv_smp = nb_midp_upper_unresolved(q.k_smp, q.alpha, q.p);
-            if (!(d2 & 1u)) pv_ind = nb_midp_upper_unresolved(q.k_ind, q.alpha_i, q.p_i);
-            slow = false;
-        }
-    }
-    // The worklist slot is requested and consumed BEFORE the result stores are issued: the vector-memory counter
-    // retires in order, so an atomic issued after the seven stores would make its wave wait for all of them to
-    // reach memory.  The Fisher combination sits between request and use to cover part of the round trip.
-    unsigned base = 0;
-    unsigned long long m = 0;
-    int leader = 0;
-    if (WORKLIST) {
-        m = __ballot(slow);
-        if (m) {
-            leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(a.worklist, (unsigned)__popcll(m));
-        }
-    }
-    const double pv_mut = slow ? 0.0 : fisher_combine_fast(pv_snv, pv_ind);   // overlaps the atomic's round trip
-    if (WORKLIST && m) {
-        const unsigned slot = kWorkHeader + __shfl(base, leader, 64) + __popcll(m & ((1ull << lane) - 1ull));
-        if (slow) a.worklist[slot] = (unsigned)i;
-    }
-    if (i < n) {
-        a.out[0 * n + i] = q.exp_snv;
-        a.out[3 * n + i] = q.theta_i;
-        a.out[4 * n + i] = q.exp_ind;
-        if (!slow) {
-            a.out[1 * n + i] = pv_snv;
-            a.out[2 * n + i] = pv_smp;
-            a.out[5 * n + i] = pv_ind;
-            a.out[6 * n + i] = pv_mut;
-        }
-    }
+    const unsigned d1 = nb_midp_upper_fast2(q.k_snv, q.k_smp, 3u, q.alpha, q.p, pv_snv, pv_smp);
+    const unsigned d2 = nb_midp_upper_fast2(q.k_ind, 0.0, 1u, q.alpha_i, q.p_i, pv_ind, dummy);
+    if (!(d1 & 1u)) pv_snv = nb_midp_upper_unresolved(q.k_snv, q.alpha, q.p);
+    if (!(d1 & 2u)) pv_smp = nb_midp_upper_unresolved(q.k_smp, q.alpha, q.p);
+    if (!(d2 & 1u)) pv_ind = nb_midp_upper_unresolved(q.k_ind, q.alpha_i, q.p_i);
+    a.out[0 * n + i] = q.exp_snv;
+    a.out[1 * n + i] = pv_snv;
+    a.out[2 * n + i] = pv_smp;
+    a.out[3 * n + i] = q.theta_i;
+    a.out[4 * n + i] = q.exp_ind;
+    a.out[5 * n + i] = pv_ind;
+    a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
 }
 
 // Pass 1, streaming form (used whenever a worklist is available): a persistent grid of 8 waves per SIMD, each wave
@@ -591,7 +559,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         else
             hipLaunchKernelGGL((element_stats_stream_kernel<false, false>), dim3(sgrid), dim3(kBlock), 0, s, a);
     } else
-        hipLaunchKernelGGL(element_stats_fast_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(element_stats_single_pass_kernel, dim3(grid), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
     if (wl) {
         hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 2 + 1, kSlowBlock, 1)), dim3(kSlowBlock), 0, s, a);
