@@ -28,6 +28,10 @@ import time
 
 import numpy as np
 
+# HIP multiplexes streams onto a few hardware queues (4 by default); with RCCL's own streams in the process the side
+# stream of the step would share the main stream's queue and serialise behind it.  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -275,34 +279,69 @@ def main():
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
     # the shard's statistics for the scale factors as one [3, C] tensor: row 0 is filled by dig_scale_suffstats each
-    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs)
-    part = torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous()
-    cj_out = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
+    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs).  Three sets, used in rotation: the
+    # scale factors of step t+1 are formed on a side stream while the statistics kernels of steps t-1 and t may still be
+    # reading theirs.
+    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(3)]
+    cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
+               for _ in range(3)]
+    main_stream = torch.cuda.current_stream(dev)
+    side_stream = torch.cuda.Stream(device=dev, priority=-1)     # own hardware queue even when RCCL holds streams too
+    side_done = [torch.cuda.Event() for _ in range(3)]      # scale factors of a step are ready
+    main_done = [torch.cuda.Event() for _ in range(3)]      # the statistics stage that read a buffer set has finished
+    step_no = [0]
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     k_pipe = []
+    # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
+    pipe = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                               td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                               td["obs_indel"], out_acc=out_acc, out_stats=out_stats)
+    scale_plan = engine.ScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"])
+
+    def enqueue_scale_factors(t):
+        """Side stream: (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
+        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t % 3."""
+        b = t % 3
+        part, cj_out = parts[b], cj_outs[b]
+        side_stream.wait_event(main_done[b])            # the statistics stage of step t-3 has released this buffer set
+        with torch.cuda.stream(side_stream):
+            if not use_dist:    # nothing to all-gather: sums and divisions come from one pair of kernels
+                scale_plan.run(part[0], cj_out[0], cj_out[1], stream=side_stream)
+            else:
+                scale_plan.run_sharded(part, cj_out[0], cj_out[1])
+            side_done[b].record(side_stream)
+
+    queued = [-1]      # last step whose scale factors have been enqueued
 
     def step(timed):
-        # (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
-        #     all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors -> (4) accumulation +
-        #     statistics block as one operation (dig_element_pipeline; all outputs of both are written)
-        if not use_dist:    # nothing to all-gather: sums and divisions come from one pair of kernels
-            cj, cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"],
-                                                    out=(cj_out[0], cj_out[1], part[0]))
-        else:
-            engine.scale_suffstats(td["bin_mu"], td["bin_flag"], out=part[0])
-            cj, cji = parallel.scale_factors_from_part(part, out=cj_out)
+        # Main stream: (4) the accumulation stage of dig_element_pipeline (needs no scale factors), wait for (3), (5) the
+        # statistics stage.  The scale factors of the NEXT step are enqueued on the side stream just before (5): that
+        # HBM-bound reduction has no room beside the register-hungry streaming kernel and ends up running beside the
+        # latency-bound compacted pass that closes the step.  All outputs of accumulation and statistics are written
+        # every step; every step computes its own scale factors from the bin tables.
+        t = step_no[0]
+        step_no[0] += 1
+        b = t % 3
+        if queued[0] < t:
+            enqueue_scale_factors(t)
+            queued[0] = t
+        cj, cji = cj_outs[b]
         e0, e1 = (ev(), ev()) if timed else (None, None)
         if timed:
             e0.record()
-        engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
-                                td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
-                                td["obs_indel"], cj, cji, out_acc=out_acc, out_stats=out_stats)
+        pipe.run(cj, cji, stages=1, stream=main_stream)
+        main_stream.wait_event(side_done[b])
+        enqueue_scale_factors(t + 1)
+        queued[0] = t + 1
+        pipe.run(cj, cji, stages=2, stream=main_stream)
+        main_done[b].record(main_stream)
         if timed:
             e1.record()
             k_pipe.append((e0, e1))
 
     def barrier():
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -47,7 +47,7 @@ _SIGNATURES = {
     "dig_scale_suffstats_host": [_vp, _vp, _i64, _i64, _vp, _int],
     "dig_scale_factors": [_vp, _int, _i64, _vp, _vp, _vp],
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _vp, _i64, _vp],
+    "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],

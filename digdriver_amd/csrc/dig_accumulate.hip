@@ -362,7 +362,7 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 }
 
 template <int NCLASS, int NT>
-__global__ __launch_bounds__(kMfmaWaves * 64) void acc_dot_mfma_kernel(
+__global__ __launch_bounds__(kMfmaWaves * 64, 3) void acc_dot_mfma_kernel(
     const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
     const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
     int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
