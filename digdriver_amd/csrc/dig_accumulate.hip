@@ -546,8 +546,9 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
                       const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
                       double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
                       double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
-                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero)
+                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero, int parts)
 {
+    // parts: bit 0 = region kernel, bit 1 = dot kernel (the pipeline may enqueue them as two calls)
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     DIG_REQUIRE(n_class == 1 || n_class == 4, "n_class must be 1 (elements) or 4 (genes)");
     if (E == 0 || C == 0) return DIG_OK;
@@ -570,13 +571,14 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
     DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
     const AccWorkspace w = acc_workspace_layout(workspace, E, C);
     DIG_REQUIRE(workspace_bytes >= w.bytes, "workspace smaller than dig_accumulate_workspace(E, C)");
-    {
+    if (parts & 1) {
         const int grid = grid_for(do_rates ? E * C : E * 16, kRegionBlock, 8);
         hipLaunchKernelGGL(acc_region_kernel, dim3(grid), dim3(kRegionBlock), 0, s, bin_mu, bin_std, bin_y, bin_flag,
                            bin_ctx, ov_ptr, ov_idx, strand_minus, MU, SIGMA, R_OBS, FLAG, R_SIZE, w.rcp, E, C,
                            make_fastdiv(C), (int)(C >= 2), d_pr, w.tab, w.n48, do_rates, zero_dwords, n_zero);
         DIG_HIP_TRY(hipGetLastError());
     }
+    if (!(parts & 2)) return DIG_OK;
     return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
                           : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
 }
@@ -594,7 +596,7 @@ int dig_accumulate_elements(const double* bin_mu, const double* bin_std, const i
 {
     return accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, n_class, strand_minus,
                              gene_length, d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace,
-                             workspace_bytes, stream, 1, nullptr, 0);
+                             workspace_bytes, stream, 1, nullptr, 0, 3);
 }
 
 int dig_accumulate_elements_host(const double* bin_mu, const double* bin_std, const int32_t* bin_y,

@@ -5,9 +5,9 @@
 // sums MU / SIGMA / R_OBS / FLAG are formed inside the statistics streaming kernel, which needs them anyway, instead
 // of being written by the region kernel and read back (24 B per (element, cohort) less HBM traffic each way and one
 // HBM-bound pass fewer).  All outputs of both operations are still written; results are bit-identical to the two
-// separate calls (tests/test_gpu_parity.py).  `stages` lets a caller enqueue the accumulation stage (which does not
-// need the scale factors) and the statistics stage separately, e.g. to compute the scale factors on another stream
-// meanwhile; the statistics stage must follow an accumulation stage on the same workspace.  Kernel sequence: acc_region_kernel (contexts + parameter table) ->
+// separate calls (tests/test_gpu_parity.py).  `stages` lets a caller enqueue the three stages (context kernel, dot
+// kernel, statistics) as separate calls in that order on the same workspace, e.g. to form the scale factors -- which
+// only the statistics stage needs -- on another stream beside the MFMA-bound dot kernel.  Kernel sequence: acc_region_kernel (contexts + parameter table) ->
 // acc_dot_mfma_kernel -> element_stats_stream_kernel<false, true> -> element_stats_slow_kernel.
 #include "dig_common.hpp"
 
@@ -28,7 +28,7 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
                       const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr, double* MU,
                       double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P, int32_t* R_SIZE, int32_t* ELT_SIZE,
                       double* P_INDEL, int64_t N, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
-                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero);
+                      void* stream, int do_rates, unsigned* zero_dwords, int n_zero, int parts);
 int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
                          const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                          const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
@@ -60,7 +60,7 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
                          int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
-    DIG_REQUIRE(stages >= 1 && stages <= 3, "stages: 1 = accumulate, 2 = statistics, 3 = both");
+    DIG_REQUIRE(stages >= 1 && stages <= 7, "stages: bit mask of DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS");
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
     DIG_REQUIRE(obs_snv && obs_samples && obs_indel && cj && cj_indel && out, "non-null statistics arguments");
@@ -71,13 +71,13 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     const int64_t acc_bytes = (dig_accumulate_workspace(E, C) + 255) / 256 * 256;
     // the first kernel also clears the worklist header of the statistics stage (64 dwords): no separate memset node
     unsigned* wl = (unsigned*)((char*)workspace + acc_bytes);
-    if (stages & 1) {
+    if (stages & 3) {
         int rc = accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, 1, strand_minus, gene_length,
                                    d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace, acc_bytes,
-                                   stream, 0, wl, 64);
+                                   stream, 0, wl, 64, stages & 3);
         if (rc) return rc;
     }
-    if (!(stages & 2)) return DIG_OK;
+    if (!(stages & 4)) return DIG_OK;
     const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG};
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
                                 out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f, 1);

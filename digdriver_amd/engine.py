@@ -263,10 +263,10 @@ _NP_DT = {np.dtype(np.float32): _lib.DIG_F32, np.dtype(np.float64): _lib.DIG_F64
 
 
 def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
-                     obs_samples, obs_indel, cj, cj_indel, gene_length=None, out_acc=None, out_stats=None, stages=3):
+                     obs_samples, obs_indel, cj, cj_indel, gene_length=None, out_acc=None, out_stats=None, stages=7):
     """accumulate_elements (n_class = 1) + element_stats as one operation on device tensors (dig_element_pipeline):
     the rate sums are formed inside the statistics kernel.  Returns (accumulate dict, statistics tensor [7, E, C]).
-    stages: 3 = both; 1 (accumulation: does not read cj / obs) then 2 (statistics) as two calls with the same outputs."""
+    stages: bit mask 1 = context kernel, 2 = dot kernel, 4 = statistics (7 = all); separate calls must keep that order."""
     import torch
     dev = bin_mu.device
     f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
@@ -332,7 +332,7 @@ class PipelinePlan:
         self._ws = p(self.ws)
         self._fn = getattr(_lib.load(), "dig_element_pipeline")
 
-    def run(self, cj, cj_indel, stages=3, stream=None):
+    def run(self, cj, cj_indel, stages=7, stream=None):
         """Enqueue the pipeline (or one of its stages) on `stream` (default: torch's current stream)."""
         rc = self._fn(*self._head, _lib.dev_ptr(cj), _lib.dev_ptr(cj_indel), *self._tail, int(stages), self._ws, self.wsb,
                       _lib.stream_ptr(stream))

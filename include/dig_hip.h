@@ -159,13 +159,15 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
  * (genic_driver_tools.py:300-431 then transfer_tools.py:1069-1087).  One fusion across the two: MU / SIGMA / R_OBS /
  * FLAG are summed inside the statistics streaming kernel instead of being written by one kernel and read back by
  * the next.  All outputs of both operations are written; results are bit-identical to the two separate calls.
- * stages: DIG_PIPE_ALL, or DIG_PIPE_ACCUMULATE then DIG_PIPE_STATISTICS as two calls on the same workspace (the
- *   accumulation stage does not read cj / cj_indel / obs_*: a caller can form the scale factors on another stream
- *   meanwhile and make `stream` wait for them before the statistics call).
+ * stages: DIG_PIPE_ALL, or the stages as separate calls in the order CONTEXTS, DOT, STATISTICS on the same workspace
+ *   (only STATISTICS reads cj / cj_indel / obs_*: a caller can form the scale factors on another stream meanwhile,
+ *   e.g. beside the MFMA-bound DOT kernel, and make `stream` wait for them before the statistics call).
  * workspace: dig_element_pipeline_workspace(E, C) bytes (0 = not available: E * C >= 2^32 - 1), 256-byte aligned. */
-#define DIG_PIPE_ACCUMULATE 1
-#define DIG_PIPE_STATISTICS 2
-#define DIG_PIPE_ALL 3
+#define DIG_PIPE_CONTEXTS 1   /* acc_region_kernel: context rows, parameter table, R_SIZE */
+#define DIG_PIPE_DOT 2        /* acc_dot_mfma_kernel: P, ELT_SIZE, P_INDEL */
+#define DIG_PIPE_ACCUMULATE 3
+#define DIG_PIPE_STATISTICS 4 /* MU, SIGMA, R_OBS, FLAG and the seven statistics planes */
+#define DIG_PIPE_ALL 7
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
                          const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
