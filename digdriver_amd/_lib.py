@@ -67,6 +67,8 @@ _SIZE_QUERIES = {
     "dig_element_pipeline_workspace": [_i64, _i64],
 }
 
+ABI_VERSION = 2          # include/dig_hip.h: DIG_ABI_VERSION
+
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")
 
@@ -100,6 +102,9 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int64
     lib.dig_abi_version.restype = ctypes.c_int
+    if lib.dig_abi_version() != ABI_VERSION:
+        raise DigHipError("%s has ABI version %d, this package needs %d: rebuild it (python -c 'import __graft_entry__ as "
+                          "g; g.build()')" % (LIB_PATH, lib.dig_abi_version(), ABI_VERSION))
     lib.dig_last_error.restype = ctypes.c_char_p
     lib.dig_device_count.restype = ctypes.c_int
     _lib = lib

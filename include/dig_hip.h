@@ -34,7 +34,7 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 1
+#define DIG_ABI_VERSION 2   /* 2: + join, contexts, scale factors, pipeline entry points */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
