@@ -426,3 +426,44 @@ def test_element_pipeline_equals_separate_calls(torch_dev):
         for j, name in enumerate(engine.ES_PLANES):
             a, b = st[name], st2[j]
             assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
+
+
+def test_degenerate_shapes_do_not_crash(torch_dev):
+    """Empty and ragged inputs through every entry point: zero elements / cohorts / regions / rows, an element without
+    bins (MU = 0, SIGMA = 0 -> NaN statistics, as numpy gives), one-pair problems."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.sequence_model import nb_model
+    dev = torch_dev
+    z64 = torch.zeros(0, dtype=torch.float64, device=dev)
+    assert nb_model.nb_pvalue_greater_midp(z64, z64, z64).numel() == 0
+    st = engine.element_stats(torch.zeros((0, 3), dtype=torch.float64, device=dev), torch.zeros((0, 3), dtype=torch.float64, device=dev),
+                              torch.zeros((0, 3), dtype=torch.float64, device=dev), z64, torch.zeros((0, 3), dtype=torch.int32, device=dev),
+                              torch.zeros((0, 3), dtype=torch.int32, device=dev), torch.zeros((0, 3), dtype=torch.int32, device=dev),
+                              torch.ones(3, dtype=torch.float64, device=dev), torch.ones(3, dtype=torch.float64, device=dev))
+    assert st["PVAL_SNV_BURDEN"].shape == (0, 3)
+    # ragged CSR: element 1 has no bins at all, element 2 has five
+    w = make_workload(n_bins=300, n_elements=4, n_cohorts=2, seed=8)
+    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    ov_ptr = torch.tensor([0, 1, 1, 6, 7], dtype=torch.int64, device=dev)
+    ov_idx = torch.tensor([3, 10, 11, 12, 13, 14, 299], dtype=torch.int32, device=dev)
+    acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], ov_ptr, ov_idx,
+                                     td["L"], td["strand_minus"], td["d_pr"])
+    assert float(acc["MU"][1].abs().sum()) == 0.0 and int(acc["R_SIZE"][1]) == 0 and int(acc["R_OBS"][1].sum()) == 0
+    want = td["bin_mu"][10:15].sum(dim=0)
+    assert torch.allclose(acc["MU"][2], want, rtol=1e-14)
+    acc2, st2 = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], ov_ptr, ov_idx,
+                                        td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"],
+                                        td["cj"], td["cj_indel"])
+    assert torch.equal(acc2["MU"], acc["MU"]) and torch.equal(acc2["FLAG"], acc["FLAG"])
+    assert bool(torch.isnan(st2[1][1]).all())                      # mu = sigma = 0 -> alpha = 0/0 -> NaN p-values (numpy semantics)
+    assert bool(torch.isfinite(st2[1][[0, 2, 3]]).all())
+    # zero regions / rows / mutations
+    g = PackedGenome.from_sequences({"1": "ACGTACGTNNACGT"})
+    assert engine.count_contexts(g, [], [], [], device=0).shape == (0, 64)
+    one = engine.count_contexts(g, ["1"], [0], [14], device=0).cpu().numpy()
+    assert one.sum() == 8                                           # centres 1..12 minus the five windows touching N
+    x = torch.zeros((5, 100, 4), dtype=torch.float32, device=dev)
+    assert engine.gather_bins(x, torch.zeros(0, dtype=torch.int64, device=dev), torch.arange(4, device=dev)).shape == (0, 100, 4)
