@@ -292,8 +292,6 @@ def main():
     ctx_done = [torch.cuda.Event() for _ in range(3)]       # the context kernel of a step has finished
     step_no = [0]
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    k_pipe = []
     # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
     pipe = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
@@ -317,7 +315,7 @@ def main():
 
     queued = [-1]      # last step whose scale factors have been enqueued
 
-    def step(timed):
+    def step():
         # Main stream: (4) the context and dot kernels of dig_element_pipeline (they need no scale factors), wait for (3),
         # (5) the statistics stage.  The scale factors of the NEXT step are released on the side stream when this step's
         # context kernel (HBM-bound, like the reduction) is done, so that the reduction runs beside the FP64-MFMA dot
@@ -331,9 +329,6 @@ def main():
             enqueue_scale_factors(t)
             queued[0] = t
         cj, cji = cj_outs[b]
-        e0, e1 = (ev(), ev()) if timed else (None, None)
-        if timed:
-            e0.record()
         pipe.run(cj, cji, stages=1, stream=main_stream)          # context kernel (HBM-bound)
         ctx_done[b].record(main_stream)
         if queued[0] < t + 1:
@@ -343,9 +338,6 @@ def main():
         main_stream.wait_event(side_done[b])
         pipe.run(cj, cji, stages=4, stream=main_stream)          # statistics
         main_done[b].record(main_stream)
-        if timed:
-            e1.record()
-            k_pipe.append((e0, e1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -354,21 +346,25 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     barrier()
+    # The step's kernels run on two streams and overlap, so the roofline is taken for the step as a whole: two HIP events
+    # on the main stream bracket the K timed steps (the main stream waits for the side stream's scale factors inside
+    # every step, so its clock covers both); per-kernel durations are in the committed rocprofv3 summary.  Events inside
+    # the loop would be barrier packets in the queue (~6 us each) and slow the thing being measured.
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    # HIP events bracket the dominant operation on a SAMPLE of the timed steps (every 4th, at least 5): each
-    # event record is a barrier packet in the queue (~6 us), so timing every step would slow the thing being measured
-    every = max(1, min(4, args.steps // 5))
-    for it in range(args.steps):
-        step(it % every == 0)
+    ev_begin.record(main_stream)
+    for _ in range(args.steps):
+        step()
+    ev_end.record(main_stream)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ms_pipe = float(np.mean([a.elapsed_time(b) for a, b in k_pipe]))
+    ms_step = ev_begin.elapsed_time(ev_end) / args.steps
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     ws = engine._WS_CACHE.get(("pipeline", dev.index))
     slow_frac = None
@@ -379,10 +375,11 @@ def main():
     if rank == 0:
         units = float(E) * C * world * args.steps
         b_acc, b_stat = algorithmic_bytes(E, C, nbar)
-        dominant = "dig_element_pipeline"
-        d_bytes, d_ms = b_acc + b_stat, ms_pipe
+        b_suff = 9.0 * N * C                                     # dig_scale_suffstats: Y_PRED f64 + FLAG u8 per (bin, cohort)
+        dominant = "step = dig_scale_factors || dig_element_pipeline"
+        d_bytes, d_ms = b_acc + b_stat + b_suff, ms_step
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
-        prefixes = ["acc_region", "acc_dot", "element_stats_"]
+        prefixes = ["acc_region", "acc_dot", "element_stats_", "suffstats", "scale_factors"]
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
         traffic, traffic_src = committed_traffic(prefixes) if default_shape else (None, None)
         res = {
@@ -397,12 +394,14 @@ def main():
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": d_bytes,
                          "avg_launch_ms": d_ms},
-            "operations": {"dig_element_pipeline": {
-                "avg_ms": ms_pipe, "kernels": "acc_region_kernel (contexts + table), acc_dot_mfma_kernel, "
-                                              "element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
-                "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat}}},
-            "kernel_timing": "HIP events on torch's current stream around dig_element_pipeline on %d of the %d timed "
-                             "steps" % (len(k_pipe), args.steps),
+            "operations": {
+                "main stream": "dig_element_pipeline: acc_region_kernel (contexts + table), acc_dot_mfma_kernel, "
+                               "element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
+                "side stream": "scale factors of the next step: suffstats_stage1, suffstats_stage2 (+ all-gather and "
+                               "scale_factors_kernel when N > 1)",
+                "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
+            "kernel_timing": "two HIP events on the main stream around the %d timed steps (the streams overlap: the "
+                             "roofline is for the step as a whole; per-kernel durations: profiles/)" % args.steps,
             "finite_pvalues": ok, "slow_pair_fraction": slow_frac,
         }
         if args.cpu_sample > 0 and world == 1:
