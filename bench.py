@@ -279,17 +279,17 @@ def main():
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
     # the shard's statistics for the scale factors as one [3, C] tensor: row 0 is filled by dig_scale_suffstats each
-    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs).  Three sets, used in rotation: the
-    # scale factors of step t+1 are formed on a side stream while the statistics kernels of steps t-1 and t may still be
-    # reading theirs.
-    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(3)]
+    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs).  Two sets, used alternately: the scale
+    # factors of step t+1 are formed on a side stream while the statistics kernels of step t read theirs.  (Set (t+1) % 2
+    # was last read by the statistics of step t-1, which precede step t's context kernel on the main stream -- the event
+    # the side stream waits for -- so no further synchronisation is needed.)
+    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(2)]
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
-               for _ in range(3)]
+               for _ in range(2)]
     main_stream = torch.cuda.current_stream(dev)
     side_stream = torch.cuda.Stream(device=dev, priority=-1)     # own hardware queue even when RCCL holds streams too
-    side_done = [torch.cuda.Event() for _ in range(3)]      # scale factors of a step are ready
-    main_done = [torch.cuda.Event() for _ in range(3)]      # the statistics stage that read a buffer set has finished
-    ctx_done = [torch.cuda.Event() for _ in range(3)]       # the context kernel of a step has finished
+    side_done = [torch.cuda.Event() for _ in range(2)]      # scale factors of a step are ready
+    ctx_done = [torch.cuda.Event() for _ in range(2)]       # the context kernel of a step has finished
     step_no = [0]
 
     # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
@@ -300,10 +300,9 @@ def main():
 
     def enqueue_scale_factors(t, after=None):
         """Side stream: (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
-        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t % 3."""
-        b = t % 3
+        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t % 2."""
+        b = t % 2
         part, cj_out = parts[b], cj_outs[b]
-        side_stream.wait_event(main_done[b])            # the statistics stage of step t-3 has released this buffer set
         if after is not None:
             side_stream.wait_event(after)
         with torch.cuda.stream(side_stream):
@@ -324,7 +323,7 @@ def main():
         # from the bin tables.
         t = step_no[0]
         step_no[0] += 1
-        b = t % 3
+        b = t % 2
         if queued[0] < t:
             enqueue_scale_factors(t)
             queued[0] = t
@@ -337,7 +336,6 @@ def main():
         pipe.run(cj, cji, stages=2, stream=main_stream)          # dot kernel
         main_stream.wait_event(side_done[b])
         pipe.run(cj, cji, stages=4, stream=main_stream)          # statistics
-        main_done[b].record(main_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -366,6 +364,17 @@ def main():
         dt = float(tmax.item())
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
     ok = bool(torch.isfinite(out_stats[1]).all().item())
+    # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
+    seq_cj, seq_cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"]) \
+        if not use_dist else cj_outs[(step_no[0] - 1) % 2] + (None,)
+    ref_acc, ref_stats = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                                 td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
+                                                 td["obs_snv"], td["obs_samples"], td["obs_indel"], seq_cj, seq_cji)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(torch.nan_to_num(ref_stats, nan=-7.0), torch.nan_to_num(out_stats, nan=-7.0))) and \
+        bool(torch.equal(ref_acc["MU"], out_acc["MU"])) and bool(torch.equal(ref_acc["P"], out_acc["P"]))
+    if not same:
+        raise SystemExit("bench: the overlapped step loop and the sequential evaluation disagree")
     ws = engine._WS_CACHE.get(("pipeline", dev.index))
     slow_frac = None
     if ws is not None:
@@ -402,7 +411,7 @@ def main():
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
             "kernel_timing": "two HIP events on the main stream around the %d timed steps (the streams overlap: the "
                              "roofline is for the step as a whole; per-kernel durations: profiles/)" % args.steps,
-            "finite_pvalues": ok, "slow_pair_fraction": slow_frac,
+            "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
         }
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
