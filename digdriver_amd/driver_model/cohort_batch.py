@@ -1,0 +1,112 @@
+"""elementDriver for MANY cohorts in one pass over device-resident tables.
+
+The reference runs one cohort per process: `DigPretrain.py elementModel` (genic_driver_tools.nonc_model) writes the
+element frame, `DigDriver.py elementDriver` (transfer_tools.run_element_region_model, transfer_tools.py:969-1096) joins
+the cohort's observed counts and computes the statistics block.  With C pretrained maps on one bin grid the same
+arithmetic is a batch along the cohort axis:
+
+    observed counts   dig_overlap_join_* + tabulate_gpu.tabulate_cohorts   -> OBS_* [E, C]     (mutation_tools.py:155-230)
+    scale factors     genome mode, transfer_tools.py:129-159: unique mutations in unflagged bins / sum Y_PRED[~FLAG]
+    element pipeline  dig_element_pipeline                                 -> every column of the result frames
+
+and the result is one frame per cohort with the reference's column names, identical to what the per-cohort route
+gives (tests/test_gpu_cohort_batch.py).
+"""
+import numpy as np
+import pandas as pd
+
+from .. import engine
+from ..data_tools import tabulate_gpu
+from ..io import mapfile
+from ..sequence_model import genic_driver_tools, nb_model
+
+_MUT_COLS10 = ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT', 'MUT_TYPE', 'CONTEXT']
+
+
+def _read_raw_mutations(f_mut):
+    df = pd.read_csv(f_mut, sep="\t", header=None, low_memory=False, dtype={0: str})
+    df = df.iloc[:, :8].copy()
+    df.columns = _MUT_COLS10[:8]
+    return df
+
+
+def genome_scale_factors(tables, cohorts, device):
+    """calc_scale_factor_efficient, genome mode (transfer_tools.py:129-159), for all cohorts: (#unique SNVs, #unique
+    indels overlapping an unflagged bin) / sum of Y_PRED over unflagged bins.  `cohorts` = encode_mutations() dicts."""
+    import torch
+    C = len(cohorts)
+    bins = tabulate_gpu.ElementBlocks(tables.chrom, tables.start, tables.start + tables.window, np.arange(len(tables.start)),
+                                      len(tables.start), device)
+    flag = torch.as_tensor(tables.flag, device=device)
+    cat = lambda k: torch.cat([c[k] for c in cohorts])
+    pm, pb = tabulate_gpu.overlap_pairs(bins, cat("chrom"), cat("start"), cat("end"))
+    pm = pm.long()
+    cohort = cat("cohort")
+    ok = flag[bins.elt[pb.long()], cohort[pm]] == 0                    # the overlapped bin is unflagged in that cohort
+    # unique (cohort, mutation uid, sample): the reference re-reads the intersected rows with drop_duplicates (:143-147)
+    uid_off = np.concatenate([[0], np.cumsum([int(c["uid"].max().item()) + 1 if c["uid"].numel() else 0 for c in cohorts])])
+    uid = torch.cat([c["uid"] + int(o) for c, o in zip(cohorts, uid_off[:-1])])
+    smp_off = np.concatenate([[0], np.cumsum([len(c["sample_names"]) for c in cohorts])])
+    smp = torch.cat([c["sample"] + int(o) for c, o in zip(cohorts, smp_off[:-1])])
+    indel = cat("indel")
+    rec = torch.stack([cohort[pm], uid[pm], smp[pm], indel[pm]], dim=1)[ok]
+    rec = torch.unique(rec, dim=0)
+    n_ind = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, rec[:, 0], rec[:, 3].double())
+    n_all = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, rec[:, 0], torch.ones(len(rec), dtype=torch.float64, device=device))
+    exp_sum = engine.scale_suffstats(torch.as_tensor(tables.mu, device=device), flag)
+    return (n_all - n_ind) / exp_sum, n_ind / exp_sum
+
+
+def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_factors=None, max_muts_per_sample=3e9,
+                        max_muts_per_elt_per_sample=3e9, device=0):
+    """One result frame per cohort (index ELT, the columns of run_element_region_model) for the mutation files
+    `f_muts[c]` against the pretrained maps `f_pretrained[c]` (one bin grid) and the element set `save_key` of
+    `f_element_data`.  scale_factors: (cj [C], cj_indel [C]) or None for the genome mode."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    assert len(f_muts) == len(f_pretrained) and len(f_muts) > 0
+    C = len(f_muts)
+    files, tables, d_pr = genic_driver_tools._load_cohorts(list(f_pretrained))
+    w = tables.window
+    elts = genic_driver_tools._element_set(f_element_data, w, save_key)
+    E = len(elts['names'])
+    ctx = tables.aligned_context(mapfile.read_array(f_element_data, 'window_{}/full_window_si_index'.format(w)),
+                                 mapfile.read_array(f_element_data, 'window_{}/full_window_si_values'.format(w)))
+    ov_ptr, ov_idx = engine.ideal_overlaps(elts['chrom'], elts['blk_ptr'], elts['blk_start'], elts['blk_end'], w,
+                                           tables.chrom, tables.start)
+    print('Tabulating mutations')
+    owner = np.repeat(np.arange(E), np.diff(elts['blk_ptr']))
+    blocks = tabulate_gpu.ElementBlocks(elts['chrom'][owner], elts['blk_start'], elts['blk_end'], owner, E, dev)
+    cohorts = [tabulate_gpu.encode_mutations(_read_raw_mutations(f), dev, cohort_id=c) for c, f in enumerate(f_muts)]
+    obs_snv, obs_smp, obs_ind, _ = tabulate_gpu.tabulate_cohorts(blocks, cohorts, drop_duplicates=True,
+                                                                 max_muts_per_sample=max_muts_per_sample,
+                                                                 max_muts_per_elt_per_sample=max_muts_per_elt_per_sample)
+    if scale_factors is None:
+        print('Calculating scale factor')
+        cj, cji = genome_scale_factors(tables, cohorts, dev)
+    else:
+        cj = torch.as_tensor(np.asarray(scale_factors[0], float), device=dev).reshape(C)
+        cji = torch.as_tensor(np.asarray(scale_factors[1], float), device=dev).reshape(C)
+    print('Calculating statistics')
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    acc, st = engine.element_pipeline(t(tables.mu), t(tables.std), t(tables.y), t(tables.flag), t(ctx), t(ov_ptr), t(ov_idx),
+                                      t(elts['L']), t(elts['strand_minus']), t(d_pr), obs_snv, obs_smp, obs_ind, cj, cji)
+    alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
+    host = lambda x: x.cpu().numpy()
+    A = {k: host(v) for k, v in acc.items()}
+    S, al, th = host(st), host(alpha), host(theta)
+    cj_h, cji_h = host(cj), host(cji)
+    o_snv, o_smp, o_ind = host(obs_snv), host(obs_smp), host(obs_ind)
+    frames = []
+    for c in range(C):
+        have_indel = o_ind[:, c].sum() != 0
+        d = {'ELT_SIZE': A['ELT_SIZE'], 'FLAG': A['FLAG'][:, c].astype(bool), 'R_SIZE': A['R_SIZE'], 'R_OBS': A['R_OBS'][:, c],
+             'R_INDEL': A['R_OBS'][:, c], 'MU': A['MU'][:, c], 'SIGMA': A['SIGMA'][:, c], 'ALPHA': al[:, c],
+             'THETA': th[:, c] * cj_h[c], 'MU_INDEL': A['MU'][:, c], 'SIGMA_INDEL': A['SIGMA'][:, c], 'ALPHA_INDEL': al[:, c],
+             'THETA_INDEL': S[3][:, c] if have_indel else th[:, c], 'Pi_SUM': A['P'][:, 0, c], 'Pi_INDEL': A['P_INDEL'],
+             'OBS_SAMPLES': o_smp[:, c].astype(float), 'OBS_SNV': o_snv[:, c].astype(float), 'OBS_INDEL': o_ind[:, c].astype(float),
+             'EXP_SNV': S[0][:, c], 'PVAL_SNV_BURDEN': S[1][:, c], 'PVAL_SAMPLE_BURDEN': S[2][:, c]}
+        if have_indel:                                       # transfer_tools.py:1079-1087
+            d.update({'EXP_INDEL': S[4][:, c], 'PVAL_INDEL_BURDEN': S[5][:, c], 'PVAL_MUT_BURDEN': S[6][:, c]})
+        frames.append(pd.DataFrame(d, index=pd.Index(elts['names'], name='ELT')))
+    return frames

@@ -1,0 +1,80 @@
+"""Many-cohort elementDriver (driver_model/cohort_batch.py) against the per-cohort route (DigPretrain elementModel ->
+run_element_region_model) on the same synthetic inputs: integers bit-exact, statistics within the tolerance contract,
+for manual scale factors and for the genome-mode scale factors."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cohort_batch_equals_per_cohort_route(tmp_path):
+    from test_gpu_onthefly import _make_case
+    from digdriver_amd.driver_model import cohort_batch, transfer_tools
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.sequence_model import genic_driver_tools, sequence_tools
+    rng = np.random.default_rng(31)
+    base = _make_case(tmp_path, rng)
+    window, C = base["window"], 3
+    # three cohorts on the same grid: own rates, flags, sequence model, mutations
+    pres, muts = [], []
+    for c in range(C):
+        rp = base["rp"].copy()
+        rp["Y_PRED"] = rng.gamma(9.0, 3.0, len(rp))
+        rp["STD"] = rng.gamma(4.0, 1.0, len(rp))
+        rp["Y_TRUE"] = rng.poisson(rp.Y_PRED.values)
+        rp["FLAG"] = rng.uniform(size=len(rp)) < 0.2
+        sm = base["sm"].copy()
+        sm["FREQ"] = rng.dirichlet(np.ones(192)) * 1e-3
+        pre = str(tmp_path / ("cohort%d.map" % c))
+        mapfile.write_frame(pre, "region_params", rp)
+        mapfile.write_frame(pre, "sequence_model_192", sm)
+        mapfile.write_array(pre, "idx", rp[["CHROM", "START", "END"]].values.astype(np.int32))
+        mapfile.write_attrs(pre, cohort_name="c%d" % c, mappability_threshold=0.5)
+        rows = []
+        for name, ch, strand, blocks in base["elts"]:
+            for _ in range(int(rng.poisson(3 + c))):
+                s, e = blocks[int(rng.integers(0, len(blocks)))]
+                p = int(rng.integers(s, e))
+                rows.append((ch, p, p + 1, "A", "T", "S%d" % rng.integers(0, 9), ".", "Noncoding", "A>T", "CAG"))
+            if rng.uniform() < 0.5:
+                p = blocks[0][0]
+                rows.append((ch, p, p + 2, "AG", "A", "S%d" % rng.integers(0, 9), ".", "INDEL", "DEL", "."))
+        for _ in range(60):                                   # background mutations outside the elements
+            ch = "12"[int(rng.integers(0, 2))]
+            p = int(rng.integers(0, 20000))
+            rows.append((ch, p, p + 1, "C", "G", "S%d" % rng.integers(0, 9), ".", "Noncoding", "C>G", "ACA"))
+        rows += rows[:5]                                       # exact duplicates
+        f = tmp_path / ("muts%d.tsv" % c)
+        pd.DataFrame(rows).to_csv(f, sep="\t", header=False, index=False)
+        pres.append(pre)
+        muts.append(str(f))
+    # element data from the sequence (window counts + block counts), shared by all cohorts
+    gc, ed = str(tmp_path / "gc.map"), str(tmp_path / "ed.map")
+    win = sequence_tools.count_contexts_in_bed(base["fa"], base["rp"][["CHROM", "START", "END"]], n_up=1, n_down=1)
+    mapfile.write_frame(gc, "all_window_genome_counts", win)
+    mapfile.write_array(gc, "idx", base["rp"][["CHROM", "START", "END"]].values.astype(np.int32))
+    sequence_tools.initialize_nonc_data(ed, gc, window)
+    L = sequence_tools.precount_region_contexts_parallel(base["bed"], base["fa"], 1, window, True)
+    sequence_tools.preprocess_nonc(base["bed"], ed, pres[0], L, "elts", window)
+    for manual in (True, False):
+        sf = (np.array([0.004, 0.002, 0.008]), np.array([0.0007, 0.0003, 0.001])) if manual else None
+        frames = cohort_batch.run_element_cohorts(muts, pres, ed, "elts", scale_factors=sf)
+        assert len(frames) == C
+        for c in range(C):
+            frame = genic_driver_tools.nonc_model_parallel(pres[c], ed, "elts", 1)
+            mapfile.write_frame(pres[c], "elts", frame)
+            kw = dict(scale_factor=sf[0][c], scale_factor_indel=sf[1][c], scale_by_expectation=False) if manual else \
+                dict(scale_by_expectation=False, scale_type="genome")
+            want = transfer_tools.run_element_region_model(muts[c], base["bed"], pres[c], "elts", fused=True, **kw)
+            got = frames[c].loc[want.index]
+            for col in ("OBS_SNV", "OBS_SAMPLES", "OBS_INDEL", "R_OBS", "R_SIZE", "ELT_SIZE"):
+                assert np.array_equal(got[col].values.astype(np.int64), want[col].values.astype(np.int64)), (c, col)
+            cols = ["MU", "SIGMA", "ALPHA", "THETA", "Pi_SUM", "Pi_INDEL", "EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN"]
+            if "PVAL_MUT_BURDEN" in want.columns:
+                cols += ["THETA_INDEL", "EXP_INDEL", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN"]
+                assert "PVAL_MUT_BURDEN" in got.columns
+            for col in cols:
+                rel_close(got[col].values.astype(float), want[col].values.astype(float), rtol=1e-9)
