@@ -277,3 +277,37 @@ def restrict_mutations_by_bed(df_mut, df_bed, unique=True, remove_X=True, replac
     if unique:
         inter = inter.drop_duplicates()
     return inter
+
+
+# ---------------------------------------------------------------------------------------------
+# sites route: mutations that hit listed (position, substitution) sites exactly
+# ---------------------------------------------------------------------------------------------
+_SITE_KEY = ['CHROM', 'START', 'END', 'REF', 'ALT', 'GENE', 'ANNOT', 'MUT_TYPE', 'CONTEXT']
+
+
+def tabulate_nonc_mutations_at_sites(f_sites, f_mut, return_sites=False):
+    """mutation_tools.py:232-276.  The sites file has the mutation-file layout with the element name in the SAMPLE
+    column; a mutation counts for a site when the nine annotation columns agree.  Indels are dropped.  Per element:
+    OBS_SAMPLES = distinct samples, OBS_SNV = matching rows."""
+    df_sites = read_mutation_file(f_sites)
+    df_sites = df_sites.rename({"SAMPLE": "ELT"}, axis=1)
+    assert 'GENE' in df_sites.columns and 'ANNOT' in df_sites.columns and 'MUT_TYPE' in df_sites.columns
+    if 'STRAND' not in df_sites.columns:
+        print("WARNING: strand column not detected in sites file. Defaulting all sites to + strand.")
+        df_sites['STRAND'] = "+"
+    df_mut = read_mutation_file(f_mut, drop_duplicates=False)
+    assert 'GENE' in df_mut.columns and 'ANNOT' in df_mut.columns and 'MUT_TYPE' in df_mut.columns
+    if len(df_mut[df_mut.ANNOT == 'INDEL']):
+        print('WARNING: INDELS found in mutation file. Dig sites model is only applicable to SNVs. INDELS will be dropped.')
+    df_mut = df_mut[df_mut.ANNOT != 'INDEL']
+    at_sites = df_mut.merge(df_sites, on=_SITE_KEY, how='inner')
+    counts = at_sites.groupby('ELT').agg(OBS_SAMPLES=('SAMPLE', lambda x: len(set(x))), OBS_SNV=('CHROM', len)).reset_index()
+    if return_sites:
+        sites = df_sites.drop(columns=['GENE', 'ANNOT', 'REF', 'ALT']).rename(columns={'SAMPLE': 'GENE'})
+        return counts, sites
+    return counts
+
+
+def tabulate_sites_in_element(f_sites, f_mut):
+    """mutation_tools.py:279-283"""
+    return tabulate_nonc_mutations_at_sites(f_sites, f_mut).set_index('ELT')[['OBS_SAMPLES', 'OBS_SNV']]

@@ -435,6 +435,34 @@ def run_element_region_model(f_mut, f_bed, f_h5_pretrain, pretrain_key, scale_fa
 
 def run_sites_region_model(f_mut, f_sites, f_h5_pretrain, pretrain_key, scale_factor=None, scale_type="genome",
                            scale_by_expectation=True):
-    """transfer_tools.py:1098-1173 -- not built in this round: tabulate_sites_in_element
-    (mutation_tools.py:232-283) is outside the hot path's first cut."""
-    raise NotImplementedError("run_sites_region_model: the --f-sites route is not implemented yet (see DESIGN.md, scope)")
+    """transfer_tools.py:1098-1173: the element model of a SITES set (pretrained from preprocess_sites) against the
+    mutations that hit those sites exactly; SNVs only.  In the genome mode the reference assigns the (snv, indel) TUPLE
+    of calc_scale_factor_efficient to cj (:1155) and fails at THETA * cj; the SNV factor is used here."""
+    df_pretrain = load_pretrained_model(f_h5_pretrain, key=pretrain_key, restrict_cols=True)
+    if scale_by_expectation:
+        print('scaling by expected synonymous mutations (excluding TP53)')
+        df_gene = load_pretrained_model(f_h5_pretrain)
+        df_mut = mutation_tools.read_mutation_file(f_mut, drop_duplicates=False)
+        not_tp53 = df_gene[df_gene.index != 'TP53']
+        cj = len(df_mut[(df_mut.GENE != 'TP53') & (df_mut.ANNOT == 'Synonymous')]) / (not_tp53.MU * not_tp53.Pi_SYN).sum()
+    elif scale_factor:
+        cj = scale_factor
+    elif scale_type == 'MSK_230':
+        print('Scaling by samples in MSK 230 gene subset.')
+        genes = _read_gene_panel('MSK_230')
+        dd = mutation_tools.read_mutation_file(f_mut, drop_duplicates=True)
+        dd = dd[(dd.ANNOT != 'Noncoding') & (dd.ANNOT != 'Synonymous') & (dd.ANNOT != 'Essential_Splice')]
+        dd = dd[dd.GENE.isin(genes)]
+        cj = len(dd.SAMPLE.unique()) / mapfile.read_attrs(f_h5_pretrain)['N_SAMPLE_MSK_230']
+    else:
+        print('Calculating scale factor')
+        cj = calc_scale_factor_efficient(f_mut, f_h5_pretrain, scale_type=scale_type)[0]
+    print("\tScale factor is: {}".format(cj))
+    print('Tabulating mutations')
+    df_mut_tab = mutation_tools.tabulate_sites_in_element(f_sites, f_mut)
+    df_model = transfer_element_model(df_mut_tab, df_pretrain, cj, use_chrom=False)
+    print('Calculating statistics')
+    df_model = element_expected_muts_nb(df_model)
+    df_model = element_pvalue_burden_nb(df_model)
+    df_model = element_pvalue_burden_nb_by_sample(df_model)
+    return df_model

@@ -242,3 +242,45 @@ def preprocess_nonc(f_nonc_bed, f_nonc_data, f_pretrained, L_contexts, save_key,
     mapfile.write_array(f_nonc_data, base + 'blk_start', blk_start)
     mapfile.write_array(f_nonc_data, base + 'blk_end', blk_end)
     mapfile.write_array(f_nonc_data, base + 'L', np.rint(L).astype(np.int32))
+
+
+def preprocess_sites(f_sites, f_nonc_data, f_pretrained, save_key, window):
+    """sequence_tools.py:643-700: element data for a SITES file (mutation-file layout, element name in the SAMPLE
+    column, one row per (position, substitution) site, optional STRAND column).  Per element: L[key] = number of its
+    sites with substitution key "XYZ>XaZ" (reverse-complemented for '-' strand elements, rows without context
+    skipped); its overlapped windows come from all site intervals.  Stored as the flat arrays preprocess_nonc writes
+    (names in sorted order, as the reference's groupby gives them); f_pretrained is accepted for compatibility."""
+    from ..data_tools import mutation_tools
+    from ..io import mapfile
+    keys = sorted(mk_trans_idx(n_up=1, n_down=1, collapse=False))
+    pos = {k: i for i, k in enumerate(keys)}
+    df = mutation_tools.read_mutation_file(f_sites)
+    df = df.drop(columns=['GENE', 'ANNOT', 'REF', 'ALT']).rename(columns={'SAMPLE': 'GENE'})
+    df.loc[df.CONTEXT.isna(), 'CONTEXT'] = 'nan'
+    if 'STRAND' not in df.columns:
+        df['STRAND'] = '.'
+    names, chroms, strands, blk_ptr, bs, be, Ls = [], [], [], [0], [], [], []
+    for name, group in df.groupby('GENE'):
+        strand = list(group['STRAND'])[0]
+        minus = strand == "-1" or strand == "-"
+        L = np.zeros(192, np.int32)
+        for m, c in zip(group['MUT_TYPE'], group['CONTEXT']):
+            key = (reverse_complement(c) + '>' + reverse_complement(c[0] + m[2] + c[2])) if minus else (c + '>' + c[0] + m[2] + c[2])
+            if 'nan' in key:
+                continue
+            L[pos[key]] += 1
+        names.append(str(name))
+        chroms.append(int(list(group['CHROM'])[0]))
+        strands.append(str(strand))
+        bs.extend(int(x) for x in group['START'])
+        be.extend(int(x) for x in group['END'])
+        blk_ptr.append(len(bs))
+        Ls.append(L)
+    base = 'window_{}/{}/'.format(window, save_key)
+    mapfile.write_array(f_nonc_data, base + 'names', np.array(names))
+    mapfile.write_array(f_nonc_data, base + 'chrom', np.array(chroms, np.int32))
+    mapfile.write_array(f_nonc_data, base + 'strand', np.array(strands))
+    mapfile.write_array(f_nonc_data, base + 'blk_ptr', np.array(blk_ptr, np.int64))
+    mapfile.write_array(f_nonc_data, base + 'blk_start', np.array(bs, np.int64))
+    mapfile.write_array(f_nonc_data, base + 'blk_end', np.array(be, np.int64))
+    mapfile.write_array(f_nonc_data, base + 'L', np.stack(Ls) if Ls else np.zeros((0, 192), np.int32))

@@ -137,7 +137,7 @@ def parse_args(text=None):
         if extra == 'element':
             e.add_argument('pretrain_key', type=str, help='key of the pretrained element model inside the map')
             e.add_argument('--f-bed', type=str, default="", help='bed12 file the element model was pretrained on')
-            e.add_argument('--f-sites', type=str, default="", help='sites file')
+            e.add_argument('--f-sites', type=str, default="", help='sites file the element model was pretrained on (SNVs only)')
         else:
             e.add_argument('f_fasta', type=str, help='reference genome FASTA (hg19)')
             e.add_argument('--f_elts_bed', type=str, default="", help='bed12 file of elements')

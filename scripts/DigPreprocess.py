@@ -59,7 +59,9 @@ def initialize_data(args):
 
 def preprocess_nonc_contexts(args):
     if args.f_sites:
-        raise SystemExit("--f-sites preprocessing is not available in this build (DESIGN.md, scope).")
+        print("preprocessing sites data")
+        sequence_tools.preprocess_sites(args.f_sites, args.f_element_data, args.f_pretrained, args.save_key, args.window)
+        return
     if not args.f_element_bed:
         raise SystemExit("ERROR: need to pass in an elements file (--f-bed) for preprocessing")
     print("Preprocessing elements")
@@ -96,7 +98,7 @@ def parse_args(text=None):
     e.add_argument('f_fasta', help='reference genome FASTA (hg19)')
     e.add_argument('save_key', help='key of the element set')
     e.add_argument('--f-bed', dest='f_element_bed', help='bed12 file of the elements')
-    e.add_argument('--f-sites', type=str, default=None, help='not supported here')
+    e.add_argument('--f-sites', type=str, default=None, help='sites file (element name in the SAMPLE column)')
     e.add_argument('--ignore-sub_elts', action='store_false', default=True, dest='use_sub_elts',
                    help='count whole element spans instead of blocks')
     e.add_argument('--n-procs', default=1, type=int, dest='N_procs', help='accepted for compatibility')

@@ -58,7 +58,7 @@ class _FakeNode:
     def __getitem__(self, key):
         node = self._resolve(key)
         if isinstance(node, dict):
-            return _FakeNode(node, node.get("__attrs__", {}))
+            return _FakeNode(node, _FakeAttrs(node))
         return _FakeDataset(node)
 
     def __contains__(self, key):
@@ -71,6 +71,16 @@ class _FakeNode:
     def keys(self):
         return [k for k in self._tree.keys() if k != "__attrs__"]
 
+    def create_dataset(self, key, data=None, **kw):
+        parts = [p for p in key.split("/") if p]
+        node = self._tree
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        if node.get(parts[-1].__str__()) is not None and not isinstance(node.get(parts[-1]), dict):
+            raise ValueError("dataset exists: " + key)
+        # a group that later receives attributes keeps its datasets under the same dict
+        node[parts[-1]] = np.asarray(data)
+
     def close(self):
         pass
 
@@ -79,6 +89,18 @@ class _FakeNode:
 
     def __exit__(self, *a):
         return False
+
+
+class _FakeAttrs(dict):
+    """attrs of a fake group: a view on node['__attrs__'] with h5py's .create()."""
+
+    def __init__(self, node):
+        super().__init__(node.get("__attrs__", {}))
+        self._node = node
+
+    def create(self, name, value):
+        self._node.setdefault("__attrs__", {})[name] = value
+        self[name] = value
 
 
 class _FakeDataset:
@@ -718,9 +740,68 @@ def gen_contexts():
     print("wrote contexts_golden.json", df64.shape, df192.shape)
 
 
+def gen_sites():
+    """The sites route (mutation_tools.py:232-283, sequence_tools.py:643-700): the reference's own preprocess_sites and
+    tabulate_sites_in_element on a small synthetic sites file."""
+    import tempfile
+    rng = np.random.default_rng(77)
+    window = 1000
+    subst = sorted(ref_seq.mk_trans_idx(n_up=1, n_down=1, collapse=False))
+    muts192 = ref_seq.mk_mutation_context(n_up=1, n_down=1, collapse=False, return_df=True) \
+        if "return_df" in ref_seq.mk_mutation_context.__code__.co_varnames else None
+    # sequence model frame (MUT_TYPE, CONTEXT) in the reference's own row order
+    keys = list(ref_seq.mk_mutation_context(n_up=1, n_down=1, collapse=False).keys())
+    df_seq = pd.DataFrame({"MUT_TYPE": [k[0] for k in keys], "CONTEXT": [k[1] for k in keys], "FREQ": rng.uniform(size=len(keys))})
+    _HDF_FRAMES[("mem://pre_sites", "sequence_model_192")] = df_seq
+    nb = {1: 30, 2: 20}
+    idx = np.array([(c, b * window, (b + 1) * window) for c, n in nb.items() for b in range(n)])
+    si = rng.integers(0, 50, (len(idx), 64))
+    _H5_FILES["mem://sites_data"] = {"window_%d" % window: {"full_window_si_index": idx, "full_window_si_values": si}}
+    rows = []
+    elts = [("siteA", 1, "+"), ("siteB", 1, "-"), ("siteC", 2, "+"), ("siteD", 2, "-"), ("siteE", 1, "+")]
+    for name, chrom, strand in elts:
+        for _ in range(int(rng.integers(2, 9))):
+            p = int(rng.integers(0, nb[chrom] * window - 1))
+            k = keys[int(rng.integers(0, len(keys)))]
+            ref_, alt_ = k[0][0], k[0][2]
+            rows.append((chrom, p, p + 1, ref_, alt_, name, "G_" + name, "Noncoding", k[0], k[1], strand))
+    rows.append((1, 999, 1000, "A", "T", "siteE", "G_siteE", "Noncoding", "A>T", "nan", "+"))     # no context
+    f_sites = os.path.join(tempfile.mkdtemp(), "sites.tsv")
+    pd.DataFrame(rows).to_csv(f_sites, sep="\t", header=False, index=False)
+    ref_seq.preprocess_sites(f_sites, "mem://sites_data", "mem://pre_sites", "mysites", window)
+    grp = _H5_FILES["mem://sites_data"]["window_%d" % window]["mysites"]
+    out = {"window": window, "sites_rows": [list(map(str, r)) for r in rows], "bin_idx": idx.tolist(), "bin_ctx": si.tolist(),
+           "seq_mut_type": df_seq.MUT_TYPE.tolist(), "seq_context": df_seq.CONTEXT.tolist(), "subst_sorted": subst, "elements": {}}
+    for name in sorted(k for k in grp.keys() if k != "__attrs__"):
+        node = grp[name]
+        out["elements"][name] = {"L_counts": np.asarray(node["L_counts"]).astype(int).tolist(),
+                                 "region_counts": np.asarray(node["region_counts"]).astype(int).tolist(),
+                                 "overlaps": [list(map(int, o)) for o in node["__attrs__"]["overlaps"]]}
+    # mutations: some exactly at the sites (same nine columns), some not
+    mrows = []
+    for r in rows[:-1]:
+        for _ in range(int(rng.integers(0, 4))):
+            mrows.append((r[0], r[1], r[2], r[3], r[4], "S%d" % rng.integers(0, 6), r[6], r[7], r[8], r[9]))
+    mrows.append((1, 5, 6, "A", "T", "S1", "X", "Noncoding", "A>T", "CAG"))
+    mrows.append((1, 7, 9, "AG", "A", "S2", "X", "INDEL", "DEL", "."))
+    f_mut = os.path.join(os.path.dirname(f_sites), "m.tsv")
+    pd.DataFrame(mrows).to_csv(f_mut, sep="\t", header=False, index=False)
+    tab = ref_mt.tabulate_sites_in_element(f_sites, f_mut)
+    out["mut_rows"] = [list(map(str, r)) for r in mrows]
+    out["tab_index"] = [str(i) for i in tab.index]
+    out["tab_obs_samples"] = tab.OBS_SAMPLES.astype(int).tolist()
+    out["tab_obs_snv"] = tab.OBS_SNV.astype(int).tolist()
+    with open(os.path.join(HERE, "sites_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote sites_golden.json", len(out["elements"]), len(tab))
+
+
 def main():
     if "--only-contexts" in sys.argv:
         gen_contexts()
+        return
+    if "--only-sites" in sys.argv:
+        gen_sites()
         return
     gen_nb_midp()
     gen_nb_exact()
@@ -733,6 +814,7 @@ def main():
     gen_sequence_model(df_empty)
     gen_cnn()
     gen_contexts()
+    gen_sites()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

@@ -198,3 +198,64 @@ def test_preprocess_pretrain_driver_chain_equals_quickdriver(tmp_path):
                 "PVAL_MUT_BURDEN"):
         rel_close(res.loc[common, col].values.astype(float), quick.loc[common, col].values.astype(float), rtol=1e-9)
     assert int(mapfile.read_frame(gc, "genome_counts").COUNT.sum()) > 0
+
+
+def test_sites_route_matches_reference_preprocessing(tmp_path):
+    """preprocess_sites -> elementModel -> elementDriver --f-sites.  The per-element L counts, overlapped windows and
+    region counts are the reference's own (tests/golden/sites_golden.json, made by running its preprocess_sites): the
+    model columns computed here from the site file must equal the ones implied by those stored vectors."""
+    import json
+    from conftest import GOLDEN
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.sequence_model import genic_driver_tools, sequence_tools
+    from oracle import dig_oracle as O
+    g = json.load(open(os.path.join(GOLDEN, "sites_golden.json")))
+    window = g["window"]
+    rng = np.random.default_rng(5)
+    idx = np.array(g["bin_idx"])
+    n = len(idx)
+    rp = pd.DataFrame({"CHROM": idx[:, 0], "START": idx[:, 1], "END": idx[:, 2], "Y_TRUE": rng.poisson(20, n),
+                       "Y_PRED": rng.gamma(9.0, 3.0, n), "STD": rng.gamma(4.0, 1.0, n), "FLAG": rng.uniform(size=n) < 0.1},
+                      index=["chr{}:{}-{}".format(*r) for r in idx])
+    sm = pd.DataFrame({"MUT_TYPE": g["seq_mut_type"], "CONTEXT": g["seq_context"], "FREQ": rng.dirichlet(np.ones(192)) * 1e-3})
+    pre, dat = str(tmp_path / "pre.map"), str(tmp_path / "dat.map")
+    mapfile.write_frame(pre, "region_params", rp)
+    mapfile.write_frame(pre, "sequence_model_192", sm)
+    mapfile.write_array(pre, "idx", idx.astype(np.int32))
+    mapfile.write_array(dat, "window_%d/full_window_si_index" % window, idx)
+    mapfile.write_array(dat, "window_%d/full_window_si_values" % window, np.array(g["bin_ctx"]))
+    fs, fm = tmp_path / "sites.tsv", tmp_path / "m.tsv"
+    pd.DataFrame(g["sites_rows"]).to_csv(fs, sep="\t", header=False, index=False)
+    pd.DataFrame(g["mut_rows"]).to_csv(fm, sep="\t", header=False, index=False)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "DigPreprocess.py"), "preprocess_element_model", dat, pre,
+                           "unused.fa", "mysites", "--f-sites", str(fs), "--window", str(window)], env=env)
+    names = list(mapfile.read_array(dat, "window_%d/mysites/names" % window).astype(str))
+    assert names == sorted(g["elements"])
+    L = mapfile.read_array(dat, "window_%d/mysites/L" % window)
+    for i, nme in enumerate(names):
+        assert L[i].tolist() == g["elements"][nme]["L_counts"], nme
+    frame = genic_driver_tools.nonc_model_parallel(pre, dat, "mysites", 1).set_index("ELT")
+    subst = [c + ">" + c[0] + m[2] + c[2] for m, c in zip(sm.MUT_TYPE, sm.CONTEXT)]
+    d_pr = sm.FREQ.values[np.argsort(np.array(subst), kind="stable")]
+    for nme in names:
+        e = g["elements"][nme]
+        rc, Lc = np.array(e["region_counts"], float), np.array(e["L_counts"], float)
+        want_p = ((d_pr / (rc * d_pr).sum()) * Lc).sum()
+        assert abs(frame.loc[nme, "P_SUM"] - want_p) <= 1e-12 * abs(want_p), nme
+        assert int(frame.loc[nme, "R_SIZE"]) == int(rc.sum() / 3) and int(frame.loc[nme, "ELT_SIZE"]) == int(Lc.sum() / 3)
+        rows = ["chr{}:{}-{}".format(*o) for o in e["overlaps"]]
+        assert abs(frame.loc[nme, "MU"] - rp.loc[rows, "Y_PRED"].sum()) < 1e-9
+    mapfile.write_frame(pre, "mysites", frame.reset_index())
+    out = tmp_path / "o"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver", str(fm), pre, "mysites",
+                           "--f-sites", str(fs), "--scale-factor-manual", "0.01", "--scale-factor-indel-manual", "0.001",
+                           "--outdir", str(out), "--outpfx", "s"], env=env)
+    res = pd.read_csv(out / "s.results.txt", sep="\t", index_col=0)
+    assert [str(i) for i in res.index] == names or set(map(str, res.index)) == set(names)
+    tab = dict(zip(g["tab_index"], g["tab_obs_snv"]))
+    for nme in names:
+        assert int(res.loc[nme, "OBS_SNV"]) == tab.get(nme, 0)
+    a = res.ALPHA.values
+    p = 1.0 / (res.THETA.values * res.Pi_SUM.values + 1.0)
+    rel_close(res.PVAL_SNV_BURDEN.values, O.nb_pvalue_greater_midp(res.OBS_SNV.values.astype(float), a, p), rtol=1e-6)

@@ -122,3 +122,17 @@ def test_mapfile_directory_roundtrip(tmp_path):
     assert mapfile.has_key(path, "region_params") and not mapfile.has_key(path, "nope")
     with pytest.raises(KeyError):
         mapfile.read_frame(path, "nope")
+
+
+def test_tabulate_sites_matches_reference(tmp_path):
+    """tabulate_sites_in_element against the reference's own output (tests/golden/sites_golden.json)."""
+    import json
+    from digdriver_amd.data_tools import mutation_tools as mt
+    g = json.load(open(os.path.join(GOLDEN, "sites_golden.json")))
+    fs, fm = tmp_path / "sites.tsv", tmp_path / "m.tsv"
+    pd.DataFrame(g["sites_rows"]).to_csv(fs, sep="\t", header=False, index=False)
+    pd.DataFrame(g["mut_rows"]).to_csv(fm, sep="\t", header=False, index=False)
+    tab = mt.tabulate_sites_in_element(str(fs), str(fm))
+    assert [str(i) for i in tab.index] == g["tab_index"]
+    assert tab.OBS_SAMPLES.astype(int).tolist() == g["tab_obs_samples"]
+    assert tab.OBS_SNV.astype(int).tolist() == g["tab_obs_snv"]
