@@ -549,9 +549,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
                 DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false, false>, kBlock, 0));
             resident[which] = per_cu > 0 ? per_cu : 4;
         }
-        int blocks_per_cu = resident[which];
-        if (const char* e = getenv("DIG_ES_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));   // tuning knob
-        const int sgrid = grid_for(E * C, kBlock, blocks_per_cu);
+        const int sgrid = grid_for(E * C, kBlock, resident[which]);
         if (which == 2)
             hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(sgrid), dim3(kBlock), 0, s, a);
         else if (which == 1)
