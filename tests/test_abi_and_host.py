@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.dig_abi_version() == 2
 
 
+def test_library_abi_version_matches_header_and_binding():
+    import re
+    from digdriver_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dig_hip.h")).read()
+    declared = int(re.search(r"#define\s+DIG_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert declared == _lib.ABI_VERSION == _lib.load().dig_abi_version()
+
+
 def test_product_never_imports_oracle_or_scipy():
     """The product path must not route through the oracle or any CPU implementation."""
     pkg = os.path.join(ROOT, "digdriver_amd")
