@@ -387,12 +387,17 @@ def test_context_counting_matches_reference_golden_and_oracle():
         a = int(rng.integers(0, n - 5000))
         s[a:a + 3000] = ord("N")
         seqs[name] = s.tobytes().decode()
+    seqs["3"] = rng.choice(np.frombuffer(b"ACGT", np.uint8), 70_001).tobytes().decode()      # N-free: the unchecked path
     genome = PackedGenome.from_sequences(seqs)
     regs = [("1", 10000 * i, 10000 * (i + 1)) for i in range(26)] + [("2", 10000 * i, 10000 * (i + 1)) for i in range(10)]
+    regs += [("3", 10000 * i, 10000 * (i + 1)) for i in range(8)] + [("3", 0, 70_001), ("3", 69_990, 70_500), ("3", 5, 5)]
     for _ in range(300):
-        c = "12"[int(rng.integers(0, 2))]
+        c = "123"[int(rng.integers(0, 3))]
         a = int(rng.integers(0, len(seqs[c])))
         regs.append((c, a, a + int(rng.integers(0, 3000))))
+    for _ in range(400):   # every alignment of short regions against the 8-base words and 32-base groups
+        a = int(rng.integers(0, 69_000))
+        regs.append(("3", a, a + int(rng.integers(0, 140))))
     chroms, starts, ends = zip(*regs)
     minus = rng.uniform(size=len(regs)) < 0.5
     got = engine.count_contexts(genome, chroms, starts, ends, minus, device=0).cpu().numpy()
