@@ -5,9 +5,13 @@
 // bin x position x track matrix is resident in HBM and a batch of bins is gathered per launch.
 //
 // Pure HBM streaming (L*T*4 B read + L*T_sel*{2,4} B written per bin):
+//   * row-major output [B, L, T], all tracks (tracks == NULL): batched contiguous block copy with
+//     conversion, 8 / 16-byte accesses (gather_block_kernel);
 //   * row-major output [B, L, T_sel]: one wave per (bin, position) row, lanes sweep the tracks,
 //     so both the read (a contiguous T-row when the track list is a range) and the write are
 //     256-B coalesced; no integer division in the inner loop;
+//   * channels-first output [B, T, L], all tracks: 64-track x L tiles transposed through LDS with
+//     4-value vector accesses on both sides (gather_transpose_all_kernel);
 //   * channels-first output [B, T_sel, L] (what conv1d consumes after the reference's
 //     transpose(x, 1, 2), cnn_predictors.py:131): a 64-track x L tile is staged through LDS
 //     ([L][65] floats, padded against bank conflicts) so reads stay track-contiguous and
@@ -55,7 +59,65 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(const S* __re
         for (int64_t l = wave; l < L; l += nw) {
             const S* xs = x + src0 + l * T;
             D* od = out + dst0 + l * T_sel;
-            for (int64_t t = lane; t < T_sel; t += 64) store_from_float<D>(od, t, load_as_float<S>(xs, tracks[t]));
+            for (int64_t t = lane; t < T_sel; t += 64) store_from_float<D>(od, t, load_as_float<S>(xs, tracks ? tracks[t] : (int)t));
+        }
+    }
+}
+
+// All tracks selected (tracks == NULL), row-major output: a bin is ONE contiguous block of L * T values on both sides, so
+// the gather is a batched block copy with conversion.  Four values per lane and access (8-byte loads of i16, 16-byte
+// of f32; 8-byte stores of bf16, 16-byte of f32), kBlockUnroll independent accesses per lane in flight.
+// grid = (chunks of a bin, bins).  Needs (L * T) % 4 == 0 so that every bin starts on a vector boundary.
+constexpr int kBlockUnroll = 4;
+
+template <typename S>
+struct Vec4In;
+template <>
+struct Vec4In<int16_t> {
+    short4 v;
+    __device__ __forceinline__ float get(int i) const { return (float)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w); }
+};
+template <>
+struct Vec4In<float> {
+    float4 v;
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <>
+struct Vec4In<double> {
+    double4 v;
+    __device__ __forceinline__ float get(int i) const { return (float)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w); }
+};
+
+__device__ __forceinline__ void store_vec4(float* p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store_vec4(__hip_bfloat16* p, float a, float b, float c, float d)
+{
+    union { __hip_bfloat16 h[4]; uint2 u; } pk;
+    pk.h[0] = __float2bfloat16(a); pk.h[1] = __float2bfloat16(b); pk.h[2] = __float2bfloat16(c); pk.h[3] = __float2bfloat16(d);
+    *reinterpret_cast<uint2*>(p) = pk.u;
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(kGatherBlock) void gather_block_kernel(const S* __restrict__ x, int64_t n_per_bin,
+                                                                    const int64_t* __restrict__ rows, int64_t B,
+                                                                    D* __restrict__ out)
+{
+    const int64_t nv = n_per_bin >> 2;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        const Vec4In<S>* src = reinterpret_cast<const Vec4In<S>*>(x + rows[b] * n_per_bin);
+        D* dst = out + b * n_per_bin;
+        for (int64_t v0 = (int64_t)blockIdx.x * (kGatherBlock * kBlockUnroll) + threadIdx.x; v0 < nv;
+             v0 += (int64_t)gridDim.x * (kGatherBlock * kBlockUnroll)) {
+            Vec4In<S> in[kBlockUnroll];
+#pragma unroll
+            for (int u = 0; u < kBlockUnroll; ++u)
+                if (v0 + u * kGatherBlock < nv) in[u] = src[v0 + u * kGatherBlock];
+#pragma unroll
+            for (int u = 0; u < kBlockUnroll; ++u)
+                if (v0 + u * kGatherBlock < nv)
+                    store_vec4(dst + 4 * (v0 + u * kGatherBlock), in[u].get(0), in[u].get(1), in[u].get(2), in[u].get(3));
         }
     }
 }
@@ -73,7 +135,7 @@ __global__ __launch_bounds__(kGatherBlock) void gather_transpose_kernel(const S*
     const int nt = (int)((T_sel - t0 < 64) ? (T_sel - t0) : 64);
     for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
         const int64_t src0 = rows[b] * L * T;
-        const int tr = (lane < nt) ? tracks[t0 + lane] : 0;
+        const int tr = (lane < nt) ? (tracks ? tracks[t0 + lane] : (int)(t0 + lane)) : 0;
         for (int64_t l = wave; l < L; l += nw)
             if (lane < nt) tile[l * 65 + lane] = load_as_float<S>(x, src0 + l * T + tr);
         __syncthreads();
@@ -85,14 +147,101 @@ __global__ __launch_bounds__(kGatherBlock) void gather_transpose_kernel(const S*
     }
 }
 
+// out[b, t, l] channels-first, all tracks (tracks == NULL), L % 4 == 0.  grid = (track tiles of 64, bins).
+// Both sides of the tile move as 4-value vectors.  A source row of the tile (64 consecutive tracks of one position) is
+// only element-aligned when T is odd.  Misaligned 8-byte loads of i16 run at half speed, so a 2-byte source is read as
+// the 17 ALIGNED 4-value vectors that cover the row (it starts `delta` = 0..3 values into the first one; values outside
+// the tile are dropped); 16-byte loads of f32 at 4-byte alignment measured faster than the 17-vector form and stay.  A lane scatters its four values into a transposed LDS tile [64][L + 1] (odd row stride: the
+// track quads x positions of a wave spread over all 32 banks) and, after the barrier, reads four consecutive positions
+// of one track and stores them as one 8 / 16-byte vector -- the 64 output rows of a tile are one contiguous block.
+constexpr int kTransUnroll = 4;
+
+template <typename S>
+struct Quad {
+    S v[4];
+};
+
 template <typename S, typename D>
-static int launch_gather(const void* x, int64_t L, int64_t T, const int64_t* rows, int64_t B, const int32_t* tracks,
+__global__ __launch_bounds__(kGatherBlock) void gather_transpose_all_kernel(const S* __restrict__ x, int64_t n_total, int L,
+                                                                            int64_t T, const int64_t* __restrict__ rows,
+                                                                            int64_t B, D* __restrict__ out)
+{
+    extern __shared__ float tile[];   // [64][L + 1]
+    const int Sr = L + 1;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int nt = (int)((T - t0 < 64) ? (T - t0) : 64);
+    constexpr bool kAligned = sizeof(S) == 2;
+    constexpr int kTransQuads = kAligned ? 17 : 16;
+    const int n_items = L * kTransQuads;           // (position, quad)
+    const float inv_L = 1.0f / (float)L;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        const int64_t src0 = rows[b] * L * T + t0;          // element index of (position 0, track t0)
+        for (int base = threadIdx.x; base < n_items; base += kGatherBlock * kTransUnroll) {
+            Quad<S> q[kTransUnroll];
+#pragma unroll
+            for (int u = 0; u < kTransUnroll; ++u) {
+                const int idx = base + u * kGatherBlock;
+                if (idx < n_items) {
+                    const int l = idx / kTransQuads, k = idx - l * kTransQuads;
+                    const int64_t row = src0 + (int64_t)l * T;
+                    const int64_t g = (kAligned ? (row & ~(int64_t)3) : row) + 4 * k;   // (x itself is 4-value aligned)
+                    if (g + 3 < n_total) {
+                        __builtin_memcpy(&q[u], x + g, sizeof(Quad<S>));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[u].v[j] = (g + j < n_total) ? x[g + j] : (S)0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kTransUnroll; ++u) {
+                const int idx = base + u * kGatherBlock;
+                if (idx < n_items) {
+                    const int l = idx / kTransQuads, k = idx - l * kTransQuads;
+                    const int delta = kAligned ? (int)((src0 + (int64_t)l * T) & 3) : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int t = 4 * k - delta + j;
+                        if (t >= 0 && t < nt) tile[t * Sr + l] = (float)q[u].v[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        D* dst = out + (b * T + t0) * L;
+        const int nvec = nt * L / 4;
+        for (int vi = threadIdx.x; vi < nvec; vi += kGatherBlock) {
+            const int e = 4 * vi;
+            const int tr = (int)(((float)e + 0.5f) * inv_L);      // e / L, exact for e < 64 * 256
+            const float* r = tile + tr * Sr + (e - tr * L);
+            store_vec4(dst + e, r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename S, typename D>
+static int launch_gather(const void* x, int64_t n_total, int64_t L, int64_t T, const int64_t* rows, int64_t B, const int32_t* tracks,
                          int64_t T_sel, void* out, int transpose_out, hipStream_t stream)
 {
-    if (!transpose_out) {
+    if (!transpose_out && !tracks && ((L * T) & 3) == 0 && ((uintptr_t)x & 31) == 0 && ((uintptr_t)out & 15) == 0) {
+        const int64_t nv = (L * T) >> 2;
+        const int chunks = (int)std::min<int64_t>((nv + kGatherBlock * kBlockUnroll - 1) / (kGatherBlock * kBlockUnroll), 64);
+        const int gy = (int)std::min<int64_t>(B, 65535);
+        hipLaunchKernelGGL((gather_block_kernel<S, D>), dim3(chunks, gy), dim3(kGatherBlock), 0, stream, (const S*)x, L * T,
+                           rows, B, (D*)out);
+    } else if (!transpose_out) {
         int grid = (int)std::min<int64_t>(B, (int64_t)cu_count() * 8);
         hipLaunchKernelGGL((gather_rows_kernel<S, D>), dim3(grid), dim3(kGatherBlock), 0, stream, (const S*)x, L, T, rows,
                            B, tracks, T_sel, (D*)out);
+    } else if (!tracks && (L & 3) == 0 && L <= 252 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)x & (4 * sizeof(S) - 1)) == 0) {
+        const size_t lds = (size_t)64 * (L + 1) * sizeof(float);
+        const int tiles = (int)((T + 63) / 64);
+        const int gy = (int)std::min<int64_t>(B, std::max<int64_t>(1, (int64_t)cu_count() * 16 / tiles));
+        DIG_HIP_TRY(hipFuncSetAttribute((const void*)gather_transpose_all_kernel<S, D>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gather_transpose_all_kernel<S, D>), dim3(tiles, gy), dim3(kGatherBlock), lds, stream,
+                           (const S*)x, n_total, (int)L, T, rows, B, (D*)out);
     } else {
         const size_t lds = (size_t)L * 65 * sizeof(float);
         if (lds > 150 * 1024) return set_error(DIG_EINVAL, "gather: L=%lld too long for the LDS transpose tile", (long long)L);
@@ -130,11 +279,12 @@ int dig_gather_bins(const void* x_data, int src_dtype, int64_t N, int64_t L, int
 {
     DIG_REQUIRE(N >= 0 && L > 0 && T > 0 && B >= 0 && T_sel >= 0, "sizes");
     if (B == 0 || T_sel == 0) return DIG_OK;
-    DIG_REQUIRE(x_data && bin_rows && tracks && out, "non-null pointers");
+    DIG_REQUIRE(x_data && bin_rows && out, "non-null pointers");
+    DIG_REQUIRE(tracks || T_sel == T, "tracks == NULL selects all tracks: T_sel must equal T");
     DIG_REQUIRE(src_dtype == DIG_F32 || src_dtype == DIG_F64 || src_dtype == DIG_I16, "src_dtype f32|f64|i16");
     DIG_REQUIRE(out_dtype == DIG_F32 || out_dtype == DIG_BF16, "out_dtype f32|bf16");
     hipStream_t s = (hipStream_t)stream;
-#define GO(S, D) return launch_gather<S, D>(x_data, L, T, bin_rows, B, tracks, T_sel, out, transpose_out, s)
+#define GO(S, D) return launch_gather<S, D>(x_data, N * L * T, L, T, bin_rows, B, tracks, T_sel, out, transpose_out, s)
     if (out_dtype == DIG_F32) {
         if (src_dtype == DIG_F32) GO(float, float);
         if (src_dtype == DIG_F64) GO(double, float);
@@ -152,22 +302,23 @@ int dig_gather_bins_host(const void* x_data, int src_dtype, int64_t N, int64_t L
 {
     DIG_REQUIRE(N >= 0 && L > 0 && T > 0 && B >= 0 && T_sel >= 0, "sizes");
     if (B == 0 || T_sel == 0) return DIG_OK;
-    DIG_REQUIRE(x_data && bin_rows && tracks && out, "non-null pointers");
+    DIG_REQUIRE(x_data && bin_rows && out, "non-null pointers");
+    DIG_REQUIRE(tracks || T_sel == T, "tracks == NULL selects all tracks: T_sel must equal T");
     const size_t ss = dtype_size(src_dtype), ds = dtype_size(out_dtype);
     DIG_REQUIRE(ss && ds, "known dtypes");
     for (int64_t b = 0; b < B; ++b) DIG_REQUIRE(bin_rows[b] >= 0 && bin_rows[b] < N, "bin_rows within [0, N)");
-    for (int64_t t = 0; t < T_sel; ++t) DIG_REQUIRE(tracks[t] >= 0 && tracks[t] < T, "tracks within [0, T)");
+    for (int64_t t = 0; tracks && t < T_sel; ++t) DIG_REQUIRE(tracks[t] >= 0 && tracks[t] < T, "tracks within [0, T)");
     DIG_HIP_TRY(hipSetDevice(device));
     DevBuf dx, dr, dt, dout;
     const size_t xb = (size_t)N * L * T * ss, ob = (size_t)B * L * T_sel * ds;
     DIG_HIP_TRY(dx.alloc(xb));
     DIG_HIP_TRY(dr.alloc((size_t)B * 8));
-    DIG_HIP_TRY(dt.alloc((size_t)T_sel * 4));
+    if (tracks) DIG_HIP_TRY(dt.alloc((size_t)T_sel * 4));
     DIG_HIP_TRY(dout.alloc(ob));
     DIG_HIP_TRY(hipMemcpy(dx.p, x_data, xb, hipMemcpyHostToDevice));
     DIG_HIP_TRY(hipMemcpy(dr.p, bin_rows, (size_t)B * 8, hipMemcpyHostToDevice));
-    DIG_HIP_TRY(hipMemcpy(dt.p, tracks, (size_t)T_sel * 4, hipMemcpyHostToDevice));
-    int rc = dig_gather_bins(dx.p, src_dtype, N, L, T, dr.as<int64_t>(), B, dt.as<int32_t>(), T_sel, dout.p, out_dtype,
+    if (tracks) DIG_HIP_TRY(hipMemcpy(dt.p, tracks, (size_t)T_sel * 4, hipMemcpyHostToDevice));
+    int rc = dig_gather_bins(dx.p, src_dtype, N, L, T, dr.as<int64_t>(), B, tracks ? dt.as<int32_t>() : nullptr, T_sel, dout.p, out_dtype,
                              transpose_out, nullptr);
     if (rc) return rc;
     DIG_HIP_TRY(hipDeviceSynchronize());

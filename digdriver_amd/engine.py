@@ -395,8 +395,8 @@ def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False,
         assert x_data.dtype in tmap and x_data.is_contiguous() and x_data.dim() == 3
         N, L, T = x_data.shape
         rows = _t(bin_rows, torch.int64, dev)
-        tr = _t(np.arange(T) if tracks is None else tracks, torch.int32, dev)
-        B, Ts = rows.numel(), tr.numel()
+        tr = None if tracks is None else _t(tracks, torch.int32, dev)      # NULL = all tracks (contiguous block copy)
+        B, Ts = rows.numel(), T if tr is None else tr.numel()
         odt = torch.float32 if out_dtype == "f32" else torch.bfloat16
         out = torch.empty((B, Ts, L) if transpose else (B, L, Ts), dtype=odt, device=dev)
         with torch.cuda.device(dev):
@@ -408,8 +408,8 @@ def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False,
     assert x.dtype in _NP_DT and x.ndim == 3
     N, L, T = x.shape
     rows = _lib.as_host(bin_rows, np.int64).ravel()
-    tr = _lib.as_host(np.arange(T) if tracks is None else tracks, np.int32).ravel()
-    B, Ts = len(rows), len(tr)
+    tr = None if tracks is None else _lib.as_host(tracks, np.int32).ravel()
+    B, Ts = len(rows), T if tr is None else len(tr)
     if out_dtype != "f32":
         raise ValueError("host path returns float32 only")
     out = np.empty((B, Ts, L) if transpose else (B, L, Ts), np.float32)

@@ -72,10 +72,10 @@ class BinTrackStore:
     def __init__(self, x_data, selected_tracks=None):
         self.x = x_data
         self.n_bins, self.length, self.n_tracks_total = x_data.shape
-        self.tracks = np.arange(self.n_tracks_total) if selected_tracks is None else np.asarray(selected_tracks)
+        self.tracks = None if selected_tracks is None else np.asarray(selected_tracks)    # None = all tracks, in order
 
     def shape(self, n):
-        return (n, self.length, len(self.tracks))
+        return (n, self.length, self.n_tracks_total if self.tracks is None else len(self.tracks))
 
     def batch(self, bin_rows, channels_first=True, out_dtype="f32"):
         """x_data[bin_rows, :, tracks] (mut_dataset.py:76-81) for a batch, optionally as [B, T, L]."""

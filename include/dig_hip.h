@@ -252,7 +252,9 @@ int dig_overlap_join_fill(const int64_t *blk_start_key, const int64_t *blk_runma
  * out[b, t, l] = ...                                            (transpose_out != 0: the
  *   channels-first layout SimpleMultiTaskResNet.forward makes with transpose(x, 1, 2),
  *   region_model/nets/cnn_predictors.py:131)
- * x_data is [N, L, T] of src_dtype (DIG_F32 | DIG_F64 | DIG_I16); out is DIG_F32 or DIG_BF16. */
+ * x_data is [N, L, T] of src_dtype (DIG_F32 | DIG_F64 | DIG_I16); out is DIG_F32 or DIG_BF16.
+ * tracks == NULL selects all tracks in order (T_sel must equal T; the reference's default when no track file is
+ * given, dataset_generator.py:52-55): a bin is then one contiguous block and is copied with 8 / 16-byte accesses. */
 int dig_gather_bins(const void *x_data, int src_dtype, int64_t N, int64_t L, int64_t T, const int64_t *bin_rows,
                     int64_t B, const int32_t *tracks, int64_t T_sel, void *out, int out_dtype, int transpose_out,
                     void *stream);

@@ -285,6 +285,18 @@ def test_gather_bins(torch_dev, src):
     assert b.dtype == torch.bfloat16
     np.testing.assert_allclose(b.float().cpu().numpy(), want.transpose(0, 2, 1), rtol=2 ** -8)
     assert engine.gather_bins(x, np.zeros(0, np.int64), tracks).shape == (0, L, len(tracks))
+    # all tracks (tracks=None -> NULL): the contiguous block copy, its bf16 form, the channels-first form, the host twin,
+    # and a bin size that is not a multiple of four values (falls back to the row kernel)
+    full = x[rows].astype(np.float32)
+    assert np.array_equal(engine.gather_bins(x, rows, None), full)
+    assert np.array_equal(engine.gather_bins(xd, rows, None, transpose=True).cpu().numpy(), full.transpose(0, 2, 1))
+    bf = engine.gather_bins(xd, rows, None, out_dtype="bf16")
+    assert bf.dtype == torch.bfloat16 and torch.equal(bf, torch.as_tensor(full, device=torch_dev).to(torch.bfloat16))
+    xo = np.ascontiguousarray(x[:, :99, :])
+    assert np.array_equal(engine.gather_bins(torch.as_tensor(xo, device=torch_dev), rows, None).cpu().numpy(),
+                          xo[rows].astype(np.float32))
+    big = rng.integers(0, N, 700)                      # more bins than one grid pass of the block kernel needs
+    assert np.array_equal(engine.gather_bins(xd, big, None).cpu().numpy(), x[big].astype(np.float32))
 
 
 def test_tiled_nb_test_vs_oracle(torch_dev):

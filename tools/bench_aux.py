@@ -42,7 +42,7 @@ def main():
         for odt in ("bf16", "f32"):
             for tr in (False, True):
                 r = rows % x.shape[0]
-                dt = timeit(lambda: engine.gather_bins(x, r, sel, out_dtype=odt, transpose=tr))
+                dt = timeit(lambda: engine.gather_bins(x, r, None, out_dtype=odt, transpose=tr))     # all tracks
                 by = B * L * T * (x.element_size() + (2 if odt == "bf16" else 4))
                 out["gather_bins"].append({"in": name, "out": odt, "channels_first": tr, "bins": B, "L": L, "T": T,
                                            "ms": dt * 1e3, "bins_per_s": B / dt, "algorithmic_GBps": by / dt / 1e9,
