@@ -313,6 +313,22 @@ def main():
             side_done[b].record(side_stream)
 
     queued = [-1]      # last step whose scale factors have been enqueued
+    # Per-stage durations are sampled INSIDE the timed loop: on every 8th step one stage (contexts, dot or statistics) is
+    # bracketed by two HIP events on the main stream.  An event record is a barrier packet (~6 us), so each step carries at
+    # most one pair and seven steps in eight carry none (< 1 % of the loop time).
+    SAMPLE_EVERY = 8
+    sample_slot = {1: "contexts", 3: "dot", 5: "statistics"}
+    samples = {"contexts": [], "dot": [], "statistics": []}
+    sampling = [False]
+
+    def staged(name, which, fn):
+        if which != name:
+            return fn()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main_stream)
+        fn()
+        b_.record(main_stream)
+        samples[name].append((a, b_))
 
     def step():
         # Main stream: (4) the context and dot kernels of dig_element_pipeline (they need no scale factors), wait for (3),
@@ -328,14 +344,15 @@ def main():
             enqueue_scale_factors(t)
             queued[0] = t
         cj, cji = cj_outs[b]
-        pipe.run(cj, cji, stages=1, stream=main_stream)          # context kernel (HBM-bound)
+        which = sample_slot.get(t % SAMPLE_EVERY) if sampling[0] else None
+        staged("contexts", which, lambda: pipe.run(cj, cji, stages=1, stream=main_stream))   # context kernel (HBM-bound)
         ctx_done[b].record(main_stream)
         if queued[0] < t + 1:
             enqueue_scale_factors(t + 1, after=ctx_done[b])      # ... beside this step's MFMA-bound dot kernel
             queued[0] = t + 1
-        pipe.run(cj, cji, stages=2, stream=main_stream)          # dot kernel
+        staged("dot", which, lambda: pipe.run(cj, cji, stages=2, stream=main_stream))        # dot kernel
         main_stream.wait_event(side_done[b])
-        pipe.run(cj, cji, stages=4, stream=main_stream)          # statistics
+        staged("statistics", which, lambda: pipe.run(cj, cji, stages=4, stream=main_stream))  # statistics
 
     def barrier():
         torch.cuda.synchronize()
@@ -353,8 +370,10 @@ def main():
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev_begin.record(main_stream)
+    sampling[0] = True
     for _ in range(args.steps):
         step()
+    sampling[0] = False
     ev_end.record(main_stream)
     barrier()
     dt = time.perf_counter() - t0
@@ -363,6 +382,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
+    stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
     seq_cj, seq_cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"]) \
@@ -385,12 +405,41 @@ def main():
         units = float(E) * C * world * args.steps
         b_acc, b_stat = algorithmic_bytes(E, C, nbar)
         b_suff = 9.0 * N * C                                     # dig_scale_suffstats: Y_PRED f64 + FLAG u8 per (bin, cohort)
-        dominant = "step = dig_scale_factors || dig_element_pipeline"
-        d_bytes, d_ms = b_acc + b_stat + b_suff, ms_step
-        achieved = d_bytes / (d_ms * 1e-3) / 1e9
-        prefixes = ["acc_region", "acc_dot", "element_stats_", "suffstats", "scale_factors"]
+        # SURVEY 8d's algorithmic bytes, split by the stage that moves them (the three parts add up to b_acc + b_stat):
+        stage_bytes = {"contexts": E * (260.0 * nbar + 4), "dot": E * 780.0 + 8.0 * E * C,
+                       "statistics": E * C * (21.0 * nbar + 24 + 100)}
+        stage_kernels = {"contexts": ["acc_region"], "dot": ["acc_dot"], "statistics": ["element_stats_"]}
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
-        traffic, traffic_src = committed_traffic(prefixes) if default_shape else (None, None)
+
+        def roof(name, by, ms, prefixes, n):
+            if not ms:
+                return None
+            traffic, src = committed_traffic(prefixes) if default_shape else (None, None)
+            ach = by / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": ach / (HBM_PEAK / 1e9), "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms, "launches_timed": n}
+
+        stage_names = {
+            "statistics": "dig_element_pipeline statistics stage: element_stats_stream_kernel<fused rates> + "
+                          "element_stats_slow_kernel (one launch each, back to back)",
+            "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
+            "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64)"}
+        stage_roofs = {k: roof(stage_names[k], stage_bytes[k], stage_ms[k], stage_kernels[k], len(samples[k]))
+                       for k in ("statistics", "contexts", "dot")}
+        if stage_ms["dot"]:
+            # the dot stage is bound by the FP64 matrix pipe, not by HBM: SURVEY 8d counts 2 dots x 192 x 2 flops per
+            # (element, cohort); the kernel issues 2/3 of that (the 64 context sums of d_pr are formed once) on 48 of 37
+            # cohort columns
+            fl = 768.0 * E * C
+            stage_roofs["dot"] = {"bound": "mfma", "kernel": stage_names["dot"], "achieved": fl / (stage_ms["dot"] * 1e-3) / 1e12,
+                                  "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (stage_ms["dot"] * 1e-3) / 78.6e12,
+                                  "traffic": stage_roofs["dot"]["traffic"], "algorithmic_flops_per_launch": fl,
+                                  "avg_launch_ms": stage_ms["dot"], "launches_timed": len(samples["dot"])}
+        d_bytes = b_acc + b_stat + b_suff
+        step_roof = roof("step = dig_scale_factors || dig_element_pipeline (both streams, overlapped)", d_bytes, ms_step,
+                         ["acc_region", "acc_dot", "element_stats_", "suffstats", "scale_factors"], args.steps)
+        dominant_roof = stage_roofs["statistics"] or step_roof
         res = {
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
@@ -399,18 +448,19 @@ def main():
             "config": {"workload": "BASELINE configs[2]: whole genome, %d 10-kb bins, %d cohorts batched, %d elements "
                                    "per GPU, K=192 substitution types, mean %.2f bins/element" % (N, C, E, nbar),
                        "bins": N, "cohorts": C, "elements_per_gpu": E, "parallelism": "elements sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": d_bytes,
-                         "avg_launch_ms": d_ms},
+            "roofline": dominant_roof,
+            "roofline_step": step_roof,
+            "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
                 "main stream": "dig_element_pipeline: acc_region_kernel (contexts + table), acc_dot_mfma_kernel, "
                                "element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
                 "side stream": "scale factors of the next step: suffstats_stage1, suffstats_stage2 (+ all-gather and "
                                "scale_factors_kernel when N > 1)",
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
-            "kernel_timing": "two HIP events on the main stream around the %d timed steps (the streams overlap: the "
-                             "roofline is for the step as a whole; per-kernel durations: profiles/)" % args.steps,
+            "kernel_timing": "HIP events on the main stream (the stream the kernels are launched on): `roofline` and "
+                             "`roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` brackets "
+                             "all %d timed steps (side-stream reduction overlapped); rocprofv3 per-kernel averages of the "
+                             "same command: profiles/" % (SAMPLE_EVERY, args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
         }
         if args.cpu_sample > 0 and world == 1:
