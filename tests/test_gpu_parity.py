@@ -371,6 +371,34 @@ def test_properties_at_baseline_size(torch_dev):
     lower = k_s < mean
     assert torch.allclose(torch.where(lower & (k_s > 0), two + m0, torch.ones_like(m0)), torch.ones_like(m0), rtol=1e-9)
     assert torch.allclose(two[~lower], m0[~lower], rtol=1e-12)
+    # (4) the fused operation bench.py runs (dig_element_pipeline) at full size against the oracle on a random subsample:
+    # 3 000 whole elements through the accumulation, their 111 000 (element, cohort) pairs through the statistics
+    acc2, st2 = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                        td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"],
+                                        td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"])
+    rng = np.random.default_rng(11)
+    es = np.sort(rng.choice(E, 3000, replace=False))
+    lens = (w["ov_ptr"][es + 1] - w["ov_ptr"][es]).astype(np.int64)
+    sub_ptr = np.concatenate([[0], np.cumsum(lens)])
+    sub_idx = np.concatenate([w["ov_idx"][w["ov_ptr"][e]:w["ov_ptr"][e + 1]] for e in es])
+    ref = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], sub_ptr, sub_idx,
+                                w["L"][es], w["strand_minus"][es].astype(bool), w["d_pr"])
+    est = torch.as_tensor(es, device=torch_dev)
+    np.testing.assert_allclose(acc2["MU"][est].cpu().numpy(), ref["MU"], rtol=1e-12)
+    np.testing.assert_allclose(acc2["SIGMA"][est].cpu().numpy(), ref["SIGMA"], rtol=1e-12)
+    np.testing.assert_allclose(acc2["P"][est].cpu().numpy(), ref["P"], rtol=1e-11)
+    np.testing.assert_allclose(acc2["P_INDEL"][est].cpu().numpy(), ref["P_INDEL"], rtol=1e-15)
+    for name in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(acc2[name][est].cpu().numpy(), ref[name]), name
+    ref_st = O.element_stats(ref["MU"], ref["SIGMA"], ref["P"][:, 0, :], ref["P_INDEL"][:, None], w["obs_snv"][es],
+                             w["obs_samples"][es], w["obs_indel"][es], w["cj"][None, :], w["cj_indel"][None, :])
+    for j, name in enumerate(engine.ES_PLANES):
+        got, want_ = st2[j][est].cpu().numpy(), ref_st[name]
+        assert (np.isnan(got) == np.isnan(want_)).all(), name
+        m = np.isfinite(want_) & (np.abs(want_) >= 1e-250)
+        rel = np.abs(got[m] - want_[m]) / np.abs(want_[m])
+        assert rel.max() <= 1e-6, (name, rel.max())           # tolerance contract of DESIGN 5
+        assert (np.abs(got[~m & np.isfinite(want_)]) < 1e-250).all(), name
 
 
 def test_context_counting_matches_reference_golden_and_oracle():
