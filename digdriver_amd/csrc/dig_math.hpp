@@ -619,10 +619,43 @@ __device__ __forceinline__ bool nb_lower_cdf_small(double k, double alpha, doubl
     return true;
 }
 
+// Both tails of nb_pvalue_exact from ONE pass of the scaled recurrence, for the common case (valid alpha, 0 < p < 1,
+// integer 0 <= k <= kSmallK, p^alpha not tiny):  S_k = sum_{j<k} pmf(j) and t_k = pmf(k) come out of the same state, the
+// lower tail I_p(alpha, k + 1) is S_k + t_k and the upper tail I_{1-p}(k, alpha) is 1 - S_k.  One log and one exp per
+// test; without this a wave whose lanes fall on both sides of the mean ran the two tail routines one after the other,
+// each with its own log / exp.  Returns false when the general routines must take over.
+__device__ __forceinline__ bool nb_exact_fast(double k, double alpha, double p, double mu, double* out)
+{
+    if (!(alpha > 0.0 && alpha < __longlong_as_double(0x7ff0000000000000LL) && p >= 2.2250738585072014e-308 && p < 1.0))
+        return false;
+    if (!(k >= 0.0) || k > (double)kSmallK || floor(k) != k) return false;
+    const double lp0 = alpha * fast_log_normal(p);
+    if (!(lp0 > -400.0)) return false;
+    const double x = 1.0 - p;
+    const double t0 = fast_exp_neg_core(lp0);
+    double N = 1.0, A = 0.0, u = alpha * x, jj = 0.0;
+    while (jj < k) pmf_scaled_step_nofact(A, N, u, jj, x);
+    const double rD = t0 * g_inv_factorial[(int)k];
+    const double S = (A * k) * rD;
+    if (k < mu) {
+        *out = S + N * rD;
+        return true;
+    }
+    if (k == 0.0) return false;                // (mean underflowed to 0: betainc(0, ., .) is the general path's business)
+    const double r = 1.0 - S;
+    if (!(r >= kDirectMin)) return false;      // cancellation: the general path sums the tail directly
+    *out = r;
+    return true;
+}
+
 // nb_model.py:298-314 (mu defaults to alpha (1-p)/p)
 __device__ inline double nb_exact(double k, double alpha, double p)
 {
     const double mu = alpha * (1.0 - p) / p;
+    {
+        double r;
+        if (nb_exact_fast(k, alpha, p, mu, &r)) return r;
+    }
     if (k < mu) {
         double s;
         if (nb_lower_cdf_small(k, alpha, p, &s)) return s;

@@ -328,11 +328,13 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     }
 }
 
-__global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restrict__ pt, int pt_per_cohort,
-                                                          const int32_t* __restrict__ k, const double* __restrict__ mu,
-                                                          const double* __restrict__ sigma, double* __restrict__ pval,
-                                                          double* __restrict__ exp_out, int64_t C, int64_t n_bins,
-                                                          int64_t n_tiles)
+// Generic form: any shape, one item per thread and grid-stride step, everything recomputed per item.
+__global__ __launch_bounds__(kBlock) void tiled_nb_generic_kernel(const double* __restrict__ pt, int pt_per_cohort,
+                                                                  const int32_t* __restrict__ k,
+                                                                  const double* __restrict__ mu,
+                                                                  const double* __restrict__ sigma,
+                                                                  double* __restrict__ pval, double* __restrict__ exp_out,
+                                                                  int64_t C, int64_t n_bins, int64_t n_tiles)
 {
     nb_tables_init();
     const int64_t per_cohort = n_bins * n_tiles;
@@ -346,6 +348,63 @@ __global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restri
         const double p = nb_success_prob(ptv, g.theta);   // 1 / (pt * theta + 1), nb_model.py:151
         pval[i] = nb_exact((double)k[i], g.alpha, p);      // :152
         exp_out[i] = mul_rn(ptv, m);                       // :157
+    }
+}
+
+// The shape that matters (200 tiles per 10-kb bin, 10^7..10^9 tiles): a workgroup takes 1024 consecutive tiles per
+// step.  They span a handful of (cohort, bin) rows, whose Gamma parameters (two IEEE divisions each) are formed once,
+// by one thread per row, into LDS; the flat index is split with the host-computed magic multipliers (the two 64-bit
+// divisions of the generic form cost more than the test itself); the four items of a thread are loaded before any of
+// them is evaluated.  Same arithmetic per item, same bits.
+constexpr int kTiledItems = 4;
+constexpr int kTiledChunk = kBlock * kTiledItems;
+constexpr int kTiledRowsMax = 64;     // rows a chunk can touch: n_tiles >= 17  =>  <= 1024 / 17 + 2
+
+__global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restrict__ pt, int pt_per_cohort,
+                                                          const int32_t* __restrict__ k, const double* __restrict__ mu,
+                                                          const double* __restrict__ sigma, double* __restrict__ pval,
+                                                          double* __restrict__ exp_out, int64_t C, int64_t n_bins,
+                                                          int64_t n_tiles, FastDiv div_tiles, FastDiv div_bins)
+{
+    __shared__ double s_alpha[kTiledRowsMax], s_theta[kTiledRowsMax], s_mu[kTiledRowsMax];
+    nb_tables_init();
+    const int64_t per_cohort = n_bins * n_tiles;
+    const int64_t n = C * per_cohort;
+    const int tid = threadIdx.x;
+    for (int64_t chunk0 = (int64_t)blockIdx.x * kTiledChunk; chunk0 < n; chunk0 += (int64_t)gridDim.x * kTiledChunk) {
+        const int64_t last = (chunk0 + kTiledChunk - 1 < n - 1) ? chunk0 + kTiledChunk - 1 : n - 1;
+        const int64_t cb0 = fastdiv(chunk0, div_tiles);
+        const int nrows = (int)(fastdiv(last, div_tiles) - cb0) + 1;
+        if (tid < nrows) {
+            const double m = mu[cb0 + tid];
+            const GammaParams g = normal_params_to_gamma(m, sigma[cb0 + tid]);
+            s_alpha[tid] = g.alpha;
+            s_theta[tid] = g.theta;
+            s_mu[tid] = m;
+        }
+        double ptv[kTiledItems];
+        int kk[kTiledItems], row[kTiledItems];
+#pragma unroll
+        for (int u = 0; u < kTiledItems; ++u) {
+            const int64_t i = chunk0 + u * kBlock + tid;
+            const int64_t ic = i < n ? i : n - 1;
+            const int64_t cb = fastdiv(ic, div_tiles);
+            row[u] = (int)(cb - cb0);
+            const int64_t c = n_bins > 1 ? fastdiv(cb, div_bins) : cb;
+            ptv[u] = pt_per_cohort ? pt[ic] : pt[ic - c * per_cohort];
+            kk[u] = k[ic];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kTiledItems; ++u) {
+            const int64_t i = chunk0 + u * kBlock + tid;
+            if (i < n) {
+                const double p = nb_success_prob(ptv[u], s_theta[row[u]]);   // 1 / (pt * theta + 1), nb_model.py:151
+                pval[i] = nb_exact((double)kk[u], s_alpha[row[u]], p);       // :152
+                exp_out[i] = mul_rn(ptv[u], s_mu[row[u]]);                   // :157
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -648,8 +707,14 @@ int dig_tiled_nb_test(const double* pt, int pt_per_cohort, const int32_t* k, con
     const int64_t n = C * n_bins * n_tiles;
     if (n == 0) return DIG_OK;
     DIG_REQUIRE(pt && k && mu && sigma && pval && exp_out, "non-null pointers");
-    hipLaunchKernelGGL(tiled_nb_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pt,
-                       pt_per_cohort, k, mu, sigma, pval, exp_out, C, n_bins, n_tiles);
+    // fastdiv is exact while i * d < 2^64 (and needs d >= 2): n * n_tiles and (C n_bins) * n_bins stay far below that
+    if (n_tiles >= 17 && n < ((int64_t)1 << 40) && n_bins < ((int64_t)1 << 24))
+        hipLaunchKernelGGL(tiled_nb_kernel, dim3(grid_for(n, kTiledChunk)), dim3(kBlock), 0, (hipStream_t)stream, pt,
+                           pt_per_cohort, k, mu, sigma, pval, exp_out, C, n_bins, n_tiles, make_fastdiv(n_tiles),
+                           make_fastdiv(n_bins));
+    else
+        hipLaunchKernelGGL(tiled_nb_generic_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pt,
+                           pt_per_cohort, k, mu, sigma, pval, exp_out, C, n_bins, n_tiles);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

@@ -318,6 +318,17 @@ def test_tiled_nb_test_vs_oracle(torch_dev):
     pt3 = np.stack([pt, pt * 0.5, pt * 0.25])
     pval3, _ = engine.tiled_nb_test(pt3, k, mu, sigma)
     assert np.array_equal(pval3[0], pval[0], equal_nan=True)
+    # other shapes: few tiles per bin (generic kernel), one bin per cohort, the reference's default 50-position tiles
+    for C, nb, nt in ((2, 7, 5), (2, 1, 17), (1, 300, 50), (5, 33, 1)):
+        mu = rng.gamma(9.0, 3.0, (C, nb))
+        sigma = rng.gamma(4.0, 1.0, (C, nb))
+        pt = rng.dirichlet(np.ones(nt), size=nb)
+        k = rng.poisson(mu[:, :, None] * pt[None] * 1.5).astype(np.int32)
+        pval, ex = engine.tiled_nb_test(pt, k, mu, sigma)
+        for c in range(C):
+            wp, we = O.tiled_nb_test(pt, k[c], mu[c], sigma[c])
+            rel_close(pval[c], wp, RTOL)
+            assert np.array_equal(ex[c], we)
 
 
 # ---------------------------------------------------------------------------------------
