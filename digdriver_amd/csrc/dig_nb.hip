@@ -85,6 +85,7 @@ struct ElementStatsArgs {
     const int32_t* ov_idx;
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
+    int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
 };
 
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
@@ -93,6 +94,7 @@ struct PairRaw {
     double mu, sigma, pi_s, pi_i, mu_i, sigma_i, cj, cji;
     int k_snv, k_smp, k_ind;
     int64_t q0, q1;   // fused pipeline: CSR range of the pair's element (instead of mu, sigma)
+    uint32_t c;       // cohort of the pair
 };
 
 struct PairInputs {
@@ -100,11 +102,10 @@ struct PairInputs {
 };
 
 template <bool FUSED_RATES = false>
-__device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i)
+__device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i, int64_t e, int64_t c)
 {
-    const int64_t e = a.use_fastdiv ? fastdiv(i, a.divC) : i;   // use_fastdiv == 0 only when C == 1
-    const int64_t c = i - e * a.C;
     PairRaw r;
+    r.c = (uint32_t)c;
     if (FUSED_RATES) {
         r.q0 = a.ov_ptr[e];
         r.q1 = a.ov_ptr[e + 1];
@@ -124,6 +125,13 @@ __device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i
     r.mu_i = a.mu_indel ? a.mu_indel[i] : r.mu;
     r.sigma_i = a.mu_indel ? a.sigma_indel[i] : r.sigma;
     return r;
+}
+
+template <bool FUSED_RATES = false>
+__device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i)
+{
+    const int64_t e = a.use_fastdiv ? fastdiv(i, a.divC) : i;   // use_fastdiv == 0 only when C == 1
+    return load_raw<FUSED_RATES>(a, i, e, i - e * a.C);
 }
 
 // Input preparation for one (element, cohort) pair, bit-identical to the reference's numpy
@@ -216,25 +224,58 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
     int64_t tile = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (tile >= n_tiles) return;
-    PairRaw nxt = load_raw<FUSED_RATES>(a, min(tile * 64 + lane, n - 1));
+    // (element, cohort) of a lane's pair: split once by division, then advanced by the wave stride -- n_waves * 64 pairs
+    // = step_e elements and step_c cohorts -- with one conditional carry (the 64-bit multiply-high of a per-tile
+    // division is four quarter-rate integer multiplies).  Lanes past the end replay the last pair (E - 1, C - 1).
+    const int64_t step_pairs = n_waves * 64;
+    const int64_t step_e = a.use_fastdiv ? fastdiv(step_pairs, a.divC) : step_pairs;
+    const uint32_t step_c = (uint32_t)(step_pairs - step_e * a.C);
+    const uint32_t C32 = (uint32_t)a.C;
+    int64_t iu = tile * 64 + lane;                    // unclamped flat index of the NEXT tile's pair
+    int64_t eu = a.use_fastdiv ? fastdiv(iu, a.divC) : iu;
+    uint32_t cu = (uint32_t)(iu - eu * a.C);
+    auto clamped_load = [&]() {
+        const bool past = iu >= n;
+        return load_raw<FUSED_RATES>(a, past ? n - 1 : iu, past ? a.E - 1 : eu, past ? (int64_t)(C32 - 1) : (int64_t)cu);
+    };
+    PairRaw nxt = clamped_load();
     unsigned parked = 0;   // wave-uniform
     for (; tile < n_tiles; tile += n_waves) {
         if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
         const int64_t i_raw = tile * 64 + lane;
         const int64_t i = min(i_raw, n - 1);
         PairRaw cur = nxt;
-        nxt = load_raw<FUSED_RATES>(a, min((tile + n_waves) * 64 + lane, n - 1));
+        iu += step_pairs;
+        eu += step_e;
+        cu += step_c;
+        if (cu >= C32) {
+            cu -= C32;
+            eu += 1;
+        }
+        nxt = clamped_load();
         if (FUSED_RATES) {
-            const int64_t c = i - (a.use_fastdiv ? fastdiv(i, a.divC) : i) * a.C;
             double mu = 0.0, var = 0.0;
             int robs = 0, flag = 0;
-            for (int64_t qq = cur.q0; qq < cur.q1; ++qq) {
-                const int64_t o = (int64_t)a.ov_idx[qq] * a.C + c;
-                const double sd = a.bin_std[o];
-                mu += a.bin_mu[o];
-                var = fma(sd, sd, var);
-                robs += a.bin_y[o];
-                flag |= (a.bin_flag[o] != 0);
+            const int32_t* oi = a.ov_idx + cur.q0;
+            const uint32_t nb = (uint32_t)(cur.q1 - cur.q0);
+            if (a.small_index) {
+                for (uint32_t j = 0; j < nb; ++j) {
+                    const uint32_t o = __umul24((uint32_t)oi[j], C32) + cur.c;   // bin row * C + cohort
+                    const double sd = a.bin_std[o];
+                    mu += a.bin_mu[o];
+                    var = fma(sd, sd, var);
+                    robs += a.bin_y[o];
+                    flag |= (a.bin_flag[o] != 0);
+                }
+            } else {
+                for (uint32_t j = 0; j < nb; ++j) {
+                    const int64_t o = (int64_t)oi[j] * a.C + cur.c;
+                    const double sd = a.bin_std[o];
+                    mu += a.bin_mu[o];
+                    var = fma(sd, sd, var);
+                    robs += a.bin_y[o];
+                    flag |= (a.bin_flag[o] != 0);
+                }
             }
             cur.mu = mu;
             cur.sigma = sqrt(var);
@@ -564,6 +605,7 @@ struct FusedRates {
     const int32_t* ov_idx;
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
+    int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
 };
 
 int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
@@ -584,11 +626,12 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (fused) {
         a.bin_mu = fused->bin_mu; a.bin_std = fused->bin_std; a.bin_y = fused->bin_y; a.bin_flag = fused->bin_flag;
         a.ov_ptr = fused->ov_ptr; a.ov_idx = fused->ov_idx;
         a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
+        a.small_index = fused->small_index;
     }
     if (wl && !worklist_already_zero) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;

@@ -21,6 +21,7 @@ struct FusedRates {
     const int32_t* ov_idx;
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
+    int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
 };
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
@@ -78,7 +79,8 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
         if (rc) return rc;
     }
     if (!(stages & 4)) return DIG_OK;
-    const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG};
+    const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
+    const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index};
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
                                 out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f, 1);
 }
