@@ -467,9 +467,15 @@ def main():
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+    # RCCL writes a version banner to the C stdout of the process, which is block-buffered when stdout is a pipe and would
+    # come out AFTER the result at exit: tear the process group down and flush the C streams first, so that the JSON
+    # line is the last line this process prints.
     if use_dist:
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
