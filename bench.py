@@ -247,6 +247,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        # only rank 0 reports: whatever the other ranks' libraries write to stdout (RCCL's banner) must not land after
+        # rank 0's JSON line
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     # CPU baselines first: the all-core one forks workers, which must happen before this process touches the GPU
