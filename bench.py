@@ -283,17 +283,19 @@ def main():
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
     # the shard's statistics for the scale factors as one [3, C] tensor: row 0 is filled by dig_scale_suffstats each
-    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs).  Two sets, used alternately: the scale
-    # factors of step t+1 are formed on a side stream while the statistics kernels of step t read theirs.  (Set (t+1) % 2
-    # was last read by the statistics of step t-1, which precede step t's context kernel on the main stream -- the event
-    # the side stream waits for -- so no further synchronisation is needed.)
-    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(2)]
+    # step, rows 1-2 hold the observed SNV / indel totals of the cohorts (inputs).  The scale factors of a step depend on
+    # that step's inputs only, so they are formed on a side stream that never waits for the main stream: every step has
+    # its own (tiny: 5 x C doubles) buffer set and its own event, the main stream waits for the event of its step before
+    # the statistics stage.  (With two alternating sets the side stream had to be released by an event recorded on the
+    # main stream; that record is a barrier packet and cost a 7 us bubble per step in front of the dot kernel, and the
+    # reduction, squeezed beside the dot kernel, finished 5 us after it: rocprofv3 kernel trace, 0.301 -> 0.290 ms.)
+    RING = args.steps + args.warmup + 2      # one set of scale-factor buffers per step: the side stream never waits
+    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(RING)]
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
-               for _ in range(2)]
+               for _ in range(RING)]
     main_stream = torch.cuda.current_stream(dev)
     side_stream = torch.cuda.Stream(device=dev, priority=-1)     # own hardware queue even when RCCL holds streams too
-    side_done = [torch.cuda.Event() for _ in range(2)]      # scale factors of a step are ready
-    ctx_done = [torch.cuda.Event() for _ in range(2)]       # the context kernel of a step has finished
+    side_done = [torch.cuda.Event() for _ in range(RING)]   # scale factors of a step are ready
     step_no = [0]
 
     # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
@@ -302,13 +304,11 @@ def main():
                                td["obs_indel"], out_acc=out_acc, out_stats=out_stats)
     scale_plan = engine.ScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"])
 
-    def enqueue_scale_factors(t, after=None):
+    def enqueue_scale_factors(t):
         """Side stream: (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
-        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t % 2."""
-        b = t % 2
+        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t."""
+        b = t % RING
         part, cj_out = parts[b], cj_outs[b]
-        if after is not None:
-            side_stream.wait_event(after)
         with torch.cuda.stream(side_stream):
             if not use_dist:    # nothing to all-gather: sums and divisions come from one pair of kernels
                 scale_plan.run(part[0], cj_out[0], cj_out[1], stream=side_stream)
@@ -335,28 +335,26 @@ def main():
         samples[name].append((a, b_))
 
     def step():
-        # Main stream: (4) the context and dot kernels of dig_element_pipeline (they need no scale factors), wait for (3),
-        # (5) the statistics stage.  The scale factors of the NEXT step are released on the side stream when this step's
-        # context kernel (HBM-bound, like the reduction) is done, so that the reduction runs beside the FP64-MFMA dot
-        # kernel, which leaves HBM idle (same-box A/B: 0.3065 against 0.3125 ms per step without the release event).
-        # All outputs of accumulation and statistics are written every step; every step computes its own scale factors
+        # One step = wait for this step's scale factors (side stream, normally long done) + ONE dig_element_pipeline
+        # call on the main stream: context kernel, dot kernel, statistics stream pass, compacted pass, back to back.  On
+        # the sampled steps the call is split into its stages so that one of them can be bracketed by events.  All
+        # outputs of accumulation and statistics are written every step; every step computes its own scale factors
         # from the bin tables.
         t = step_no[0]
         step_no[0] += 1
-        b = t % 2
-        if queued[0] < t:
-            enqueue_scale_factors(t)
-            queued[0] = t
+        b = t % RING
+        while queued[0] < t + 1:                 # this step's (first call only) and the next step's scale factors
+            queued[0] += 1
+            enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
-        which = sample_slot.get(t % SAMPLE_EVERY) if sampling[0] else None
-        staged("contexts", which, lambda: pipe.run(cj, cji, stages=1, stream=main_stream))   # context kernel (HBM-bound)
-        ctx_done[b].record(main_stream)
-        if queued[0] < t + 1:
-            enqueue_scale_factors(t + 1, after=ctx_done[b])      # ... beside this step's MFMA-bound dot kernel
-            queued[0] = t + 1
-        staged("dot", which, lambda: pipe.run(cj, cji, stages=2, stream=main_stream))        # dot kernel
         main_stream.wait_event(side_done[b])
-        staged("statistics", which, lambda: pipe.run(cj, cji, stages=4, stream=main_stream))  # statistics
+        which = sample_slot.get(t % SAMPLE_EVERY) if sampling[0] else None
+        if which is None:
+            pipe.run(cj, cji, stages=7, stream=main_stream)
+        else:
+            staged("contexts", which, lambda: pipe.run(cj, cji, stages=1, stream=main_stream))    # context kernel
+            staged("dot", which, lambda: pipe.run(cj, cji, stages=2, stream=main_stream))         # dot kernel
+            staged("statistics", which, lambda: pipe.run(cj, cji, stages=4, stream=main_stream))  # statistics
 
     def barrier():
         torch.cuda.synchronize()
@@ -390,7 +388,7 @@ def main():
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
     seq_cj, seq_cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"]) \
-        if not use_dist else cj_outs[(step_no[0] - 1) % 2] + (None,)
+        if not use_dist else cj_outs[(step_no[0] - 1) % RING] + (None,)
     ref_acc, ref_stats = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
                                                  td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
                                                  td["obs_snv"], td["obs_samples"], td["obs_indel"], seq_cj, seq_cji)
@@ -456,10 +454,10 @@ def main():
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
-                "main stream": "dig_element_pipeline: acc_region_kernel (contexts + table), acc_dot_mfma_kernel, "
-                               "element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
-                "side stream": "scale factors of the next step: suffstats_stage1, suffstats_stage2 (+ all-gather and "
-                               "scale_factors_kernel when N > 1)",
+                "main stream": "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
+                               "acc_dot_mfma_kernel, element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
+                "side stream": "scale factors of the coming steps, free-running (own buffers and event per step): "
+                               "suffstats_stage1, suffstats_stage2 (+ all-gather and scale_factors_kernel when N > 1)",
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
             "kernel_timing": "HIP events on the main stream (the stream the kernels are launched on): `roofline` and "
                              "`roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` brackets "
