@@ -52,6 +52,32 @@ def test_nb_midp_upper_golden_host_and_device(torch_dev):
     assert e[1] == 0.5 and e[2] == 0.0 and np.isnan(e[3]) and np.isnan(e[4]) and np.isnan(e[5])
 
 
+def test_nb_wide_parameter_sweep_vs_scipy(torch_dev):
+    """Far outside the workload's ranges: alpha 1e-3 .. 1e6, p 1e-9 .. 1 - 1e-12, k 0 .. 1e5 (fast recurrence, rescaled
+    recurrence, tail series and the lgamma + continued-fraction fallback all get traffic), against the scipy expressions the
+    reference evaluates (oracle), under the tolerance contract."""
+    from digdriver_amd.sequence_model import nb_model
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(77)
+    n = 120_000
+    alpha = 10.0 ** rng.uniform(-3, 6, n)
+    p = np.where(rng.uniform(size=n) < 0.5, 10.0 ** rng.uniform(-9, 0, n), 1.0 - 10.0 ** rng.uniform(-12, 0, n))
+    p = np.clip(p, 1e-9, 1.0)
+    mean = alpha * (1 - p) / p
+    kind = rng.integers(0, 4, n)
+    with np.errstate(all="ignore"):
+        k = np.where(kind == 0, rng.poisson(np.minimum(mean, 5e4)),                       # near the mean
+            np.where(kind == 1, np.floor(np.minimum(mean, 2e4) * rng.uniform(1, 6, n) + rng.integers(0, 30, n)),   # upper tail
+            np.where(kind == 2, rng.integers(0, 70, n), rng.integers(0, 100_000, n)))).astype(float)
+    with np.errstate(all="ignore"):
+        want = O.nb_pvalue_greater_midp(k, alpha, p)
+    got = nb_model.nb_pvalue_greater_midp(k, alpha, p)
+    rel_close(got, want, RTOL)
+    with np.errstate(all="ignore"):
+        rel_close(nb_model.nb_pvalue_exact(k, alpha, p), O.nb_pvalue_exact(k, alpha, p), RTOL)
+        rel_close(nb_model.nb_pvalue_greater(k, alpha, p), O.nb_pvalue_greater(k, alpha, p), RTOL)
+
+
 def test_nb_scalar_siblings_golden(torch_dev):
     from digdriver_amd.sequence_model import nb_model
     d = np.load(os.path.join(GOLDEN, "nb_exact_golden.npz"))
