@@ -211,7 +211,12 @@ static int launch_acc_v1(const AccArgs& a, hipStream_t stream)
 //   acc_dot_mfma_kernel  the [E x 256] x [256 x C] FP64 product on the matrix cores, quotient and element sizes.
 // =======================================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int kMfmaWaves = 8;                 // waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS)
+#ifndef DIG_MFMA_WAVES
+#define DIG_MFMA_WAVES 12
+#endif
+// waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS): three per SIMD hide the LDS / HBM waits better
+// than two (127.7 -> 124.2 us per accumulate call); four would cap the kernel at 128 VGPRs and spill
+constexpr int kMfmaWaves = DIG_MFMA_WAVES;
 constexpr int kMfmaSteps = 64;                // 256 K rows / 4
 constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
 
@@ -290,17 +295,49 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
         }
     }
 
+    // phase B, software-pipelined over the wave's quads: the chain CSR bounds -> bin indices -> context rows is three
+    // dependent memory latencies, and a wave has only three or four quads; so while the rows of quad t are in flight the
+    // bin indices of quad t + nwaves and the CSR bounds of quad t + 2 nwaves are requested (first two bins of an element
+    // ahead of time; further bins, rare, in the plain loop).
     const int sub = lane >> 4, l16 = lane & 15;
     const int4* ctx4 = reinterpret_cast<const int4*>(bin_ctx);
     const int64_t n_quads = (E + 3) >> 2;
-    for (int64_t t = wave0; t < n_quads; t += nwaves) {
+    struct Bounds { int64_t q0, q1; int minus; };
+    struct First { int i0, i1; };
+    auto load_bounds = [&](int64_t t) {
+        Bounds r{0, 0, 0};
         const int64_t e = t * 4 + sub;
-        if (e < E) {   // uniform within each 16-lane group
-            const int64_t q0 = ov_ptr[e], q1 = ov_ptr[e + 1];
-            int minus = strand_minus[e];           // requested with the CSR bounds, consumed after the bin loop
-            asm volatile("" : "+v"(minus));        // (keeps the compiler from sinking the load below the loop)
+        if (t < n_quads && e < E) {   // uniform within each 16-lane group
+            r.q0 = ov_ptr[e];
+            r.q1 = ov_ptr[e + 1];
+            r.minus = strand_minus[e];
+        }
+        return r;
+    };
+    auto load_first = [&](const Bounds& r) {
+        First f{-1, -1};
+        if (r.q1 > r.q0) f.i0 = ov_idx[r.q0];
+        if (r.q1 > r.q0 + 1) f.i1 = ov_idx[r.q0 + 1];
+        return f;
+    };
+    int64_t t = wave0;
+    Bounds b0 = load_bounds(t), b1 = load_bounds(t + nwaves);
+    First f0 = load_first(b0);
+    for (; t < n_quads; t += nwaves) {
+        const Bounds b2 = load_bounds(t + 2 * nwaves);
+        const First f1 = load_first(b1);
+        const int64_t e = t * 4 + sub;
+        if (e < E) {
             int4 acc = make_int4(0, 0, 0, 0);
-            for (int64_t q = q0; q < q1; ++q) {
+            if (f0.i0 >= 0) {
+                const int4 v = ctx4[(int64_t)f0.i0 * 16 + l16];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (f0.i1 >= 0) {
+                const int4 v = ctx4[(int64_t)f0.i1 * 16 + l16];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            for (int64_t q = b0.q0 + 2; q < b0.q1; ++q) {
                 const int4 v = ctx4[(int64_t)ov_idx[q] * 16 + l16];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (l16 == 0) R_SIZE[e] = s;                              // genic_driver_tools.py:375
-            if (!minus) {
+            if (!b0.minus) {
                 reinterpret_cast<int4*>(rcp)[e * 16 + l16] = acc;
             } else {                                                  // sequence_tools.py:633-634
                 int32_t* row = rcp + e * 64;
@@ -319,6 +356,9 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
                 row[revcomp_ctx(c0 + 3)] = acc.w;
             }
         }
+        b0 = b1;
+        b1 = b2;
+        f0 = f1;
     }
 }
 
@@ -362,7 +402,7 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 }
 
 template <int NCLASS, int NT>
-__global__ __launch_bounds__(kMfmaWaves * 64, 3) void acc_dot_mfma_kernel(
+__global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
     const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
     const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
     int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
@@ -371,16 +411,18 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 3) void acc_dot_mfma_kernel(
     {
         // stage this chunk's NT tiles of the pre-swizzled table (global layout: 3 tiles per step); all loads of a
         // thread are issued before its first LDS write
-        constexpr int kPer = (kMfmaSteps * NT * 64) / (kMfmaWaves * 64);   // 4 * NT doubles per thread
+        constexpr int kTotal = kMfmaSteps * NT * 64;
+        constexpr int kPer = (kTotal + kMfmaWaves * 64 - 1) / (kMfmaWaves * 64);   // doubles per thread
         double v[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int idx = threadIdx.x + k * kMfmaWaves * 64;
             const int lane_ = idx & 63, nt = (idx >> 6) % NT, step = idx / (NT * 64);
-            v[k] = tab_g[(step * 3 + nt) * 64 + lane_];
+            v[k] = idx < kTotal ? tab_g[(step * 3 + nt) * 64 + lane_] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) tab[threadIdx.x + k * kMfmaWaves * 64] = v[k];
+        for (int k = 0; k < kPer; ++k)
+            if (threadIdx.x + k * kMfmaWaves * 64 < kTotal) tab[threadIdx.x + k * kMfmaWaves * 64] = v[k];
     }
     __syncthreads();
 
