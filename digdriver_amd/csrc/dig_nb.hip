@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void element_stats_single_pass_kernel(Eleme
     a.out[6 * n + i] = fisher_combine_fast(pv_snv, pv_ind);
 }
 
-// Pass 1, streaming form (used whenever a worklist is available): a persistent grid of 8 waves per SIMD, each wave
+// Pass 1, streaming form (used whenever a worklist is available): a persistent grid of 5 or 6 workgroups per CU, each wave
 // walking 64-pair tiles with stride n_waves.  Profiling the one-shot form showed its waves spending two thirds of
 // their life in s_waitcnt (input loads at the start, the worklist atomic's round trip at the end) with 5.3 of 8
 // wave slots filled on average, i.e. a latency problem, not an arithmetic one.  Here
