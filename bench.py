@@ -232,8 +232,8 @@ def cpu_baseline_all_cores(w, want_seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--bins", type=int, default=288_000)
     ap.add_argument("--elements", type=int, default=120_091)
     ap.add_argument("--cohorts", type=int, default=37)
