@@ -206,7 +206,7 @@ int dig_scale_factors_local(const double *bin_mu, const uint8_t *bin_flag, int64
  * count_sequence_context over fetch_sequence (sequence_model/sequence_tools.py:21-29,42-55,65-80), for a batch of
  * regions: count_contexts_by_regions (:82-99), nonc_elt_context_count (:527-566), DIG_onthefly
  * (driver_model/onthefly_tools.py:70-71,120).
- *   genome_words u32 [n_words]: 4 bits per base (A=0 C=1 G=2 T=3, anything else 4), 8 bases per word, base 0 in the
+ *   genome_words u32 [n_words], 16-byte aligned (device entry point): 4 bits per base (A=0 C=1 G=2 T=3, anything else 4), 8 bases per word, base 0 in the
  *       low nibble; word 0 and word n_words-1 are all-N pad words; chromosome c occupies bases
  *       chrom_off[c] .. chrom_off[c] + chrom_len[c] - 1 counted from word 1, chrom_off[c] % 8 == 0.
  *   region r: centre positions max(start, 1) .. min(end, chrom_len - 1) - 1 of chromosome reg_chrom[r] (the fetch is
