@@ -489,7 +489,9 @@ def test_element_pipeline_equals_separate_calls(torch_dev):
     import torch
     from bench import make_workload
     from digdriver_amd import engine
-    for (nb, E, C, seed) in ((3000, 2500, 5, 1), (900, 700, 37, 2), (400, 333, 1, 3)):
+    # cohort counts on both sides of the dot kernel's 16-column tiles and 48-cohort chunks
+    for (nb, E, C, seed) in ((3000, 2500, 5, 1), (900, 700, 37, 2), (400, 333, 1, 3), (1200, 1000, 49, 4), (500, 450, 17, 5),
+                             (300, 260, 100, 6), (200, 7, 48, 7)):
         w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
         td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
         # make a few pairs take the compacted pass and a few be degenerate
