@@ -377,6 +377,7 @@ def main():
         step()
     sampling[0] = False
     ev_end.record(main_stream)
+    host_enqueue_s = time.perf_counter() - t0        # the host's share: enqueueing K steps (it must stay below dt)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -464,6 +465,7 @@ def main():
                              "all %d timed steps (side-stream reduction overlapped); rocprofv3 per-kernel averages of the "
                              "same command: profiles/" % (SAMPLE_EVERY, args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
+            "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
         }
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
