@@ -325,10 +325,18 @@ def main():
     samples = {"contexts": [], "dot": [], "statistics": []}
     sampling = [False]
 
+    # every event of the run exists before the loop starts (HIP creates the object behind a torch event at its first
+    # record, and a growing pool of them costs a one-off stall of tens of milliseconds at some point of the loop)
+    n_sample_events = 2 * (3 * ((args.steps + args.warmup) // SAMPLE_EVERY + 2))
+    sample_events = [torch.cuda.Event(enable_timing=True) for _ in range(n_sample_events)]
+    for e in side_done + sample_events:
+        e.record(main_stream)
+    torch.cuda.synchronize()
+
     def staged(name, which, fn):
         if which != name:
             return fn()
-        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a, b_ = sample_events.pop(), sample_events.pop()
         a.record(main_stream)
         fn()
         b_.record(main_stream)
