@@ -445,8 +445,9 @@ __global__ __launch_bounds__(kBlock) void tiled_nb_kernel(const double* __restri
             const int64_t i = chunk0 + u * kBlock + tid;
             if (i < n) {
                 const double p = nb_success_prob(ptv[u], s_theta[row[u]]);   // 1 / (pt * theta + 1), nb_model.py:151
-                pval[i] = nb_exact((double)kk[u], s_alpha[row[u]], p);       // :152
-                exp_out[i] = mul_rn(ptv[u], s_mu[row[u]]);                   // :157
+                // (written once, read by nobody on the device: non-temporal)
+                __builtin_nontemporal_store(nb_exact((double)kk[u], s_alpha[row[u]], p), &pval[i]);       // :152
+                __builtin_nontemporal_store(mul_rn(ptv[u], s_mu[row[u]]), &exp_out[i]);                   // :157
             }
         }
         __syncthreads();
