@@ -181,3 +181,6 @@ def test_run_element_region_model_end_to_end(_gpu, tmp_path):
               'PVAL_MUT_BURDEN'):
         rel_close(a[c].values, want[c], 1e-6)
     assert a.OBS_SNV.sum() > 0 and a.OBS_INDEL.sum() > 0 and (a.OBS_SAMPLES <= a.OBS_SNV + a.OBS_INDEL).all()
+    # the reference's key guard (transfer_tools.py:1020-1021): PCAWG_cds scaling needs the PCAWG_cds model
+    with pytest.raises(AssertionError):
+        tt.run_element_region_model(str(mut), str(bed), path, "my_elts", scale_by_expectation=False, scale_type="PCAWG_cds")

@@ -179,3 +179,21 @@ def test_sequence_model_matches_reference():
             want[s] += 1
     assert got == want
     assert st.reverse_complement("AACGN") == "NCGTT"
+
+
+def test_element_data_needs_matching_window_size(tmp_path):
+    """sequence_tools.py:476: the genome-wide window counts an element-data container is started from must be on the
+    requested window size."""
+    import pandas as pd
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.sequence_model import sequence_tools
+    gc, ed = str(tmp_path / "genome_counts"), str(tmp_path / "element_data")
+    idx = np.array([[1, 0, 10000], [1, 10000, 20000]], np.int32)
+    frame = pd.DataFrame(np.ones((2, 64), np.int64), index=["chr1:0-10000", "chr1:10000-20000"],
+                         columns=sequence_tools.mk_context_idx() if hasattr(sequence_tools, "mk_context_idx") else None)
+    mapfile.write_array(gc, "idx", idx)
+    mapfile.write_frame(gc, "all_window_genome_counts", frame)
+    with pytest.raises(AssertionError):
+        sequence_tools.initialize_nonc_data(ed, gc, 5000)
+    sequence_tools.initialize_nonc_data(ed, gc, 10000)
+    assert mapfile.has_key(ed, "window_10000/full_window_si_values") and mapfile.has_key(ed, "substitution_idx")
