@@ -302,7 +302,12 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
         DIG_STREAM_STORE(&a.out[3 * n + i], q.theta_i);
         DIG_STREAM_STORE(&a.out[4 * n + i], q.exp_ind);
         DIG_STREAM_STORE(&a.out[5 * n + i], pv_ind);
-        DIG_STREAM_STORE(&a.out[6 * n + i], fisher_combine_fast(pv_snv, pv_ind));
+        // (a parked pair has placeholder zeros here: without the guard its lane sends the whole wave through the
+        // library log / exp fallback of the combination -- 58 % of the tiles hold such a lane -- for a value the
+        // compacted pass overwrites anyway)
+        double pv_mut = 0.0;
+        if (!slow) pv_mut = fisher_combine_fast(pv_snv, pv_ind);
+        DIG_STREAM_STORE(&a.out[6 * n + i], pv_mut);
     }
     if (parked) park_flush(a.worklist, park, parked, lane);
 }
