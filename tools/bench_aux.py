@@ -97,6 +97,31 @@ def main():
     out["count_contexts"] = [{"windows": nwin, "window_bp": window, "bases": nbases, "ms": dt * 1e3,
                               "bases_per_s": nbases / dt, "algorithmic_GBps": by / dt / 1e9,
                               "frac_hbm_peak": by / dt / HBM_PEAK, "total_counted": int(res.sum(dtype=torch.int64).item())}]
+    # ---- f1: mutation x element-block interval join (dig_overlap_join_count / fill) ----------------------------------
+    del words, res
+    torch.cuda.empty_cache()
+    from digdriver_amd.data_tools import tabulate_gpu
+    rng = np.random.default_rng(7)
+    n_blk, n_mut = 360_000, 20_000_000                      # 120 k elements x 3 blocks; 37 cohorts x ~5e5 mutations
+    per_chrom = 130_000_000
+    b_chrom = rng.integers(1, 23, n_blk)
+    b_start = rng.integers(0, per_chrom, n_blk)
+    b_end = b_start + rng.integers(200, 3000, n_blk)
+    blocks = tabulate_gpu.ElementBlocks(b_chrom, b_start, b_end, np.arange(n_blk) // 3, n_blk // 3, dev)
+    m_chrom = torch.randint(1, 23, (n_mut,), dtype=torch.int64, device=dev, generator=g)
+    m_start = torch.randint(0, per_chrom, (n_mut,), dtype=torch.int64, device=dev, generator=g)
+    m_end = m_start + 1
+    pairs = [0]
+
+    def run_join():
+        pm, pb = tabulate_gpu.overlap_pairs(blocks, m_chrom, m_start, m_end)
+        pairs[0] = pm.numel()
+    dt = timeit(run_join, n=3, warm=1)
+    by = n_mut * 24.0 + pairs[0] * 8.0
+    out["overlap_join"] = [{"mutations": n_mut, "blocks": n_blk, "pairs": pairs[0], "ms": dt * 1e3,
+                            "mutations_per_s": n_mut / dt, "algorithmic_GBps": by / dt / 1e9,
+                            "note": "count + prefix sum + fill; two binary searches over the block keys per mutation "
+                                    "(latency-bound, not HBM-bound)"}]
     print(json.dumps(out))
 
 
