@@ -122,6 +122,25 @@ def main():
                             "mutations_per_s": n_mut / dt, "algorithmic_GBps": by / dt / 1e9,
                             "note": "count + prefix sum + fill; two binary searches over the block keys per mutation "
                                     "(latency-bound, not HBM-bound)"}]
+    # the whole observed-count tabulation (join + de-duplication + per-(element, sample) counts + [E, C] planes)
+    n_coh, per = 37, n_mut // 37
+    cohorts = []
+    for c in range(n_coh):
+        sl = slice(c * per, (c + 1) * per)
+        cohorts.append(dict(chrom=m_chrom[sl], start=m_start[sl], end=m_end[sl],
+                            uid=torch.arange(per, dtype=torch.int64, device=dev),
+                            sample=torch.randint(0, 500, (per,), dtype=torch.int64, device=dev, generator=g),
+                            indel=(torch.rand(per, device=dev, generator=g) < 0.08).long(),
+                            cohort=torch.full((per,), c, dtype=torch.int64, device=dev),
+                            sample_names=["S%d" % j for j in range(500)]))
+    tot = [0]
+
+    def run_tab():
+        o1, o2, o3, _ = tabulate_gpu.tabulate_cohorts(blocks, cohorts)
+        tot[0] = int(o1.sum().item() + o3.sum().item())
+    dt = timeit(run_tab, n=3, warm=1)
+    out["tabulate_cohorts"] = [{"cohorts": n_coh, "mutations": n_coh * per, "elements": blocks.n_elements,
+                                "counted": tot[0], "ms": dt * 1e3, "mutations_per_s": n_coh * per / dt}]
     print(json.dumps(out))
 
 
