@@ -26,6 +26,65 @@ def _softplus_inv(v):
     return math.log(math.expm1(v))
 
 
+def _lower_solve(L, B):
+    """L^-1 B for a lower-triangular [m, m] factor and a wide [m, n] right-hand side.  With n in the hundreds of thousands
+    (the 150 000-row training cap of gp_trainer.py:55) rocBLAS' trsm cannot allocate its workspace
+    (HIPBLAS_STATUS_ALLOC_FAILED); the m x m inverse is formed by one small triangular solve instead and applied as a
+    GEMM, which is also what the MFMA units are good at.  m <= a few thousand and the factor carries jitter, so the
+    explicit inverse is harmless in FP64."""
+    if B.shape[-1] <= 4096:
+        return torch.linalg.solve_triangular(L, B, upper=False)
+    Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
+    return _WideMatmul.apply(Linv, B)
+
+
+def _outer_wide(X, Y, chunks=64):
+    """X @ Y.T for two [m, n] matrices with n >> m.  The product has only (m / 128)^2 output tiles, so a plain GEMM keeps a
+    dozen of the 256 CUs busy (measured: 48 GFLOP in 24 ms); splitting the long dimension into batched products and
+    summing them fills the chip."""
+    m, n = X.shape
+    if n < 8192:
+        return X @ Y.T
+    pad = (-n) % chunks
+    if pad:
+        X = torch.nn.functional.pad(X, (0, pad))
+        Y = torch.nn.functional.pad(Y, (0, pad))
+    Xc = X.view(m, chunks, -1).transpose(0, 1)           # [chunks, m, n / chunks]
+    Yc = Y.view(Y.shape[0], chunks, -1).transpose(0, 1)
+    return torch.bmm(Xc, Yc.transpose(1, 2)).sum(0)
+
+
+class _WideMatmul(torch.autograd.Function):
+    """S @ K for a small [m, m] S and a wide [m, n] K: the gradient with respect to S is a long-dimension product too."""
+
+    @staticmethod
+    def forward(ctx, S, K):
+        ctx.save_for_backward(S, K)
+        return S @ K
+
+    @staticmethod
+    def backward(ctx, g):
+        S, K = ctx.saved_tensors
+        return _outer_wide(g, K), S.T @ g
+
+
+class _CrossTerm(torch.autograd.Function):
+    """a @ b.T for a small [m, d] a (the inducing points) and a long [n, d] b (the training rows): the gradient with
+    respect to a is g[m, n] @ b -- 150 000 deep with a 400 x 16 result, one workgroup's worth of output for a plain GEMM."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a @ b.T
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = _outer_wide(g, b.T.contiguous()) if ctx.needs_input_grad[0] else None
+        db = g.T @ a if ctx.needs_input_grad[1] else None
+        return da, db
+
+
 class SparseGP(torch.nn.Module):
     """SGPR with learnable inducing locations."""
 
@@ -43,7 +102,7 @@ class SparseGP(torch.nn.Module):
     noise = property(lambda self: torch.nn.functional.softplus(self.raw_noise) + 1e-4)
 
     def kernel(self, a, b):
-        d2 = (a * a).sum(-1, keepdim=True) - 2.0 * a @ b.T + (b * b).sum(-1)[None, :]
+        d2 = (a * a).sum(-1, keepdim=True) - 2.0 * _CrossTerm.apply(a, b) + (b * b).sum(-1)[None, :]
         return self.outputscale * torch.exp(-0.5 * d2.clamp_min(0.0) / self.lengthscale ** 2)
 
     def _factor(self):
@@ -52,8 +111,8 @@ class SparseGP(torch.nn.Module):
         Kmm = self.kernel(Z, Z) + _JITTER * self.outputscale.detach() * torch.eye(m, dtype=Z.dtype, device=Z.device)
         L = torch.linalg.cholesky(Kmm)
         sig = torch.sqrt(self.noise)
-        A = torch.linalg.solve_triangular(L, self.kernel(Z, X), upper=False) / sig        # [m, n]
-        B = torch.eye(m, dtype=Z.dtype, device=Z.device) + A @ A.T
+        A = _lower_solve(L, self.kernel(Z, X)) / sig        # [m, n]
+        B = torch.eye(m, dtype=Z.dtype, device=Z.device) + _outer_wide(A, A)
         LB = torch.linalg.cholesky(B)
         r = self.train_y - self.mean_const
         c = torch.linalg.solve_triangular(LB, (A @ r)[:, None], upper=False)[:, 0] / sig
@@ -75,8 +134,8 @@ class SparseGP(torch.nn.Module):
         means, stds = [], []
         for s in range(0, x.shape[0], chunk):
             xs = x[s:s + chunk]
-            t1 = torch.linalg.solve_triangular(L, self.kernel(self.inducing_points, xs), upper=False)
-            t2 = torch.linalg.solve_triangular(LB, t1, upper=False)
+            t1 = _lower_solve(L, self.kernel(self.inducing_points, xs))
+            t2 = _lower_solve(LB, t1)
             means.append(self.mean_const + t2.T @ c)
             var = self.outputscale - (t1 * t1).sum(0) + (t2 * t2).sum(0)
             stds.append(torch.sqrt(var.clamp_min(0.0)))

@@ -197,3 +197,33 @@ def test_element_data_needs_matching_window_size(tmp_path):
         sequence_tools.initialize_nonc_data(ed, gc, 5000)
     sequence_tools.initialize_nonc_data(ed, gc, 10000)
     assert mapfile.has_key(ed, "window_10000/full_window_si_values") and mapfile.has_key(ed, "substitution_idx")
+
+
+def test_sgpr_long_dimension_products_match_plain_matmuls():
+    """The split products the SGPR uses when the training set is long (gp_trainer._outer_wide, _WideMatmul, _CrossTerm,
+    _lower_solve) against plain matmuls / triangular solves, values and gradients."""
+    import torch
+    from digdriver_amd.region_model.trainers import gp_trainer as G
+    torch.manual_seed(0)
+    m, n, d = 12, 9001, 5                                  # n above the thresholds and not a multiple of the chunk count
+    X = torch.randn(m, n, dtype=torch.float64, requires_grad=True)
+    Y = torch.randn(m, n, dtype=torch.float64, requires_grad=True)
+    a = G._outer_wide(X, Y)
+    b = X @ Y.T
+    assert torch.allclose(a, b, rtol=1e-12, atol=1e-10)
+    ga = torch.autograd.grad(a.square().sum(), (X, Y))
+    gb = torch.autograd.grad(b.square().sum(), (X, Y))
+    assert all(torch.allclose(u, v, rtol=1e-10, atol=1e-8) for u, v in zip(ga, gb))
+    S = torch.randn(m, m, dtype=torch.float64, requires_grad=True)
+    w1, w2 = G._WideMatmul.apply(S, X), S @ X
+    assert torch.equal(w1, w2)
+    g1 = torch.autograd.grad((w1 * Y.detach()).sum(), (S, X))
+    g2 = torch.autograd.grad((w2 * Y.detach()).sum(), (S, X))
+    assert all(torch.allclose(u, v, rtol=1e-10, atol=1e-8) for u, v in zip(g1, g2))
+    Z = torch.randn(m, d, dtype=torch.float64, requires_grad=True)
+    T = torch.randn(n, d, dtype=torch.float64)
+    c1, c2 = G._CrossTerm.apply(Z, T), Z @ T.T
+    assert torch.equal(c1, c2)
+    assert torch.allclose(torch.autograd.grad(c1.sin().sum(), Z)[0], torch.autograd.grad(c2.sin().sum(), Z)[0], rtol=1e-10, atol=1e-8)
+    L = torch.linalg.cholesky(torch.eye(m, dtype=torch.float64) * 3 + 0.1 * (S.detach() @ S.detach().T))
+    assert torch.allclose(G._lower_solve(L, X.detach()), torch.linalg.solve_triangular(L, X.detach(), upper=False), rtol=1e-10, atol=1e-10)
