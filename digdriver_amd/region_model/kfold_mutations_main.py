@@ -177,7 +177,7 @@ def main(input_args=None):
                 torch.save(best['model'].state_dict(), os.path.join(out_dir, 'best_model_fold_{}.pt'.format(k)))
                 np.save(os.path.join(out_dir, 'val_indices_fold_{}'.format(k)), val_rows)
             if args.run_gaussian > 0:
-                ho_pred, ho_feat, ho_acc = predict(best['model'], data.store, ho_rows, labels=data.labels, fold_bn=False)
+                ho_pred, ho_feat, ho_acc = predict(best["model"], data.store, ho_rows, labels=data.labels)
                 print('Model held-out accuracy: {}'.format(ho_acc))
                 C = len(args.label_ids)
                 ho = dict(feat=[ho_feat[c] for c in range(C)], lbls=[data.labels[c][ho_rows] for c in range(C)],
@@ -190,7 +190,7 @@ def main(input_args=None):
                     summary.append(scores)
                     if args.sub_mapp and len(data.below_mapp):
                         sub_rows = np.asarray(data.below_mapp)
-                        _, sub_feat, _ = predict(best['model'], data.store, sub_rows, fold_bn=False)
+                        _, sub_feat, _ = predict(best["model"], data.store, sub_rows)
                         sub = dict(feat=[sub_feat[c] for c in range(C)], lbls=[data.labels[c][sub_rows] for c in range(C)],
                                    meta=data.meta(sub_rows))
                         run_gp_fold(args, device, os.path.join(out_dir, 'sub_mapp_results_fold_{}'.format(k)), args.label_ids,
