@@ -23,13 +23,18 @@ def predict(model, store, bin_rows, labels=None, batch_size=2048, fold_bn=True, 
     arrives channels-first straight from dig_gather_bins."""
     net = model.fold_batchnorm() if fold_bn and not getattr(model, "_folded", False) else model
     net = net.eval()
+    if dtype != next(net.parameters()).dtype:          # reduced-precision inference: a converted copy, never the caller's model
+        import copy
+        net = (copy.deepcopy(net) if net is model else net).to(dtype)
+        net._gw = None
     dev = next(net.parameters()).device
     bin_rows = np.asarray(bin_rows)
     preds, feats = [], []
     use_gemm = getattr(net, "_folded", False) and not net.get_attention_maps
     for s in range(0, len(bin_rows), batch_size):
         # GEMM path consumes the row-major (channels-last) batch directly; the conv path wants channels-first
-        xb = store.batch(bin_rows[s:s + batch_size], channels_first=not use_gemm)
+        xb = store.batch(bin_rows[s:s + batch_size], channels_first=not use_gemm,
+                         out_dtype="bf16" if dtype == torch.bfloat16 else "f32")
         if xb.device != dev:
             xb = xb.to(dev)
         out, fv, _ = net.forward_gemm(xb.to(dtype)) if use_gemm else net.forward_channels_first(xb.to(dtype))

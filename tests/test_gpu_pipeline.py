@@ -40,6 +40,12 @@ def test_gather_plus_cnn_predict_matches_cpu_reference():
     assert torch.equal(store16.batch(rows), store.batch(rows))             # the gathered batch is bit-identical
     preds16, _, _ = predict(net, store16, rows, batch_size=64)
     np.testing.assert_allclose(preds16, preds, rtol=1e-4, atol=1e-5)       # MIOpen may pick another conv algorithm
+    # reduced-precision inference (bf16 weights and activations; an option, the parity path is fp32): same shapes, close
+    # values, and the caller's model is left in fp32
+    pb, fb, _ = predict(net, store16, rows, batch_size=64, dtype=torch.bfloat16)
+    assert pb.shape == preds.shape and fb.shape == feats.shape and np.isfinite(pb).all()
+    assert np.abs(pb - preds).max() <= 0.05 * np.abs(preds).max() + 0.05
+    assert next(net.parameters()).dtype == torch.float32
 
 
 def test_cli_pretrain_then_driver(tmp_path):
