@@ -113,6 +113,14 @@ def main():
     t6 = time.time()
     both = one.index.intersection(f0.index)
     assert len(both) == a.elements and np.array_equal(one.loc[both].OBS_SNV.values.astype(int), f0.loc[both].OBS_SNV.values.astype(int))
+    # quickDriver (driver_model/onthefly_tools.DIG_onthefly): everything from the FASTA, no element-data container
+    from digdriver_amd.driver_model import onthefly_tools
+    t7 = time.time()
+    quick = onthefly_tools.DIG_onthefly(pres[0], muts[0], fa, f_elts_bed=bed, scale_factor=1.0, scale_factor_indel=1.0,
+                                        scale_by_expectation=False)
+    t8 = time.time()
+    assert len(quick) == a.elements and np.isfinite(quick.PVAL_SNV_BURDEN.values.astype(float)).all()
+    print("quickDriver, cohort 0: %.1f s" % (t8 - t7))
     print("per-cohort route, cohort 0: nonc_model_parallel %.1f s, run_element_region_model %.1f s" % (t5 - t4, t6 - t5))
     print("inputs written %.1f s | context counting + element data %.1f s | run_element_cohorts (%d cohorts x %d elements, "
           "%d mutations) %.1f s" % (t1 - t0, t2 - t1, a.cohorts, a.elements, a.cohorts * a.muts_per_cohort, t3 - t2))
