@@ -438,6 +438,38 @@ def test_properties_at_baseline_size(torch_dev):
         assert (np.abs(got[~m & np.isfinite(want_)]) < 1e-250).all(), name
 
 
+def test_genic_accumulation_at_gene_set_size(torch_dev):
+    """genic_model's four mutation classes (n_class = 4, P_INDEL from the gene length) at the size of the reference's gene
+    list (20 091 genes x 37 cohorts on the 288 000-bin grid) against the oracle on a random subsample."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    E, C = 20091, 37
+    w = make_workload(288_000, E, C, seed=5)
+    rng = np.random.default_rng(1)
+    L1 = w["L"].reshape(E, -1)[:, :192]
+    L4 = np.ascontiguousarray(np.stack([L1] + [rng.poisson(L1 * f).astype(np.int32) for f in (0.7, 0.2, 0.1)], axis=1))
+    glen = rng.integers(300, 9000, E).astype(np.int32)
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                     td["ov_idx"], torch.as_tensor(L4, device=torch_dev), td["strand_minus"], td["d_pr"],
+                                     gene_length=torch.as_tensor(glen, device=torch_dev))
+    es = np.sort(rng.choice(E, 800, replace=False))
+    lens = (w["ov_ptr"][es + 1] - w["ov_ptr"][es]).astype(np.int64)
+    sub_ptr = np.concatenate([[0], np.cumsum(lens)])
+    sub_idx = np.concatenate([w["ov_idx"][w["ov_ptr"][e]:w["ov_ptr"][e + 1]] for e in es])
+    ref = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], sub_ptr, sub_idx, L4[es],
+                                w["strand_minus"][es].astype(bool), w["d_pr"], gene_length=glen[es])
+    est = torch.as_tensor(es, device=torch_dev)
+    assert acc["P"].shape == (E, 4, C)
+    np.testing.assert_allclose(acc["P"][est].cpu().numpy(), ref["P"], rtol=1e-11)
+    np.testing.assert_allclose(acc["MU"][est].cpu().numpy(), ref["MU"], rtol=1e-12)
+    np.testing.assert_allclose(acc["P_INDEL"][est].cpu().numpy(), ref["P_INDEL"], rtol=1e-15)
+    for name in ("ELT_SIZE", "R_SIZE", "R_OBS", "FLAG"):
+        assert np.array_equal(acc[name][est].cpu().numpy(), ref[name]), name
+
+
 def test_context_counting_matches_reference_golden_and_oracle():
     """dig_count_contexts (device-resident and host twin) against the reference's own counts on the golden genome and
     against the oracle on a larger random genome (bit-exact)."""
