@@ -544,6 +544,52 @@ def test_element_pipeline_equals_separate_calls(torch_dev):
             assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
 
 
+def test_pipeline_with_more_than_2_to_24_bins(torch_dev):
+    """Bin rows beyond 2^24: the statistics stream pass then leaves its 24-bit multiply-add for 64-bit offsets.  Pipeline
+    against the two separate calls (bit-identical) and against the oracle on the bins the elements touch."""
+    import torch
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    dev = torch_dev
+    N, C, E = (1 << 24) + 4096, 2, 1500
+    g = torch.Generator(device=dev).manual_seed(3)
+    bin_mu = torch.empty((N, C), dtype=torch.float64, device=dev).uniform_(5.0, 60.0, generator=g)
+    bin_std = torch.empty((N, C), dtype=torch.float64, device=dev).uniform_(1.0, 8.0, generator=g)
+    bin_y = torch.randint(0, 60, (N, C), dtype=torch.int32, device=dev, generator=g)
+    bin_flag = (torch.rand((N, C), device=dev, generator=g) < 0.1).to(torch.uint8)
+    bin_ctx = torch.randint(0, 400, (N, 64), dtype=torch.int32, device=dev, generator=g)
+    rng = np.random.default_rng(8)
+    n_ov = rng.integers(1, 4, E)
+    first = np.where(rng.uniform(size=E) < 0.5, rng.integers(N - 5000, N - 3, E), rng.integers(0, N - 3, E))
+    ov_ptr = np.concatenate([[0], np.cumsum(n_ov)]).astype(np.int64)
+    ov_idx = np.concatenate([np.arange(f, f + k) for f, k in zip(first, n_ov)]).astype(np.int32)
+    L = rng.integers(0, 40, (E, 1, 192)).astype(np.int32)
+    strand = rng.integers(0, 2, E).astype(np.uint8)
+    d_pr = rng.dirichlet(np.ones(192), size=C) * 1e-6
+    obs = [rng.poisson(3.0, (E, C)).astype(np.int32) for _ in range(3)]
+    obs[1] = np.minimum(obs[1], obs[0])
+    obs[0][::50] += 80                                              # some pairs for the compacted pass
+    cj, cji = np.array([0.7, 1.9]), np.array([0.3, 0.2])
+    t = lambda a: torch.as_tensor(a, device=dev)
+    args = (bin_mu, bin_std, bin_y, bin_flag, bin_ctx, t(ov_ptr), t(ov_idx), t(L), t(strand), t(d_pr))
+    acc = engine.accumulate_elements(*args)
+    st = engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], t(obs[0]), t(obs[1]), t(obs[2]), t(cj), t(cji))
+    acc2, st2 = engine.element_pipeline(*args, t(obs[0]), t(obs[1]), t(obs[2]), t(cj), t(cji))
+    for k in acc:
+        assert torch.equal(acc[k], acc2[k]), k
+    for j, name in enumerate(engine.ES_PLANES):
+        assert torch.equal(torch.nan_to_num(st[name], nan=-7.0), torch.nan_to_num(st2[j], nan=-7.0)), name
+    # oracle on the touched bins only (re-indexed compactly)
+    used, inv = np.unique(ov_idx, return_inverse=True)
+    ui = t(used.astype(np.int64))
+    ref = O.accumulate_elements(bin_mu[ui].cpu().numpy(), bin_std[ui].cpu().numpy(), bin_y[ui].cpu().numpy(),
+                                bin_flag[ui].cpu().numpy(), bin_ctx[ui].cpu().numpy(), ov_ptr, inv.astype(np.int32), L,
+                                strand.astype(bool), d_pr)
+    np.testing.assert_allclose(acc2["MU"].cpu().numpy(), ref["MU"], rtol=1e-12)
+    np.testing.assert_allclose(acc2["P"].cpu().numpy(), ref["P"], rtol=1e-11)
+    assert np.array_equal(acc2["R_OBS"].cpu().numpy(), ref["R_OBS"]) and np.array_equal(acc2["R_SIZE"].cpu().numpy(), ref["R_SIZE"])
+
+
 def test_degenerate_shapes_do_not_crash(torch_dev):
     """Empty and ragged inputs through every entry point: zero elements / cohorts / regions / rows, an element without
     bins (MU = 0, SIGMA = 0 -> NaN statistics, as numpy gives), one-pair problems."""
