@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdig_hip.so")
+# (DIG_HIP_LIB: developer override used to A/B kernel builds -- tools/variant_bench.py; still a HIP library, no fallback)
+LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_hip.so")
 
 DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
 ES_PLANES = ("EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "THETA_INDEL", "EXP_INDEL",

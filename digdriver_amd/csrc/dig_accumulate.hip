@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
                     const int64_t o = b * a.C + col;
                     const double sd = a.bin_std[o];
                     mu += a.bin_mu[o];            // genic_driver_tools.py:265
-                    var = fma(sd, sd, var);       // :266
+                    var += mul_rn(sd, sd);      // :266
                     robs += a.bin_y[o];           // :267
                     flag |= (a.bin_flag[o] != 0); // :268 (numpy bool '+' is a logical OR)
                 }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
                 const int64_t o = (int64_t)ov_idx[q] * C + c;
                 const double sd = bin_std[o];
                 mu += bin_mu[o];                 // :265
-                var = fma(sd, sd, var);          // :266
+                var += mul_rn(sd, sd);         // :266
                 robs += bin_y[o];                // :267
                 flag |= (bin_flag[o] != 0);      // :268 (numpy bool '+' is a logical OR)
             }

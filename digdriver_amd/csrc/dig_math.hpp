@@ -30,7 +30,7 @@ namespace dig {
 constexpr double kCfEps = 1e-15;
 constexpr int kCfMaxIt = 20000;
 constexpr double kFpMin = 1e-300;
-constexpr int kSmallK = 64;          // direct-summation limit
+constexpr int kSmallK = 128;         // direct-summation limit of the fast recurrence (see kFastLp0Min)
 constexpr double kDirectMin = 1e-6;  // accept 1 - S - t/2 when >= this: abs err <= ~65 ulp(1) = 7e-15 -> rel 7e-9
 
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
@@ -119,12 +119,176 @@ __device__ __forceinline__ double fast_exp_neg(double x)
     return fast_exp_neg_core(x);
 }
 
-// ---- natural logarithm, < 1 ulp, ~1/3 of the instructions of the library log ---------------
-// Classical reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = f / (2 + f), f = m - 1,
-// with the degree-14 minimax polynomial in s^2 (the coefficients are the standard ones of this scheme).
-// Arguments that are not positive normal numbers go to the library log.
-// x must be a positive normal number (no checks).
+// ---- natural logarithm from a 128-entry LDS table + a short polynomial ---------------------------------------------
+// x = 2^k z, z in [0.6875, 1.375) (bits(x) - bits(0.6875): the exponent field of the difference is k, its top seven
+// mantissa bits select the bin); with c the bin centre, invc = double(1 / c) and logc = double(-log(invc)):
+//     log x = k ln2 + logc + log1p(r),   r = z * invc - 1 (one fma, |r| <= 0.0046),
+//     log1p(r) = r + r^2 P(r), P of degree 4 (truncation < 1.3e-19 absolute).
+// 18 vector instructions and one 16-byte LDS read against ~40 for the classical atanh form this replaces (three logs
+// per (element, cohort) pair in the statistics kernels).  Error: <= 1.2e-16 * max(|log x|, 0.005) absolute -- the
+// quantity that matters here, since every use multiplies the result by alpha and exponentiates (or adds 1 to it).
+// Table and coefficients: tools/gen_log_table.py (mpmath, 80 digits).  Every kernel that reaches this function calls
+// nb_tables_init() first.  x must be a positive normal number (no checks).
+static __device__ __constant__ const double kLogTabRom[128][2] = {
+    {0x1.734f0c541fe8dp+0, -0x1.7cc7f7db46a0ep-2},
+    {0x1.713786d9c7c09p+0, -0x1.76feecb947176p-2},
+    {0x1.6f26016f26017p+0, -0x1.713e33a46a17cp-2},
+    {0x1.6d1a62681c861p+0, -0x1.6b85b4cffa3fdp-2},
+    {0x1.6b1490aa31a3dp+0, -0x1.65d558d4ce00bp-2},
+    {0x1.691473a88d0c0p+0, -0x1.602d08af091ecp-2},
+    {0x1.6719f3601671ap+0, -0x1.5a8cadbbedfa1p-2},
+    {0x1.6524f853b4aa3p+0, -0x1.54f431b7be1a8p-2},
+    {0x1.63356b88ac0dep+0, -0x1.4f637ebba9810p-2},
+    {0x1.614b36831ae94p+0, -0x1.49da7f3bcc420p-2},
+    {0x1.5f66434292dfcp+0, -0x1.44591e0539f49p-2},
+    {0x1.5d867c3ece2a5p+0, -0x1.3edf463c1683ep-2},
+    {0x1.5babcc647fa91p+0, -0x1.396ce359bbf53p-2},
+    {0x1.59d61f123ccaap+0, -0x1.3401e12aecba0p-2},
+    {0x1.5805601580560p+0, -0x1.2e9e2bce12286p-2},
+    {0x1.56397ba7c52e2p+0, -0x1.2941afb186b7cp-2},
+    {0x1.54725e6bb82fep+0, -0x1.23ec5991eba49p-2},
+    {0x1.52aff56a8054bp+0, -0x1.1e9e1678899f5p-2},
+    {0x1.50f22e111c4c5p+0, -0x1.1956d3b9bc2f9p-2},
+    {0x1.4f38f62dd4c9bp+0, -0x1.14167ef367784p-2},
+    {0x1.4d843bedc2c4cp+0, -0x1.0edd060b78082p-2},
+    {0x1.4bd3edda68fe1p+0, -0x1.09aa572e6c6d4p-2},
+    {0x1.4a27fad76014ap+0, -0x1.047e60cde83b7p-2},
+    {0x1.4880522014880p+0, -0x1.feb2233ea07cbp-3},
+    {0x1.46dce34596066p+0, -0x1.f474b134df228p-3},
+    {0x1.453d9e2c776cap+0, -0x1.ea4449f04aaf5p-3},
+    {0x1.43a2730abee4dp+0, -0x1.e020cc6235ab5p-3},
+    {0x1.420b5265e5951p+0, -0x1.d60a17f903514p-3},
+    {0x1.40782d10e6566p+0, -0x1.cc000c9db3c52p-3},
+    {0x1.3ee8f42a5af07p+0, -0x1.c2028ab17f9b5p-3},
+    {0x1.3d5d991aa75c6p+0, -0x1.b811730b823d4p-3},
+    {0x1.3bd60d9232955p+0, -0x1.ae2ca6f672bd8p-3},
+    {0x1.3a524387ac822p+0, -0x1.a454082e6ab03p-3},
+    {0x1.38d22d366088ep+0, -0x1.9a8778debaa3ap-3},
+    {0x1.3755bd1c945eep+0, -0x1.90c6db9fcbcdbp-3},
+    {0x1.35dce5f9f2af8p+0, -0x1.871213750e994p-3},
+    {0x1.34679ace01346p+0, -0x1.7d6903caf5acdp-3},
+    {0x1.32f5ced6a1dfap+0, -0x1.73cb9074fd14dp-3},
+    {0x1.3187758e9ebb6p+0, -0x1.6a399dabbd383p-3},
+    {0x1.301c82ac40260p+0, -0x1.60b3100b09474p-3},
+    {0x1.2eb4ea1fed14bp+0, -0x1.5737cc9018cddp-3},
+    {0x1.2d50a012d50a0p+0, -0x1.4dc7b897bc1c7p-3},
+    {0x1.2bef98e5a3711p+0, -0x1.4462b9dc9b3dcp-3},
+    {0x1.2a91c92f3c105p+0, -0x1.3b08b6757f2a7p-3},
+    {0x1.293725bb804a5p+0, -0x1.31b994d3a4f86p-3},
+    {0x1.27dfa38a1ce4dp+0, -0x1.28753bc11aba2p-3},
+    {0x1.268b37cd60127p+0, -0x1.1f3b925f25d44p-3},
+    {0x1.2539d7e9177b2p+0, -0x1.160c8024b27b0p-3},
+    {0x1.23eb79717605bp+0, -0x1.0ce7ecdccc28bp-3},
+    {0x1.22a0122a0122ap+0, -0x1.03cdc0a51ec0dp-3},
+    {0x1.21579804855e6p+0, -0x1.f57bc7d9005dbp-4},
+    {0x1.2012012012012p+0, -0x1.e3707ee30487bp-4},
+    {0x1.1ecf43c7fb84cp+0, -0x1.d179788219362p-4},
+    {0x1.1d8f5672e4abdp+0, -0x1.bf968769fca18p-4},
+    {0x1.1c522fc1ce059p+0, -0x1.adc77ee5aea8ep-4},
+    {0x1.1b17c67f2bae3p+0, -0x1.9c0c32d4d254dp-4},
+    {0x1.19e0119e0119ep+0, -0x1.8a6477a91dc29p-4},
+    {0x1.18ab083902bdbp+0, -0x1.78d02263d82d7p-4},
+    {0x1.1778a191bd684p+0, -0x1.674f089365a78p-4},
+    {0x1.1648d50fc3201p+0, -0x1.55e10050e0382p-4},
+    {0x1.151b9a3fdd5c9p+0, -0x1.4485e03dbdfb0p-4},
+    {0x1.13f0e8d344724p+0, -0x1.333d7f8183f4ap-4},
+    {0x1.12c8b89edc0acp+0, -0x1.2207b5c7854a1p-4},
+    {0x1.11a3019a74826p+0, -0x1.10e45b3cae829p-4},
+    {0x1.107fbbe011080p+0, -0x1.ffa6911ab9309p-5},
+    {0x1.0f5edfab325a2p+0, -0x1.dda8adc67ee59p-5},
+    {0x1.0e40655826011p+0, -0x1.bbcebfc68f424p-5},
+    {0x1.0d24456359e3ap+0, -0x1.9a187b573de81p-5},
+    {0x1.0c0a7868b4171p+0, -0x1.788595a3577c8p-5},
+    {0x1.0af2f722eecb5p+0, -0x1.5715c4c03cee1p-5},
+    {0x1.09ddba6af8360p+0, -0x1.35c8bfaa13069p-5},
+    {0x1.08cabb37565e2p+0, -0x1.149e3e4005a8dp-5},
+    {0x1.07b9f29b8eae2p+0, -0x1.e72bf2813ce6ap-6},
+    {0x1.06ab59c7912fbp+0, -0x1.a55f548c5c427p-6},
+    {0x1.059eea0727586p+0, -0x1.63d6178690bbep-6},
+    {0x1.04949cc1664c5p+0, -0x1.228fb1fea2e0ap-6},
+    {0x1.038c6b78247fcp+0, -0x1.c317384c75f0dp-7},
+    {0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7},
+    {0x1.0182436517a37p+0, -0x1.8121214586b02p-8},
+    {0x1.0080402010080p+0, -0x1.0040155d5881ep-9},
+    {0x1.fe01fe01fe020p-1, 0x1.ff00aa2b10ba0p-9},
+    {0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7},
+    {0x1.f6310aca0dbb5p-1, 0x1.3cea44346a584p-6},
+    {0x1.f25f644230ab5p-1, 0x1.b9fc027af919ap-6},
+    {0x1.ee9c7f8458e02p-1, 0x1.1b0d98923d97fp-5},
+    {0x1.eae807aba01ebp-1, 0x1.58a5bafc8e4d3p-5},
+    {0x1.e741aa59750e4p-1, 0x1.95c830ec8e3f2p-5},
+    {0x1.e3a9179dc1a73p-1, 0x1.d276b8adb0b56p-5},
+    {0x1.e01e01e01e01ep-1, 0x1.075983598e471p-4},
+    {0x1.dca01dca01dcap-1, 0x1.253f62f0a1417p-4},
+    {0x1.d92f2231e7f8ap-1, 0x1.42edcbea646eep-4},
+    {0x1.d5cac807572b2p-1, 0x1.60658a93750c4p-4},
+    {0x1.d272ca3fc5b1ap-1, 0x1.7da766d7b12d0p-4},
+    {0x1.cf26e5c44bfc6p-1, 0x1.9ab42462033aep-4},
+    {0x1.cbe6d9601cbe7p-1, 0x1.b78c82bb0eda0p-4},
+    {0x1.c8b265afb8a42p-1, 0x1.d4313d66cb35dp-4},
+    {0x1.c5894d10d4986p-1, 0x1.f0a30c01162a4p-4},
+    {0x1.c26b5392ea01cp-1, 0x1.0671512ca596fp-3},
+    {0x1.bf583ee868d8bp-1, 0x1.14785846742acp-3},
+    {0x1.bc4fd65883e7bp-1, 0x1.2266f190a5acdp-3},
+    {0x1.b951e2b18ff23p-1, 0x1.303d718e47fd5p-3},
+    {0x1.b65e2e3beee05p-1, 0x1.3dfc2b0ecc62ap-3},
+    {0x1.b37484ad806cep-1, 0x1.4ba36f39a55e5p-3},
+    {0x1.b094b31d922a4p-1, 0x1.59338d9982085p-3},
+    {0x1.adbe87f94905ep-1, 0x1.66acd4272ad51p-3},
+    {0x1.aaf1d2f87ebfdp-1, 0x1.740f8f54037a3p-3},
+    {0x1.a82e65130e159p-1, 0x1.815c0a14357e9p-3},
+    {0x1.a574107688a4ap-1, 0x1.8e928de886d41p-3},
+    {0x1.a2c2a87c51ca0p-1, 0x1.9bb362e7dfb85p-3},
+    {0x1.a01a01a01a01ap-1, 0x1.a8becfc882f19p-3},
+    {0x1.9d79f176b682dp-1, 0x1.b5b519e8fb5a6p-3},
+    {0x1.9ae24ea5510dap-1, 0x1.c2968558c18c2p-3},
+    {0x1.9852f0d8ec0ffp-1, 0x1.cf6354e09c5ddp-3},
+    {0x1.95cbb0be377aep-1, 0x1.dc1bca0abec7bp-3},
+    {0x1.934c67f9b2ce6p-1, 0x1.e8c0252aa5a60p-3},
+    {0x1.90d4f120190d5p-1, 0x1.f550a564b7b37p-3},
+    {0x1.8e6527af1373fp-1, 0x1.00e6c45ad501dp-2},
+    {0x1.8bfce8062ff3ap-1, 0x1.071b85fcd590dp-2},
+    {0x1.899c0f601899cp-1, 0x1.0d46b579ab74bp-2},
+    {0x1.87427bcc092b9p-1, 0x1.136870293a8b0p-2},
+    {0x1.84f00c2780614p-1, 0x1.1980d2dd4236fp-2},
+    {0x1.82a4a0182a4a0p-1, 0x1.1f8ff9e48a2f3p-2},
+    {0x1.8060180601806p-1, 0x1.2596010df763ap-2},
+    {0x1.7e225515a4f1dp-1, 0x1.2b9303ab89d25p-2},
+    {0x1.7beb3922e017cp-1, 0x1.31871c9544185p-2},
+    {0x1.79baa6bb6398bp-1, 0x1.3772662bfd85cp-2},
+    {0x1.77908119ac60dp-1, 0x1.3d54fa5c1f710p-2},
+    {0x1.756cac201756dp-1, 0x1.432ef2a04e813p-2},
+};
+__shared__ __attribute__((aligned(16))) double g_log_tab[128][2];
+
+__device__ __forceinline__ double fast_log_normal_classic(double x);
 __device__ __forceinline__ double fast_log_normal(double x)
+{
+#ifdef DIG_CLASSIC_LOG
+    return fast_log_normal_classic(x);
+#endif
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const uint32_t hx = (uint32_t)(bits >> 32);
+    const uint32_t tmp = hx - 0x3fe60000u;                     // high word of bits(x) - bits(0.6875) (low word of OFF is 0)
+    const int k = (int)tmp >> 20;
+    const uint32_t zh = hx - (tmp & 0xfff00000u);
+    const double z = __longlong_as_double((long long)(((unsigned long long)zh << 32) | (bits & 0xffffffffull)));
+    const double2 t = *reinterpret_cast<const double2*>(&g_log_tab[(tmp >> 13) & 127u][0]);   // {invc, logc}
+    const double r = fma(z, t.x, -1.0);
+    const double r2 = r * r;
+    double P = -0.16666950550827794;
+    P = fma_sconst(P, r, 0.20000270365390174);
+    P = fma_sconst(P, r, -0.24999999998388212);
+    P = fma_sconst(P, r, 0.33333333332309978);
+    P = fma(P, r, -0.5);
+    const double y = fma(r2, P, r);
+    const double dk = (double)k;
+    const double w = fma(dk, 6.93147180369123816490e-01, t.y);  // exact product (ln2_hi has 32 trailing zero bits)
+    return w + fma(dk, 1.90821492927058770002e-10, y);
+}
+
+// Classical form (x = 2^k m, log m = 2 atanh(s) with the degree-14 polynomial in s^2; < 1 ulp, ~40 instructions).
+__device__ __forceinline__ double fast_log_normal_classic(double x)
 {
     const long long bits = __double_as_longlong(x);
     int hx = (int)(bits >> 32);
@@ -150,6 +314,7 @@ __device__ __forceinline__ double fast_log_normal(double x)
     const double dk = (double)k;
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
+
 
 __device__ __forceinline__ double fast_log(double x)
 {
@@ -434,7 +599,23 @@ static __device__ __constant__ const double kInvFactorialRom[kSmallK + 1] = {
     0x1.56457989358c9p-226, 0x1.9d4f1058674dfp-232, 0x1.e9d8f6ed83eaap-238, 0x1.1d008faac5c50p-243,
     0x1.45b77f9e98e12p-249, 0x1.6db793c887b97p-255, 0x1.938cc661b03f6p-261, 0x1.b5bfc17fa97d3p-267,
     0x1.d2eeac43e7fcfp-273, 0x1.e9e56d649f768p-279, 0x1.f9b3059128bc7p-285, 0x1.00dcf6a320e1cp-290,
-    0x1.00dcf6a320e1cp-296,
+    0x1.00dcf6a320e1cp-296, 0x1.f9d2a2bb5471bp-303, 0x1.ea7ead50ce01ap-309, 0x1.d48849da8f4a3p-315,
+    0x1.b8f8bdfae136cp-321, 0x1.99046602abcaep-327, 0x1.75f56494ba532p-333, 0x1.5116e3adb9fb9p-339,
+    0x1.2ba2917dfaa6cp-345, 0x1.06b1981a48762p-351, 0x1.c6639f500ea2dp-358, 0x1.83bed30a49edfp-364,
+    0x1.4685bf3115d5dp-370, 0x1.0f653132c5ae6p-376, 0x1.bd5dda94f5a18p-383, 0x1.68cda75b82f10p-389,
+    0x1.20a485e2cf273p-395, 0x1.c8206e6fe560bp-402, 0x1.64005631debbep-408, 0x1.1281cd42368abp-414,
+    0x1.a24be3711628bp-421, 0x1.3af3de7343e26p-427, 0x1.d4c44522a0927p-434, 0x1.58d700d5cb749p-440,
+    0x1.f595d2ab567b0p-447, 0x1.68b0c583d6a34p-453, 0x1.007db446ff080p-459, 0x1.68c751f8f632ap-466,
+    0x1.f5f3ec7bc5d72p-473, 0x1.596e0e189e2b7p-479, 0x1.d65f64e59b771p-486, 0x1.3ce1f3216b6dep-492,
+    0x1.a6829981e4928p-499, 0x1.16c503a23d142p-505, 0x1.6c1b7275dcd65p-512, 0x1.d6c3cf76c59bap-519,
+    0x1.2d4a1e607e781p-525, 0x1.7dd50faf84657p-532, 0x1.df297d187dfcdp-539, 0x1.29bb552f8772dp-545,
+    0x1.6e7068d8092aep-552, 0x1.beb4eb15fc8c1p-559, 0x1.0db5afbffdea5p-565, 0x1.42a4b5885d350p-572,
+    0x1.7e64655f3f0f6p-579, 0x1.c10c3547ec1b7p-586, 0x1.05439cac2c47dp-592, 0x1.2d470c4e9d270p-599,
+    0x1.585132a2fcbeep-606, 0x1.8605e345153bep-613, 0x1.b5eba9d8cb7dap-620, 0x1.e76cb424808bdp-627,
+    0x1.0cec86b309210p-633, 0x1.263516a53c4fep-640, 0x1.3f23e47f2bba7p-647, 0x1.5746e043f2ccep-654,
+    0x1.6e2977bff1eb9p-661, 0x1.83584be68daafp-668, 0x1.9665084a05f24p-675, 0x1.a6ea2e16eb219p-682,
+    0x1.b48ea3306e964p-689, 0x1.bf08d841fa750p-696, 0x1.c6215db8ddeccp-703, 0x1.c9b4c7476cc64p-710,
+    0x1.c9b4c7476cc64p-717,
 };
 __shared__ double g_inv_factorial[kSmallK + 1];
 
@@ -442,6 +623,7 @@ __device__ __forceinline__ void nb_tables_init()
 {
     const unsigned t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     if (t <= (unsigned)kSmallK) g_inv_factorial[t] = kInvFactorialRom[t];
+    for (unsigned i = t; i < 256u; i += blockDim.x * blockDim.y * blockDim.z) (&g_log_tab[0][0])[i] = (&kLogTabRom[0][0])[i];
     __syncthreads();
 }
 
@@ -483,8 +665,12 @@ __device__ __forceinline__ void pmf_scaled_step_nofact(double& A, double& N, dou
     jj += 1.0;
 }
 
+// Range of the scaled recurrence: N_k <= k! / t_0 must stay finite, i.e. log(k!) - lp0 < 709.  64! = e^205 allows
+// lp0 > -400; 128! = e^496 allows lp0 > -200 (bench workload: lp0 > -100 for 99 % of the pairs with counts above 64).
+__device__ __forceinline__ double fast_lp0_min(double kmax) { return kmax <= 64.0 ? -400.0 : -200.0; }
+
 // The recurrence itself for eligible counts (integers 0 .. kSmallK; -1 = not requested), valid (alpha, p) and
-// lp0 = alpha log p > -400 (keeps N_k <= k! / t_0 far from overflow).  TWO = false skips the intermediate evaluation.
+// lp0 = alpha log p > fast_lp0_min(kmax).  TWO = false skips the intermediate evaluation.
 //   N_j = prod_{i<j} (alpha + i) x,  A_j = S_j (j-1)! / t_0  (A_{j+1} = A_j * j + N_j):  one step is 4 full-rate FP64
 //   operations with no memory access and no division; the trip count is tested on the FP64 counter itself.
 template <int W2, bool TWO>
@@ -519,11 +705,11 @@ __device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, 
 {
     if (!(p >= 2.2250738585072014e-308)) return 0u;   // subnormal p: leave it to the general path
     const double lp0 = alpha * fast_log_normal(p);
-    if (!(lp0 > -400.0)) return 0u;
-    const double x = 1.0 - p;
     const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
     // the lane's loop ends at the larger count; only the smaller one needs recording on the way
     const double kmax = fmax(k1d, k2d), kmin = fmin(k1d, k2d);
+    if (!(lp0 > fast_lp0_min(kmax))) return 0u;
+    const double x = 1.0 - p;
     double r_min = 0.0, r_max = 0.0;
     if (two) nb_fast_recurrence<W2, true>(kmin, kmax, alpha, x, lp0, r_min, r_max);
     else nb_fast_recurrence<W2, false>(kmin, kmax, alpha, x, lp0, r_min, r_max);
@@ -630,7 +816,7 @@ __device__ __forceinline__ bool nb_exact_fast(double k, double alpha, double p, 
         return false;
     if (!(k >= 0.0) || k > (double)kSmallK || floor(k) != k) return false;
     const double lp0 = alpha * fast_log_normal(p);
-    if (!(lp0 > -400.0)) return false;
+    if (!(lp0 > fast_lp0_min(k))) return false;
     const double x = 1.0 - p;
     const double t0 = fast_exp_neg_core(lp0);
     double N = 1.0, A = 0.0, u = alpha * x, jj = 0.0;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kBlock) void nb3_kernel(const double* __restrict__ 
 __global__ __launch_bounds__(kBlock) void fisher_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
                                                         double* __restrict__ out, int64_t n)
 {
+    nb_tables_init();
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
         out[i] = fisher_combine_fast(p1[i], p2[i]);   // same code path as the fused statistics kernels
@@ -86,6 +87,9 @@ struct ElementStatsArgs {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
+#ifdef DIG_DEV_ABLATE
+    int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
+#endif
 };
 
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
@@ -261,13 +265,16 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
             double mu = 0.0, var = 0.0;
             int robs = 0, flag = 0;
             const int32_t* oi = a.ov_idx + cur.q0;
-            const uint32_t nb = (uint32_t)(cur.q1 - cur.q0);
+            uint32_t nb = (uint32_t)(cur.q1 - cur.q0);
+#ifdef DIG_DEV_ABLATE
+            if (a.ablate & 4) nb = 0;
+#endif
             if (a.small_index) {
                 for (uint32_t j = 0; j < nb; ++j) {
                     const uint32_t o = __umul24((uint32_t)oi[j], C32) + cur.c;   // bin row * C + cohort
                     const double sd = a.bin_std[o];
                     mu += a.bin_mu[o];
-                    var = fma(sd, sd, var);
+                    var += mul_rn(sd, sd);
                     robs += a.bin_y[o];
                     flag |= (a.bin_flag[o] != 0);
                 }
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
                     const int64_t o = (int64_t)oi[j] * a.C + cur.c;
                     const double sd = a.bin_std[o];
                     mu += a.bin_mu[o];
-                    var = fma(sd, sd, var);
+                    var += mul_rn(sd, sd);
                     robs += a.bin_y[o];
                     flag |= (a.bin_flag[o] != 0);
                 }
@@ -288,10 +295,23 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
             DIG_STREAM_STORE(&a.r_obs[i], robs);
             DIG_STREAM_STORE(&a.flag[i], flag);
         }
+#ifdef DIG_DEV_ABLATE
+        if (a.ablate & 2) cur.k_snv = cur.k_smp = cur.k_ind = 0;
+        if (a.ablate & 8) {
+            const double v = cur.mu + cur.sigma + cur.pi_s + cur.pi_i + (double)(cur.k_snv + cur.k_smp + cur.k_ind) + cur.cj + cur.cji;
+            if (!(a.ablate & 1) || v == 12345.678) {
+                for (int pl = 0; pl < 7; ++pl) DIG_STREAM_STORE(&a.out[pl * n + i], v);
+            }
+            continue;
+        }
+#endif
         const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
         double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
         const unsigned d1 = nb_fast2_counts<1>(cur.k_snv, cur.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_fast2_counts<1>(cur.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
+#ifdef DIG_DEV_ABLATE
+        if ((a.ablate & 1) && !(pv_snv + pv_smp + pv_ind + q.exp_snv + q.exp_ind + q.theta_i == 12345.678)) continue;
+#endif
         const bool slow = ((d1 != 3u) || (d2 != 1u)) && i_raw < n;
         const unsigned long long m = __ballot(slow);
         if (slow) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
@@ -312,6 +332,178 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
     if (parked) park_flush(a.worklist, park, parked, lane);
 }
 
+// ---- Pass 1 of dig_element_pipeline: fused rates, three-deep software pipeline -----------------------------------------
+// Ablation of the two-stage form above on the bench workload (tools/variant_bench.py): its loads and
+// stores alone take 125 us (the practical HBM rate for this read/write mix), its arithmetic alone 89 us of VALU time
+// per SIMD -- and together 165 us, because the rate sums start with two DEPENDENT loads per tile (bin index, then the
+// bin's rates) that are issued after the previous tile's eleven stores: the in-order memory counter makes the wave sit
+// out the stores' acknowledgement plus two round trips, once per tile.  Here every load of a tile is in flight a full
+// tile ahead and none is issued behind a store it has to wait for:
+//     top of iteration t :  CSR pointers of tile t+2;  bin indices + per-pair inputs of tile t+1 (pointers have arrived)
+//     arithmetic of tile t  (its inputs and bin rates were requested during iteration t-1)
+//     bin rates of tile t+1 (indices have arrived meanwhile)  ->  stores of tile t
+// The first kPre bins of a pair travel through the pipeline in registers; a tile in which some pair overlaps more bins
+// finishes those sums with the plain loop (wave-uniform branch; gene-sized elements).  Same operations in the same
+// order per pair as acc_region_kernel (genic_driver_tools.py:262-271: mu += Y_PRED, var += STD**2 in CSR order).
+constexpr int kPre = 3;
+
+struct StagePtr {            // tile t+2
+    int64_t q0, q1;
+    uint32_t i, e, c;
+};
+struct StageIn {             // tile t+1
+    int32_t idx[kPre];
+    double pi_s, pi_i, cj, cji;
+    int k_snv, k_smp, k_ind;
+    int64_t q0;
+    uint32_t nb, i, c;
+};
+struct StageBin {            // tile t+1
+    double mu[kPre], sd[kPre];
+    int32_t y[kPre];
+    uint8_t fl[kPre];
+};
+
+__global__ __launch_bounds__(kBlock) void element_stats_stream_fused_kernel(ElementStatsArgs a)
+{
+    __shared__ unsigned park_all[kBlock / 64][kParkCap];
+    nb_tables_init();
+    unsigned* park = park_all[threadIdx.x >> 6];
+    const int64_t n = a.E * a.C;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    int64_t tile = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (tile >= n_tiles) return;
+    const int64_t step_pairs = n_waves * 64;
+    const int64_t step_e = a.use_fastdiv ? fastdiv(step_pairs, a.divC) : step_pairs;
+    const uint32_t step_c = (uint32_t)(step_pairs - step_e * a.C);
+    const uint32_t C32 = (uint32_t)a.C;
+    int64_t iu = tile * 64 + lane;                    // unclamped flat index of the pair the pointer stage fetches next
+    int64_t eu = a.use_fastdiv ? fastdiv(iu, a.divC) : iu;
+    uint32_t cu = (uint32_t)(iu - eu * a.C);
+    auto fetch_ptr = [&]() {                          // lanes (and whole tiles) past the end replay the last pair
+        StagePtr s;
+        const bool past = iu >= n;
+        s.i = (uint32_t)(past ? n - 1 : iu);
+        s.e = (uint32_t)(past ? a.E - 1 : eu);
+        s.c = past ? C32 - 1 : cu;
+        s.q0 = a.ov_ptr[s.e];
+        s.q1 = a.ov_ptr[s.e + 1];
+        iu += step_pairs;
+        eu += step_e;
+        cu += step_c;
+        if (cu >= C32) {
+            cu -= C32;
+            eu += 1;
+        }
+        return s;
+    };
+    // every element's CSR range lies inside [0, nnz); with an empty CSR the index loads replay ov_ptr[0] (= 0: row 0)
+    const int64_t nnz = a.ov_ptr[a.E];
+    const int32_t* oi_base = nnz > 0 ? a.ov_idx : reinterpret_cast<const int32_t*>(a.ov_ptr);
+    const int64_t oi_last = nnz > 0 ? nnz - 1 : 0;
+    auto fetch_in = [&](const StagePtr& s) {
+        StageIn r;
+        r.q0 = s.q0;
+        r.nb = (uint32_t)(s.q1 - s.q0);
+        r.i = s.i;
+        r.c = s.c;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j)      // unconditional (the memory counter stays exact): bins past the pair's last replay a valid entry
+            r.idx[j] = oi_base[min(s.q0 + j, oi_last)];
+        r.pi_s = a.pi_sum[s.i];
+        r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
+        r.k_snv = a.obs_snv[s.i];
+        r.k_smp = a.obs_samples[s.i];
+        r.k_ind = a.obs_indel[s.i];
+        r.cj = a.cj[s.c];
+        r.cji = a.cj_indel[s.c];
+        return r;
+    };
+    auto fetch_bin = [&](const StageIn& r) {
+        StageBin b;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const int64_t o = a.small_index ? (int64_t)(__umul24((uint32_t)r.idx[j], C32) + r.c)
+                                            : (int64_t)r.idx[j] * a.C + r.c;      // bin row * C + cohort
+            b.mu[j] = a.bin_mu[o];
+            b.sd[j] = a.bin_std[o];
+            b.y[j] = a.bin_y[o];
+            b.fl[j] = a.bin_flag[o];
+        }
+        return b;
+    };
+    // pipeline fill: pointers of the first two tiles, inputs and bin rates of the first
+    StagePtr ptr_n = fetch_ptr();
+    StageIn in_c = fetch_in(ptr_n);
+    ptr_n = fetch_ptr();
+    StageBin bin_c = fetch_bin(in_c);
+    unsigned parked = 0;   // wave-uniform
+    for (; tile < n_tiles; tile += n_waves) {
+        if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
+        const bool live = tile * 64 + lane < n;
+        const StageIn cur = in_c;
+        const StageBin bin = bin_c;
+        in_c = fetch_in(ptr_n);          // tile t+1: indices + inputs
+        ptr_n = fetch_ptr();             // tile t+2: pointers
+        const int64_t i = cur.i;
+        // rate sums (genic_driver_tools.py:262-271)
+        double mu = 0.0, var = 0.0;
+        int robs = 0, flag = 0;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {      // (bins past the pair's last were fetched from a replayed row: skipped here)
+            if ((uint32_t)j < cur.nb) {
+                mu += bin.mu[j];
+                var += mul_rn(bin.sd[j], bin.sd[j]);
+                robs += bin.y[j];
+                flag |= (bin.fl[j] != 0);
+            }
+        }
+        if (__any(cur.nb > (uint32_t)kPre)) {
+            const int32_t* oi = a.ov_idx + cur.q0;
+            for (uint32_t j = kPre; j < cur.nb; ++j) {
+                const int64_t o = (int64_t)oi[j] * a.C + cur.c;
+                const double sd = a.bin_std[o];
+                mu += a.bin_mu[o];
+                var += mul_rn(sd, sd);
+                robs += a.bin_y[o];
+                flag |= (a.bin_flag[o] != 0);
+            }
+        }
+        PairRaw w;
+        w.mu = w.mu_i = mu;
+        w.sigma = w.sigma_i = sqrt(var);
+        w.pi_s = cur.pi_s; w.pi_i = cur.pi_i; w.cj = cur.cj; w.cji = cur.cji;
+        w.k_snv = cur.k_snv; w.k_smp = cur.k_smp; w.k_ind = cur.k_ind;
+        w.q0 = w.q1 = 0; w.c = cur.c;
+        const PairInputs q = prepare_pair(w, false);
+        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        const unsigned d1 = nb_fast2_counts<1>(w.k_snv, w.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
+        const unsigned d2 = nb_fast2_counts<1>(w.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
+        const bool slow = ((d1 != 3u) || (d2 != 1u)) && live;
+        double pv_mut = 0.0;
+        if (!slow) pv_mut = fisher_combine_fast(pv_snv, pv_ind);
+        bin_c = fetch_bin(in_c);         // tile t+1: bin rates (requested BEFORE this tile's stores)
+        const unsigned long long m = __ballot(slow);
+        if (slow) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
+        parked += (unsigned)__popcll(m);
+        DIG_STREAM_STORE(&a.mu_w[i], w.mu);
+        DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
+        DIG_STREAM_STORE(&a.r_obs[i], robs);
+        DIG_STREAM_STORE(&a.flag[i], flag);
+        DIG_STREAM_STORE(&a.out[0 * n + i], q.exp_snv);
+        DIG_STREAM_STORE(&a.out[1 * n + i], pv_snv);
+        DIG_STREAM_STORE(&a.out[2 * n + i], pv_smp);
+        DIG_STREAM_STORE(&a.out[3 * n + i], q.theta_i);
+        DIG_STREAM_STORE(&a.out[4 * n + i], q.exp_ind);
+        DIG_STREAM_STORE(&a.out[5 * n + i], pv_ind);
+        DIG_STREAM_STORE(&a.out[6 * n + i], pv_mut);
+    }
+    if (parked) park_flush(a.worklist, park, parked, lane);
+}
+
 // Pass 2: the compacted slow pairs.  Three lanes of a quad per pair (lane & 3: 0 = SNV, 1 = SAMPLE, 2 = INDEL), lane
 // 0 combines.  Most of the pass is the k-step recurrence of pairs with counts above kSmallK, and a wave runs until
 // its longest lane is done, so every workgroup first orders its 256 pairs by count (descending, 16-wide buckets in
@@ -326,8 +518,9 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     __shared__ unsigned s_hist[kSlowBuckets], s_perm[kSlowPairs];
     nb_tables_init();
     const int64_t n = a.E * a.C;
-    const unsigned count = a.worklist[0];
+    const unsigned count = (unsigned)min((int64_t)a.worklist[0], n);   // (never more entries than pairs, whatever the header holds)
     const int tid = threadIdx.x, role = tid & 3, lane = tid & 63, quad = tid >> 2;
+    if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist (header [0] is cleared below)
     // pairs per workgroup and round: all of kSlowPairs when there is enough work, fewer when the worklist is short, so
     // that every CU gets a share
     const unsigned per = min((unsigned)kSlowPairs, max(16u, (count + gridDim.x - 1) / gridDim.x));
@@ -375,6 +568,15 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
             a.out[6 * n + i] = fisher_combine_fast(pv, pv_ind);
         }
         __syncthreads();
+    }
+    // The last workgroup to finish leaves the header cleared (every workgroup read the count before it got here), so a
+    // later statistics-only call on this workspace needs no memset in front of it (DIG_PIPE_WORKLIST_CLEAN).
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&a.worklist[1], 1u) == gridDim.x - 1) {
+            a.worklist[0] = 0;
+            a.worklist[1] = 0;
+        }
     }
 }
 
@@ -618,6 +820,18 @@ struct FusedRates {
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
 };
 
+// DIG_ES_FORM / DIG_ES_BLOCKS_PER_CU are developer knobs for A/B runs (tools/variant_bench.py).
+static int stream_form()      // 1 = three-deep pipelined fused kernel (default), 0 = two-stage form
+{
+    const char* e = getenv("DIG_ES_FORM");
+    return e ? atoi(e) : 1;
+}
+static int stream_blocks_per_cu(int dflt)
+{
+    const char* e = getenv("DIG_ES_BLOCKS_PER_CU");
+    return e ? std::max(1, atoi(e)) : dflt;
+}
+
 int element_stats_launch(const double* mu, const double* sigma, const double* mu_indel, const double* sigma_indel,
                          const double* pi_sum, const double* pi_indel, int pi_indel_per_cohort, const int32_t* obs_snv,
                          const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
@@ -636,13 +850,20 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0
+#ifdef DIG_DEV_ABLATE
+                       , 0
+#endif
+    };
     if (fused) {
         a.bin_mu = fused->bin_mu; a.bin_std = fused->bin_std; a.bin_y = fused->bin_y; a.bin_flag = fused->bin_flag;
         a.ov_ptr = fused->ov_ptr; a.ov_idx = fused->ov_idx;
         a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
         a.small_index = fused->small_index;
     }
+#ifdef DIG_DEV_ABLATE
+    a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;
+#endif
     if (wl && !worklist_already_zero) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
     DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
@@ -665,7 +886,12 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         // within 3 % -- and slightly fewer than the maximum measured best (fewer waves contend for the scalar unit and the
         // instruction cache): 6 for the plain form, 5 for the fused-rates form.
         const int sgrid = grid_for(E * C, kBlock, std::min(resident[which], which == 2 ? 5 : 6));
-        if (which == 2)
+        if (which == 2 && stream_form() == 1) {
+            static int res_f = 0;
+            if (!res_f) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_f, element_stats_stream_fused_kernel, kBlock, 0));
+            const int g = grid_for(E * C, kBlock, std::min(std::max(res_f, 1), stream_blocks_per_cu(8)));
+            hipLaunchKernelGGL(element_stats_stream_fused_kernel, dim3(g), dim3(kBlock), 0, s, a);
+        } else if (which == 2)
             hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(sgrid), dim3(kBlock), 0, s, a);
         else if (which == 1)
             hipLaunchKernelGGL((element_stats_stream_kernel<true, false>), dim3(sgrid), dim3(kBlock), 0, s, a);

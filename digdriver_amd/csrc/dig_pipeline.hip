@@ -61,6 +61,8 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
                          int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
+    const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
+    stages &= ~DIG_PIPE_WORKLIST_CLEAN;
     DIG_REQUIRE(stages >= 1 && stages <= 7, "stages: bit mask of DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS");
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
@@ -82,7 +84,10 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
     const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index};
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
-                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f, 1);
+                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f,
+                                /* worklist header cleared by the context kernel of THIS call; a statistics-only call
+                                   (new scale factors on an existing accumulation) clears it itself */
+                                (stages & 1) != 0 || worklist_clean);
 }
 
 }  // extern "C"

@@ -89,9 +89,12 @@ def encode_mutations(df_mut, device, cohort_id=0):
                     ref_id.astype(np.int64), alt_id.astype(np.int64)], axis=1)
     uid = np.unique(key, axis=0, return_inverse=True)[1].reshape(-1) if len(key) else np.zeros(0, np.int64)
     samp, sample_names = pd.factorize(df_mut.SAMPLE.astype(str).values)
+    # gene label of the row (get_unique_indels keys on it, mutation_tools.py:111-117); files without the column: one label
+    gene = pd.factorize(df_mut.GENE.astype(str).values)[0] if 'GENE' in df_mut.columns else np.zeros(len(df_mut), np.int64)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=device)
     return dict(chrom=t(ch.values, np.int64), start=t(df_mut.START.values, np.int64), end=t(df_mut.END.values, np.int64),
                 uid=t(uid, np.int64), sample=t(samp, np.int64), indel=t((df_mut.ANNOT == 'INDEL').values, np.int64),
+                gene=t(gene, np.int64),
                 cohort=torch.full((len(df_mut),), int(cohort_id), dtype=torch.int64, device=device),
                 sample_names=list(sample_names))
 

@@ -43,18 +43,28 @@ def genome_scale_factors(tables, cohorts, device):
     pm = pm.long()
     cohort = cat("cohort")
     ok = flag[bins.elt[pb.long()], cohort[pm]] == 0                    # the overlapped bin is unflagged in that cohort
-    # unique (cohort, mutation uid, sample): the reference re-reads the intersected rows with drop_duplicates (:143-147)
+    # the reference re-reads the intersected rows with read_mutation_file(drop_duplicates=True, unique_indels=True)
+    # (mutation_tools.py:22-43,45-104), i.e. two de-duplications one after the other:
     uid_off = np.concatenate([[0], np.cumsum([int(c["uid"].max().item()) + 1 if c["uid"].numel() else 0 for c in cohorts])])
     uid = torch.cat([c["uid"] + int(o) for c, o in zip(cohorts, uid_off[:-1])])
     smp_off = np.concatenate([[0], np.cumsum([len(c["sample_names"]) for c in cohorts])])
     smp = torch.cat([c["sample"] + int(o) for c, o in zip(cohorts, smp_off[:-1])])
     indel = cat("indel")
-    rec = torch.stack([cohort[pm], uid[pm], smp[pm], indel[pm]], dim=1)[ok]
-    rec = torch.unique(rec, dim=0)
-    n_ind = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, rec[:, 0], rec[:, 3].double())
-    n_all = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, rec[:, 0], torch.ones(len(rec), dtype=torch.float64, device=device))
+    gene_off = np.concatenate([[0], np.cumsum([int(c["gene"].max().item()) + 1 if c["gene"].numel() else 0 for c in cohorts])])
+    gene = torch.cat([c["gene"] + int(o) for c, o in zip(cohorts, gene_off[:-1])])
+    pm_ok = pm[ok]
+    # step 1, drop_duplicate_mutations (mutation_tools.py:106-108): first row of every (cohort, uid, sample)
+    key, inv = torch.unique(torch.stack([cohort[pm_ok], uid[pm_ok], smp[pm_ok]], dim=1), dim=0, return_inverse=True)
+    first = torch.full((key.shape[0],), torch.iinfo(torch.int64).max, dtype=torch.int64, device=device)
+    first.scatter_reduce_(0, inv, pm_ok, reduce="amin", include_self=True)      # file order = row index
+    is_ind = indel[first] != 0
+    n_snv = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, key[~is_ind, 0], torch.ones(int((~is_ind).sum()), dtype=torch.float64, device=device))
+    # step 2, get_unique_indels (mutation_tools.py:110-117): indels recurring in several samples count once per
+    # (CHROM, START, END, REF, ALT, GENE) -- GENE is that of the row step 1 kept
+    ind_key = torch.unique(torch.stack([key[is_ind, 0], key[is_ind, 1], gene[first[is_ind]]], dim=1), dim=0)
+    n_ind = torch.zeros(C, dtype=torch.float64, device=device).index_add_(0, ind_key[:, 0], torch.ones(ind_key.shape[0], dtype=torch.float64, device=device))
     exp_sum = engine.scale_suffstats(torch.as_tensor(tables.mu, device=device), flag)
-    return (n_all - n_ind) / exp_sum, n_ind / exp_sum
+    return n_snv / exp_sum, n_ind / exp_sum
 
 
 def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_factors=None, max_muts_per_sample=3e9,

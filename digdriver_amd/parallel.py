@@ -140,3 +140,54 @@ def average_gradients(params, group=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def strided_positions(n_rows, bs, rank, world):
+    """Positions, in the global visiting order of an epoch, of the rows rank `rank` processes when every batch of `bs`
+    rows is dealt out as batch[rank::world] (NNTrainer.train)."""
+    pos = [np.arange(j + rank, min(j + bs, n_rows), world) for j in range(0, n_rows, bs)]
+    return np.concatenate(pos) if pos else np.zeros(0, np.int64)
+
+
+def gather_visiting_order(t, n_rows, bs, group=None):
+    """Re-assemble per-row tensors of a data-parallel epoch in the GLOBAL visiting order on every rank: each rank holds
+    the rows of strided_positions(n_rows, bs, rank, world) (dim 0 of `t`); one padded all-gather, then a scatter by
+    position.  The GP of the region model must see the activations of all training rows, as nn.DataParallel hands
+    them to the reference (kfold_mutations_main.py:143,177), not a 1/world sample."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    pos = [strided_positions(n_rows, bs, r, world) for r in range(world)]
+    mx = max(len(p) for p in pos)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    out = torch.empty((n_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    for r in range(world):
+        out[torch.as_tensor(pos[r], device=t.device)] = bufs[r][: len(pos[r])]
+    return out
+
+
+def broadcast_module_buffers(module, src=0, group=None):
+    """BatchNorm running statistics (and every other buffer) of rank `src` to all ranks: nn.DataParallel keeps the
+    running statistics of replica 0 only (the other replicas' updates are discarded), so this is the reference's
+    semantics -- and it keeps eval-mode outputs, and therefore every epoch-selection decision, identical on all ranks."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for b in module.buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
+def broadcast_flag(value, device, src=0, group=None):
+    """A yes/no decision taken on rank `src`, made known to every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(value)
+    f = torch.tensor([1 if value else 0], dtype=torch.int32, device=device)
+    dist.broadcast(f, src=src, group=group)
+    return bool(f.item())

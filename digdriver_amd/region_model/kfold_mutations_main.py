@@ -134,7 +134,9 @@ def main(input_args=None):
     device = torch.device('cuda', local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        # rank 0 fits the GPs of a fold while the other ranks wait in a broadcast: no collective may time out meanwhile
+        from datetime import timedelta
+        dist.init_process_group('nccl', device_id=device, timeout=timedelta(hours=12))
     rank = dist.get_rank() if world > 1 else 0
     labels_str = '-'.join(args.label_ids)
     out_dir = os.path.join(args.out_dir, 'kfold', labels_str)
@@ -163,7 +165,9 @@ def main(input_args=None):
                 _, val_accs, va_feat, _, va_true, _ = trainer.test(epoch, r)
                 live = int((np.abs(tr_feat[0]).mean(axis=0) > 0).sum())
                 print('#non-zero features: {}'.format(live))
-                if val_accs[0] > best['acc'] and live > 1:                       # kfold_mutations_main.py:170-177
+                # the decision is rank 0's (the ranks hold the same weights, running statistics and gathered features, so
+                # they agree anyway; broadcasting it rules out a rank leaving the collective sequence on a rounding tie)
+                if parallel.broadcast_flag(val_accs[0] > best['acc'] and live > 1, device):   # kfold_mutations_main.py:170-177
                     best = dict(acc=val_accs[0], accs=val_accs, model=copy.deepcopy(trainer.model),
                                 train=dict(feat=tr_feat, lbls=tr_true, rows=trainer.last_train_rows),
                                 val=dict(feat=va_feat, lbls=va_true))

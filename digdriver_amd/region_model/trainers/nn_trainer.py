@@ -72,9 +72,25 @@ class NNTrainer:
             if n_batches >= 10 and j % max(1, int(n_batches * print_interval / 100)) == 0 and j > 0:
                 print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {}'.format(epoch, j, n_batches, 100. * j / n_batches,
                                                                           loss_sums / (j + 1)))
-        cat = lambda lst: [torch.cat(v).cpu().numpy() for v in lst]
+        # With a process group every rank saw batch[rank::world]: put the per-row outputs of all ranks back into the global
+        # visiting order (the GP is fitted on the activations of ALL training rows, kfold_mutations_main.py:177), take
+        # rank 0's BatchNorm running statistics (what nn.DataParallel keeps) and average the per-batch scores.
+        n_rows = len(order)
+        if self.world > 1:
+            whole = lambda v, width: parallel.gather_visiting_order(
+                torch.cat(v) if v else torch.zeros((0,) + width, dtype=torch.float32, device=self.device), n_rows, self.bs, self.group)
+            feats = [[whole(f, (16,))] for f in feats]
+            preds = [[whole(q, ())] for q in preds]
+            true = [[whole(t, ())] for t in true]
+            parallel.broadcast_module_buffers(self.model, 0, self.group)
+            sc = torch.as_tensor(np.stack([loss_sums, acc_sums]), device=self.device)
+            sc = parallel.rank_ordered_sum(sc, self.group) / self.world
+            loss_sums, acc_sums = sc[0].cpu().numpy(), sc[1].cpu().numpy()
+            self.last_train_rows = order
+        else:
+            self.last_train_rows = np.concatenate(seen) if seen else np.zeros(0, np.int64)   # visiting order of the features
+        cat = lambda lst: [(torch.cat(v) if v else torch.zeros(0)).cpu().numpy() for v in lst]
         losses, accs = loss_sums / n_batches, acc_sums / n_batches
-        self.last_train_rows = np.concatenate(seen) if seen else np.zeros(0, np.int64)   # visiting order of the features
         print('====> Epoch: {}, Average loss: {}, Average accuracy: {}'.format(epoch, losses, accs))
         return losses, accs, cat(feats), cat(preds), cat(true)
 

@@ -117,3 +117,37 @@ def test_two_rank_gradient_average_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "grad_ok.npy")
+
+
+def _visit_worker(rank, world, port, tmp):
+    """What the data-parallel CNN epoch hands to the GP: per-row outputs of batch[rank::world] slices, re-assembled in the
+    global visiting order on every rank; BatchNorm running statistics taken from rank 0; decisions taken on rank 0."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_rows, bs = 37, 8                                    # ragged last batch, odd batch size per rank
+        order = np.random.default_rng(4).permutation(1000)[:n_rows]
+        mine = np.concatenate([order[j:j + bs][rank::world] for j in range(0, n_rows, bs)])
+        assert np.array_equal(order[parallel.strided_positions(n_rows, bs, rank, world)], mine)
+        feats = torch.tensor(mine, dtype=torch.float32)[:, None] * torch.arange(1, 17, dtype=torch.float32)[None, :]
+        whole = parallel.gather_visiting_order(feats, n_rows, bs)
+        assert whole.shape == (n_rows, 16)
+        assert torch.equal(whole[:, 0], torch.tensor(order, dtype=torch.float32))          # every row, global order
+        assert torch.equal(whole[:, 15], torch.tensor(order, dtype=torch.float32) * 16)
+        bn = torch.nn.BatchNorm1d(4)
+        bn.running_mean.fill_(float(rank + 1))
+        parallel.broadcast_module_buffers(bn, 0)
+        assert torch.equal(bn.running_mean, torch.ones(4))
+        assert parallel.broadcast_flag(rank == 0, torch.device("cpu")) is True             # rank 0 decides
+        assert parallel.broadcast_flag(rank != 0, torch.device("cpu")) is False
+        if rank == 0:
+            np.save(os.path.join(tmp, "visit_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_feature_gather_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_visit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "visit_ok.npy")

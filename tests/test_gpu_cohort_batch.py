@@ -47,6 +47,12 @@ def test_cohort_batch_equals_per_cohort_route(tmp_path):
             p = int(rng.integers(0, 20000))
             rows.append((ch, p, p + 1, "C", "G", "S%d" % rng.integers(0, 9), ".", "Noncoding", "C>G", "ACA"))
         rows += rows[:5]                                       # exact duplicates
+        # the same indel in several samples: get_unique_indels (mutation_tools.py:110-117) counts it once per GENE label
+        # in the genome-mode scale factor, while the per-element tabulation keeps one per sample
+        blk = base["elts"][c][3][0]
+        for smp, gene in (("S1", "."), ("S2", "."), ("S3", "."), ("S4", "G2"), ("S5", "G2")):
+            rows.append((base["elts"][c][1], blk[0] + 3, blk[0] + 6, "ACG", "A", smp, gene, "INDEL", "DEL", "."))
+            rows.append(("1", 15000 + c, 15003 + c, "TTA", "T", smp, gene, "INDEL", "DEL", "."))
         f = tmp_path / ("muts%d.tsv" % c)
         pd.DataFrame(rows).to_csv(f, sep="\t", header=False, index=False)
         pres.append(pre)
