@@ -364,18 +364,26 @@ struct StageBin {            // tile t+1
     uint8_t fl[kPre];
 };
 
-__global__ __launch_bounds__(kBlock) void element_stats_stream_fused_kernel(ElementStatsArgs a)
+// TICKETS: the tiles of a workgroup (tile = ticket * gridDim.x + blockIdx.x: the whole grid still sweeps the arrays as one
+// moving window) are drawn by its waves from one LDS counter instead of being dealt out in advance.  With static
+// shares the waves of a SIMD finish one after the other (the arbiter issues oldest-first): rocprofv3 shows an average wave
+// lifetime of 68 % of the kernel's duration with the VALU 85 % busy while waves are resident -- the tail, where a SIMD is
+// down to one or two waves, is where the pass loses its time.  With a shared queue all waves of a CU end together.
+template <int TB, bool TICKETS>
+__global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
-    __shared__ unsigned park_all[kBlock / 64][kParkCap];
+    __shared__ unsigned park_all[TB / 64][kParkCap];
+    __shared__ unsigned s_ticket;
+    if (TICKETS && threadIdx.x == 0) s_ticket = 0;
     nb_tables_init();
     unsigned* park = park_all[threadIdx.x >> 6];
     const int64_t n = a.E * a.C;
     const int lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    int64_t tile = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (tile >= n_tiles) return;
+    const int64_t n_waves = ((int64_t)gridDim.x * TB) >> 6;
+    int64_t tile = ((int64_t)blockIdx.x * TB + threadIdx.x) >> 6;
+    if (!TICKETS && tile >= n_tiles) return;
     const int64_t step_pairs = n_waves * 64;
     const int64_t step_e = a.use_fastdiv ? fastdiv(step_pairs, a.divC) : step_pairs;
     const uint32_t step_c = (uint32_t)(step_pairs - step_e * a.C);
@@ -383,20 +391,35 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_fused_kernel(Elem
     int64_t iu = tile * 64 + lane;                    // unclamped flat index of the pair the pointer stage fetches next
     int64_t eu = a.use_fastdiv ? fastdiv(iu, a.divC) : iu;
     uint32_t cu = (uint32_t)(iu - eu * a.C);
+    auto draw = [&]() -> int64_t {                    // next tile of this workgroup (wave-uniform)
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(&s_ticket, 1u);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        return (int64_t)t * gridDim.x + blockIdx.x;
+    };
+    int64_t tile_ptr = 0;                             // TICKETS: tile the last pointer fetch was for
     auto fetch_ptr = [&]() {                          // lanes (and whole tiles) past the end replay the last pair
         StagePtr s;
+        if (TICKETS) {
+            tile_ptr = draw();
+            iu = tile_ptr * 64 + lane;
+            eu = a.use_fastdiv ? fastdiv(min(iu, n - 1), a.divC) : iu;
+            cu = (uint32_t)(min(iu, n - 1) - eu * a.C);
+        }
         const bool past = iu >= n;
         s.i = (uint32_t)(past ? n - 1 : iu);
         s.e = (uint32_t)(past ? a.E - 1 : eu);
         s.c = past ? C32 - 1 : cu;
         s.q0 = a.ov_ptr[s.e];
         s.q1 = a.ov_ptr[s.e + 1];
-        iu += step_pairs;
-        eu += step_e;
-        cu += step_c;
-        if (cu >= C32) {
-            cu -= C32;
-            eu += 1;
+        if (!TICKETS) {
+            iu += step_pairs;
+            eu += step_e;
+            cu += step_c;
+            if (cu >= C32) {
+                cu -= C32;
+                eu += 1;
+            }
         }
         return s;
     };
@@ -436,17 +459,21 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_fused_kernel(Elem
         return b;
     };
     // pipeline fill: pointers of the first two tiles, inputs and bin rates of the first
+    if (TICKETS) __syncthreads();        // the counter is zero
     StagePtr ptr_n = fetch_ptr();
+    if (TICKETS) tile = tile_ptr;        // tickets come out in ascending order: the wave's tiles are tile, tile_n1, tile_ptr
     StageIn in_c = fetch_in(ptr_n);
     ptr_n = fetch_ptr();
+    int64_t tile_n1 = tile_ptr;
     StageBin bin_c = fetch_bin(in_c);
     unsigned parked = 0;   // wave-uniform
-    for (; tile < n_tiles; tile += n_waves) {
+    for (; tile < n_tiles; tile = TICKETS ? tile_n1 : tile + n_waves) {
         if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
         const bool live = tile * 64 + lane < n;
         const StageIn cur = in_c;
         const StageBin bin = bin_c;
         in_c = fetch_in(ptr_n);          // tile t+1: indices + inputs
+        if (TICKETS) tile_n1 = tile_ptr;
         ptr_n = fetch_ptr();             // tile t+2: pointers
         const int64_t i = cur.i;
         // rate sums (genic_driver_tools.py:262-271)
@@ -887,10 +914,20 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         // instruction cache): 6 for the plain form, 5 for the fused-rates form.
         const int sgrid = grid_for(E * C, kBlock, std::min(resident[which], which == 2 ? 5 : 6));
         if (which == 2 && stream_form() == 1) {
-            static int res_f = 0;
-            if (!res_f) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_f, element_stats_stream_fused_kernel, kBlock, 0));
-            const int g = grid_for(E * C, kBlock, std::min(std::max(res_f, 1), stream_blocks_per_cu(8)));
-            hipLaunchKernelGGL(element_stats_stream_fused_kernel, dim3(g), dim3(kBlock), 0, s, a);
+            static const int tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
+            if (tickets == 1024) {
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            } else if (tickets == 256) {
+                static int res_t = 0;
+                if (!res_t) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_t, (element_stats_stream_fused_kernel<256, true>), 256, 0));
+                const int g = grid_for(E * C, 256, std::min(std::max(res_t, 1), stream_blocks_per_cu(8)));
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, true>), dim3(g), dim3(256), 0, s, a);
+            } else {
+                static int res_f = 0;
+                if (!res_f) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_f, (element_stats_stream_fused_kernel<256, false>), kBlock, 0));
+                const int g = grid_for(E * C, kBlock, std::min(std::max(res_f, 1), stream_blocks_per_cu(8)));
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, false>), dim3(g), dim3(kBlock), 0, s, a);
+            }
         } else if (which == 2)
             hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(sgrid), dim3(kBlock), 0, s, a);
         else if (which == 1)

@@ -1,0 +1,753 @@
+"""h5lite -- a small, dependency-free HDF5 reader / writer for the mutation-map files of the DIG pipeline.
+
+Why: the reference keeps its pretrained maps, element data and per-fold results in HDF5 (h5py + pandas/PyTables,
+DigPretrain.py:82-96,156-177,207-266; sequence_tools.py:460-478,639-641; gp_trainer.py:206-245) and this image has
+neither h5py nor PyTables in the interpreter that carries torch.  The subset below is what those files use, as the
+HDF5 library writes it with its default ("earliest") format bounds -- which is what h5py and PyTables produce:
+
+    read   superblock v0/v1 (v2/v3 with v1/v2 object headers), old-style groups (symbol table: v1 B-tree + local heap +
+           SNOD) and compact new-style groups (link messages), v1 / v2 object headers with continuation blocks, datasets
+           with compact / contiguous / chunked (v1 B-tree) layout, deflate + shuffle + fletcher32 filters, fixed-point,
+           IEEE float, fixed and variable-length strings, bitfield, enum (h5py / PyTables booleans), variable-length
+           sequences (PyTables VLArray: pickled object blocks), attributes (v1-v3), global heap collections
+    write  superblock v0, old-style groups (multi-level B-trees), contiguous datasets of integers / floats / booleans
+           (enum) / fixed strings / one-row vlen uint8 (pickled objects), attributes: numeric scalars and arrays,
+           fixed-length strings (PyTables style) and variable-length UTF-8 strings (h5py style, through a global heap)
+
+Not supported (raises H5LiteError): dense groups / dense attributes (fractal heaps), compound and reference types,
+layout v4 chunk indexes, external storage, big-endian data.  Files are rewritten whole (`write_tree`); `update` reads
+a file into a tree first.  Cross-checked against h5py 3.3 in both directions (tests/test_h5_io.py).
+
+Structures follow the public "HDF5 File Format Specification Version 3.0".
+"""
+import pickle
+import struct
+import zlib
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIG = b"\x89HDF\r\n\x1a\n"
+
+
+class H5LiteError(RuntimeError):
+    pass
+
+
+# =====================================================================================================================
+# in-memory tree
+# =====================================================================================================================
+class FixedString:
+    """Attribute value stored as a fixed-length HDF5 string (what PyTables writes for str / bytes attributes)."""
+
+    def __init__(self, value, utf8=True):
+        self.data = value.encode("utf-8") if isinstance(value, str) else bytes(value)
+        self.utf8 = bool(utf8)
+
+    def __repr__(self):
+        return "FixedString(%r)" % (self.data,)
+
+
+class VLenObject:
+    """Dataset payload stored the way PyTables' VLArray(ObjectAtom) stores one pickled object: a one-row dataset of
+    variable-length uint8 sequences (pandas "fixed" frames keep object-dtype blocks like this)."""
+
+    def __init__(self, obj=None, raw=None):
+        self.raw = raw if raw is not None else pickle.dumps(obj, protocol=4)
+
+    def load(self):
+        return pickle.loads(self.raw)
+
+
+class Dataset:
+    def __init__(self, data, attrs=None):
+        self.data = data            # numpy array (numeric / bool / 'S') or VLenObject
+        self.attrs = dict(attrs or {})
+
+    @property
+    def shape(self):
+        return self.data.shape if isinstance(self.data, np.ndarray) else (1,)
+
+    @property
+    def dtype(self):
+        return self.data.dtype if isinstance(self.data, np.ndarray) else np.dtype(object)
+
+    def __getitem__(self, item):
+        return self.data[item]
+
+
+class Group:
+    def __init__(self, attrs=None, children=None):
+        self.attrs = dict(attrs or {})
+        self.children = dict(children or {})
+
+    def keys(self):
+        return self.children.keys()
+
+    def __contains__(self, path):
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path):
+        node = self
+        for part in [p for p in str(path).split("/") if p]:
+            if not isinstance(node, Group) or part not in node.children:
+                raise KeyError(path)
+            node = node.children[part]
+        return node
+
+    def require_group(self, path):
+        node = self
+        for part in [p for p in str(path).split("/") if p]:
+            nxt = node.children.get(part)
+            if nxt is None:
+                nxt = node.children[part] = Group()
+            elif not isinstance(nxt, Group):
+                raise H5LiteError("%r is a dataset, not a group" % part)
+            node = nxt
+        return node
+
+    def set(self, path, node):
+        parts = [p for p in str(path).split("/") if p]
+        self.require_group("/".join(parts[:-1])).children[parts[-1]] = node
+
+    def remove(self, path):
+        parts = [p for p in str(path).split("/") if p]
+        parent = self["/".join(parts[:-1])] if len(parts) > 1 else self
+        parent.children.pop(parts[-1], None)
+
+
+# =====================================================================================================================
+# reader
+# =====================================================================================================================
+class _Reader:
+    def __init__(self, buf):
+        self.b = buf
+        self.gheaps = {}
+
+    # ---- primitives ----
+    def u(self, off, n):
+        return int.from_bytes(self.b[off:off + n], "little")
+
+    def read_superblock(self):
+        b = self.b
+        base = 0
+        while b[base:base + 8] != SIG:
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(b):
+                raise H5LiteError("not an HDF5 file (no signature)")
+        ver = b[base + 8]
+        if ver in (0, 1):
+            so, sl = b[base + 13], b[base + 14]
+            if so != 8 or sl != 8:
+                raise H5LiteError("only 8-byte offsets / lengths are supported")
+            p = base + 24 + (4 if ver == 1 else 0)
+            self.base_addr = self.u(p, 8)
+            root_entry = p + 32
+            return self.u(root_entry + 8, 8)          # object header address of the root group
+        if ver in (2, 3):
+            if b[base + 9] != 8 or b[base + 10] != 8:
+                raise H5LiteError("only 8-byte offsets / lengths are supported")
+            self.base_addr = self.u(base + 12, 8)
+            return self.u(base + 36, 8)
+        raise H5LiteError("superblock version %d is not supported" % ver)
+
+    # ---- object headers ----
+    def messages(self, addr):
+        """[(type, flags, payload bytes)] of the object header at `addr` (v1 or v2), continuation blocks followed."""
+        b = self.b
+        out = []
+        if b[addr:addr + 4] == b"OHDR":
+            flags = b[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            nsz = 1 << (flags & 3)
+            size0 = self.u(p, nsz)
+            p += nsz
+            track = bool(flags & 0x04)
+            blocks = [(p, p + size0)]
+            while blocks:
+                lo, hi = blocks.pop(0)
+                q = lo
+                while q + 4 <= hi:
+                    mtype, msize, mflags = b[q], self.u(q + 1, 2), b[q + 3]
+                    q += 4 + (2 if track else 0)
+                    data = b[q:q + msize]
+                    if mtype == 0x10:
+                        caddr, clen = self.u(q, 8), self.u(q + 8, 8)
+                        blocks.append((caddr + 4, caddr + clen - 4))      # "OCHK" ... checksum
+                    elif mtype != 0:
+                        out.append((mtype, mflags, data))
+                    q += msize
+            return out
+        if b[addr] != 1:
+            raise H5LiteError("object header version %d at %d is not supported" % (b[addr], addr))
+        nmsg, size0 = self.u(addr + 2, 2), self.u(addr + 8, 4)
+        blocks = [(addr + 16, addr + 16 + size0)]
+        while blocks and len(out) < nmsg + 64:
+            lo, hi = blocks.pop(0)
+            q = lo
+            while q + 8 <= hi:
+                mtype, msize, mflags = self.u(q, 2), self.u(q + 2, 2), b[q + 4]
+                data = b[q + 8:q + 8 + msize]
+                if mtype == 0x10:
+                    blocks.append((self.u(q + 8, 8), self.u(q + 8, 8) + self.u(q + 16, 8)))
+                elif mtype != 0:
+                    out.append((mtype, mflags, data))
+                q += 8 + msize
+        return out
+
+    # ---- datatypes ----
+    def parse_dtype(self, d, off=0):
+        """-> (descriptor, bytes consumed).  descriptor: ('num', np.dtype) | ('str', size, utf8) | ('bool', np.dtype)
+        | ('vlen_str', utf8) | ('vlen', base descriptor) | ('enum', np.dtype)"""
+        cls, ver = d[off] & 0x0F, d[off] >> 4
+        bits = d[off + 1] | (d[off + 2] << 8) | (d[off + 3] << 16)
+        size = int.from_bytes(d[off + 4:off + 8], "little")
+        p = off + 8
+        if cls in (0, 4):
+            if bits & 1:
+                raise H5LiteError("big-endian data is not supported")
+            kind = ("i" if (bits & 8) else "u") if cls == 0 else "u"
+            return ("num", np.dtype("<%s%d" % (kind, size))), p + 4 - off
+        if cls == 1:
+            if bits & 1:
+                raise H5LiteError("big-endian data is not supported")
+            return ("num", np.dtype("<f%d" % size)), p + 12 - off
+        if cls == 3:
+            return ("str", size, ((bits >> 4) & 0xF) == 1), p - off
+        if cls == 9:
+            base, used = self.parse_dtype(d, p)
+            if (bits & 0xF) == 1:
+                return ("vlen_str", ((bits >> 8) & 0xF) == 1), p + used - off
+            return ("vlen", base), p + used - off
+        if cls == 8:
+            base, used = self.parse_dtype(d, p)
+            n = bits & 0xFFFF
+            q = p + used
+            names = []
+            for _ in range(n):
+                e = d.index(b"\x00", q)
+                names.append(bytes(d[q:e]))
+                ln = e - q + 1
+                q += ln if ver >= 3 else (ln + 7) // 8 * 8
+            q += n * base[1].itemsize
+            if sorted(names) == [b"FALSE", b"TRUE"] and base[1].itemsize == 1:
+                return ("bool", base[1]), q - off
+            return ("enum", base[1]), q - off
+        raise H5LiteError("datatype class %d is not supported" % cls)
+
+    def parse_dataspace(self, d):
+        ver, rank, flags = d[0], d[1], d[2]
+        if ver == 1:
+            p = 8
+        elif ver == 2:
+            if d[3] == 2:
+                return None          # null dataspace
+            p = 4
+        else:
+            raise H5LiteError("dataspace version %d" % ver)
+        return tuple(int.from_bytes(d[p + 8 * i:p + 8 * i + 8], "little") for i in range(rank))
+
+    # ---- global heap (variable-length data) ----
+    def gheap_object(self, addr, index):
+        col = self.gheaps.get(addr)
+        if col is None:
+            b = self.b
+            if b[addr:addr + 4] != b"GCOL":
+                raise H5LiteError("bad global heap collection at %d" % addr)
+            size = self.u(addr + 8, 8)
+            col, q = {}, addr + 16
+            while q + 16 <= addr + size:
+                idx, osz = self.u(q, 2), self.u(q + 8, 8)
+                if idx == 0:
+                    break
+                col[idx] = (q + 16, osz)
+                q += 16 + (osz + 7) // 8 * 8
+            self.gheaps[addr] = col
+        off, osz = col[index]
+        return bytes(self.b[off:off + osz])
+
+    def decode(self, desc, shape, raw):
+        """raw bytes of a dataset / attribute -> numpy array (or python object for scalars of string type)."""
+        n = int(np.prod(shape)) if shape is not None else 0
+        kind = desc[0]
+        if kind in ("num", "enum"):
+            a = np.frombuffer(raw, dtype=desc[1], count=n).reshape(shape).copy()
+            return a
+        if kind == "bool":
+            return np.frombuffer(raw, dtype=np.uint8, count=n).reshape(shape).astype(bool)
+        if kind == "str":
+            a = np.frombuffer(raw, dtype="S%d" % desc[1], count=n).reshape(shape).copy()
+            return a
+        if kind in ("vlen_str", "vlen"):
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                ln = int.from_bytes(raw[16 * i:16 * i + 4], "little")
+                addr = int.from_bytes(raw[16 * i + 4:16 * i + 12], "little")
+                idx = int.from_bytes(raw[16 * i + 12:16 * i + 16], "little")
+                if ln == 0 or addr in (0, UNDEF):
+                    payload = b""
+                else:
+                    payload = self.gheap_object(addr + self.base_addr, idx)
+                if kind == "vlen_str":
+                    payload = payload[:ln] if ln <= len(payload) else payload
+                    out[i] = payload.decode("utf-8", "replace") if desc[1] else payload
+                else:
+                    base = desc[1]
+                    out[i] = np.frombuffer(payload, dtype=base[1], count=ln).copy() if base[0] == "num" else payload
+            return out.reshape(shape)
+        raise H5LiteError("cannot decode %r" % (desc,))
+
+    # ---- attributes ----
+    def parse_attribute(self, d):
+        ver = d[0]
+        nsz, tsz, ssz = self.u_(d, 2, 2), self.u_(d, 4, 2), self.u_(d, 6, 2)
+        p = 8 + (1 if ver == 3 else 0)
+        pad = (lambda x: (x + 7) // 8 * 8) if ver == 1 else (lambda x: x)
+        name = bytes(d[p:p + nsz]).split(b"\x00")[0].decode("utf-8")
+        p += pad(nsz)
+        desc, _ = self.parse_dtype(d, p)
+        p += pad(tsz)
+        shape = self.parse_dataspace(d[p:p + ssz])
+        p += pad(ssz)
+        if shape is None:
+            return name, None
+        val = self.decode(desc, shape, d[p:])
+        if shape == ():
+            val = val[()]
+            if desc[0] == "str":
+                val = bytes(val)          # numpy strips trailing NULs, which is what fixed strings are padded with
+                if desc[2]:
+                    try:
+                        val = val.decode("utf-8")
+                    except UnicodeDecodeError:
+                        pass
+        return name, val
+
+    @staticmethod
+    def u_(d, off, n):
+        return int.from_bytes(d[off:off + n], "little")
+
+    # ---- groups ----
+    def symbol_table_members(self, btree, heap):
+        b = self.b
+        if b[heap:heap + 4] != b"HEAP":
+            raise H5LiteError("bad local heap")
+        data = self.u(heap + 24, 8) + self.base_addr
+        out = []
+
+        def walk(node):
+            if b[node:node + 4] == b"SNOD":
+                for i in range(self.u(node + 6, 2)):
+                    e = node + 8 + 40 * i
+                    noff = data + self.u(e, 8)
+                    name = bytes(b[noff:b.index(b"\x00", noff)]).decode("utf-8")
+                    out.append((name, self.u(e + 8, 8) + self.base_addr))
+                return
+            if b[node:node + 4] != b"TREE" or b[node + 4] != 0:
+                raise H5LiteError("bad group B-tree node")
+            n = self.u(node + 6, 2)
+            for i in range(n):
+                walk(self.u(node + 24 + 8 + 16 * i, 8) + self.base_addr)
+
+        walk(btree)
+        return out
+
+    def parse_link(self, d):
+        flags = d[1]
+        p = 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = d[p]
+            p += 1
+        if flags & 0x04:
+            p += 8
+        if flags & 0x10:
+            p += 1
+        lsz = 1 << (flags & 3)
+        nlen = self.u_(d, p, lsz)
+        p += lsz
+        name = bytes(d[p:p + nlen]).decode("utf-8")
+        p += nlen
+        if ltype != 0:
+            return name, None                       # soft / external links are skipped
+        return name, self.u_(d, p, 8) + self.base_addr
+
+    # ---- datasets ----
+    def read_chunked(self, btree, shape, chunk, itemsize, filters):
+        b = self.b
+        rank = len(shape)
+        full = np.zeros(tuple(shape) + (itemsize,), dtype=np.uint8)
+
+        def unfilter(raw, mask):
+            for i, (fid, cd) in reversed(list(enumerate(filters))):
+                if mask & (1 << i):
+                    continue
+                if fid == 1:
+                    raw = zlib.decompress(raw)
+                elif fid == 2:
+                    es = cd[0] if cd else itemsize
+                    a = np.frombuffer(raw, dtype=np.uint8)
+                    n = len(a) // es
+                    raw = a[:n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
+                elif fid == 3:
+                    raw = raw[:-4]
+                else:
+                    raise H5LiteError("filter %d is not supported" % fid)
+            return raw
+
+        def walk(node):
+            if b[node:node + 4] != b"TREE" or b[node + 4] != 1:
+                raise H5LiteError("bad chunk B-tree node")
+            level, n = b[node + 5], self.u(node + 6, 2)
+            ksz = 8 + 8 * (rank + 1)
+            p = node + 24
+            for i in range(n):
+                csize, mask = self.u(p, 4), self.u(p + 4, 4)
+                offs = [self.u(p + 8 + 8 * j, 8) for j in range(rank)]
+                child = self.u(p + ksz, 8) + self.base_addr
+                if level > 0:
+                    walk(child)
+                else:
+                    raw = unfilter(bytes(b[child:child + csize]), mask)
+                    blk = np.frombuffer(raw, dtype=np.uint8, count=int(np.prod(chunk)) * itemsize).reshape(tuple(chunk) + (itemsize,))
+                    sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
+                    full[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+                p += ksz + 8
+
+        if btree not in (UNDEF, UNDEF + self.base_addr):
+            walk(btree)
+        return full.tobytes()
+
+    def read_object(self, addr):
+        msgs = self.messages(addr)
+        types = {t for t, _, _ in msgs}
+        attrs = {}
+        for t, _, d in msgs:
+            if t == 0x0C:
+                name, val = self.parse_attribute(d)
+                attrs[name] = val
+            elif t == 0x15 and self.u_(d, 2 + (2 if d[1] & 1 else 0), 8) != UNDEF:
+                raise H5LiteError("dense attribute storage is not supported")
+        if 0x08 in types and 0x03 in types:                                   # dataset
+            desc = shape = layout = None
+            filters = []
+            for t, _, d in msgs:
+                if t == 0x03:
+                    desc, _ = self.parse_dtype(d)
+                    tsize = self.u_(d, 4, 4)
+                elif t == 0x01:
+                    shape = self.parse_dataspace(d)
+                elif t == 0x08:
+                    layout = d
+                elif t == 0x0B:
+                    if d[0] == 1:
+                        p = 8
+                        for _ in range(d[1]):
+                            fid, nlen, ncd = self.u_(d, p, 2), self.u_(d, p + 2, 2), self.u_(d, p + 6, 2)
+                            p += 8 + (nlen + 7) // 8 * 8
+                            cd = [self.u_(d, p + 4 * j, 4) for j in range(ncd)]
+                            p += 4 * ncd + (4 if ncd % 2 else 0)
+                            filters.append((fid, cd))
+                    else:
+                        p = 2
+                        for _ in range(d[1]):
+                            fid = self.u_(d, p, 2)
+                            p += 2
+                            nlen = 0
+                            if fid >= 256:
+                                nlen = self.u_(d, p, 2)
+                                p += 2
+                            ncd = self.u_(d, p + 2, 2)
+                            p += 4 + nlen
+                            cd = [self.u_(d, p + 4 * j, 4) for j in range(ncd)]
+                            p += 4 * ncd
+                            filters.append((fid, cd))
+            if shape is None:
+                return Dataset(np.zeros(0), attrs)
+            n = int(np.prod(shape))
+            if layout[0] != 3:
+                raise H5LiteError("data layout message version %d is not supported" % layout[0])
+            cls = layout[1]
+            if cls == 0:
+                raw = bytes(layout[4:4 + self.u_(layout, 2, 2)])
+            elif cls == 1:
+                a, sz = self.u_(layout, 2, 8), self.u_(layout, 10, 8)
+                raw = b"" if a == UNDEF else bytes(self.b[a + self.base_addr:a + self.base_addr + sz])
+                if len(raw) < n * tsize:
+                    raw = raw + b"\x00" * (n * tsize - len(raw))
+            elif cls == 2:
+                dim = layout[2]
+                bt = self.u_(layout, 3, 8)
+                dims = [self.u_(layout, 11 + 4 * j, 4) for j in range(dim)]
+                raw = self.read_chunked(bt + self.base_addr if bt != UNDEF else UNDEF, shape, dims[:-1], tsize, filters)
+            else:
+                raise H5LiteError("layout class %d" % cls)
+            if desc[0] == "vlen" and n == 1 and desc[1][0] == "num" and desc[1][1].itemsize == 1:
+                obj = self.decode(desc, shape, raw).reshape(-1)[0]
+                return Dataset(VLenObject(raw=bytes(np.asarray(obj, dtype=np.uint8).tobytes())), attrs)
+            return Dataset(self.decode(desc, shape, raw), attrs)
+        # group
+        members = []
+        for t, _, d in msgs:
+            if t == 0x11:
+                members += self.symbol_table_members(self.u_(d, 0, 8) + self.base_addr, self.u_(d, 8, 8) + self.base_addr)
+            elif t == 0x06:
+                name, child = self.parse_link(d)
+                if child is not None:
+                    members.append((name, child))
+            elif t == 0x02:
+                flags = d[1]
+                p = 2 + (8 if flags & 1 else 0)
+                if self.u_(d, p, 8) != UNDEF:
+                    raise H5LiteError("dense link storage (fractal heap) is not supported")
+        g = Group(attrs)
+        for name, child in members:
+            g.children[name] = self.read_object(child)
+        return g
+
+
+def read_tree(path):
+    """Whole file -> Group tree (datasets fully loaded)."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    r = _Reader(buf)
+    root = r.read_superblock()
+    return r.read_object(root + r.base_addr)
+
+
+# =====================================================================================================================
+# writer
+# =====================================================================================================================
+def _pad8(b):
+    return b + b"\x00" * (-len(b) % 8)
+
+
+def _dt_fixed(dtype):
+    dt = np.dtype(dtype)
+    if dt.kind in "iu":
+        bits = 0x08 if dt.kind == "i" else 0
+        return bytes([0x10, bits, 0, 0]) + struct.pack("<I", dt.itemsize) + struct.pack("<HH", 0, 8 * dt.itemsize)
+    if dt.kind == "f":
+        if dt.itemsize == 8:
+            props = struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+            signloc = 63
+        elif dt.itemsize == 4:
+            props = struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+            signloc = 31
+        elif dt.itemsize == 2:
+            props = struct.pack("<HHBBBBI", 0, 16, 10, 5, 0, 10, 15)
+            signloc = 15
+        else:
+            raise H5LiteError("float%d" % (8 * dt.itemsize))
+        return bytes([0x11, 0x20, signloc, 0]) + struct.pack("<I", dt.itemsize) + props
+    if dt.kind == "S":
+        return bytes([0x13, 0x00, 0, 0]) + struct.pack("<I", max(dt.itemsize, 1))
+    if dt.kind == "b":
+        base = _dt_fixed(np.int8)
+        names = _pad8(b"FALSE\x00") + _pad8(b"TRUE\x00")
+        return bytes([0x18, 2, 0, 0]) + struct.pack("<I", 1) + base + names + bytes([0, 1])
+    raise H5LiteError("dtype %r cannot be written" % (dt,))
+
+
+def _dt_string(size, utf8):
+    return bytes([0x13, 0x10 if utf8 else 0x00, 0, 0]) + struct.pack("<I", max(size, 1))
+
+
+def _dt_vlen_str(utf8=True):
+    base = bytes([0x13, 0x10 if utf8 else 0x00, 0, 0]) + struct.pack("<I", 1)
+    return bytes([0x19, 0x01, 0x01 if utf8 else 0x00, 0]) + struct.pack("<I", 16) + base
+
+
+def _dt_vlen_u8():
+    return bytes([0x19, 0x00, 0, 0]) + struct.pack("<I", 16) + _dt_fixed(np.uint8)
+
+
+def _dataspace(shape):
+    if shape == ():
+        return bytes([1, 0, 0, 0, 0, 0, 0, 0])
+    return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b"".join(struct.pack("<Q", int(s)) for s in shape)
+
+
+def _msg(mtype, data, flags=0):
+    data = _pad8(data)
+    if len(data) > 0xFFF8:
+        raise H5LiteError("object header message too large (%d bytes)" % len(data))
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+class _Writer:
+    LEAF_K, INTERNAL_K = 4, 16
+
+    def __init__(self):
+        self.buf = bytearray(96)              # superblock goes here at the end
+        self.gheap = []                       # pending vlen objects of the current collection: bytes
+
+    def alloc(self, data):
+        off = len(self.buf)
+        self.buf += data
+        self.buf += b"\x00" * (-len(self.buf) % 8)
+        return off
+
+    # ---- variable-length payloads: one global heap collection per call (flushed immediately) ----
+    def vlen_ref(self, payloads):
+        """Writes a global heap collection holding `payloads`; returns the 16-byte vlen descriptors."""
+        body = bytearray()
+        for i, p in enumerate(payloads, start=1):
+            body += struct.pack("<HHIQ", i, 1, 0, len(p)) + _pad8(p)
+        size = max(4096, 16 + len(body) + 16)
+        size = (size + 7) // 8 * 8
+        free = size - 16 - len(body)
+        col = bytearray(b"GCOL" + bytes([1, 0, 0, 0]) + struct.pack("<Q", size)) + body
+        if free >= 16:
+            col += struct.pack("<HHIQ", 0, 0, 0, free)      # free-space object: its size counts its own header
+        col += b"\x00" * (size - len(col))
+        addr = self.alloc(bytes(col))
+        return [struct.pack("<IQI", len(p), addr, i) for i, p in enumerate(payloads, start=1)]
+
+    # ---- attributes ----
+    def attribute(self, name, value):
+        nm = name.encode("utf-8") + b"\x00"
+        if isinstance(value, FixedString):
+            dt, ds, data = _dt_string(len(value.data), value.utf8), _dataspace(()), value.data or b"\x00"
+        elif isinstance(value, str):
+            dt, ds = _dt_vlen_str(True), _dataspace(())
+            data = self.vlen_ref([value.encode("utf-8")])[0]
+        elif isinstance(value, (bytes, np.bytes_)):
+            dt, ds = _dt_vlen_str(False), _dataspace(())
+            data = self.vlen_ref([bytes(value)])[0]
+        else:
+            a = np.asarray(value)
+            if a.dtype.kind == "U":
+                flat = [s.encode("utf-8") for s in a.reshape(-1).tolist()]
+                dt, ds, data = _dt_vlen_str(True), _dataspace(a.shape), b"".join(self.vlen_ref(flat))
+            elif a.dtype.kind == "O":
+                raise H5LiteError("attribute %r: object arrays cannot be written" % name)
+            else:
+                shape = a.shape             # (np.ascontiguousarray turns 0-d into 1-d)
+                a = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<"))) if a.dtype.kind in "iuf" else np.ascontiguousarray(a)
+                dt, ds = _dt_fixed(a.dtype), _dataspace(shape)
+                data = a.astype(np.uint8).tobytes() if a.dtype.kind == "b" else a.tobytes()
+        body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
+        return _msg(0x0C, body)
+
+    def object_header(self, msgs):
+        body = b"".join(msgs)
+        hdr = struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body))
+        return self.alloc(hdr + body)
+
+    # ---- datasets ----
+    def write_dataset(self, ds):
+        data = ds.data
+        if isinstance(data, VLenObject):
+            ref = self.vlen_ref([data.raw])[0]
+            raw, dt, shape = ref, _dt_vlen_u8(), (1,)
+        else:
+            a = np.asarray(data)
+            if a.dtype.kind == "U":
+                a = np.char.encode(a, "utf-8")
+            if a.dtype.kind == "O":
+                raise H5LiteError("object arrays must be wrapped in VLenObject")
+            if a.dtype.kind in "iuf" and a.dtype.byteorder == ">":
+                a = a.astype(a.dtype.newbyteorder("<"))
+            shape = a.shape
+            a = np.ascontiguousarray(a)
+            if a.dtype.kind == "S" and a.dtype.itemsize == 0:
+                a = a.astype("S1")
+            dt = _dt_fixed(a.dtype)
+            raw = a.astype(np.uint8).tobytes() if a.dtype.kind == "b" else a.tobytes()
+        addr = self.alloc(raw) if len(raw) else UNDEF
+        msgs = [_msg(0x01, _dataspace(shape)), _msg(0x03, dt, flags=1), _msg(0x05, bytes([2, 1, 1, 0])),
+                _msg(0x08, bytes([3, 1]) + struct.pack("<QQ", addr, len(raw)))]
+        msgs += [self.attribute(k, v) for k, v in ds.attrs.items()]
+        return self.object_header(msgs)
+
+    # ---- groups ----
+    def write_group(self, g):
+        """Children first, then local heap + SNODs + B-tree + object header.  Returns (header addr, btree, heap)."""
+        entries = []
+        for name in sorted(g.children, key=lambda s: s.encode("utf-8")):
+            child = g.children[name]
+            if isinstance(child, Group):
+                haddr, bt, hp = self.write_group(child)
+                entries.append((name, haddr, 1, struct.pack("<QQ", bt, hp)))
+            else:
+                entries.append((name, self.write_dataset(child), 0, b"\x00" * 16))
+        # local heap: "" at offset 0, then the names
+        heap_data = bytearray(b"\x00" * 8)
+        name_off = {}
+        for name, _, _, _ in entries:
+            name_off[name] = len(heap_data)
+            heap_data += _pad8(name.encode("utf-8") + b"\x00")
+        data_addr = self.alloc(bytes(heap_data))
+        heap_addr = self.alloc(b"HEAP" + bytes(4) + struct.pack("<QQQ", len(heap_data), 1, data_addr))
+        # leaves
+        cap = 2 * self.LEAF_K
+        level = []            # (address, largest name offset)
+        for i in range(0, len(entries), cap):
+            part = entries[i:i + cap]
+            node = bytearray(b"SNOD" + bytes([1, 0]) + struct.pack("<H", len(part)))
+            for name, haddr, ctype, scratch in part:
+                node += struct.pack("<QQII", name_off[name], haddr, ctype, 0) + scratch
+            node += b"\x00" * (8 + 40 * cap - len(node))
+            level.append((self.alloc(bytes(node)), name_off[part[-1][0]] if part else 0))
+        depth = 0
+        fan = 2 * self.INTERNAL_K
+        while True:
+            nodes = []
+            for i in range(0, max(len(level), 1), fan):
+                part = level[i:i + fan]
+                node = bytearray(b"TREE" + bytes([0, depth]) + struct.pack("<H", len(part)) + struct.pack("<QQ", UNDEF, UNDEF))
+                node += struct.pack("<Q", 0)                                   # key 0: the empty string
+                for addr, last in part:
+                    node += struct.pack("<QQ", addr, last)
+                node += b"\x00" * (24 + 8 + 16 * fan - len(node))
+                nodes.append([len(self.buf), part[-1][1] if part else 0, node])
+                self.alloc(bytes(node))
+            # sibling pointers and first keys inside one level
+            for j, (addr, _, node) in enumerate(nodes):
+                left = nodes[j - 1][0] if j else UNDEF
+                right = nodes[j + 1][0] if j + 1 < len(nodes) else UNDEF
+                first_key = nodes[j - 1][1] if j else 0
+                self.buf[addr + 8:addr + 24] = struct.pack("<QQ", left, right)
+                self.buf[addr + 24:addr + 32] = struct.pack("<Q", first_key)
+            level = [(addr, last) for addr, last, _ in nodes]
+            depth += 1
+            if len(level) <= 1:
+                break
+        btree = level[0][0]
+        msgs = [_msg(0x11, struct.pack("<QQ", btree, heap_addr))] + [self.attribute(k, v) for k, v in g.attrs.items()]
+        return self.object_header(msgs), btree, heap_addr
+
+    def finish(self, root):
+        haddr, bt, hp = self.write_group(root)
+        sb = bytearray(SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", self.LEAF_K, self.INTERNAL_K, 0))
+        sb += struct.pack("<QQQQ", 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack("<QQII", 0, haddr, 1, 0) + struct.pack("<QQ", bt, hp)
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_tree(path, root):
+    data = _Writer().finish(root)
+    tmp = str(path) + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(data)
+    import os
+    os.replace(tmp, path)
+
+
+def update(path, fn):
+    """Read `path` (or start from an empty tree), apply fn(root), write it back."""
+    import os
+    root = read_tree(path) if os.path.exists(path) else Group()
+    fn(root)
+    write_tree(path, root)

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02h
-python tools/variant_bench.py base.so pipe3.so k128.so pipe3.so k128.so > gpurun_out/r02h/v.txt 2>&1
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r02h/pytest.log
+mkdir -p gpurun_out/r02l
+python tools/variant_bench.py k128.so tick.so:DIG_ES_TICKETS=0 tick.so:DIG_ES_TICKETS=1024 tick.so:DIG_ES_TICKETS=256 k128.so tick.so:DIG_ES_TICKETS=1024 tick.so:DIG_ES_TICKETS=256 tick.so:DIG_ES_TICKETS=256,DIG_ES_BLOCKS_PER_CU=4 > gpurun_out/r02l/v.txt 2>&1
