@@ -37,15 +37,57 @@ class H5LiteError(RuntimeError):
 # =====================================================================================================================
 # in-memory tree
 # =====================================================================================================================
-class FixedString:
-    """Attribute value stored as a fixed-length HDF5 string (what PyTables writes for str / bytes attributes)."""
+class FixedStr(str):
+    """Text stored as a fixed-length, NUL-terminated UTF-8 HDF5 string (what PyTables writes for str attributes).  Plain
+    `str` values are written the h5py way, as variable-length UTF-8 strings.  The reader returns FixedStr / FixedBytes
+    for fixed strings, so that a file read into a tree and written back keeps its attribute forms."""
 
-    def __init__(self, value, utf8=True):
-        self.data = value.encode("utf-8") if isinstance(value, str) else bytes(value)
-        self.utf8 = bool(utf8)
+
+class FixedBytes(bytes):
+    """Bytes stored as a fixed-length ASCII HDF5 string (PyTables: pickled attribute values, e.g. b'N.' for None)."""
+
+
+def FixedString(value, utf8=True):
+    if isinstance(value, str):
+        return FixedStr(value)
+    return FixedStr(bytes(value).decode("utf-8")) if utf8 else FixedBytes(value)
+
+
+class NullString:
+    """The empty string as PyTables stores it: string type of size 1 with a NULL dataspace (reads back as this object;
+    str() of it is '')."""
+
+    def __str__(self):
+        return ""
+
+    def __bool__(self):
+        return False
 
     def __repr__(self):
-        return "FixedString(%r)" % (self.data,)
+        return "NullString()"
+
+    def __eq__(self, other):
+        return isinstance(other, NullString) or other == "" or other is None
+
+    def __hash__(self):
+        return hash("")
+
+
+class B8:
+    """Boolean data written as an HDF5 bitfield (H5T_STD_B8LE), PyTables' representation of numpy bool -- plain numpy
+    bool arrays are written the h5py way (enum FALSE / TRUE over int8).  Both read back as bool."""
+
+    def __init__(self, value):
+        self.value = np.asarray(value, dtype=bool)
+
+    def __bool__(self):
+        return bool(self.value)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.value if dtype is None else self.value.astype(dtype)
+
+    def __repr__(self):
+        return "B8(%r)" % (self.value.tolist(),)
 
 
 class VLenObject:
@@ -59,18 +101,51 @@ class VLenObject:
         return pickle.loads(self.raw)
 
 
+class _Lazy:
+    """Payload of a dataset that has not been read yet (read_tree(lazy=True)): load() -> array, rows(lo, hi) -> the
+    slice [lo:hi] along the first dimension, touching only the bytes / chunks it needs."""
+
+    def __init__(self, shape, dtype, load, rows):
+        self.shape, self.dtype, self.load, self.rows = shape, dtype, load, rows
+
+
 class Dataset:
     def __init__(self, data, attrs=None):
-        self.data = data            # numpy array (numeric / bool / 'S') or VLenObject
+        self._data = data           # numpy array (numeric / bool / 'S'), VLenObject, B8 or _Lazy
         self.attrs = dict(attrs or {})
+        self.bitfield = False       # reader: booleans were stored as H5T_STD_B8 (kept when the tree is written back)
+
+    @property
+    def data(self):
+        if isinstance(self._data, _Lazy):
+            self._data = self._data.load()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
+    def read_rows(self, lo, hi):
+        """data[lo:hi] without materialising the whole dataset when it was opened lazily."""
+        if isinstance(self._data, _Lazy):
+            return self._data.rows(int(lo), int(hi))
+        return self.data[lo:hi]
 
     @property
     def shape(self):
-        return self.data.shape if isinstance(self.data, np.ndarray) else (1,)
+        d = self._data
+        if isinstance(d, _Lazy):
+            return d.shape
+        if isinstance(d, B8):
+            return d.value.shape
+        return d.shape if isinstance(d, np.ndarray) else (1,)
 
     @property
     def dtype(self):
-        return self.data.dtype if isinstance(self.data, np.ndarray) else np.dtype(object)
+        d = self._data
+        if isinstance(d, _Lazy):
+            return d.dtype
+        return d.dtype if isinstance(d, np.ndarray) else np.dtype(object)
 
     def __getitem__(self, item):
         return self.data[item]
@@ -124,9 +199,10 @@ class Group:
 # reader
 # =====================================================================================================================
 class _Reader:
-    def __init__(self, buf):
+    def __init__(self, buf, lazy=False):
         self.b = buf
         self.gheaps = {}
+        self.lazy = lazy
 
     # ---- primitives ----
     def u(self, off, n):
@@ -214,6 +290,8 @@ class _Reader:
         if cls in (0, 4):
             if bits & 1:
                 raise H5LiteError("big-endian data is not supported")
+            if cls == 4 and size == 1:
+                return ("bool", np.dtype(np.uint8)), p + 4 - off      # H5T_STD_B8: what PyTables stores booleans as
             kind = ("i" if (bits & 8) else "u") if cls == 0 else "u"
             return ("num", np.dtype("<%s%d" % (kind, size))), p + 4 - off
         if cls == 1:
@@ -318,18 +396,27 @@ class _Reader:
         shape = self.parse_dataspace(d[p:p + ssz])
         p += pad(ssz)
         if shape is None:
-            return name, None
+            return name, (NullString() if desc[0] == "str" else None)
         val = self.decode(desc, shape, d[p:])
+        if desc[0] == "bool" and self._is_bitfield(d, ver, nsz):
+            return name, B8(val)
         if shape == ():
             val = val[()]
             if desc[0] == "str":
                 val = bytes(val)          # numpy strips trailing NULs, which is what fixed strings are padded with
                 if desc[2]:
                     try:
-                        val = val.decode("utf-8")
+                        val = FixedStr(val.decode("utf-8"))
                     except UnicodeDecodeError:
-                        pass
+                        val = FixedBytes(val)
+                else:
+                    val = FixedBytes(val)
         return name, val
+
+    def _is_bitfield(self, d, ver, nsz):
+        p = 8 + (1 if ver == 3 else 0)
+        p += (nsz + 7) // 8 * 8 if ver == 1 else nsz
+        return (d[p] & 0x0F) == 4
 
     @staticmethod
     def u_(d, off, n):
@@ -348,7 +435,7 @@ class _Reader:
                 for i in range(self.u(node + 6, 2)):
                     e = node + 8 + 40 * i
                     noff = data + self.u(e, 8)
-                    name = bytes(b[noff:b.index(b"\x00", noff)]).decode("utf-8")
+                    name = bytes(b[noff:b.find(b"\x00", noff)]).decode("utf-8")
                     out.append((name, self.u(e + 8, 8) + self.base_addr))
                 return
             if b[node:node + 4] != b"TREE" or b[node + 4] != 0:
@@ -381,9 +468,14 @@ class _Reader:
         return name, self.u_(d, p, 8) + self.base_addr
 
     # ---- datasets ----
-    def read_chunked(self, btree, shape, chunk, itemsize, filters):
+    def read_chunked(self, btree, shape, chunk, itemsize, filters, rows=None):
+        """All chunks (rows=None) or those intersecting rows = (lo, hi) of the first dimension; returns raw bytes of
+        the (windowed) array."""
         b = self.b
         rank = len(shape)
+        r0, r1 = (0, shape[0]) if rows is None or rank == 0 else rows
+        if rank:
+            shape = (max(r1 - r0, 0),) + tuple(shape[1:])
         full = np.zeros(tuple(shape) + (itemsize,), dtype=np.uint8)
 
         def unfilter(raw, mask):
@@ -415,11 +507,17 @@ class _Reader:
                 child = self.u(p + ksz, 8) + self.base_addr
                 if level > 0:
                     walk(child)
-                else:
+                elif rank == 0 or (offs[0] < r1 and offs[0] + chunk[0] > r0):
                     raw = unfilter(bytes(b[child:child + csize]), mask)
                     blk = np.frombuffer(raw, dtype=np.uint8, count=int(np.prod(chunk)) * itemsize).reshape(tuple(chunk) + (itemsize,))
-                    sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
-                    full[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+                    if rank:
+                        offs = [offs[0] - r0] + offs[1:]
+                    src, dst = [], []
+                    for o, c, sz in zip(offs, chunk, shape):
+                        lo_, hi_ = max(o, 0), min(o + c, sz)
+                        dst.append(slice(lo_, hi_))
+                        src.append(slice(lo_ - o, hi_ - o))
+                    full[tuple(dst)] = blk[tuple(src)]
                 p += ksz + 8
 
         if btree not in (UNDEF, UNDEF + self.base_addr):
@@ -443,6 +541,7 @@ class _Reader:
                 if t == 0x03:
                     desc, _ = self.parse_dtype(d)
                     tsize = self.u_(d, 4, 4)
+                    dtype_msg = d
                 elif t == 0x01:
                     shape = self.parse_dataspace(d)
                 elif t == 0x08:
@@ -472,28 +571,45 @@ class _Reader:
                             filters.append((fid, cd))
             if shape is None:
                 return Dataset(np.zeros(0), attrs)
-            n = int(np.prod(shape))
             if layout[0] != 3:
                 raise H5LiteError("data layout message version %d is not supported" % layout[0])
             cls = layout[1]
-            if cls == 0:
-                raw = bytes(layout[4:4 + self.u_(layout, 2, 2)])
-            elif cls == 1:
-                a, sz = self.u_(layout, 2, 8), self.u_(layout, 10, 8)
-                raw = b"" if a == UNDEF else bytes(self.b[a + self.base_addr:a + self.base_addr + sz])
-                if len(raw) < n * tsize:
-                    raw = raw + b"\x00" * (n * tsize - len(raw))
-            elif cls == 2:
+            if cls not in (0, 1, 2):
+                raise H5LiteError("layout class %d" % cls)
+
+            def raw_bytes(rows=None):
+                """Raw bytes of the whole dataset, or of rows = (lo, hi) of the first dimension."""
+                win = shape if rows is None or not shape else (max(rows[1] - rows[0], 0),) + tuple(shape[1:])
+                nbytes = int(np.prod(win)) * tsize
+                row_bytes = (int(np.prod(shape[1:])) if shape else 1) * tsize
+                lo_b = 0 if rows is None or not shape else rows[0] * row_bytes
+                if cls == 0:
+                    return bytes(layout[4:4 + self.u_(layout, 2, 2)])[lo_b:lo_b + nbytes]
+                if cls == 1:
+                    a, sz = self.u_(layout, 2, 8), self.u_(layout, 10, 8)
+                    raw = b"" if a == UNDEF else bytes(self.b[a + self.base_addr + lo_b:a + self.base_addr + min(sz, lo_b + nbytes)])
+                    return raw + b"\x00" * (nbytes - len(raw))
                 dim = layout[2]
                 bt = self.u_(layout, 3, 8)
                 dims = [self.u_(layout, 11 + 4 * j, 4) for j in range(dim)]
-                raw = self.read_chunked(bt + self.base_addr if bt != UNDEF else UNDEF, shape, dims[:-1], tsize, filters)
+                return self.read_chunked(bt + self.base_addr if bt != UNDEF else UNDEF, shape, dims[:-1], tsize, filters, rows)
+
+            def load(rows=None):
+                win = shape if rows is None or not shape else (max(rows[1] - rows[0], 0),) + tuple(shape[1:])
+                raw = raw_bytes(rows)
+                if desc[0] == "vlen" and int(np.prod(shape)) == 1 and desc[1][0] == "num" and desc[1][1].itemsize == 1:
+                    obj = self.decode(desc, shape, raw).reshape(-1)[0]
+                    return VLenObject(raw=bytes(np.asarray(obj, dtype=np.uint8).tobytes()))
+                return self.decode(desc, win, raw)
+
+            if self.lazy and desc[0] in ("num", "bool", "str", "enum") and shape:
+                np_dtype = np.dtype(bool) if desc[0] == "bool" else (np.dtype("S%d" % desc[1]) if desc[0] == "str" else desc[1])
+                ds = Dataset(_Lazy(tuple(shape), np_dtype, load,
+                                   lambda lo, hi: load((max(lo, 0), min(hi, shape[0])))), attrs)
             else:
-                raise H5LiteError("layout class %d" % cls)
-            if desc[0] == "vlen" and n == 1 and desc[1][0] == "num" and desc[1][1].itemsize == 1:
-                obj = self.decode(desc, shape, raw).reshape(-1)[0]
-                return Dataset(VLenObject(raw=bytes(np.asarray(obj, dtype=np.uint8).tobytes())), attrs)
-            return Dataset(self.decode(desc, shape, raw), attrs)
+                ds = Dataset(load(), attrs)
+            ds.bitfield = desc[0] == "bool" and (dtype_msg[0] & 0x0F) == 4     # PyTables boolean: written back as B8
+            return ds
         # group
         members = []
         for t, _, d in msgs:
@@ -514,11 +630,14 @@ class _Reader:
         return g
 
 
-def read_tree(path):
-    """Whole file -> Group tree (datasets fully loaded)."""
+def read_tree(path, lazy=False):
+    """File -> Group tree.  lazy=False: every dataset is loaded.  lazy=True: the file is memory-mapped and array
+    datasets are read on first access of `.data` / by `read_rows(lo, hi)` (training matrices do not fit in host memory;
+    the map stays valid for as long as the tree is alive)."""
+    import mmap
     with open(path, "rb") as f:
-        buf = f.read()
-    r = _Reader(buf)
+        buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if lazy else f.read()
+    r = _Reader(buf, lazy=lazy)
     root = r.read_superblock()
     return r.read_object(root + r.base_addr)
 
@@ -615,8 +734,16 @@ class _Writer:
     # ---- attributes ----
     def attribute(self, name, value):
         nm = name.encode("utf-8") + b"\x00"
-        if isinstance(value, FixedString):
-            dt, ds, data = _dt_string(len(value.data), value.utf8), _dataspace(()), value.data or b"\x00"
+        if isinstance(value, NullString) or value is None or (isinstance(value, (FixedStr, FixedBytes)) and len(value) == 0):
+            dt, ds, data = _dt_string(1, True), bytes([2, 0, 0, 2]), b""     # PyTables: empty string = size 1, NULL dataspace
+        elif isinstance(value, FixedStr):
+            raw = value.encode("utf-8")
+            dt, ds, data = _dt_string(len(raw), True), _dataspace(()), raw
+        elif isinstance(value, FixedBytes):
+            dt, ds, data = _dt_string(len(value), False), _dataspace(()), bytes(value)
+        elif isinstance(value, B8):
+            dt = bytes([0x14, 0, 0, 0]) + struct.pack("<I", 1) + struct.pack("<HH", 0, 8)
+            ds, data = _dataspace(value.value.shape), value.value.astype(np.uint8).tobytes()
         elif isinstance(value, str):
             dt, ds = _dt_vlen_str(True), _dataspace(())
             data = self.vlen_ref([value.encode("utf-8")])[0]
@@ -646,9 +773,14 @@ class _Writer:
     # ---- datasets ----
     def write_dataset(self, ds):
         data = ds.data
+        if getattr(ds, "bitfield", False) and isinstance(data, np.ndarray) and data.dtype.kind == "b":
+            data = B8(data)
         if isinstance(data, VLenObject):
             ref = self.vlen_ref([data.raw])[0]
             raw, dt, shape = ref, _dt_vlen_u8(), (1,)
+        elif isinstance(data, B8):
+            dt = bytes([0x14, 0, 0, 0]) + struct.pack("<I", 1) + struct.pack("<HH", 0, 8)
+            raw, shape = np.ascontiguousarray(data.value).astype(np.uint8).tobytes(), data.value.shape
         else:
             a = np.asarray(data)
             if a.dtype.kind == "U":

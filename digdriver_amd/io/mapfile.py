@@ -8,11 +8,11 @@ The reference keeps everything in one HDF5 file (DigPretrain.py:82-96,156-177,20
 and the per-element context counts in a second HDF5 file (sequence_tools.py:460-478,639-641).
 
 Backends, chosen by the path:
-  *.h5 / *.hdf5   HDF5.  Frames are read/written with pandas when PyTables is importable, otherwise read
-                  through h5py by decoding the PyTables "fixed" layout (axis0/axis1/block*_items/
-                  block*_values).  Needs h5py; raises MapFileError when neither is available.
-  anything else   a directory of .npy files ("DIG map mirror"): same keys, same frames, no HDF5
-                  dependency.  This is what the tests and the synthetic benchmarks use.
+  *.h5 / *.hdf5   HDF5, read and written by this package's own implementation: io/h5lite.py (the HDF5 container:
+                  what h5py / PyTables write with the library's default format) + io/pandas_fixed.py (the
+                  DataFrame.to_hdf "fixed" layout).  No h5py, no PyTables needed; pinned to files written by those
+                  libraries (tests/golden/*_genuine.h5) and cross-checked with h5py and h5dump (tests/test_h5_io.py).
+  anything else   a directory of .npy files ("DIG map mirror"): same keys, same frames.
 """
 import json
 import os
@@ -92,72 +92,116 @@ def _dir_write_attrs(path, **kw):
     os.makedirs(path, exist_ok=True)
     cur = _dir_read_attrs(path)
     for k, v in kw.items():
-        cur[k] = v.item() if isinstance(v, np.generic) else v
+        cur[k] = v.item() if isinstance(v, np.generic) else (v.tolist() if isinstance(v, np.ndarray) else v)
     with open(_dir_attrs_path(path), "w") as f:
         json.dump(cur, f)
 
 
 # ---------------------------------------------------------------------------------------------
-# HDF5 backend
+# HDF5 backend: h5lite (own reader / writer) + pandas_fixed (pandas' "fixed" frame layout); no h5py, no PyTables
 # ---------------------------------------------------------------------------------------------
-def _h5py():
+from . import h5lite, pandas_fixed          # noqa: E402
+
+_TREE_CACHE = {}      # path -> (mtime_ns, size, lazy tree): a driver run reads several keys of the same map
+
+
+def _h5_tree(path):
+    path = os.fspath(path)
+    if path in _PENDING:
+        return _PENDING[path]
     try:
-        import h5py
-        return h5py
-    except ImportError as exc:
-        raise MapFileError("reading %s needs h5py (or use the directory mirror format)" % "HDF5 maps") from exc
+        st = os.stat(path)
+    except FileNotFoundError:
+        raise MapFileError("no such HDF5 map: %s" % path)
+    key = (st.st_mtime_ns, st.st_size)
+    hit = _TREE_CACHE.get(path)
+    if hit is None or hit[0] != key:
+        try:
+            hit = (key, h5lite.read_tree(path, lazy=True))
+        except h5lite.H5LiteError as exc:
+            raise MapFileError("%s: %s" % (path, exc)) from exc
+        _TREE_CACHE.clear()
+        _TREE_CACHE[path] = hit
+    return hit[1]
 
 
-def _decode(a):
-    a = np.asarray(a)
-    if a.dtype.kind == "S":
-        return np.char.decode(a, "utf-8")
-    if a.dtype == object:
-        return np.array([x.decode("utf-8") if isinstance(x, bytes) else x for x in a])
-    return a
+_PENDING = {}         # path -> tree of an open batch()
 
 
-def _h5_read_fixed_frame(path, key):
-    """Decode a PyTables 'fixed' DataFrame group with h5py: axis0 = columns, axis1 = index,
-    block{i}_items = column names of block i, block{i}_values = [n_rows, n_cols_in_block]."""
-    h5py = _h5py()
-    with h5py.File(path, "r") as h5:
-        if key not in h5:
-            raise KeyError("no frame %r in %s" % (key, path))
-        g = h5[key]
-        if "axis0" not in g or "axis1" not in g:
-            raise MapFileError("%s:%s is not a PyTables fixed-format frame (table format is not supported)" % (path, key))
-        columns = list(_decode(g["axis0"][:]))
-        index = _decode(g["axis1"][:])
-        nblocks = int(g.attrs.get("nblocks", sum(1 for k in g.keys() if k.endswith("_items"))))
-        data = {}
-        for b in range(nblocks):
-            items = _decode(g["block%d_items" % b][:])
-            vals = g["block%d_values" % b]
-            if vals.dtype.kind == "O" or vals.shape == () or vals.ndim != 2:
-                raise MapFileError("%s:%s block %d holds pickled objects; re-save the frame with numeric/string "
-                                   "columns or install PyTables" % (path, key, b))
-            vals = _decode(vals[:])
-            for j, name in enumerate(items):
-                data[name] = vals[:, j]
-    return pd.DataFrame(data, index=pd.Index(index))[columns]
+class batch:
+    """`with mapfile.batch(path): ...` -- every write to the HDF5 map `path` inside the block goes to one in-memory tree
+    that is written once at the end (h5lite rewrites the file on every update; a fold-results file takes hundreds of
+    small writes).  Reads of the same path inside the block see the pending tree.  No effect on directory maps."""
+
+    def __init__(self, path):
+        self.path = os.fspath(path)
+
+    def __enter__(self):
+        if _is_h5(self.path) and self.path not in _PENDING:
+            _TREE_CACHE.pop(self.path, None)
+            _PENDING[self.path] = h5lite.read_tree(self.path) if os.path.exists(self.path) else h5lite.Group()
+            self.owner = True
+        else:
+            self.owner = False
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.owner:
+            root = _PENDING.pop(self.path)
+            if exc_type is None:
+                h5lite.write_tree(self.path, root)
+        return False
+
+
+def _h5_update(path, fn):
+    path = os.fspath(path)
+    _TREE_CACHE.pop(path, None)
+    if path in _PENDING:
+        root = _PENDING[path]
+        for k, v in (("CLASS", "GROUP"), ("VERSION", "1.0"), ("TITLE", ""), ("PYTABLES_FORMAT_VERSION", "2.1")):
+            root.attrs.setdefault(k, h5lite.FixedStr(v))
+        fn(root)
+        return
+
+    def apply(root):
+        # what PyTables puts on the root group of every file it creates (pandas.read_hdf opens maps through it)
+        for k, v in (("CLASS", "GROUP"), ("VERSION", "1.0"), ("TITLE", ""), ("PYTABLES_FORMAT_VERSION", "2.1")):
+            root.attrs.setdefault(k, h5lite.FixedStr(v))
+        fn(root)
+
+    h5lite.update(path, apply)
 
 
 def _h5_read_frame(path, key):
+    root = _h5_tree(path)
+    if key not in root:
+        raise KeyError("no frame %r in %s" % (key, path))
     try:
-        import tables  # noqa: F401
-        return pd.read_hdf(path, key)
-    except ImportError:
-        return _h5_read_fixed_frame(path, key)
+        return pandas_fixed.decode_frame(root[key])
+    except pandas_fixed.FrameFormatError as exc:
+        raise MapFileError("%s:%s: %s" % (path, key, exc)) from exc
 
 
 def _h5_write_frame(path, key, df):
-    try:
-        import tables  # noqa: F401
-    except ImportError as exc:
-        raise MapFileError("writing DataFrames into HDF5 needs PyTables (pandas.to_hdf); use the directory "
-                           "mirror format instead") from exc
-    df.to_hdf(path, key=key, mode="a")
+    g = pandas_fixed.encode_frame(df)
+    _h5_update(path, lambda root: root.set(key, g))
+
+
+def _attr_value(v):
+    if isinstance(v, h5lite.NullString):
+        return ""
+    if isinstance(v, h5lite.B8):
+        return bool(v) if v.value.shape == () else v.value
+    if isinstance(v, str):
+        return str(v)
+    if isinstance(v, (bytes, np.bytes_)):
+        try:
+            return bytes(v).decode("utf-8")
+        except UnicodeDecodeError:
+            return bytes(v)
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
 
 
 # ---------------------------------------------------------------------------------------------
@@ -173,40 +217,80 @@ def write_frame(path, key, df):
 
 def read_array(path, key):
     if _is_h5(path):
-        with _h5py().File(path, "r") as h5:
-            return h5[key][:]
+        root = _h5_tree(path)
+        if key not in root or not isinstance(root[key], h5lite.Dataset):
+            raise KeyError("no array %r in %s" % (key, path))
+        return root[key].data
     return _dir_read_array(path, key)
 
 
-def write_array(path, key, arr, **kw):
+def read_array_rows(path, key, lo, hi):
+    """array[lo:hi] along the first dimension; an HDF5 map reads only the chunks / bytes it needs (track matrices)."""
     if _is_h5(path):
-        with _h5py().File(path, "a") as h5:
-            if key in h5:
-                del h5[key]
-            h5.create_dataset(key, data=np.asarray(arr), **kw)
+        root = _h5_tree(path)
+        if key not in root:
+            raise KeyError("no array %r in %s" % (key, path))
+        return root[key].read_rows(lo, hi)
+    return _dir_read_array(path, key)[lo:hi]
+
+
+def array_shape(path, key):
+    if _is_h5(path):
+        return tuple(_h5_tree(path)[key].shape)
+    return tuple(_dir_read_array(path, key).shape)
+
+
+def write_array(path, key, arr, **kw):
+    """(compression keywords of the reference's create_dataset calls are accepted and ignored: datasets are written
+    contiguous, which every HDF5 reader handles)"""
+    if _is_h5(path):
+        a = np.asarray(arr)
+        if a.dtype.kind == "U":
+            a = np.char.encode(a, "utf-8")
+        elif a.dtype == object:
+            a = np.array([str(x).encode("utf-8") for x in a.reshape(-1)]).reshape(a.shape)
+        _h5_update(path, lambda root: root.set(key, h5lite.Dataset(a)))
         return
     _dir_write_array(path, key, arr)
 
 
-def read_attrs(path):
+def read_attrs(path, key=None):
+    """Attributes of the root group (or of the object `key`)."""
     if _is_h5(path):
-        with _h5py().File(path, "r") as h5:
-            return {k: (v.item() if isinstance(v, np.generic) else v) for k, v in h5.attrs.items()}
-    return _dir_read_attrs(path)
+        node = _h5_tree(path) if key is None else _h5_tree(path)[key]
+        return {k: _attr_value(v) for k, v in node.attrs.items()
+                if not (key is None and k in ("CLASS", "VERSION", "TITLE", "PYTABLES_FORMAT_VERSION"))}
+    if key is None:
+        return {k: v for k, v in _dir_read_attrs(path).items() if "@" not in k}
+    pre = key.strip("/") + "@"
+    return {k[len(pre):]: v for k, v in _dir_read_attrs(path).items() if k.startswith(pre)}
 
 
-def write_attrs(path, **kw):
+def write_attrs(path, _key=None, **kw):
+    """Attributes of the root group, or of the group / dataset `_key` (created as a group when missing): the
+    reference's `h5.attrs[...] = ...` and `grp.attrs['R2'] = ...`."""
     if _is_h5(path):
-        with _h5py().File(path, "a") as h5:
+        def put(root):
+            node = root if _key is None else (root[_key] if _key in root else root.require_group(_key))
             for k, v in kw.items():
-                h5.attrs[k] = v
+                node.attrs[k] = v if isinstance(v, (str, bytes)) else np.asarray(v)[()]
+        _h5_update(path, put)
         return
+    if _key is not None:
+        kw = {_key.strip("/") + "@" + k: v for k, v in kw.items()}
     _dir_write_attrs(path, **kw)
+
+
+def list_keys(path, key=""):
+    """Names of the members of group `key` of an HDF5 map."""
+    if not _is_h5(path):
+        raise MapFileError("list_keys is for HDF5 maps")
+    node = _h5_tree(path)[key] if key else _h5_tree(path)
+    return list(node.keys()) if isinstance(node, h5lite.Group) else []
 
 
 def has_key(path, key):
     if _is_h5(path):
-        with _h5py().File(path, "r") as h5:
-            return key in h5
+        return os.path.exists(path) and key in _h5_tree(path)
     s = _safe(key)
     return os.path.exists(os.path.join(path, "A." + s + ".npy")) or os.path.exists(os.path.join(path, "F." + s + ".json"))

@@ -103,23 +103,28 @@ def run_gp_fold(args, device, path, label_ids, train, val, ho, nn_scores, seed, 
     """OutputGenerator.run_gp (mutations_main.py:202-247) for one fold: `train` / `val` / `ho` are dicts with
     feat [C][n,16], lbls [C][n], meta (chr_locs, mappability, quantiles).  Returns the per-label fold r^2."""
     scores = []
-    for l, lbl in enumerate(label_ids):
-        print('Running gaussian process model for {}...'.format(lbl))
-        tup = lambda d: (np.asarray(d['feat'][l]), np.asarray(d['lbls'][l])) + tuple(d['meta'])
-        results, means, stds = gp_trainer.run_gp(device, tup(train), tup(val), tup(ho), n_runs=args.run_gaussian,
-                                                 n_iter=args.n_iter, n_inducing=args.n_inducing, gp_reruns=args.gp_reruns,
-                                                 gp_delta=args.gp_delta, nn_r2=float(nn_scores[l]), seed=seed + 17 * l)
-        _write_set(path, '{}/train/'.format(lbl), train['feat'][l], train['lbls'][l], train['meta'])
-        _write_set(path, '{}/val/'.format(lbl), val['feat'][l], val['lbls'][l], val['meta'])
-        _write_set(path, '{}/{}/'.format(lbl, held_key), ho['feat'][l], ho['lbls'][l], ho['meta'])
-        for j, res in enumerate(results):
-            base = '{}/{}/{}/'.format(lbl, held_key, j)
-            mapfile.write_array(path, base + 'mean', res['gp_mean'])
-            mapfile.write_array(path, base + 'std', res['gp_std'])
-            mapfile.write_array(path, base + 'params', res['params'])
-        fold_r2 = r2_score(ho['lbls'][l], means)
-        print('Fold pretrained model R2: {}'.format(fold_r2))
-        scores.append(fold_r2)
+    with mapfile.batch(path):                      # an HDF5 results file is written once, when the fold is complete
+        for l, lbl in enumerate(label_ids):
+            print('Running gaussian process model for {}...'.format(lbl))
+            tup = lambda d: (np.asarray(d['feat'][l]), np.asarray(d['lbls'][l])) + tuple(d['meta'])
+            results, means, stds = gp_trainer.run_gp(device, tup(train), tup(val), tup(ho), n_runs=args.run_gaussian,
+                                                     n_iter=args.n_iter, n_inducing=args.n_inducing, gp_reruns=args.gp_reruns,
+                                                     gp_delta=args.gp_delta, nn_r2=float(nn_scores[l]), seed=seed + 17 * l)
+            _write_set(path, '{}/train/'.format(lbl), train['feat'][l], train['lbls'][l], train['meta'])
+            _write_set(path, '{}/val/'.format(lbl), val['feat'][l], val['lbls'][l], val['meta'])
+            _write_set(path, '{}/{}/'.format(lbl, held_key), ho['feat'][l], ho['lbls'][l], ho['meta'])
+            for j, res in enumerate(results):                                   # GPTrainer.save_results, gp_trainer.py:224-245
+                for grp, r in ((held_key, res), ('val', res.get('val'))):
+                    if r is None:
+                        continue
+                    base = '{}/{}/{}/'.format(lbl, grp, j)
+                    mapfile.write_array(path, base + 'mean', r['gp_mean'])
+                    mapfile.write_array(path, base + 'std', r['gp_std'])
+                    mapfile.write_array(path, base + 'params', r['params'])
+                    mapfile.write_attrs(path, base.rstrip('/'), R2=float(r['r2']), loss=float(r['loss']))
+            fold_r2 = r2_score(ho['lbls'][l], means)
+            print('Fold pretrained model R2: {}'.format(fold_r2))
+            scores.append(fold_r2)
     return scores
 
 
@@ -189,7 +194,7 @@ def main(input_args=None):
                 best['train']['meta'] = data.meta(best['train']['rows'])       # features are in visiting order
                 best['val']['meta'] = data.meta(val_rows)
                 try:
-                    scores = run_gp_fold(args, device, os.path.join(out_dir, 'gp_results_fold_{}'.format(k)), args.label_ids,
+                    scores = run_gp_fold(args, device, os.path.join(out_dir, 'gp_results_fold_{}.h5'.format(k)), args.label_ids,
                                          best['train'], best['val'], ho, best['accs'], seed=args.seed + 31 * k)
                     summary.append(scores)
                     if args.sub_mapp and len(data.below_mapp):
@@ -197,7 +202,7 @@ def main(input_args=None):
                         _, sub_feat, _ = predict(best["model"], data.store, sub_rows)
                         sub = dict(feat=[sub_feat[c] for c in range(C)], lbls=[data.labels[c][sub_rows] for c in range(C)],
                                    meta=data.meta(sub_rows))
-                        run_gp_fold(args, device, os.path.join(out_dir, 'sub_mapp_results_fold_{}'.format(k)), args.label_ids,
+                        run_gp_fold(args, device, os.path.join(out_dir, 'sub_mapp_results_fold_{}.h5'.format(k)), args.label_ids,
                                     best['train'], best['val'], sub, [-np.inf] * C, seed=args.seed + 31 * k + 5)
                 except AssertionError as exc:
                     print('GP run failed: {}'.format(exc))

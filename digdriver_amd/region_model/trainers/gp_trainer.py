@@ -234,9 +234,10 @@ def run_gp(device, train_tup, val_tup, heldout_tup, n_runs=5, n_iter=50, n_induc
             try:
                 tr = GPTrainer(device, train_tup, val_tup, heldout_tup, n_iter=n_iter, n_inducing=m,
                                seed=seed + 1000 * run + attempt)
-                _, hld = tr.run()
+                val, hld = tr.run()
                 if nn_r2 is not None and hld['r2'] - nn_r2 < -gp_delta:
                     raise RuntimeError("GP R2 %.4f fell below CNN R2 %.4f" % (hld['r2'], nn_r2))
+                hld = dict(hld, val=val)                                          # the validation results of the same fit
                 done = hld
             except (RuntimeError, torch.linalg.LinAlgError) as exc:
                 print('GP attempt failed: {}'.format(exc))

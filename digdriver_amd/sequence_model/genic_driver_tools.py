@@ -98,8 +98,41 @@ def _load_cohorts(f_pretrained, key='region_params'):
     return files, tables, d_pr
 
 
+def _minus_strand_order():
+    """Order in which preprocess_nonc lists the 192 region counts of a '-' element (sequence_tools.py:633-634): positions
+    sorted by the reverse complement of their substitution string."""
+    from . import sequence_tools
+    keys = sorted(sequence_tools.mk_trans_idx(n_up=1, n_down=1, collapse=False))
+    rc = [sequence_tools.reverse_complement(k.split('>')[0]) + '>' + sequence_tools.reverse_complement(k.split('>')[1]) for k in keys]
+    return np.array(sorted(range(192), key=lambda i: rc[i]), dtype=np.int64)
+
+
+def _element_set_reference_layout(f_data, window, save_key, names=None):
+    """The element container the REFERENCE writes (preprocess_nonc / preprocess_sites, sequence_tools.py:605-641,655-700):
+    one HDF5 group per element, window_{w}/{key}/{elt}/{L_counts, region_counts} + attribute `overlaps` [(chrom, start,
+    end)].  The overlapped bins come straight from the attribute; the strand is not stored, but region_counts is (the
+    window contexts summed, listed in reverse-complement order for '-' elements), which is enough to recover it."""
+    base = 'window_{}/{}'.format(window, save_key)
+    all_names = mapfile.list_keys(f_data, base)
+    use = list(names) if names is not None else all_names
+    missing = [n for n in use if n not in set(all_names)]
+    if missing:
+        raise KeyError("elements %r are not in %s:%s" % (missing[:5], f_data, base))
+    L = np.zeros((len(use), 1, 192), np.int32)
+    rc = np.zeros((len(use), 192), np.int64)
+    ov = []
+    for j, n in enumerate(use):
+        L[j, 0] = np.asarray(mapfile.read_array(f_data, '{}/{}/L_counts'.format(base, n))).astype(np.int32)
+        rc[j] = np.asarray(mapfile.read_array(f_data, '{}/{}/region_counts'.format(base, n))).astype(np.int64)
+        o = np.asarray(mapfile.read_attrs(f_data, '{}/{}'.format(base, n))['overlaps'])
+        ov.append(np.array([[int(str(r[0]).replace('chr', '')), int(r[1])] for r in o.reshape(-1, 3)], dtype=np.int64).reshape(-1, 2))
+    return dict(names=np.array(use, dtype=str), L=L, region_counts=rc, overlaps=ov)
+
+
 def _element_set(f_data, window, save_key, names=None):
     base = 'window_{}/{}/'.format(window, save_key)
+    if not mapfile.has_key(f_data, base + 'names') and mapfile._is_h5(f_data) and mapfile.has_key(f_data, base.rstrip('/')):
+        return _element_set_reference_layout(f_data, window, save_key, names)
     all_names = mapfile.read_array(f_data, base + 'names').astype(str)
     sel = np.arange(len(all_names))
     if names is not None:
@@ -125,8 +158,28 @@ def _accumulate(tables, d_pr, f_data, elts, gene_length=None):
     si_index = mapfile.read_array(f_data, 'window_{}/full_window_si_index'.format(w))
     si_values = mapfile.read_array(f_data, 'window_{}/full_window_si_values'.format(w))
     ctx = tables.aligned_context(si_index, si_values)
-    ov_ptr, ov_idx = engine.ideal_overlaps(elts['chrom'], elts['blk_ptr'], elts['blk_start'], elts['blk_end'], w,
-                                           tables.chrom, tables.start)
+    if 'overlaps' in elts:                                   # reference-layout container: bins from the stored attribute
+        row = {(int(c), int(s)): i for i, (c, s) in enumerate(zip(tables.chrom, tables.start))}
+        try:
+            idx = [np.sort(np.array([row[(int(c), int(s))] for c, s in o], dtype=np.int32)) for o in elts['overlaps']]
+        except KeyError as exc:
+            raise KeyError("an element overlaps bin chr%s:%s, which region_params does not have" % exc.args[0]) from exc
+        ov_ptr = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).astype(np.int64)
+        ov_idx = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+        plus = np.repeat(np.add.reduceat(ctx[ov_idx].astype(np.int64), ov_ptr[:-1], axis=0), 3, axis=1) if len(ov_idx) else \
+            np.zeros((len(idx), 192), np.int64)
+        plus[np.diff(ov_ptr) == 0] = 0
+        minus = plus[:, _minus_strand_order()]
+        is_plus = (plus == elts['region_counts']).all(axis=1)
+        is_minus = (minus == elts['region_counts']).all(axis=1)
+        if not (is_plus | is_minus).all():
+            bad = elts['names'][~(is_plus | is_minus)][:5]
+            raise ValueError("region_counts of elements %r do not match the window contexts of their overlapped bins "
+                             "(was the element data built on another genome-counts file?)" % (list(bad),))
+        elts = dict(elts, strand_minus=(~is_plus).astype(np.uint8))
+    else:
+        ov_ptr, ov_idx = engine.ideal_overlaps(elts['chrom'], elts['blk_ptr'], elts['blk_start'], elts['blk_end'], w,
+                                               tables.chrom, tables.start)
     return engine.accumulate_elements(tables.mu, tables.std, tables.y, tables.flag, ctx, ov_ptr, ov_idx, elts['L'],
                                       elts['strand_minus'], d_pr, gene_length=gene_length)
 
@@ -162,7 +215,11 @@ def nonc_model_parallel(f_pretrained, f_nonc_data, nonc_L_key, N_procs, indels_d
     first = f_pretrained if isinstance(f_pretrained, (str, bytes)) else list(f_pretrained)[0]
     idx = mapfile.read_array(first, 'idx')
     window = int(idx[0, 2] - idx[0, 1])
-    names = mapfile.read_array(f_nonc_data, 'window_{}/{}/names'.format(window, nonc_L_key)).astype(str)
+    base = 'window_{}/{}'.format(window, nonc_L_key)
+    if mapfile.has_key(f_nonc_data, base + '/names'):
+        names = mapfile.read_array(f_nonc_data, base + '/names').astype(str)
+    else:                                                   # the reference's per-element groups (genic_driver_tools.py:443)
+        names = mapfile.list_keys(f_nonc_data, base)
     return nonc_model(list(names), f_pretrained, f_nonc_data, nonc_L_key, indels_direct)
 
 
