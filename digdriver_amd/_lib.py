@@ -57,6 +57,8 @@ _SIGNATURES = {
     "dig_gather_bins": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp],
     "dig_gather_bins_host": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _int],
     "dig_tiled_nb_test": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
+    "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
 }
 

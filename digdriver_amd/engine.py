@@ -472,3 +472,75 @@ def tiled_nb_test(pt, k, mu, sigma, device=0):
     _lib.call("dig_tiled_nb_test_host", _lib.host_ptr(pt), int(pt.ndim == 3), _lib.host_ptr(k), _lib.host_ptr(mu),
               _lib.host_ptr(sigma), _lib.host_ptr(pval), _lib.host_ptr(ex), C, nb, nt, device)
     return pval, ex
+
+
+# ---------------------------------------------------------------------------
+# per-base / tiled route: front half (dig_base_tile_probs + dig_tile_mut_counts) and the whole chain
+# ---------------------------------------------------------------------------
+def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None, device=0):
+    """Tile probabilities of regions of a PackedGenome for C cohorts at once (sequence_tools.py:292-317 + the tiling of
+    nb_model.py:126-186, trinucleotide contexts).  s_prob: f64 [C, 64] in context index order (16 b0 + 4 b1 + b2).
+    Returns device tensors (pt [C, R, n_tiles], first_pos [R], n_valid [R]); n_tiles defaults to what the longest region
+    needs."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    ci = genome.chrom_index(chroms)
+    R = len(ci)
+    st, en = _lib.as_host(starts, np.int64).ravel(), _lib.as_host(ends, np.int64).ravel()
+    if (st < 0).any() or (en < 0).any():
+        raise ValueError("negative region coordinates")
+    binsize = int(binsize)
+    if n_tiles is None:
+        n_tiles = int(max(1, -(-int((en - st).max() if R else 1) // binsize)))
+    s_prob = _t(s_prob, torch.float64, dev)
+    assert s_prob.dim() == 2 and s_prob.shape[1] == 64, "s_prob must be [C, 64] (trinucleotide contexts)"
+    C = s_prob.shape[0]
+    words, off, ln = genome.on_device(dev)
+    t = lambda a: torch.as_tensor(a, device=dev)
+    rc, rs, re_ = t(ci), t(st), t(en)
+    pt = torch.empty((C, R, n_tiles), dtype=torch.float64, device=dev)
+    first = torch.empty(R, dtype=torch.int64, device=dev)
+    nval = torch.empty(R, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("dig_base_tile_probs", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln),
+                  len(genome.names), _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), R, _lib.dev_ptr(s_prob), C,
+                  binsize, n_tiles, _lib.dev_ptr(pt), _lib.dev_ptr(first), _lib.dev_ptr(nval), _lib.stream_ptr())
+    return pt, first, nval
+
+
+def tile_mut_counts(genome, chroms, starts, ends, first_pos, n_valid, mut_chrom, mut_start, mut_end, mut_cohort, C, binsize,
+                    n_tiles):
+    """k i32 [C, R, n_tiles]: mutation rows per tile and cohort (nb_model.py:133-136,160-163).  Regions and mutations
+    are joined with the interval-join kernels (a tabix fetch returns the rows overlapping the region); a row counts in
+    the tile that holds its START.  mut_* are device tensors or host arrays (chromosome labels as in `chroms`)."""
+    import torch
+    from .data_tools import tabulate_gpu
+    dev = first_pos.device
+    R = first_pos.numel()
+    ci = genome.chrom_index(chroms)
+    blocks = tabulate_gpu.ElementBlocks(ci, _lib.as_host(starts, np.int64).ravel(), _lib.as_host(ends, np.int64).ravel(),
+                                        np.arange(R), R, dev)
+    mc = torch.as_tensor(genome.chrom_index(list(np.asarray(mut_chrom).astype(str))) if not _is_cuda(mut_chrom) else mut_chrom,
+                         device=dev).to(torch.int64)
+    ms, me = _t(mut_start, torch.int64, dev), _t(mut_end, torch.int64, dev)
+    co = _t(mut_cohort, torch.int32, dev)
+    pm, pb = tabulate_gpu.overlap_pairs(blocks, mc, ms, me)
+    pr = blocks.elt[pb.long()].to(torch.int32).contiguous()          # block row -> region index
+    k = torch.empty((int(C), R, int(n_tiles)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("dig_tile_mut_counts", _lib.dev_ptr(pm), _lib.dev_ptr(pr), pm.numel(), _lib.dev_ptr(ms), _lib.dev_ptr(co),
+                  _lib.dev_ptr(first_pos), _lib.dev_ptr(n_valid), int(binsize), int(n_tiles), R, int(C), _lib.dev_ptr(k),
+                  _lib.stream_ptr())
+    return k
+
+
+def tiled_nb_model(genome, chroms, starts, ends, s_prob, mu, sigma, mut_chrom, mut_start, mut_end, mut_cohort, binsize=50,
+                   device=0):
+    """nb_model (nb_model.py:188-234) for C cohorts x R regions in three launches + the interval join:
+    base_tile_probs -> tile_mut_counts -> tiled_nb_test.  mu, sigma: [C, R].  Returns a dict of device tensors
+    pval, exp, pt [C, R, n_tiles], k i32 [C, R, n_tiles], first_pos [R], n_valid [R]."""
+    pt, first, nval = base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, device=device)
+    C, R, n_tiles = pt.shape
+    k = tile_mut_counts(genome, chroms, starts, ends, first, nval, mut_chrom, mut_start, mut_end, mut_cohort, C, binsize, n_tiles)
+    pval, ex = tiled_nb_test(pt, k, mu, sigma)
+    return dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first, n_valid=nval)

@@ -123,3 +123,84 @@ def fisher_combine(p1, p2, device=0):
         import pandas as pd
         return pd.Series(out, index=ser.index)
     return out if shape else float(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-base / tiled route (nb_model.py:126-234, 340-342)
+# ---------------------------------------------------------------------------------------------
+def _s_prob64(d_pr):
+    """S_prob (dict / Series keyed by trinucleotide) -> 64 values in context index order; other key lengths are the
+    reference's penta-nucleotide mode (n_up = n_down = 2), which no part of the live pipeline trains a model for."""
+    import itertools
+    keys = ["".join(t) for t in itertools.product("ACGT", repeat=3)]
+    try:
+        return np.array([float(d_pr[k]) for k in keys])
+    except KeyError as exc:
+        raise NotImplementedError("the tile kernels take trinucleotide models (n_up = n_down = 1); key %s is missing" % exc) from exc
+
+
+def _mutation_rows(f_mut):
+    """The rows a tabix fetch hands to tabix_to_dataframe (nb_model.py:13-33): CHROM, START, END of a bed-like mutation
+    file (plain or gzip; 6-9 columns)."""
+    import pandas as pd
+    df = pd.read_csv(f_mut, sep="\t", header=None, usecols=[0, 1, 2], names=["CHROM", "START", "END"], dtype={0: str},
+                     comment="#", low_memory=False)
+    df["CHROM"] = df.CHROM.str.replace("chr", "", regex=False)
+    return df
+
+
+def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=1, n_down=1, binsize=50, collapse=False, device=0):
+    """nb_model.py:188-234: the tiled NB test over the bins `idx` [(chrom, start, end)] of one cohort; returns the
+    reference's frame (CHROM, POS, OBS, EXP, PVAL, Pi, MU, SIGMA, REGION; numeric columns as float, as its np.hstack makes
+    them).  `f_tabix`: the cohort's bed-like mutation file (the reference reads it through tabix; here it is joined on the
+    GPU in one pass); `f_fasta`: the genome (data_tools.genome.PackedGenome or a FASTA path).  All bins in three launches
+    (engine.tiled_nb_model); the reference's default penta-nucleotide mode (n_up = n_down = 2) is not built."""
+    import pandas as pd
+    from .. import engine
+    from ..data_tools import genome as genome_mod
+    if (n_up, n_down) != (1, 1) or collapse:
+        raise NotImplementedError("the tile kernels take trinucleotide contexts: n_up = n_down = 1, collapse=False")
+    g = f_fasta if isinstance(f_fasta, genome_mod.PackedGenome) else genome_mod.PackedGenome.from_fasta(f_fasta)
+    idx = np.asarray(idx)
+    chroms = [str(c) for c in idx[:, 0]]
+    starts, ends = idx[:, 1].astype(np.int64), idx[:, 2].astype(np.int64)
+    muts = f_tabix if isinstance(f_tabix, pd.DataFrame) else _mutation_rows(f_tabix)
+    known = set(n.replace("chr", "") for n in g.names)
+    muts = muts[muts.CHROM.astype(str).str.replace("chr", "", regex=False).isin(known)]
+    res = engine.tiled_nb_model(g, chroms, starts, ends, _s_prob64(d_pr)[None, :], np.asarray(mu_lst, float)[None, :],
+                                np.asarray(sigma_lst, float)[None, :], muts.CHROM.astype(str).values, muts.START.values,
+                                muts.END.values, np.zeros(len(muts), np.int32), binsize=binsize, device=device)
+    host = {k: v.cpu().numpy() for k, v in res.items()}
+    first, nval = host["first_pos"], host["n_valid"]
+    n_pos = np.minimum(ends, np.array([g.lengths[i] for i in g.chrom_index(chroms)]) - 1) - first
+    rows = []
+    for r in range(len(idx)):
+        nt = int(nval[r])
+        t = np.arange(nt)
+        lo = first[r] + t * binsize
+        hi = np.minimum(lo + binsize, first[r] + n_pos[r]) - 1
+        rows.append(pd.DataFrame({
+            "CHROM": float(idx[r, 0]), "POS": (lo + hi) / 2.0 if binsize > 1 else lo.astype(float),
+            "OBS": host["k"][0, r, :nt].astype(float), "EXP": host["exp"][0, r, :nt], "PVAL": host["pval"][0, r, :nt],
+            "Pi": host["pt"][0, r, :nt], "MU": float(mu_lst[r]), "SIGMA": float(sigma_lst[r]),
+            "REGION": "{}:{}-{}".format(idx[r, 0], idx[r, 1], idx[r, 2])}))
+    cols = ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi", "MU", "SIGMA", "REGION"]
+    return pd.concat(rows, ignore_index=True)[cols] if rows else pd.DataFrame(columns=cols)
+
+
+def get_q_vals(pvals_lst):
+    """nb_model.py:340-342: Benjamini-Hochberg q-values, statsmodels.stats.multitest.fdrcorrection(pvals)[1] (method
+    'indep'): q_(i) = min_{j >= i} p_(j) n / j in ascending order of p, capped at 1.  NaNs propagate the way the sort
+    places them (last)."""
+    p = np.asarray(pvals_lst, dtype=np.float64)
+    n = p.size
+    if n == 0:
+        return p.copy()
+    order = np.argsort(p, kind="stable")
+    ps = p[order]
+    q = ps / (np.arange(1, n + 1) / float(n))          # statsmodels' own operation order (p / ecdf): bit-identical
+    q = np.minimum.accumulate(q[::-1])[::-1]
+    q = np.minimum(q, 1.0)
+    out = np.empty_like(q)
+    out[order] = q
+    return out

@@ -181,6 +181,29 @@ int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int3
                          int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
                          int stages, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- per-base / tiled route, front half -------------------------------------------------- *
+ * base_probabilities_by_region (sequence_model/sequence_tools.py:292-317) + the tiling of apply_nb_to_region
+ * (sequence_model/nb_model.py:126-186) for trinucleotide contexts (n_up = n_down = 1), all cohorts at once; the back
+ * half is dig_tiled_nb_test.  Genome layout as dig_count_contexts.
+ *   region r: positions max(start, 1) .. min(end, chrom_len - 1) - 1 (fetch_sequence :21-29); tile t = positions
+ *       first + t * binsize .. (the last tile of a region may be shorter); n_valid[r] = number of tiles the region has
+ *       (<= n_tiles), first_pos[r] = its first position.
+ *   s_prob f64 [C, 64]: S_prob of cohort c by context index 16 b0 + 4 b1 + b2; a position whose window holds a non-ACGT
+ *       base has probability 0.
+ *   pt f64 [C, R, n_tiles]: (sum of S_prob over the tile's positions) / (sum over the region's positions); tiles past
+ *       n_valid[r] are NaN.  Sums are regrouped by context (exact integer counts x table): a few ulp from the reference's
+ *       normalise-then-np.sum order.
+ * dig_tile_mut_counts: k i32 [C, R, n_tiles] (cleared by the call) from (mutation, region) pairs as produced by
+ *   dig_overlap_join_count/fill with the regions as blocks: a pair counts when the mutation's START is one of the
+ *   region's positions (value_counts of START, nb_model.py:135-136,160-163). */
+int dig_base_tile_probs(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off, const int64_t *chrom_len,
+                        int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start, const int64_t *reg_end, int64_t R,
+                        const double *s_prob, int64_t C, int binsize, int64_t n_tiles, double *pt, int64_t *first_pos,
+                        int32_t *n_valid, void *stream);
+int dig_tile_mut_counts(const int32_t *pair_mut, const int32_t *pair_reg, int64_t n_pairs, const int64_t *mut_start,
+                        const int32_t *mut_cohort, const int64_t *first_pos, const int32_t *n_valid, int binsize,
+                        int64_t n_tiles, int64_t R, int64_t C, int32_t *k, void *stream);
+
 /* ---- per-cohort sufficient statistics for the scale factors --------------------------- *
  * calc_scale_factor_efficient, genome mode (driver_model/transfer_tools.py:148-156):
  *   out_sum[c] = sum over bins with FLAG == 0 of Y_PRED[bin, c]   (N_SNV_EXP per cohort);

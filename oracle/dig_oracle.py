@@ -401,3 +401,52 @@ def expand_contexts_192(counts64):
     pos = {c: i for i, c in enumerate(ctx)}
     cols = np.array([pos[k.split(">")[0]] for k in keys])
     return np.asarray(counts64)[..., cols], keys
+
+
+# --------------------------------------------------------------------------
+# per-base route, front half (sequence_tools.py:292-317, nb_model.py:126-186; trinucleotide contexts, n_up = n_down = 1)
+# --------------------------------------------------------------------------
+def base_probabilities_by_region(chrom_seq, s_prob64, start, end):
+    """sequence_tools.py:292-317 with n_up = n_down = 1, normed=True.  chrom_seq: the chromosome string; s_prob64: 64
+    probabilities in context64() order.  fetch_sequence (:21-29): START == 0 becomes 1, the fetch is widened by one base
+    on either side and truncated at the chromosome end; a position whose triplet holds a non-ACGT letter gets 0.
+    Returns (probs, positions): probs normalised over the region (np.sum, as the reference)."""
+    if start == 0:
+        start = 1
+    seq = chrom_seq[start - 1:end + 1].upper()
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    probs, poss = [], []
+    for i in range(1, len(seq) - 1):
+        poss.append(start - 1 + i)
+        tri = seq[i - 1:i + 2]
+        if all(ch in code for ch in tri):
+            probs.append(s_prob64[16 * code[tri[0]] + 4 * code[tri[1]] + code[tri[2]]])
+        else:
+            probs.append(0)
+    probs = np.array(probs, dtype=float)
+    with np.errstate(all="ignore"):
+        probs = probs / np.sum(probs)
+    return probs, np.array(poss)
+
+
+def apply_nb_to_region(chrom_seq, s_prob64, start, end, mu, sigma, mut_starts, binsize):
+    """nb_model.py:126-186: tiles of `binsize` consecutive positions (the last one may be shorter); pt = np.sum of the
+    tile's normalised probabilities, k = number of mutation rows whose START is one of the tile's positions
+    (value_counts of START, :135-136,160-163), p = 1 / (pt theta + 1), nb_pvalue_exact, exp = pt mu, pos = mean position.
+    mut_starts: START of every mutation row of this chromosome.  Returns (pvals, pos, obs, exps, pts)."""
+    probs, pos_lst = base_probabilities_by_region(chrom_seq, s_prob64, start, end)
+    mut_starts = np.asarray(mut_starts, np.int64)
+    alpha, theta = normal_params_to_gamma(mu, sigma)
+    pv, ps, ob, ex, pts = [], [], [], [], []
+    for i in range(0, len(pos_lst), binsize):
+        with np.errstate(all="ignore"):
+            pt = np.sum(probs[i:i + binsize])
+            lo, hi = pos_lst[i], pos_lst[min(i + binsize, len(pos_lst)) - 1]
+            k = int(((mut_starts >= lo) & (mut_starts <= hi)).sum())
+            p = 1 / (pt * theta + 1)
+            pv.append(float(nb_pvalue_exact(np.array([float(k)]), np.array([alpha]), np.array([p]))[0]))
+        ps.append(float(np.mean(pos_lst[i:i + binsize])))
+        ob.append(k)
+        ex.append(pt * mu)
+        pts.append(pt)
+    return np.array(pv), np.array(ps), np.array(ob), np.array(ex), np.array(pts)

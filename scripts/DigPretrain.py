@@ -12,7 +12,7 @@ Drop-in for the sub-commands of the reference's scripts/DigPretrain.py (:280-477
 
 Same positional arguments and option names.  `countNonc_context` is the reference's own deprecated
 sub-command (it calls a function that does not exist, DigPretrain.py:222) and is not provided.
-Maps may be HDF5 (h5py/PyTables needed) or the directory mirror (digdriver_amd/io/mapfile.py).
+Maps may be HDF5 (`*.h5`, read and written by io/h5lite.py + io/pandas_fixed.py: no h5py or PyTables needed) or the directory mirror (digdriver_amd/io/mapfile.py).
 """
 import argparse
 import os

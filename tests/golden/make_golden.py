@@ -740,6 +740,67 @@ def gen_contexts():
     print("wrote contexts_golden.json", df64.shape, df192.shape)
 
 
+class _FakeTabix:
+    """pysam.TabixFile look-alike over in-memory mutation rows (chrom, start, end, ref, alt, id): fetch(chrom, start,
+    end) yields the tab-joined rows overlapping [start, end), as tabix does for 0-based half-open bed intervals."""
+    tables = {}
+
+    def __init__(self, path):
+        self._rows = _FakeTabix.tables[path]
+
+    def fetch(self, chrom, start, end):
+        for r in self._rows:
+            if r[0] == chrom and r[1] < end and r[2] > start:
+                yield "\t".join(str(x) for x in r)
+
+
+def gen_tiled():
+    """The per-base / tiled route (nb_model.py:126-234 -> sequence_tools.py:292-317, nb_model.py:298-314): the
+    reference's own nb_model on a small genome (N runs, soft-masked stretches, a bin at position 0 and one cut off by
+    the chromosome end), trinucleotide contexts (n_up = n_down = 1), tiles of 1 and of 50 positions, two cohorts."""
+    rng = np.random.default_rng(126)
+    genome = {}
+    for chrom, n in (("chr1", 2600), ("chr2", 1437)):
+        seq = rng.choice(list("ACGT"), n)
+        for _ in range(3):
+            a = int(rng.integers(0, n - 60))
+            seq[a:a + int(rng.integers(1, 60))] = "N"
+        a = int(rng.integers(0, n - 200))
+        seq[a:a + 150] = np.char.lower(seq[a:a + 150])
+        genome[chrom] = "".join(seq)
+    _FakeFasta.genomes["mem://tiled"] = genome
+    sys.modules["pysam"].FastaFile = _FakeFasta
+    sys.modules["pysam"].TabixFile = _FakeTabix
+    window = 500
+    idx = [(1, s, s + window) for s in range(0, 2600, window)] + [(2, s, s + window) for s in range(0, 1437, window)]
+    ctx = ["".join(t) for t in __import__("itertools").product("ACGT", repeat=3)]
+    out = dict(genome=genome, idx=[list(map(int, r)) for r in idx], window=window, contexts=ctx, cohorts=[])
+    for c in range(2):
+        d_pr = dict(zip(ctx, (rng.dirichlet(np.ones(64)) * 1e-2).tolist()))
+        rows = []
+        for chrom, n in (("1", 2600), ("2", 1437)):
+            for _ in range(90 + 40 * c):
+                p = int(rng.integers(0, n))
+                rows.append((chrom, p, p + 1, "A", "T", "S%d" % rng.integers(0, 6)))
+            for _ in range(6):                                  # positions hit more than once, and an indel-like longer row
+                p = int(rng.integers(0, n - 5))
+                rows += [(chrom, p, p + 1, "C", "G", "S1"), (chrom, p, p + 1, "C", "G", "S2"), (chrom, p, p + 4, "CAGT", "C", "S3")]
+        rows.sort()
+        _FakeTabix.tables["mem://muts%d" % c] = rows
+        mu = rng.gamma(9.0, 3.0, len(idx))
+        sigma = rng.gamma(4.0, 1.0, len(idx))
+        coh = dict(d_pr=d_pr, rows=[list(r) for r in rows], mu=mu.tolist(), sigma=sigma.tolist(), runs={})
+        for binsize in (1, 50):
+            df = ref_nb.nb_model(d_pr, idx, mu, sigma, "mem://muts%d" % c, "mem://tiled", n_up=1, n_down=1, binsize=binsize)
+            coh["runs"][str(binsize)] = {k: df[k].astype(float).tolist() for k in ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi"]}
+            coh["runs"][str(binsize)]["REGION_first_last"] = [df["REGION"].iloc[0], df["REGION"].iloc[-1]]
+        out["cohorts"].append(coh)
+    import gzip
+    with gzip.GzipFile(os.path.join(HERE, "tiled_golden.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
+    print("wrote tiled_golden.json.gz", {b: len(out["cohorts"][0]["runs"][b]["PVAL"]) for b in ("1", "50")})
+
+
 def gen_sites():
     """The sites route (mutation_tools.py:232-283, sequence_tools.py:643-700): the reference's own preprocess_sites and
     tabulate_sites_in_element on a small synthetic sites file."""
@@ -803,6 +864,9 @@ def main():
     if "--only-sites" in sys.argv:
         gen_sites()
         return
+    if "--only-tiled" in sys.argv:
+        gen_tiled()
+        return
     gen_nb_midp()
     gen_nb_exact()
     gen_element_stats()
@@ -815,6 +879,7 @@ def main():
     gen_cnn()
     gen_contexts()
     gen_sites()
+    gen_tiled()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

@@ -259,3 +259,75 @@ def test_sites_route_matches_reference_preprocessing(tmp_path):
     a = res.ALPHA.values
     p = 1.0 / (res.THETA.values * res.Pi_SUM.values + 1.0)
     rel_close(res.PVAL_SNV_BURDEN.values, O.nb_pvalue_greater_midp(res.OBS_SNV.values.astype(float), a, p), rtol=1e-6)
+
+
+def test_cli_chain_on_hdf5_maps(tmp_path):
+    """The drop-in claim on the reference's file format: the whole chain -- DigPreprocess countGenomeContext /
+    initialize_f_data / preprocess_element_model -> DigPretrain elementModel -> DigDriver elementDriver -- on `.h5` maps
+    (pretrained map, genome counts and element data all HDF5, written and read by io/h5lite.py + io/pandas_fixed.py) gives
+    the table the directory-mirror run gives; and DigPretrain elementModel on an element container in the REFERENCE's
+    own layout (one group per element with L_counts / region_counts / attrs['overlaps'], sequence_tools.py:639-641)
+    gives the same element frame."""
+    from digdriver_amd.io import h5lite, mapfile
+    from digdriver_amd.sequence_model import genic_driver_tools
+    rng = np.random.default_rng(23)
+    case = _make_case(tmp_path, rng)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda *a: subprocess.check_call([sys.executable] + [str(x) for x in a], env=env)
+    wbed = tmp_path / "windows.bed"
+    case["rp"][["CHROM", "START", "END"]].to_csv(wbed, sep="\t", header=False, index=False)
+    pre_h5 = str(tmp_path / "cohort.Pretrained.h5")
+    for key in ("region_params", "sequence_model_192"):
+        mapfile.write_frame(pre_h5, key, mapfile.read_frame(case["pre"], key))
+    mapfile.write_array(pre_h5, "idx", mapfile.read_array(case["pre"], "idx"), compression="gzip")
+    mapfile.write_attrs(pre_h5, cohort_name="synthetic")
+    results = {}
+    for tag, pre, ext in (("dir", case["pre"], ".map"), ("h5", pre_h5, ".h5")):
+        gc, ed = str(tmp_path / ("genome_counts" + ext)), str(tmp_path / ("element_data" + ext))
+        pp = os.path.join(ROOT, "scripts", "DigPreprocess.py")
+        run(pp, "countGenomeContext", case["fa"], gc, "--bed", wbed)
+        run(pp, "initialize_f_data", ed, gc)
+        run(pp, "preprocess_element_model", ed, pre, case["fa"], "myelts", "--f-bed", case["bed"], "--window", case["window"])
+        run(os.path.join(ROOT, "scripts", "DigPretrain.py"), "elementModel", pre, ed, "myelts")
+        out = tmp_path / ("o_" + tag)
+        run(os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver", case["mut"], pre, "myelts", "--f-bed", case["bed"],
+            "--scale-factor-manual", 0.004, "--scale-factor-indel-manual", 0.0007, "--outdir", out, "--outpfx", "e")
+        results[tag] = (pd.read_csv(out / "e.results.txt", sep="\t", index_col=0), ed)
+    a, b = results["dir"][0], results["h5"][0]
+    assert len(a) > 5 and list(a.index) == list(b.index) and list(a.columns) == list(b.columns)
+    pd.testing.assert_frame_equal(a, b, check_exact=True)
+    assert (a.PVAL_MUT_BURDEN.values > 0).all() and mapfile.has_key(pre_h5, "myelts")
+    # the element frame stored in the HDF5 map is a genuine pandas "fixed" group
+    g = h5lite.read_tree(pre_h5)["myelts"]
+    assert str(g.attrs["pandas_type"]) == "frame" and "axis0" in g.children and "block0_values" in g.children
+    # ---- the reference's per-element container for the same elements ----
+    ed_h5 = results["h5"][1]
+    w = case["window"]
+    names = mapfile.read_array(ed_h5, "window_%d/myelts/names" % w).astype(str)
+    L = mapfile.read_array(ed_h5, "window_%d/myelts/L" % w)
+    strand = mapfile.read_array(ed_h5, "window_%d/myelts/strand" % w).astype(str)
+    chrom = mapfile.read_array(ed_h5, "window_%d/myelts/chrom" % w)
+    ptr = mapfile.read_array(ed_h5, "window_%d/myelts/blk_ptr" % w)
+    bs, be = mapfile.read_array(ed_h5, "window_%d/myelts/blk_start" % w), mapfile.read_array(ed_h5, "window_%d/myelts/blk_end" % w)
+    si_index = mapfile.read_array(ed_h5, "window_%d/full_window_si_index" % w)
+    si_values = mapfile.read_array(ed_h5, "window_%d/full_window_si_values" % w)
+    row = {(int(c), int(s)): i for i, (c, s, _) in enumerate(si_index)}
+    order = genic_driver_tools._minus_strand_order()
+    ref_ed = str(tmp_path / "element_data_reference_layout.h5")
+    root = h5lite.Group()
+    root.set("window_%d/full_window_si_index" % w, h5lite.Dataset(np.asarray(si_index)))
+    root.set("window_%d/full_window_si_values" % w, h5lite.Dataset(np.asarray(si_values)))
+    for j, nme in enumerate(names):
+        bins = sorted({(int(chrom[j]), int(x)) for s, e in zip(bs[ptr[j]:ptr[j + 1]], be[ptr[j]:ptr[j + 1]])
+                       for x in range((int(s) // w) * w, -(-int(e) // w) * w, w)})          # get_ideal_overlaps (:275-283)
+        rc = np.repeat(np.sum([si_values[row[b]] for b in bins], axis=0), 3)
+        if strand[j] in ("-", "-1"):
+            rc = rc[order]
+        grp = "window_%d/refelts/%s" % (w, nme)
+        root.set(grp + "/L_counts", h5lite.Dataset(np.asarray(L[j]).reshape(-1).astype(float)))
+        root.set(grp + "/region_counts", h5lite.Dataset(rc))
+        root[grp].attrs["overlaps"] = np.array([[c, s, s + w] for c, s in bins])
+    h5lite.write_tree(ref_ed, root)
+    want = genic_driver_tools.nonc_model_parallel(pre_h5, ed_h5, "myelts", 1).set_index("ELT")
+    got = genic_driver_tools.nonc_model_parallel(pre_h5, ref_ed, "refelts", 1).set_index("ELT").loc[want.index]
+    pd.testing.assert_frame_equal(got, want, check_exact=True)

@@ -1,0 +1,145 @@
+"""Per-base / tiled route (BASELINE configs[4]): dig_base_tile_probs + dig_tile_mut_counts +
+dig_tiled_nb_test against the REFERENCE's own nb_model output (tests/golden/tiled_golden.json.gz, made by running
+nb_model.py:188-234 with in-memory fasta / tabix stand-ins), tiles of 1 and of 50 positions, and at the full size of
+configs[4] through properties that do not need an oracle."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden():
+    return json.loads(gzip.open(os.path.join(GOLDEN, "tiled_golden.json.gz")).read())
+
+
+@pytest.mark.parametrize("binsize", [1, 50])
+def test_nb_model_matches_reference(binsize):
+    """nb_model (host mirror, one cohort) == the reference's frame: integer columns exact, Pi / EXP to 1e-12, PVAL within
+    the tolerance contract.  The genome holds N runs and soft-masked stretches, one bin starts at 0 and one is cut off by
+    the chromosome end; some mutation rows hit a position twice, some are longer than one base."""
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.sequence_model import nb_model
+    g = _golden()
+    genome = PackedGenome.from_sequences(g["genome"])
+    for coh in g["cohorts"]:
+        muts = pd.DataFrame(coh["rows"], columns=["CHROM", "START", "END", "REF", "ALT", "ID"])
+        muts["CHROM"] = muts.CHROM.astype(str)
+        df = nb_model.nb_model(coh["d_pr"], np.array(g["idx"]), coh["mu"], coh["sigma"], muts, genome, n_up=1, n_down=1,
+                               binsize=binsize)
+        run = coh["runs"][str(binsize)]
+        assert len(df) == len(run["PVAL"])
+        assert np.array_equal(df.OBS.values, np.array(run["OBS"])) and np.array_equal(df.POS.values, np.array(run["POS"]))
+        assert np.array_equal(df.CHROM.values, np.array(run["CHROM"]))
+        assert [df.REGION.iloc[0], df.REGION.iloc[-1]] == run["REGION_first_last"]
+        np.testing.assert_allclose(df.Pi.values, run["Pi"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(df.EXP.values, run["EXP"], rtol=1e-12, atol=0)
+        rel_close(df.PVAL.values, np.array(run["PVAL"]), rtol=1e-6)
+        assert int(df.OBS.sum()) > 0 and (df.OBS.values > 1).any()
+
+
+def test_two_cohorts_in_one_call_equal_single_cohort_calls():
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    g = _golden()
+    genome = PackedGenome.from_sequences(g["genome"])
+    ctx = g["contexts"]
+    idx = np.array(g["idx"])
+    chroms = [str(c) for c in idx[:, 0]]
+    S = np.array([[coh["d_pr"][c] for c in ctx] for coh in g["cohorts"]])
+    mu = np.array([coh["mu"] for coh in g["cohorts"]])
+    sg = np.array([coh["sigma"] for coh in g["cohorts"]])
+    rows = [(r[0], r[1], r[2], c) for c, coh in enumerate(g["cohorts"]) for r in coh["rows"]]
+    mc, ms, me, co = (np.array([r[j] for r in rows]) for j in range(4))
+    both = engine.tiled_nb_model(genome, chroms, idx[:, 1], idx[:, 2], S, mu, sg, mc.astype(str), ms, me, co.astype(np.int32), binsize=50)
+    for c in range(2):
+        sel = co == c
+        one = engine.tiled_nb_model(genome, chroms, idx[:, 1], idx[:, 2], S[c:c + 1], mu[c:c + 1], sg[c:c + 1], mc[sel].astype(str),
+                                    ms[sel], me[sel], np.zeros(sel.sum(), np.int32), binsize=50)
+        for key in ("pt", "k", "pval", "exp"):
+            a, b = both[key][c].cpu().numpy(), one[key][0].cpu().numpy()
+            assert np.array_equal(a, b, equal_nan=True), (c, key)
+    nv = both["n_valid"].cpu().numpy()
+    assert nv.tolist() == [10, 10, 10, 10, 10, 2, 10, 10, 9]            # 499 / 500 / 99 (chr1 end) / 436 (chr2 end) positions
+    assert np.isnan(both["pt"][0, 5, 2:].cpu().numpy()).all()          # tiles a short region does not have
+
+
+@pytest.mark.timeout(900)
+def test_full_size_configs4_properties():
+    """BASELINE configs[4] on one GPU at full size: 288 000 bins of 10 kb x 37 cohorts x 200 tiles of 50 positions =
+    2.13 G tile tests from a 2.88 Gb genome.  Oracle-free properties: tile probabilities of a bin sum to 1, tile counts
+    sum to the mutations inside the bins' positions, pt agrees with an independent torch evaluation on sampled bins,
+    p-values are finite probabilities, and a sample of tiles agrees with the elementwise entry point dig_nb_exact."""
+    import torch
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.sequence_model import nb_model
+    dev = torch.device("cuda:0")
+    R, C, W, B = 288_000, 37, 10_000, 50
+    n_chrom = 24
+    per = R // n_chrom
+    gen = torch.Generator(device=dev).manual_seed(4)
+    lengths = np.full(n_chrom, per * W, np.int64)
+    n_words = int(lengths.sum() // 8) + 2
+    words = torch.randint(0, 2 ** 31 - 1, (n_words,), generator=gen, device=dev, dtype=torch.int64).to(torch.int32) & 0x33333333
+    words[0] = 0x44444444
+    words[-1] = 0x44444444
+    genome = PackedGenome(["chr%d" % i for i in range(n_chrom)], np.arange(n_chrom) * per * W, lengths,
+                          np.zeros(2, np.uint32))
+    genome._dev[(dev.type, dev.index)] = (words, torch.as_tensor(genome.offsets, device=dev), torch.as_tensor(genome.lengths, device=dev))
+    chroms = np.repeat(["chr%d" % i for i in range(n_chrom)], per)
+    starts = np.tile(np.arange(per) * W, n_chrom).astype(np.int64)
+    ends = starts + W
+    S = torch.rand((C, 64), generator=gen, device=dev, dtype=torch.float64) * 1e-2
+    mu = torch.rand((C, R), generator=gen, device=dev, dtype=torch.float64) * 40 + 5
+    sg = torch.rand((C, R), generator=gen, device=dev, dtype=torch.float64) * 6 + 1
+    M = 4_000_000
+    m_chrom = torch.randint(0, n_chrom, (M,), generator=gen, device=dev)
+    m_start = torch.randint(0, per * W, (M,), generator=gen, device=dev)
+    m_coh = torch.randint(0, C, (M,), generator=gen, device=dev, dtype=torch.int64).to(torch.int32)
+    pt, first, nval = engine.base_tile_probs(genome, chroms, starts, ends, S, B, device=dev)
+    assert pt.shape == (C, R, 200)
+    k = engine.tile_mut_counts(genome, chroms, starts, ends, first, nval, m_chrom, m_start, m_start + 1, m_coh, C, B, 200)
+    pval, ex = engine.tiled_nb_test(pt, k, mu, sg)
+    torch.cuda.synchronize()
+    assert int(nval.min()) == 200 and int(nval.max()) == 200
+    sums = pt.sum(dim=2)
+    assert float((sums - 1).abs().max()) < 1e-12
+    # every mutation lies in exactly one bin; those at a chromosome's position 0 or last position have no window
+    pos_in_chrom = m_start
+    inside = (pos_in_chrom >= 1) & (pos_in_chrom <= per * W - 2)
+    assert int(k.sum()) == int(inside.sum())
+    per_cohort = torch.bincount(m_coh[inside].long(), minlength=C)
+    assert torch.equal(k.sum(dim=(1, 2)), per_cohort)
+    # independent evaluation of pt on sampled bins: per-position contexts with torch
+    code = torch.stack([(words >> (4 * j)) & 15 for j in range(8)], dim=1).reshape(-1)[8:]      # bases from word 1 on
+    for r in (0, 1, per - 1, per, 17 * per + 123, R - 1):
+        ci, s = r // per, (r % per) * W
+        f = max(s, 1)
+        stop = min(s + W, per * W - 1)
+        g0 = ci * per * W
+        a, b, c_ = code[g0 + f - 1:g0 + stop - 1], code[g0 + f:g0 + stop], code[g0 + f + 1:g0 + stop + 1]
+        ctx = (16 * a + 4 * b + c_).long()
+        probs = S[:, ctx]                                                   # [C, n_pos]
+        tot = probs.sum(dim=1, keepdim=True)
+        n_pos = probs.shape[1]
+        pad = (-n_pos) % B
+        tiles = torch.nn.functional.pad(probs, (0, pad)).reshape(C, -1, B).sum(dim=2) / tot
+        got = pt[:, r, :tiles.shape[1]]
+        assert float(((got - tiles).abs() / tiles).max()) < 1e-12, r
+    assert bool(torch.isfinite(pval).all()) and float(pval.min()) >= 0.0 and float(pval.max()) <= 1.0
+    assert float((ex - pt * mu[:, :, None]).abs().max()) == 0.0
+    # the same arithmetic through the elementwise entry point on a sample (incl. the tiles holding the largest counts)
+    flat = torch.cat([torch.randint(0, pval.numel(), (200_000,), generator=gen, device=dev), (k.reshape(-1) >= 2).nonzero().reshape(-1)[:5000],
+                      k.reshape(-1).argmax().reshape(1)])
+    cc, rr = flat // (R * 200), (flat // 200) % R
+    alpha, theta = nb_model.normal_params_to_gamma(mu[cc, rr], sg[cc, rr])
+    p = 1.0 / (pt.reshape(-1)[flat] * theta + 1.0)
+    want = nb_model.nb_pvalue_exact(k.reshape(-1)[flat].double(), alpha, p)
+    assert torch.equal(pval.reshape(-1)[flat], want)

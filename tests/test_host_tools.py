@@ -136,3 +136,16 @@ def test_tabulate_sites_matches_reference(tmp_path):
     assert [str(i) for i in tab.index] == g["tab_index"]
     assert tab.OBS_SAMPLES.astype(int).tolist() == g["tab_obs_samples"]
     assert tab.OBS_SNV.astype(int).tolist() == g["tab_obs_snv"]
+
+
+def test_get_q_vals_equals_statsmodels():
+    """nb_model.get_q_vals (reference: nb_model.py:340-342 = statsmodels fdrcorrection, method 'indep') against values
+    produced by statsmodels 0.12.2 under the image's second interpreter (ties, a zero, a one, a denormal-scale value)."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from digdriver_amd.sequence_model import nb_model
+    g = json.load(open(os.path.join(GOLDEN, "qvals_golden.json")))
+    assert np.array_equal(nb_model.get_q_vals(np.array(g["p"])), np.array(g["q"]))
+    assert nb_model.get_q_vals([]).size == 0

@@ -292,3 +292,28 @@ def test_context_counting_oracle_matches_reference():
     got192, keys = O.expand_contexts_192(O.count_contexts_regions(g["genome"], chroms, starts, ends, minus))
     assert keys == g["columns192"]
     assert np.array_equal(got192, np.array(g["counts192"]))
+
+
+def test_per_base_front_half_oracle_vs_reference_nb_model():
+    """oracle.base_probabilities_by_region / apply_nb_to_region against the reference's own nb_model output
+    (tests/golden/tiled_golden.json.gz: nb_model.py:188-234 run with in-memory fasta / tabix stand-ins)."""
+    import gzip
+    import json
+    g = json.loads(gzip.open(os.path.join(GOLDEN, "tiled_golden.json.gz")).read())
+    ctx = O.context64()
+    assert g["contexts"] == ctx
+    for coh in g["cohorts"]:
+        s64 = np.array([coh["d_pr"][c] for c in ctx])
+        for binsize in (1, 50):
+            run = coh["runs"][str(binsize)]
+            pv, ps, ob, ex, pt = [], [], [], [], []
+            for (chrom, s, e), mu, sigma in zip(g["idx"], coh["mu"], coh["sigma"]):
+                starts = [r[1] for r in coh["rows"] if r[0] == str(chrom)]
+                a, b, c_, d, f = O.apply_nb_to_region(g["genome"]["chr%d" % chrom], s64, s, e, mu, sigma, starts, binsize)
+                pv.append(a); ps.append(b); ob.append(c_); ex.append(d); pt.append(f)
+            pv, ps, ob, ex, pt = (np.concatenate(v) for v in (pv, ps, ob, ex, pt))
+            assert len(pv) == len(run["PVAL"])
+            assert np.array_equal(ob, np.array(run["OBS"]).astype(int)) and np.array_equal(ps, np.array(run["POS"]))
+            np.testing.assert_allclose(pt, run["Pi"], rtol=1e-14, atol=0)
+            np.testing.assert_allclose(ex, run["EXP"], rtol=1e-14, atol=0)
+            rel_close(pv, np.array(run["PVAL"]), rtol=1e-12)
