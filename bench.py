@@ -16,9 +16,16 @@ synthetic data per SURVEY 8d.  One "element tested" = one (element, cohort) pair
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); every rank holds its own
-shard of elements (weak scaling) and the only exchange is the all-gather of the per-cohort
-sufficient statistics.  Rank 0 prints ONE JSON line.
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).  --mode (BASELINE configs[3]: "whole genome x 37
+cohorts bin-sharded across 8 GPUs, RCCL all-gather of sufficient stats"):
+    sharded   (default) ONE genome of 288 000 bins cut into contiguous bin ranges, one per rank (+ the halo of foreign bins
+              its boundary elements touch); the element set grows with N (120 091 per GPU, each element on the rank that
+              owns its first bin), so per-GPU work is fixed ("weak").  Every step all-gathers the chunk sums of the
+              per-cohort sufficient statistics and forms the scale factors from all of them (first-to-last sum over 64
+              canonical chunks: identical bits for every N, tests/test_gpu_sharded.py).  N = 1 is configs[2] exactly.
+    strong    the same sharding of ONE configs[2] problem (120 091 elements in all): strong scaling, extra curve.
+    replicas  every rank its own whole-genome problem, no exchange inside the step.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -239,6 +246,8 @@ def main():
     ap.add_argument("--cohorts", type=int, default=37)
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="elements in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--mode", choices=["sharded", "strong", "replicas"], default="sharded",
+                    help="how N > 1 ranks divide the work (see the module docstring); all three are configs[2] at N = 1")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed: the sequential evaluation the loop is checked against is repeated for this long before "
                          "the W warm-up steps (brings the GPU out of its idle power state; 0 = evaluate once)")
@@ -256,12 +265,20 @@ def main():
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    # The global problem and this rank's shard of it (at N = 1 the shard is the whole problem)
+    sharded = args.mode != "replicas" and world > 1
+    n_elements_global = args.elements * (world if args.mode == "sharded" else 1)
+    w_global = make_workload(args.bins, n_elements_global if sharded else args.elements, args.cohorts,
+                             seed=args.seed + (0 if sharded else rank))
+    plan = parallel.plan_shards(w_global["ov_ptr"], w_global["ov_idx"], args.bins, world if sharded else 1)[rank if sharded else 0]
+    w = parallel.shard_inputs(w_global, plan, world if sharded else 1)
+    w["cj"], w["cj_indel"] = w_global["cj"], w_global["cj_indel"]
+    E_total = n_elements_global if sharded else args.elements * world
+    del w_global
     # CPU baselines first: the all-core one forks workers, which must happen before this process touches the GPU
-    w, cpu_res = None, (None, None)
-    if world == 1:
-        w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
-        if args.cpu_sample > 0:
-            cpu_res = (cpu_baseline(w, args.cpu_sample), cpu_baseline_all_cores(w))
+    cpu_res = (None, None)
+    if world == 1 and args.cpu_sample > 0:
+        cpu_res = (cpu_baseline(w, args.cpu_sample), cpu_baseline_all_cores(w))
     _lib.require_device()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -277,12 +294,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    if w is None:
-        w = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
     E, C = w["L"].shape[0], w["d_pr"].shape[0]
-    N = w["bin_mu"].shape[0]
+    N = w["bin_mu"].shape[0]                          # rows this rank holds (own range + halo)
+    N_own = int(w["chunk_rows"][-1] - w["chunk_rows"][0])
     nbar = float(len(w["ov_idx"])) / E
-    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray) and k not in ("chunk_rows", "elements")}
     out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=dev)
     out_acc = engine.alloc_accumulate_outputs(E, C, 1, dev)
     # the shard's statistics for the scale factors as one [3, C] tensor: row 0 is filled by dig_scale_suffstats each
@@ -293,7 +309,6 @@ def main():
     # main stream; that record is a barrier packet and cost a 7 us bubble per step in front of the dot kernel, and the
     # reduction, squeezed beside the dot kernel, finished 5 us after it: rocprofv3 kernel trace, 0.301 -> 0.290 ms.)
     RING = args.steps + args.warmup + 2      # one set of scale-factor buffers per step: the side stream never waits
-    parts = [torch.stack([torch.zeros_like(td["n_snv_obs"]), td["n_snv_obs"], td["n_ind_obs"]]).contiguous() for _ in range(RING)]
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
                for _ in range(RING)]
     main_stream = torch.cuda.current_stream(dev)
@@ -305,18 +320,20 @@ def main():
     pipe = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
                                td["obs_indel"], out_acc=out_acc, out_stats=out_stats)
-    scale_plan = engine.ScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"])
+    # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
+    # exchanges nothing (its plan has world = 1)
+    exchange = use_dist and (sharded or world == 1)
+    scale_plan = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"],
+                                               parallel.N_CHUNKS, world=None if exchange else 1)
 
     def enqueue_scale_factors(t):
-        """Side stream: (1) per-cohort sufficient statistics of this shard (transfer_tools.py:148-156) -> (2) rank-ordered
-        all-gather sum over RCCL when N > 1 (3 x C doubles per rank) -> (3) scale factors of step t, into buffer set t."""
+        """Side stream: (1) chunk sums of the per-cohort sufficient statistics of this rank's bins (transfer_tools.py:148-156)
+        -> (2) all-gather of [chunk sums ; observed counts] over RCCL when the bins are sharded ((64 / N + 2) x C doubles per
+        rank) -> (3) first-to-last sum of all 64 chunk sums and the divisions: scale factors of step t, into buffer set t."""
         b = t % RING
-        part, cj_out = parts[b], cj_outs[b]
+        cj_out = cj_outs[b]
         with torch.cuda.stream(side_stream):
-            if not use_dist:    # nothing to all-gather: sums and divisions come from one pair of kernels
-                scale_plan.run(part[0], cj_out[0], cj_out[1], stream=side_stream)
-            else:
-                scale_plan.run_sharded(part, cj_out[0], cj_out[1])
+            scale_plan.run(cj_out[0], cj_out[1], stream=side_stream)
             side_done[b].record(side_stream)
 
     queued = [-1]      # last step whose scale factors have been enqueued
@@ -377,13 +394,13 @@ def main():
     # --settle-ms.  A fresh process starts from the GPU's idle power state and a cold TLB / L2: with W = 5 warm-up
     # steps (1.5 ms of GPU time) the first timed steps ran 10-15 % slower than the sustained rate (BENCH_r01: 0.301 ms
     # at --steps 20 against 0.27-0.29 ms at --steps 1000).  This is setup work, not a step: no timed step depends on it.
-    seq_cj, seq_cji = None, None
-    if not use_dist:
-        seq_cj, seq_cji, _ = engine.scale_factors_local(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"])
+    seq_cj = torch.empty(C, dtype=torch.float64, device=dev)
+    seq_cji = torch.empty(C, dtype=torch.float64, device=dev)
+    scale_plan.run(seq_cj, seq_cji)                  # (a collective when the bins are sharded: every rank is here)
     t_settle = time.perf_counter()
     ref_acc = ref_stats = None
     n_settle = 0
-    settle_cj, settle_cji = (seq_cj, seq_cji) if not use_dist else (td["cj"], td["cj_indel"])   # N > 1: re-evaluated below
+    settle_cj, settle_cji = seq_cj, seq_cji
     while True:
         ref_acc, ref_stats = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
                                                      td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
@@ -422,12 +439,10 @@ def main():
     stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
-    if use_dist:     # the scale factors come out of the all-gather: evaluate sequentially with the last step's
-        seq_cj, seq_cji = cj_outs[(step_no[0] - 1) % RING]
-        ref_acc, ref_stats = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
-                                                     td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
-                                                     td["obs_snv"], td["obs_samples"], td["obs_indel"], seq_cj, seq_cji)
     torch.cuda.synchronize()
+    last_cj, last_cji = cj_outs[(step_no[0] - 1) % RING]
+    if not (torch.equal(last_cj, seq_cj) and torch.equal(last_cji, seq_cji)):
+        raise SystemExit("bench: the scale factors of the overlapped loop and of the sequential evaluation disagree")
     same = bool(torch.equal(torch.nan_to_num(ref_stats, nan=-7.0), torch.nan_to_num(out_stats, nan=-7.0))) and \
         bool(torch.equal(ref_acc["MU"], out_acc["MU"])) and bool(torch.equal(ref_acc["P"], out_acc["P"]))
     if not same:
@@ -439,14 +454,14 @@ def main():
         slow_frac = float(ws[off + 8:off + 12].view(torch.int32)[0].item()) / (E * C)    # header [2]: length of the last worklist
 
     if rank == 0:
-        units = float(E) * C * world * args.steps
+        units = float(E_total) * C * args.steps
         b_acc, b_stat = algorithmic_bytes(E, C, nbar)
-        b_suff = 9.0 * N * C                                     # dig_scale_suffstats: Y_PRED f64 + FLAG u8 per (bin, cohort)
+        b_suff = 9.0 * N_own * C                                 # sufficient statistics: Y_PRED f64 + FLAG u8 per (own bin, cohort)
         # SURVEY 8d's algorithmic bytes, split by the stage that moves them (the three parts add up to b_acc + b_stat):
         stage_bytes = {"contexts": E * (260.0 * nbar + 4), "dot": E * 780.0 + 8.0 * E * C,
                        "statistics": E * C * (21.0 * nbar + 24 + 100)}
         stage_kernels = {"contexts": ["acc_region"], "dot": ["acc_dot"], "statistics": ["element_stats_"]}
-        default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37)
+        default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37) and world == 1
 
         def roof(name, by, ms, prefixes, n):
             if not ms:
@@ -481,10 +496,18 @@ def main():
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: whole genome, %d 10-kb bins, %d cohorts batched, %d elements "
-                                   "per GPU, K=192 substitution types, mean %.2f bins/element" % (N, C, E, nbar),
-                       "bins": N, "cohorts": C, "elements_per_gpu": E, "parallelism": "elements sharded x%d" % world},
+            "scaling": "strong" if args.mode == "strong" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[2]: whole genome, %d 10-kb bins, %d cohorts batched, %d elements, K=192 "
+                                    "substitution types, mean %.2f bins/element" % (args.bins, C, E_total, nbar)) if world == 1 else
+                                   {"sharded": "BASELINE configs[3]: ONE genome of %d 10-kb bins cut into %d contiguous bin ranges (one per "
+                                               "GPU, + halo), %d cohorts batched, %d elements in all (%d per GPU: the element set grows "
+                                               "with N), all-gather of the per-cohort chunk sums every step",
+                                    "strong": "BASELINE configs[3], strong form: ONE configs[2] problem (%d bins / %d ranks, %d cohorts, %d "
+                                              "elements in all, about %d per GPU), all-gather of the per-cohort chunk sums every step",
+                                    "replicas": "%d-bin genome replicated on each of %d GPUs, %d cohorts, %d elements in all (%d per GPU), "
+                                                "no exchange"}[args.mode] % (args.bins, world, C, E_total, E_total // world),
+                       "mode": args.mode, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
+                       "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if args.mode != "replicas" else "replicas x%d" % world},
             "roofline": dominant_roof,
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
@@ -492,7 +515,8 @@ def main():
                 "main stream": "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
                                "acc_dot_mfma_kernel, element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
                 "side stream": "scale factors of the coming steps, free-running (own buffers and event per step): "
-                               "suffstats_stage1, suffstats_stage2 (+ all-gather and scale_factors_kernel when N > 1)",
+                               "suffstats_chunk_stage1, suffstats_chunk_stage2 (+ all-gather of the chunk sums when N > 1), "
+                               "scale_factors_chunked_kernel",
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
             "kernel_timing": "HIP events on the main stream (the stream the kernels are launched on): `roofline` and "
                              "`roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` brackets "

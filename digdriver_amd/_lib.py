@@ -47,6 +47,8 @@ _SIGNATURES = {
     "dig_scale_suffstats": [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp],
     "dig_scale_suffstats_host": [_vp, _vp, _i64, _i64, _vp, _int],
     "dig_scale_factors": [_vp, _int, _i64, _vp, _vp, _vp],
+    "dig_scale_suffstats_chunked": [_vp, _vp, _i64, _vp, _int, _vp, _vp, _i64, _vp],
+    "dig_scale_factors_chunked": [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -68,6 +70,7 @@ _SIZE_QUERIES = {
     "dig_accumulate_workspace": [_i64, _i64],
     "dig_scale_suffstats_workspace": [_i64, _i64],
     "dig_element_pipeline_workspace": [_i64, _i64],
+    "dig_scale_suffstats_chunked_workspace": [_vp, _int, _i64],
 }
 
 ABI_VERSION = 2          # include/dig_hip.h: DIG_ABI_VERSION

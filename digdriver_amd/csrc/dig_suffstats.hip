@@ -118,6 +118,111 @@ __global__ void scale_factors_kernel(const double* __restrict__ parts, int world
     }
 }
 
+// ---- chunked form: sums that do not depend on how the bins are sharded ---------------------------------------------
+// The plain form above fixes its summation order for ONE table; split the bins over ranks and the rank-ordered sum of the
+// rank totals is a different floating-point expression, so the scale factors of a sharded run would differ from the
+// single-GPU run in the last bits.  The chunked form defines the result as
+//     S[c] = ((P_0[c] + P_1[c]) + ... ) + P_{K-1}[c],   P_j = sum over the bins of chunk j
+// with K canonical chunks of the GLOBAL bin grid (boundaries floor(N j / K); K = 64 in digdriver_amd/parallel.py, so every
+// shard boundary of 1, 2, 4, ... 64 ranks is a chunk boundary) and P_j summed in an order that depends on nothing but the
+// chunk's own rows and C (fixed rows per workgroup, fixed lane assignment, partials added first to last).  A rank
+// computes the P_j of the chunks it owns, the chunk sums are all-gathered in chunk order, and every rank adds the K
+// of them first to last: identical bits for any number of ranks (tests/test_gpu_sharded.py).
+constexpr int kSsMaxChunks = 256;
+struct ChunkTable {
+    int64_t row[kSsMaxChunks + 1];     // first row of every chunk in THIS table (+ end)
+    int32_t blk[kSsMaxChunks + 1];     // first workgroup of every chunk (+ end)
+    int n;
+};
+
+__global__ __launch_bounds__(kSsBlock) void suffstats_chunk_stage1(const double* __restrict__ bin_mu,
+                                                                   const uint8_t* __restrict__ bin_flag, int64_t C,
+                                                                   int64_t rows_per_block, ChunkTable tab,
+                                                                   double* __restrict__ partial)
+{
+    __shared__ double part[kSsBlock];
+    const int tid = threadIdx.x;
+    int j = 0;
+    while (j + 1 < tab.n && (int)blockIdx.x >= tab.blk[j + 1]) ++j;          // (uniform, at most kSsMaxChunks steps)
+    const int64_t r_begin = tab.row[j] + (int64_t)((int)blockIdx.x - tab.blk[j]) * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < tab.row[j + 1]) ? r_begin + rows_per_block : tab.row[j + 1];
+    const int rpp = kSsBlock / (int)C;              // rows per pass (C <= kSsBlock)
+    const int col = tid % (int)C, rg = tid / (int)C;
+    double acc = 0.0;
+    if (rg < rpp) {
+        int64_t r = r_begin + rg;
+        for (; r + 7 * rpp < r_end; r += 8 * rpp) {
+            double v[8];
+            uint8_t f[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t o = (r + (int64_t)q * rpp) * C + col;
+                v[q] = bin_mu[o];
+                f[q] = bin_flag[o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += f[q] ? 0.0 : v[q];
+        }
+        for (; r < r_end; r += rpp) {
+            const int64_t o = r * C + col;
+            acc += bin_flag[o] ? 0.0 : bin_mu[o];
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < C) {
+        double s = 0.0;
+        for (int g = 0; g < rpp; ++g) s += part[g * (int)C + tid];
+        partial[(int64_t)blockIdx.x * C + tid] = s;
+    }
+}
+
+// one workgroup per chunk: thread c adds the chunk's workgroup partials first to last
+__global__ __launch_bounds__(kSsBlock) void suffstats_chunk_stage2(const double* __restrict__ partial, int64_t C, ChunkTable tab,
+                                                                   double* __restrict__ out_chunks)
+{
+    const int j = blockIdx.x;
+    for (int64_t c = threadIdx.x; c < C; c += kSsBlock) {
+        double s = 0.0;
+        for (int b = tab.blk[j]; b < tab.blk[j + 1]; ++b) s += partial[(int64_t)b * C + c];
+        out_chunks[(int64_t)j * C + c] = s;
+    }
+}
+
+// cj[c] = (sum over ranks of obs_snv) / (sum over ALL chunks, first to last); obs [world, 2, C] hold integer counts.
+__global__ void scale_factors_chunked_kernel(const double* __restrict__ chunk_sums, int n_chunks, const double* __restrict__ obs,
+                                             int world, int C, double* __restrict__ out_sum, double* __restrict__ cj,
+                                             double* __restrict__ cj_indel)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double e = 0.0, s = 0.0, d = 0.0;
+        for (int j = 0; j < n_chunks; ++j) e += chunk_sums[(int64_t)j * C + c];
+        for (int r = 0; r < world; ++r) {
+            s += obs[((int64_t)r * 2 + 0) * C + c];
+            d += obs[((int64_t)r * 2 + 1) * C + c];
+        }
+        if (out_sum) out_sum[c] = e;
+        cj[c] = s / e;            // transfer_tools.py:153
+        cj_indel[c] = d / e;      // :154
+    }
+}
+
+// Rows per workgroup of the chunked form: a function of C only (never of the device or of the table's size).
+static int64_t ss_chunk_rows_per_block(int64_t C) { return 16 * (kSsBlock / C); }
+
+static int ss_fill_chunk_table(const int64_t* chunk_rows, int n_chunks, int64_t C, ChunkTable* tab)
+{
+    const int64_t rpb = ss_chunk_rows_per_block(C);
+    int64_t blocks = 0;
+    tab->n = n_chunks;
+    for (int j = 0; j <= n_chunks; ++j) {
+        tab->row[j] = chunk_rows[j];
+        tab->blk[j] = (int32_t)blocks;
+        if (j < n_chunks) blocks += (chunk_rows[j + 1] - chunk_rows[j] + rpb - 1) / rpb;
+    }
+    return (int)blocks;
+}
+
 // Rows per workgroup: a multiple of 8 passes (the unrolled inner loop keeps 8 row loads in flight per thread; a
 // ragged remainder would be walked one load at a time), sized for ~8 workgroups per CU.
 static int64_t ss_rows_per_block(int64_t N, int64_t C)
@@ -199,6 +304,49 @@ int dig_scale_factors(const double* parts, int world, int64_t C, double* cj, dou
     DIG_REQUIRE(C <= 0x7fffffff, "C fits in 32 bits");
     hipLaunchKernelGGL(scale_factors_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
                        world, (int)C, cj, cj_indel);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int64_t dig_scale_suffstats_chunked_workspace(const int64_t* chunk_rows, int n_chunks, int64_t C)
+{
+    if (!chunk_rows || n_chunks <= 0 || n_chunks > kSsMaxChunks || C <= 0 || C > kSsBlock) return 0;
+    ChunkTable tab;
+    const int blocks = ss_fill_chunk_table(chunk_rows, n_chunks, C, &tab);
+    return (int64_t)std::max(blocks, 1) * C * (int64_t)sizeof(double);
+}
+
+int dig_scale_suffstats_chunked(const double* bin_mu, const uint8_t* bin_flag, int64_t C, const int64_t* chunk_rows, int n_chunks,
+                                double* out_chunks, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    DIG_REQUIRE(chunk_rows && n_chunks >= 1 && n_chunks <= kSsMaxChunks, "1 .. 256 chunks, chunk_rows on the host");
+    DIG_REQUIRE(C >= 1 && C <= kSsBlock, "1 <= C <= 256 for the chunked form");
+    for (int j = 0; j < n_chunks; ++j) DIG_REQUIRE(chunk_rows[j] >= 0 && chunk_rows[j + 1] >= chunk_rows[j], "chunk_rows ascending");
+    DIG_REQUIRE(out_chunks && workspace, "non-null output and workspace");
+    ChunkTable tab;
+    const int blocks = ss_fill_chunk_table(chunk_rows, n_chunks, C, &tab);
+    DIG_REQUIRE(workspace_bytes >= (int64_t)std::max(blocks, 1) * C * (int64_t)sizeof(double), "workspace smaller than dig_scale_suffstats_chunked_workspace");
+    hipStream_t s = (hipStream_t)stream;
+    if (blocks > 0) {
+        DIG_REQUIRE(bin_mu && bin_flag, "non-null inputs");
+        hipLaunchKernelGGL(suffstats_chunk_stage1, dim3(blocks), dim3(kSsBlock), 0, s, bin_mu, bin_flag, C, ss_chunk_rows_per_block(C), tab,
+                           (double*)workspace);
+        DIG_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(suffstats_chunk_stage2, dim3(n_chunks), dim3(kSsBlock), 0, s, (const double*)workspace, C, tab, out_chunks);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_scale_factors_chunked(const double* chunk_sums, int n_chunks, const double* obs, int world, int64_t C, double* out_sum,
+                              double* cj, double* cj_indel, void* stream)
+{
+    DIG_REQUIRE(n_chunks >= 1 && world >= 1 && C >= 0, "n_chunks >= 1, world >= 1, C >= 0");
+    if (C == 0) return DIG_OK;
+    DIG_REQUIRE(chunk_sums && obs && cj && cj_indel, "non-null pointers");
+    DIG_REQUIRE(C <= 0x7fffffff, "C fits in 32 bits");
+    hipLaunchKernelGGL(scale_factors_chunked_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chunk_sums,
+                       n_chunks, obs, world, (int)C, out_sum, cj, cj_indel);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

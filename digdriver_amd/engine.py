@@ -544,3 +544,77 @@ def tiled_nb_model(genome, chroms, starts, ends, s_prob, mu, sigma, mut_chrom, m
     k = tile_mut_counts(genome, chroms, starts, ends, first, nval, mut_chrom, mut_start, mut_end, mut_cohort, C, binsize, n_tiles)
     pval, ex = tiled_nb_test(pt, k, mu, sigma)
     return dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first, n_valid=nval)
+
+
+# ---------------------------------------------------------------------------
+# scale factors in canonical chunks: identical bits for any sharding of the bins (dig_scale_suffstats_chunked)
+# ---------------------------------------------------------------------------
+class ChunkedScaleFactorPlan:
+    """Scale factors of one shard of the bin grid (transfer_tools.py:148-156) with cached arguments.
+
+    bin_mu / bin_flag: this rank's rows (device tensors, halo included); chunk_rows: first row, in THIS table, of every
+    canonical chunk the rank owns (+ end) -- parallel.canonical_chunks / parallel.plan_shards give them; n_snv_obs,
+    n_ind_obs: this rank's observed counts per cohort (integers).  run():
+        own chunk sums (dig_scale_suffstats_chunked) -> all-gather of [chunk sums ; observed counts] over the process group
+        -> every rank adds the K chunk sums first to last and divides (dig_scale_factors_chunked).
+    Without a process group the all-gather is skipped: same kernels, same bits."""
+
+    def __init__(self, bin_mu, bin_flag, n_snv_obs, n_ind_obs, chunk_rows, n_chunks_total, group=None, world=None):
+        import torch
+        import torch.distributed as dist
+        dev = bin_mu.device
+        self.mu, self.flag = _t(bin_mu, torch.float64, dev), _t(bin_flag, torch.uint8, dev)
+        self.C = int(self.mu.shape[1])
+        self.chunk_rows = np.ascontiguousarray(chunk_rows, np.int64)
+        self.n_own, self.n_total, self.group = len(self.chunk_rows) - 1, int(n_chunks_total), group
+        self.dist_world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # (world may be given explicitly to walk the ranks of a plan one after the other on one device:
+        #  enqueue_part() per rank, then finish() on the stacked parts -- tests/test_gpu_sharded.py)
+        self.world = int(world) if world is not None else self.dist_world
+        assert self.n_own * self.world == self.n_total, "every rank owns n_chunks_total / world canonical chunks"
+        lib = _lib.load()
+        self.wsb = int(lib.dig_scale_suffstats_chunked_workspace(_lib.host_ptr(self.chunk_rows), self.n_own, self.C))
+        self.ws = torch.empty(max(self.wsb, 8), dtype=torch.uint8, device=dev)
+        # what a rank contributes: its chunk sums [n_own, C] followed by its observed counts [2, C]
+        self.part = torch.zeros((self.n_own + 2, self.C), dtype=torch.float64, device=dev)
+        self.part[self.n_own] = _t(n_snv_obs, torch.float64, dev)
+        self.part[self.n_own + 1] = _t(n_ind_obs, torch.float64, dev)
+        self.all = torch.empty((self.world, self.n_own + 2, self.C), dtype=torch.float64, device=dev) if self.world > 1 else None
+        self.sums = torch.empty((self.n_total, self.C), dtype=torch.float64, device=dev)
+        self.obs = torch.empty((self.world, 2, self.C), dtype=torch.float64, device=dev)
+        self._lib = lib
+
+    def enqueue_part(self, stream=None):
+        """This rank's contribution [n_own + 2, C]: chunk sums of its own chunks, then its observed counts."""
+        p = _lib.dev_ptr
+        rc = self._lib.dig_scale_suffstats_chunked(p(self.mu), p(self.flag), self.C, _lib.host_ptr(self.chunk_rows), self.n_own,
+                                                   p(self.part), p(self.ws), self.wsb, _lib.stream_ptr(stream))
+        if rc != 0:
+            raise _lib.DigHipError("dig_scale_suffstats_chunked failed (%d): %s" % (rc, _lib.last_error()))
+        return self.part
+
+    def finish(self, all_parts, cj, cj_indel, out_sum=None, stream=None):
+        """all_parts [world, n_own + 2, C] (rank order = chunk order) -> scale factors on this rank."""
+        p = _lib.dev_ptr
+        if self.world > 1:
+            self.sums.view(self.world, self.n_own, self.C).copy_(all_parts[:, :self.n_own])
+            self.obs.copy_(all_parts[:, self.n_own:])
+            sums, obs = self.sums, self.obs
+        else:
+            sums, obs = all_parts[0, :self.n_own], all_parts[0, self.n_own:]
+        rc = self._lib.dig_scale_factors_chunked(p(sums), self.n_total, p(obs), self.world, self.C,
+                                                 p(out_sum) if out_sum is not None else None, p(cj), p(cj_indel),
+                                                 _lib.stream_ptr(stream))
+        if rc != 0:
+            raise _lib.DigHipError("dig_scale_factors_chunked failed (%d): %s" % (rc, _lib.last_error()))
+
+    def run(self, cj, cj_indel, out_sum=None, stream=None):
+        """Enqueue on `stream` (default: torch's current stream; with a process group the collective runs there too)."""
+        import torch.distributed as dist
+        assert self.world in (1, self.dist_world), "run() needs the process group the plan was built for"
+        part = self.enqueue_part(stream)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, part, group=self.group)
+            self.finish(self.all, cj, cj_indel, out_sum, stream)
+        else:
+            self.finish(part.unsqueeze(0), cj, cj_indel, out_sum, stream)

@@ -22,6 +22,71 @@ def bin_ranges(n_bins, world):
     return [(edges[r], edges[r + 1]) for r in range(world)]
 
 
+N_CHUNKS = 64      # canonical chunks of the bin grid: every shard boundary of 1, 2, 4, ..., 64 ranks is a chunk boundary
+
+
+def canonical_chunks(n_bins, k=N_CHUNKS):
+    """Boundaries floor(n_bins j / k), j = 0..k, of the canonical chunks the sufficient statistics are summed in
+    (dig_scale_suffstats_chunked): the chunk sums, added first to last, give the same bits however the bins are sharded."""
+    return np.array([(int(n_bins) * j) // k for j in range(k + 1)], dtype=np.int64)
+
+
+def shard_inputs(w, plan, world, n_chunks=N_CHUNKS):
+    """This rank's slice of a global problem `w` (host arrays in the layouts of include/dig_hip.h, e.g.
+    bench.make_workload): bin-table rows (own range + halo), its elements with the CSR re-indexed into those rows, its
+    canonical chunks as row offsets into the local table, and its share of the cohort totals (integer counts)."""
+    assert n_chunks % world == 0, "the number of ranks must divide the %d canonical chunks" % n_chunks
+    rows, elts, r = plan["bin_rows"], plan["elements"], plan["rank"]
+    n_bins = w["bin_mu"].shape[0]
+    lo, hi = bin_ranges(n_bins, world)[r]
+    halo_lo = int(np.searchsorted(rows, lo))                    # halo rows in front of the rank's own range
+    edges = canonical_chunks(n_bins, n_chunks)
+    per = n_chunks // world
+    own = edges[r * per:(r + 1) * per + 1]
+    assert own[0] == lo and own[-1] == hi
+    out = {k: np.ascontiguousarray(w[k][rows]) for k in ("bin_mu", "bin_std", "bin_y", "bin_flag", "bin_ctx")}
+    for k in ("L", "strand_minus", "obs_snv", "obs_samples", "obs_indel"):
+        out[k] = np.ascontiguousarray(w[k][elts])
+    out["ov_ptr"], out["ov_idx"], out["d_pr"] = plan["ov_ptr"], plan["ov_idx"], w["d_pr"]
+    out["chunk_rows"] = (own - lo + halo_lo).astype(np.int64)
+    share = lambda tot: np.floor(np.asarray(tot, np.float64) * (r + 1) / world) - np.floor(np.asarray(tot, np.float64) * r / world)
+    out["n_snv_obs"], out["n_ind_obs"] = share(w["n_snv_obs"]), share(w["n_ind_obs"])
+    out["elements"] = elts
+    return out
+
+
+class ShardedPipeline:
+    """One rank of the bin-sharded burden-test path (BASELINE configs[3]): the shard's tables resident on the
+    device, scale factors through the chunked all-gather, dig_element_pipeline on the shard's elements.  The reference
+    has no counterpart (one cohort per process, single GPU)."""
+
+    def __init__(self, shard, device, group=None, n_chunks=N_CHUNKS, world=None):
+        import torch
+        from . import engine
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
+        self.td = {k: t(v) for k, v in shard.items() if isinstance(v, np.ndarray) and k not in ("chunk_rows", "elements")}
+        self.elements = shard["elements"]
+        E, C = shard["L"].shape[0], shard["d_pr"].shape[0]
+        self.E, self.C = E, C
+        self.out_acc = engine.alloc_accumulate_outputs(E, C, 1, device)
+        self.out_stats = torch.empty((len(engine.ES_PLANES), E, C), dtype=torch.float64, device=device)
+        td = self.td
+        self.pipe = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                        td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                                        td["obs_indel"], out_acc=self.out_acc, out_stats=self.out_stats) if E else None
+        self.scale = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"],
+                                                   shard["chunk_rows"], n_chunks, group=group, world=world)
+        self.cj = torch.empty(C, dtype=torch.float64, device=device)
+        self.cj_indel = torch.empty(C, dtype=torch.float64, device=device)
+
+    def step(self, stream=None):
+        """Scale factors (own chunk sums -> all-gather -> first-to-last sum) then the element pipeline of the shard."""
+        self.scale.run(self.cj, self.cj_indel, stream=stream)
+        if self.pipe is not None:
+            self.pipe.run(self.cj, self.cj_indel, stages=7, stream=stream)
+        return self.out_acc, self.out_stats
+
+
 def plan_shards(ov_ptr, ov_idx, n_bins, world):
     """Partition elements by the owner of their first overlapped bin and build each rank's local CSR.
 
@@ -191,3 +256,25 @@ def broadcast_flag(value, device, src=0, group=None):
     f = torch.tensor([1 if value else 0], dtype=torch.int32, device=device)
     dist.broadcast(f, src=src, group=group)
     return bool(f.item())
+
+
+def chunked_scale_factors_reference(part, n_own, group=None):
+    """The exchange of engine.ChunkedScaleFactorPlan on host tensors (gloo tests, small tools): `part` [n_own + 2, C] =
+    this rank's chunk sums followed by its observed SNV / indel counts -> all-gather -> chunk sums added first to last in
+    chunk (= rank) order, counts added in rank order -> (cj, cj_indel).  The device path does the same in
+    dig_scale_factors_chunked."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(parts, part.contiguous(), group=group)
+    else:
+        parts = [part]
+    e = torch.zeros_like(part[0])
+    for p in parts:                       # chunk order: rank r owns chunks r * n_own .. (r + 1) * n_own - 1
+        for j in range(n_own):
+            e = e + p[j]
+    s = sum(p[n_own] for p in parts)
+    d = sum(p[n_own + 1] for p in parts)
+    return s / e, d / e

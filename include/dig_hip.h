@@ -181,6 +181,20 @@ int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int3
                          int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
                          int stages, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- sufficient statistics in canonical chunks (bin-sharded runs) --------------------------- *
+ * Same quantity as dig_scale_suffstats / dig_scale_factors, defined so that it does not depend on the sharding: the bins
+ * are cut into K canonical chunks of the GLOBAL grid (boundaries floor(N j / K)); a rank computes the chunk sums of the
+ * chunks it owns (out_chunks [n_chunks, C], each in an order fixed by the chunk's rows and C alone), the chunk sums of
+ * all ranks are all-gathered in chunk order and added first to last; obs f64 [world, 2, C] hold every rank's observed
+ * SNV / indel counts (integers).  Bit-identical scale factors for any number of ranks.
+ *   chunk_rows int64 [n_chunks + 1], HOST memory: first row of every chunk in this rank's table (+ end); n_chunks <= 256;
+ *   C <= 256.  workspace: dig_scale_suffstats_chunked_workspace(chunk_rows, n_chunks, C) bytes. */
+int64_t dig_scale_suffstats_chunked_workspace(const int64_t *chunk_rows, int n_chunks, int64_t C);
+int dig_scale_suffstats_chunked(const double *bin_mu, const uint8_t *bin_flag, int64_t C, const int64_t *chunk_rows,
+                                int n_chunks, double *out_chunks, void *workspace, int64_t workspace_bytes, void *stream);
+int dig_scale_factors_chunked(const double *chunk_sums, int n_chunks, const double *obs, int world, int64_t C,
+                              double *out_sum, double *cj, double *cj_indel, void *stream);
+
 /* ---- per-base / tiled route, front half -------------------------------------------------- *
  * base_probabilities_by_region (sequence_model/sequence_tools.py:292-317) + the tiling of apply_nb_to_region
  * (sequence_model/nb_model.py:126-186) for trinucleotide contexts (n_up = n_down = 1), all cohorts at once; the back

@@ -151,3 +151,44 @@ def test_two_rank_feature_gather_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_visit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "visit_ok.npy")
+
+
+def _chunk_worker(rank, world, port, tmp):
+    """Bin-sharded scale factors through canonical chunks: every rank sums the chunks it owns (one fixed order per chunk),
+    the chunk sums are all-gathered and added first to last -> the SAME bits as the single-process evaluation."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = make_workload(n_bins=2003, n_elements=700, n_cohorts=3, seed=13)
+        edges = parallel.canonical_chunks(2003)
+
+        def chunk_sum(rows_lo, rows_hi):          # the fixed per-chunk order of this test: plain row order
+            acc = torch.zeros(3, dtype=torch.float64)
+            for r in range(rows_lo, rows_hi):
+                acc = acc + torch.tensor(w["bin_mu"][r] * (w["bin_flag"][r] == 0))
+            return acc
+
+        plans = parallel.plan_shards(w["ov_ptr"], w["ov_idx"], 2003, world)
+        sh = parallel.shard_inputs(w, plans[rank], world)
+        n_own = parallel.N_CHUNKS // world
+        cr = sh["chunk_rows"]
+        rows = plans[rank]["bin_rows"]
+        part = torch.stack([chunk_sum(int(rows[cr[j]]), int(rows[cr[j + 1] - 1]) + 1) if cr[j + 1] > cr[j] else torch.zeros(3, dtype=torch.float64)
+                            for j in range(n_own)] + [torch.tensor(sh["n_snv_obs"]), torch.tensor(sh["n_ind_obs"])])
+        cj, cji = parallel.chunked_scale_factors_reference(part, n_own)
+        # single-process evaluation of the same definition
+        e = torch.zeros(3, dtype=torch.float64)
+        for j in range(parallel.N_CHUNKS):
+            e = e + chunk_sum(int(edges[j]), int(edges[j + 1]))
+        assert torch.equal(cj, torch.tensor(w["n_snv_obs"]) / e) and torch.equal(cji, torch.tensor(w["n_ind_obs"]) / e)
+        if rank == 0:
+            np.save(os.path.join(tmp, "chunk_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_chunked_scale_factors_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_chunk_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "chunk_ok.npy")
