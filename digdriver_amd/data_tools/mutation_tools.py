@@ -26,68 +26,70 @@ _INT_COLS = ('POS', 'START', 'END')
 _AUTOSOMES = [str(i) for i in range(1, 23)]
 
 
+_MUT_KEY = ['CHROM', 'START', 'END', 'REF', 'ALT']
+
+
+def _first_row_width(path):
+    """Number of tab-separated fields of the first row of a plain or gzip file."""
+    for opener in (open, lambda q: gzip.open(q, 'rt')):
+        try:
+            with opener(path) as handle:
+                return len(next(csv.reader(handle, delimiter='\t', skipinitialspace=True)))
+        except UnicodeDecodeError:
+            continue
+    raise ValueError("cannot read {}".format(path))
+
+
 def read_mutation_file(path, drop_sex=True, drop_duplicates=False, unique_indels=True):
-    """mutation_tools.py:45-104: header-less TSV, schema chosen by the column count of the first
-    row; plain or gzip."""
-    try:
-        with open(path) as f:
-            first_row = next(csv.reader(f, delimiter='\t', skipinitialspace=True))
-    except UnicodeDecodeError:  # gzip
-        with gzip.open(path, 'rt') as f:
-            first_row = next(csv.reader(f, delimiter='\t', skipinitialspace=True))
-    cols = _MUT_COLS[len(first_row)]
-    dtype = {c: (int if c in _INT_COLS else str) for c in cols}
-    df = pd.read_csv(path, sep="\t", low_memory=False, names=cols, dtype=dtype)
+    """mutation_tools.py:45-104: header-less TSV whose schema follows from its column count (5 ... 11), plain or gzip;
+    optionally autosomes only (CHROM becomes int), unique rows, unique indels."""
+    names = _MUT_COLS[_first_row_width(path)]
+    rows = pd.read_csv(path, sep="\t", names=names, low_memory=False, dtype={c: (int if c in _INT_COLS else str) for c in names})
     if drop_sex:
-        if set(df.CHROM.unique()) - set(_AUTOSOMES):
+        autosomal = rows.CHROM.isin(_AUTOSOMES)
+        if not autosomal.all():
             print('Restricting to autosomes')
-            df = df[df.CHROM.isin(_AUTOSOMES)]
-        df['CHROM'] = df.CHROM.astype(int)
+            rows = rows.loc[autosomal]
+        rows = rows.assign(CHROM=rows.CHROM.astype(int))
     if drop_duplicates:
-        df = drop_duplicate_mutations(df)
-    if unique_indels:
-        df = get_unique_indels(df)
-    return df
+        rows = drop_duplicate_mutations(rows)
+    return get_unique_indels(rows) if unique_indels else rows
 
 
 def drop_duplicate_mutations(df_mut):
-    """mutation_tools.py:107-109"""
-    return df_mut.drop_duplicates(['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE'])
+    """mutation_tools.py:107-109: one row per (mutation, sample)."""
+    return df_mut.drop_duplicates(_MUT_KEY + ['SAMPLE'])
 
 
 def get_unique_indels(df_mut):
-    """mutation_tools.py:111-117: indels de-duplicated on (CHROM, START, END, REF, ALT, GENE); SNVs first."""
-    df_indel = df_mut[df_mut.ANNOT == 'INDEL']
-    df_snv = df_mut[df_mut.ANNOT != 'INDEL']
-    df_indel = df_indel.drop_duplicates(subset=['CHROM', 'START', 'END', 'REF', 'ALT', 'GENE'])
-    return pd.concat([df_snv, df_indel])
+    """mutation_tools.py:111-117: an indel seen in several samples is kept once per GENE label; SNV rows come first."""
+    indel = df_mut.ANNOT == 'INDEL'
+    return pd.concat([df_mut.loc[~indel], df_mut.loc[indel].drop_duplicates(subset=_MUT_KEY + ['GENE'])])
 
 
 def filter_hypermut_samples(df_mut, max_muts_per_sample, return_blacklist=False):
-    """mutation_tools.py:293-304"""
-    sample_cnt = df_mut.SAMPLE.value_counts()
-    samples_blacklist = sample_cnt[sample_cnt > max_muts_per_sample].index.to_list()
-    df_whitelist = df_mut[~df_mut.SAMPLE.isin(samples_blacklist)]
-    if return_blacklist:
-        return df_whitelist, samples_blacklist
-    return df_whitelist
+    """mutation_tools.py:293-304: drop every row of the samples with more than `max_muts_per_sample` rows."""
+    load = df_mut.SAMPLE.value_counts()
+    hyper = load.index[load > max_muts_per_sample].to_list()
+    kept = df_mut.loc[~df_mut.SAMPLE.isin(hyper)]
+    return (kept, hyper) if return_blacklist else kept
+
+
+_ANNOT_TO_OBS = {'Missense': 'OBS_MIS', 'Nonsense': 'OBS_NONS', 'Synonymous': 'OBS_SYN', 'Essential_Splice': 'OBS_SPL',
+                 'INDEL': 'OBS_INDEL'}
 
 
 def mutations_per_gene(df_mut_cds, max_muts_per_gene_per_sample=3e9):
-    """mutation_tools.py:329-361: per (GENE, SAMPLE, ANNOT) counts, capped, summed per gene; integer frame
-    with columns renamed to OBS_MIS / OBS_NONS / OBS_SYN / OBS_SPL / OBS_INDEL."""
-    df_group = df_mut_cds.groupby(['GENE', 'SAMPLE', 'ANNOT']).size().reset_index(name='COUNT')
-    df_group.loc[df_group.COUNT > max_muts_per_gene_per_sample, 'COUNT'] = max_muts_per_gene_per_sample
-    df_pivot = df_group.pivot_table(index=['GENE', 'ANNOT'], values='COUNT', aggfunc="sum").reset_index()
-    df_counts = df_pivot.pivot(index='GENE', columns='ANNOT', values='COUNT')
-    df_counts = df_counts.fillna(0).astype(int)
-    df_counts.columns = df_counts.columns.to_list()
-    for col in ("Missense", "Nonsense", "Synonymous", "Essential_Splice", "INDEL"):
-        if col not in df_counts.columns:
-            df_counts[col] = 0
-    df_counts.rename({'Missense': 'OBS_MIS', 'Nonsense': 'OBS_NONS', 'Synonymous': 'OBS_SYN',
-                      'Essential_Splice': 'OBS_SPL', 'INDEL': 'OBS_INDEL'}, axis=1, inplace=True)
-    return df_counts
+    """mutation_tools.py:329-361: rows per (GENE, SAMPLE, ANNOT), capped per sample, summed per (GENE, ANNOT) -> integer
+    frame indexed by GENE with one column per annotation class present, the five tested classes named OBS_* (0 when the
+    cohort has none)."""
+    per_sample = df_mut_cds.groupby(['GENE', 'SAMPLE', 'ANNOT']).size().clip(upper=max_muts_per_gene_per_sample)
+    table = per_sample.groupby(level=['GENE', 'ANNOT']).sum().unstack('ANNOT').fillna(0).astype(int)
+    table.columns = table.columns.to_list()
+    for annot in _ANNOT_TO_OBS:
+        if annot not in table.columns:
+            table[annot] = 0
+    return table.rename(columns=_ANNOT_TO_OBS)
 
 
 def bed12_boundaries(f_bed):
@@ -183,60 +185,53 @@ def tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=False, drop_dup
     """mutation_tools.py:191-230: mutations x element blocks -> per (ELT, SAMPLE) integer counts
     OBS_SNV / OBS_INDEL / OBS_MUT.  The raw file rows are joined (no autosome filter), duplicates on
     (chrom, start, end, ref, alt, sample, elt) dropped when asked (:208), SNV vs INDEL by ANNOT (:211-213)."""
-    df_mut = pd.read_csv(f_mut, sep="\t", header=None, low_memory=False, dtype={0: str})
-    df_bed = pd.read_csv(f_elt_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
-    blocks = _bed12_to_bed6(df_bed) if bed12 else df_bed.rename(columns={0: 'CHROM', 1: 'START', 2: 'END', 3: 'ELT'})
-    mi, bi = _overlap_pairs(df_mut[0].values, df_mut[1].values, df_mut[2].values,
-                            blocks.CHROM.values, blocks.START.values, blocks.END.values)
-    empty = pd.DataFrame({'ELT': [], 'SAMPLE': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'OBS_MUT': []})
+    muts = pd.read_csv(f_mut, sep="\t", header=None, low_memory=False, dtype={0: str})
+    bed = pd.read_csv(f_elt_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
+    blocks = _bed12_to_bed6(bed) if bed12 else bed.rename(columns={0: 'CHROM', 1: 'START', 2: 'END', 3: 'ELT'})
+    mi, bi = _overlap_pairs(muts[0].values, muts[1].values, muts[2].values, blocks.CHROM.values, blocks.START.values,
+                            blocks.END.values)
+    out_cols = ['ELT', 'SAMPLE', 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']
     if len(mi) == 0:
-        return empty
-    inter = df_mut.iloc[mi, :8].reset_index(drop=True)
-    inter.columns = range(inter.shape[1])
-    inter[13] = blocks.ELT.values[bi]
+        return pd.DataFrame({c: [] for c in out_cols})
+    hits = pd.DataFrame({'ELT': blocks.ELT.values[bi], 'SAMPLE': muts[5].values[mi],
+                         'KIND': np.where(muts[7].values[mi] == 'INDEL', 'OBS_INDEL', 'OBS_SNV')})
     if drop_duplicates:
-        inter = inter.drop_duplicates([0, 1, 2, 3, 4, 5, 13])
-    is_indel = inter[7] == 'INDEL'
-    cnt_snv = inter[~is_indel].groupby([13, 5]).size().reset_index(name='OBS_SNV')
-    cnt_ind = inter[is_indel].groupby([13, 5]).size().reset_index(name='OBS_INDEL')
-    df_cnt = cnt_snv.merge(cnt_ind, how='outer')
-    df_cnt['OBS_SNV'] = df_cnt.OBS_SNV.fillna(0)
-    df_cnt['OBS_INDEL'] = df_cnt.OBS_INDEL.fillna(0)
-    df_cnt['OBS_MUT'] = df_cnt.OBS_SNV + df_cnt.OBS_INDEL
-    df_cnt = df_cnt[[13, 5, 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']]
-    df_cnt.columns = ['ELT', 'SAMPLE', 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']
-    return df_cnt
+        ident = muts.iloc[mi, :5].reset_index(drop=True)
+        hits = hits.loc[~pd.concat([ident, hits[['SAMPLE', 'ELT']]], axis=1).duplicated().values]
+    # counts per (element, sample); the reference merges its SNV table with its INDEL table (outer): SNV pairs first,
+    # each part in (ELT, SAMPLE) order
+    wide = hits.groupby(['ELT', 'SAMPLE', 'KIND']).size().unstack('KIND')
+    for kind in ('OBS_SNV', 'OBS_INDEL'):
+        if kind not in wide.columns:
+            wide[kind] = np.nan
+    with_snv = wide.OBS_SNV.notna()
+    wide = pd.concat([wide.loc[with_snv], wide.loc[~with_snv]]).fillna(0.0).reset_index()
+    wide['OBS_MUT'] = wide.OBS_SNV + wide.OBS_INDEL
+    return wide[out_cols].rename_axis(columns=None)
 
 
 def tabulate_mutations_in_element(f_mut, f_elt_bed, bed12=False, drop_duplicates=False, all_elements=False,
                                   max_muts_per_sample=1e9, max_muts_per_elt_per_sample=3e9, return_blacklist=False):
     """mutation_tools.py:155-189: hypermutator blacklist, per-(element, sample) cap, then per-element
     OBS_SAMPLES (= number of distinct samples), OBS_SNV, OBS_INDEL."""
-    df_cnt = tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=bed12, drop_duplicates=drop_duplicates)
-    df_cnt = df_cnt.rename({'SAMPLE': 'OBS_SAMPLES'}, axis=1)
-    if len(df_cnt) > 0:
-        per_sample = df_cnt.groupby('OBS_SAMPLES').OBS_MUT.sum()
-        blacklist = per_sample[per_sample > max_muts_per_sample].index
-        df_cnt = df_cnt[~df_cnt.OBS_SAMPLES.isin(blacklist)].copy()
+    per_pair = tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=bed12, drop_duplicates=drop_duplicates)
+    blacklist = []
+    if len(per_pair):
+        load = per_pair.groupby('SAMPLE').OBS_MUT.sum()
+        blacklist = load.index[load > max_muts_per_sample]
+        per_pair = per_pair.loc[~per_pair.SAMPLE.isin(blacklist)]
+    capped = per_pair.assign(OBS_SNV=per_pair.OBS_SNV.clip(upper=max_muts_per_elt_per_sample),
+                             OBS_INDEL=per_pair.OBS_INDEL.clip(upper=max_muts_per_elt_per_sample))
+    if len(capped):
+        summary = capped.groupby('ELT').agg(OBS_INDEL=('OBS_INDEL', 'sum'), OBS_SAMPLES=('SAMPLE', len), OBS_SNV=('OBS_SNV', 'sum'))
     else:
-        blacklist = []
-    df_cnt.loc[df_cnt.OBS_SNV > max_muts_per_elt_per_sample, 'OBS_SNV'] = max_muts_per_elt_per_sample
-    df_cnt.loc[df_cnt.OBS_INDEL > max_muts_per_elt_per_sample, 'OBS_INDEL'] = max_muts_per_elt_per_sample
-    if len(df_cnt) == 0:
-        df_summary = pd.DataFrame({'OBS_SAMPLES': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'ELT': []}).set_index('ELT')
-    else:
-        df_summary = df_cnt.groupby('ELT').agg(OBS_INDEL=('OBS_INDEL', 'sum'), OBS_SAMPLES=('OBS_SAMPLES', len),
-                                               OBS_SNV=('OBS_SNV', 'sum'))
-    if all_elements:
-        df_bed = pd.read_csv(f_elt_bed, sep="\t", header=None).set_index(3)
-        df_bed.index.rename('ELT', inplace=True)
-        df_summary = df_bed.merge(df_summary, left_index=True, right_index=True, how='left')
-        for c in ('OBS_SNV', 'OBS_INDEL', 'OBS_SAMPLES'):
-            df_summary[c] = df_summary[c].fillna(0)
-    out = df_summary[['OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL']]
-    if return_blacklist:
-        return out, blacklist
-    return out
+        summary = pd.DataFrame({'OBS_SAMPLES': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'ELT': []}).set_index('ELT')
+    if all_elements:                                  # every element of the bed, zero counts included (:176-183)
+        listed = pd.read_csv(f_elt_bed, sep="\t", header=None).set_index(3).rename_axis('ELT')
+        summary = listed.merge(summary, left_index=True, right_index=True, how='left')
+        summary[['OBS_SNV', 'OBS_INDEL', 'OBS_SAMPLES']] = summary[['OBS_SNV', 'OBS_INDEL', 'OBS_SAMPLES']].fillna(0)
+    table = summary[['OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL']]
+    return (table, blacklist) if return_blacklist else table
 
 
 def restrict_mutations_by_bed_efficient(f_mut, f_bed, bed12=False, drop_duplicates=False, drop_sex=False,

@@ -20,10 +20,9 @@ from . import transfer_tools
 
 def region_str_to_params(region_str):
     """onthefly_tools.py:19-27: 'chr1:100-200' -> ('1', 100, 200)."""
-    col_split = region_str.split(":")
-    chrom = col_split[0].lstrip("chr")
-    pos_split = col_split[1].split("-")
-    return chrom, int(pos_split[0]), int(pos_split[1])
+    name, _, span = region_str.partition(":")
+    lo, _, hi = span.partition("-")
+    return name.lstrip("chr"), int(lo), int(hi)          # (lstrip of the CHARACTERS c, h, r, as the reference does)
 
 
 def DIG_onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed=None, region_str=None, scale_factor=None,
@@ -34,11 +33,11 @@ def DIG_onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed=None, region_str=None,
     transfer_tools.py:737); False applies it once."""
     assert f_elts_bed or region_str, "ERROR: you must provide --f-bed or --region_str."
     temp_name = None
-    if region_str:
-        temp_file, temp_name = tempfile.mkstemp()
-        CHROM, START, END = region_str_to_params(region_str)
-        os.write(temp_file, "{}\t{}\t{}\tUserELT\t0\t+\t0\t0\t.\t1\t{},\t0,".format(CHROM, START, END, END - START).encode())
-        os.close(temp_file)
+    if region_str:                                   # one single-block '+' element named UserELT (:33-38)
+        c, lo, hi = region_str_to_params(region_str)
+        handle, temp_name = tempfile.mkstemp()
+        with os.fdopen(handle, "w") as bed:
+            bed.write("\t".join(str(x) for x in (c, lo, hi, "UserELT", 0, "+", 0, 0, ".", 1, "%d," % (hi - lo), "0,")))
         f_elts_bed = temp_name
     try:
         return _onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed, scale_factor, scale_factor_indel, scale_type,
@@ -56,25 +55,18 @@ def _onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed, scale_factor, scale_fact
     df_mut_tab, blacklist = mutation_tools.tabulate_mutations_in_element(
         f_mut, f_elts_bed, bed12=True, drop_duplicates=True, all_elements=True, max_muts_per_sample=max_muts_per_sample,
         max_muts_per_elt_per_sample=max_muts_per_elt_per_sample, return_blacklist=True)
+    run = transfer_tools.CohortRun(f_mut, f_pretrained)          # the scale-factor rules are shared with elementDriver
     if scale_by_expectation:
         print('scaling by expected number of mutations')
-        df_gene = transfer_tools.load_pretrained_model(f_pretrained)
-        df_mut = transfer_tools.read_mutations_cds(f_mut)
-        df_mut = df_mut[~df_mut.SAMPLE.isin(blacklist)]
-        df_syn = df_mut[(df_mut.ANNOT == 'Synonymous') & (df_mut.GENE != 'TP53')].drop_duplicates()
-        not_tp53 = df_gene[df_gene.index != 'TP53']
-        cj = len(df_syn) / (not_tp53.MU * not_tp53.Pi_SYN).sum()
-        if all_cosmic is None:
-            all_cosmic = transfer_tools._read_gene_panel('CGC_ALL') + ['CDKN2A.p14arf', 'CDKN2A.p16INK4a']
-        df_gene_null = df_gene[~df_gene.index.isin(all_cosmic)]
-        df_mut_null = df_mut[~df_mut.index.isin(all_cosmic)]      # row-index filter = no-op, as in the reference (:59)
-        exp_indel = (df_gene_null.Pi_INDEL * df_gene_null.ALPHA_INDEL * df_gene_null.THETA_INDEL).sum()
-        cj_indel = len(df_mut_null[df_mut_null.ANNOT == 'INDEL']) / exp_indel
+        coding = run.coding_rows()
+        coding = coding.loc[~coding.SAMPLE.isin(blacklist)]
+        cj = run.synonymous_scale(run.gene_model(), coding, dedup=True)                                        # :44-50
+        cj_indel = run.uniform_indel_scale(run.gene_model(), coding, transfer_tools.cosmic_null_set(all_cosmic))   # :52-63
     elif scale_factor:
         cj, cj_indel = scale_factor, scale_factor_indel
     else:
         print('Calculating scale factor')
-        cj, cj_indel = transfer_tools.calc_scale_factor_efficient(f_mut, f_pretrained, scale_type=scale_type)
+        cj, cj_indel = run.genome_scale(scale_type)
 
     genome = sequence_tools.load_genome(f_fasta)
     # element block contexts (strand-aware), onthefly_tools.py:70-71
@@ -116,11 +108,9 @@ def _onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed, scale_factor, scale_fact
         'THETA_INDEL': theta * cj_indel if strict_reference else theta,
         'Pi_SUM': acc['P'][:, 0, 0], 'Pi_INDEL': acc['P_INDEL']}, index=df_elts.ELT.values)
 
-    df_model = df_mut_tab.merge(pretrain_df, left_on='ELT', right_index=True)
-    df_model = transfer_tools.element_expected_muts_nb(df_model)
-    if not skip_pvals:
-        df_model = transfer_tools.element_pvalue_burden_nb(df_model)
-        df_model = transfer_tools.element_pvalue_burden_nb_by_sample(df_model)
-        df_model = transfer_tools.element_pvalue_indel(df_model, cj_indel)
-        df_model = transfer_tools.combine_snv_indel(df_model, 'PVAL_SNV_BURDEN')
-    return df_model
+    T = transfer_tools
+    df_model = T.element_expected_muts_nb(df_mut_tab.merge(pretrain_df, left_on='ELT', right_index=True))
+    if skip_pvals:
+        return df_model
+    df_model = T.element_pvalue_burden_nb_by_sample(T.element_pvalue_burden_nb(df_model))
+    return T.combine_snv_indel(T.element_pvalue_indel(df_model, cj_indel), 'PVAL_SNV_BURDEN')

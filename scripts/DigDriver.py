@@ -4,8 +4,8 @@
 Drop-in for the reference's scripts/DigDriver.py: the same four sub-commands with the same positional
 arguments and option names (DigDriver.py:160-275), and the same output, a tab-separated
 ``<outdir>/<outpfx>.results.txt`` with header and index column (DigDriver.py:38-43,115-118).  The statistics
-run through libdig_hip.so; `model` may be the reference's HDF5 map (needs h5py/PyTables) or the directory
-mirror described in digdriver_amd/io/mapfile.py.
+run through libdig_hip.so; `model` may be the reference's HDF5 map (`*.h5`, read by io/h5lite.py +
+io/pandas_fixed.py: no h5py or PyTables needed) or the directory mirror described in digdriver_amd/io/mapfile.py.
 """
 import argparse
 import os
@@ -20,6 +20,11 @@ CGC_SETS = ['CGC_ALL', 'CGC_ONC', 'CGC_TSG']
 SCALE_TYPES = ['genome', 'exome', 'sample', 'MSK_230', 'PCAWG_cds']
 
 
+def _use_panel_dir(args):
+    if getattr(args, 'panel_dir', None):
+        transfer_tools.set_panel_dir(args.panel_dir)
+
+
 def write_results(frame, args):
     os.makedirs(args.outdir, exist_ok=True)
     target = os.path.join(args.outdir, args.outpfx + '.results.txt')
@@ -28,6 +33,7 @@ def write_results(frame, args):
 
 
 def cmd_gene(args):
+    _use_panel_dir(args)
     print('Running gene driver detection')
     res = transfer_tools.run_gene_model(
         args.fmut, args.model, scale_by_sample=args.scale_by_samples, pval_burden_nb=args.pval_burden,
@@ -37,6 +43,7 @@ def cmd_gene(args):
 
 
 def cmd_target(args):
+    _use_panel_dir(args)
     print('Running MSK-IMPACT driver detection')
     res = transfer_tools.run_target_model(
         args.fmut, args.model, scale_by_sample=args.scale_by_samples, panel=args.panel,
@@ -55,6 +62,7 @@ def _scale_mode(args):
 
 
 def cmd_element(args):
+    _use_panel_dir(args)
     if not (args.f_bed or args.f_sites):
         raise SystemExit("ERROR: you must provide --f-bed or --f-sites.")
     print('Running user-defined element driver detection')
@@ -76,6 +84,7 @@ def cmd_element(args):
 
 
 def cmd_quick(args):
+    _use_panel_dir(args)
     if not (args.f_elts_bed or args.region_str):
         raise SystemExit("ERROR: you must provide --f_elts_bed or --region_str.")
     from digdriver_amd.driver_model import onthefly_tools
@@ -96,6 +105,10 @@ def cmd_quick(args):
 def _common(p, element_caps):
     p.add_argument('fmut', type=str, help='annotated mutation file (DigPreprocess.py annotMutationFile format)')
     p.add_argument('model', type=str, help='pretrained mutation map')
+    # not a reference option: the reference finds its gene panels (genes_CGC_ALL.txt, genes_MSK_341.txt, ...) inside its
+    # installed package; here they are looked up in this directory, then $DIG_DATA_DIR, digdriver_amd/data/ and an
+    # installed DIGDriver package
+    p.add_argument('--panel-dir', type=str, default=None, help='directory holding the gene panel files genes_<NAME>.txt')
     return p
 
 

@@ -740,6 +740,55 @@ def gen_contexts():
     print("wrote contexts_golden.json", df64.shape, df192.shape)
 
 
+def gen_run_element_expectation():
+    """run_element_region_model in its DEFAULT mode (scale_by_expectation=True, transfer_tools.py:969-1096): the
+    reference function itself, with the three things this image cannot provide handed in as fixtures -- the packaged CGC
+    panel (pkg_resources.resource_stream -> a synthetic panel), the pretrained frames (pd.read_hdf -> in-memory frames) and
+    the bedtools tabulation (tabulate_mutations_in_element -> a fixed table + sample blacklist).  Pins the synonymous
+    scale factor on blacklist-filtered, de-duplicated rows and the uniform indel factor whose CGC exclusion of the
+    mutation frame is a no-op (:1014)."""
+    import io as _io
+    rng = np.random.default_rng(969)
+    g = np.load(os.path.join(HERE, "gene_stats_golden.npz"), allow_pickle=False)
+    genes = [str(x) for x in g["genes"]]
+    frame = pd.DataFrame(g["frame_vals"], columns=[str(c) for c in g["frame_cols"]])
+    frame.insert(0, "GENE", genes)
+    frame.insert(0, "CHROM", g["frame_chrom"])
+    for c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+        frame[c] = frame[c].astype(int)
+    n = 400
+    mu = np.exp(rng.uniform(np.log(0.5), np.log(300.0), n))
+    sigma = mu * np.exp(rng.uniform(np.log(0.05), np.log(1.2), n))
+    elts = pd.DataFrame(dict(ELT=["elt%d" % i for i in range(n)], ELT_SIZE=rng.integers(100, 5000, n), FLAG=rng.integers(0, 2, n).astype(bool),
+                             R_SIZE=rng.integers(9000, 30000, n), R_OBS=rng.integers(0, 500, n), R_INDEL=rng.integers(0, 500, n),
+                             MU=mu, SIGMA=sigma, MU_INDEL=mu, SIGMA_INDEL=sigma,
+                             P_SUM=np.exp(rng.uniform(np.log(1e-4), np.log(0.5), n)), P_INDEL=np.exp(rng.uniform(np.log(1e-4), np.log(0.5), n))))
+    _HDF_FRAMES[("mem://run.h5", "genic_model")] = frame
+    _HDF_FRAMES[("mem://run.h5", "myelts")] = elts
+    panel = ["G%d" % i for i in range(0, 600, 3)] + ["TP53"]
+    sys.modules["pkg_resources"].resource_stream = lambda pkg, name: _io.BytesIO(("\n".join(panel) + "\n").encode())
+    ref_tt.pkg_resources = sys.modules["pkg_resources"]
+    present = rng.uniform(size=n) > 0.25
+    tab = pd.DataFrame(dict(OBS_SAMPLES=rng.poisson(3, n), OBS_SNV=rng.poisson(4, n), OBS_INDEL=rng.poisson(0.7, n)),
+                       index=pd.Index(elts.ELT.values, name="ELT"))[present].astype(float)
+    blacklist = ["S7", "S123", "S250"]
+    real_tab = ref_mt.tabulate_mutations_in_element
+    ref_mt.tabulate_mutations_in_element = lambda *a, **k: (tab.copy(), list(blacklist))
+    try:
+        with np.errstate(all="ignore"):
+            out = ref_tt.run_element_region_model(os.path.join(HERE, "gene_mutations.tsv"), "unused.bed", "mem://run.h5", "myelts",
+                                                  scale_by_expectation=True)
+    finally:
+        ref_mt.tabulate_mutations_in_element = real_tab
+    num = [c for c in out.columns]
+    save_npz("run_element_expectation_golden.npz", elt_cols=np.array([c for c in elts.columns if c != "ELT"]),
+             elt_vals=elts[[c for c in elts.columns if c != "ELT"]].values.astype(float), elt_names=np.array(elts.ELT.values).astype(str),
+             panel=np.array(panel), tab_index=np.array(tab.index).astype(str), tab_vals=tab[["OBS_SAMPLES", "OBS_SNV", "OBS_INDEL"]].values,
+             blacklist=np.array(blacklist), out_index=np.array(out.index).astype(str), out_cols=np.array(num).astype(str),
+             out_vals=out[num].values.astype(float))
+    print("wrote run_element_expectation_golden.npz", out.shape)
+
+
 class _FakeTabix:
     """pysam.TabixFile look-alike over in-memory mutation rows (chrom, start, end, ref, alt, id): fetch(chrom, start,
     end) yields the tab-joined rows overlapping [start, end), as tabix does for 0-based half-open bed intervals."""
@@ -867,6 +916,9 @@ def main():
     if "--only-tiled" in sys.argv:
         gen_tiled()
         return
+    if "--only-run-element" in sys.argv:
+        gen_run_element_expectation()
+        return
     gen_nb_midp()
     gen_nb_exact()
     gen_element_stats()
@@ -880,6 +932,7 @@ def main():
     gen_contexts()
     gen_sites()
     gen_tiled()
+    gen_run_element_expectation()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

@@ -1,0 +1,126 @@
+"""GP calibration.  gpytorch is absent and unpinned, so parity with the reference's GP stays
+"unpinned"; what is pinned here: the SGPR oracle is self-consistent (two independent numpy forms of Titsias' bound),
+GPTrainer.standardize is sklearn's StandardScaler, and -- on the GPU -- SparseGP's bound, its gradients and its
+predictive mean / standard deviation equal the oracle's at fixed hyper-parameters, at the reference's sizes too."""
+import numpy as np
+import pytest
+
+from oracle import sgpr_oracle as S
+
+
+def _problem(n, m, d, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, d))
+    w = rng.normal(size=d)
+    y = np.sin(X @ w) + 0.3 * rng.normal(size=n)
+    return X, y, X[:m].copy() + 0.05 * rng.normal(size=(m, d))
+
+
+def test_oracle_forms_agree():
+    X, y, Z = _problem(300, 30, 5, 0)
+    for ls, os_, s2, c in ((1.3, 0.8, 0.2, 0.1), (0.7, 2.0, 0.05, -0.3)):
+        a = S.bound_dense(X, y, Z, ls, os_, s2, c)
+        b = S.bound_woodbury(X, y, Z, ls, os_, s2, c)
+        assert abs(a - b) <= 1e-9 * abs(a), (a, b)
+    # m = n inducing points at the data: the bound is the exact GP log marginal likelihood (jitter aside)
+    Xs, ys, _ = _problem(60, 5, 3, 1)
+    K = S.rbf(Xs, Xs, 1.1, 0.9) + 0.3 * np.eye(60)
+    exact = -0.5 * (60 * np.log(2 * np.pi) + np.linalg.slogdet(K)[1] + ys @ np.linalg.solve(K, ys))
+    assert abs(S.bound_woodbury(Xs, ys, Xs, 1.1, 0.9, 0.3, 0.0) - exact) < 1e-4
+    mu, sd = S.predict(Xs, ys, Xs, Xs[:7], 1.1, 0.9, 0.3, 0.0)
+    Ks = S.rbf(Xs[:7], Xs, 1.1, 0.9)
+    np.testing.assert_allclose(mu, Ks @ np.linalg.solve(K, ys), atol=1e-4)
+
+
+def test_standardize_is_sklearn_standard_scaler():
+    """gp_trainer.py:107-120: StandardScaler().fit(train) applied to every set; y by the training mean and (population) std."""
+    from sklearn.preprocessing import StandardScaler
+    from digdriver_amd.region_model.trainers.gp_trainer import GPTrainer
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(200, 16)) * rng.uniform(0.1, 5, 16)
+    X[:, 3] = 0.0                                   # dead feature (zero variance: left unscaled)
+    Y = rng.poisson(30, 200).astype(float)
+    Xt, Yt, scaler, ym, ys = GPTrainer.standardize(X, Y)
+    sk = StandardScaler().fit(X)
+    np.testing.assert_allclose(Xt, sk.transform(X), rtol=1e-13, atol=1e-13)
+    assert ym == Y.mean() and ys == Y.std()
+    X2 = rng.normal(size=(50, 16))
+    np.testing.assert_allclose(GPTrainer.standardize(X2, Y[:50], scaler, ym, ys)[0], sk.transform(X2), rtol=1e-13, atol=1e-13)
+
+
+def _model(X, y, Z, ls, os_, s2, c, dev):
+    import math
+    import torch
+    from digdriver_amd.region_model.trainers.gp_trainer import SparseGP
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev)
+    gp = SparseGP(t(X), t(y), n_inducing=len(Z))
+    inv = lambda v: math.log(math.expm1(v))
+    with torch.no_grad():
+        gp.inducing_points.copy_(t(Z))
+        gp.raw_lengthscale.fill_(inv(ls))
+        gp.raw_outputscale.fill_(inv(os_))
+        gp.raw_noise.fill_(inv(s2 - 1e-4))
+        gp.mean_const.fill_(c)
+    return gp
+
+
+@pytest.mark.gpu
+def test_sparse_gp_bound_gradient_and_prediction_vs_oracle():
+    import torch
+    dev = torch.device("cuda:0")
+    X, y, Z = _problem(2000, 50, 6, 3)
+    ls, os_, s2, c = 1.4, 0.9, 0.25, 0.05
+    gp = _model(X, y, Z, ls, os_, s2, c, dev)
+    loss = gp.neg_bound_per_point()
+    want = -S.bound_woodbury(X, y, Z, ls, os_, s2, c) / len(y)
+    assert abs(loss.item() - want) <= 1e-10 * abs(want)
+    # gradients: autograd against central differences of the oracle, through the softplus parametrisation
+    loss.backward()
+    sp = lambda r: np.log1p(np.exp(r))
+    raw = {"ls": gp.raw_lengthscale.item(), "os": gp.raw_outputscale.item(), "s2": gp.raw_noise.item()}
+
+    def f(ls_r, os_r, s2_r, c_, Z_):
+        return -S.bound_woodbury(X, y, Z_, sp(ls_r), sp(os_r), sp(s2_r) + 1e-4, c_, jitter_abs=1e-6 * os_) / len(y)
+
+    h = 1e-5
+    fd = {"ls": (f(raw["ls"] + h, raw["os"], raw["s2"], c, Z) - f(raw["ls"] - h, raw["os"], raw["s2"], c, Z)) / (2 * h),
+          "os": (f(raw["ls"], raw["os"] + h, raw["s2"], c, Z) - f(raw["ls"], raw["os"] - h, raw["s2"], c, Z)) / (2 * h),
+          "s2": (f(raw["ls"], raw["os"], raw["s2"] + h, c, Z) - f(raw["ls"], raw["os"], raw["s2"] - h, c, Z)) / (2 * h),
+          "c": (f(raw["ls"], raw["os"], raw["s2"], c + h, Z) - f(raw["ls"], raw["os"], raw["s2"], c - h, Z)) / (2 * h)}
+    got = {"ls": gp.raw_lengthscale.grad.item(), "os": gp.raw_outputscale.grad.item(), "s2": gp.raw_noise.grad.item(),
+           "c": gp.mean_const.grad.item()}
+    for k in fd:
+        assert abs(got[k] - fd[k]) <= 1e-6 * max(abs(fd[k]), 1e-3), (k, got[k], fd[k])
+    for (i, j) in ((0, 0), (7, 3), (49, 5)):                     # a few inducing-point coordinates
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[i, j] += h
+        Zm[i, j] -= h
+        g_fd = (f(raw["ls"], raw["os"], raw["s2"], c, Zp) - f(raw["ls"], raw["os"], raw["s2"], c, Zm)) / (2 * h)
+        assert abs(gp.inducing_points.grad[i, j].item() - g_fd) <= 1e-6 * max(abs(g_fd), 1e-4), (i, j)
+    Xs = np.random.default_rng(9).normal(size=(500, 6))
+    mu, sd = gp.predict(torch.as_tensor(Xs, dtype=torch.float64, device=dev))
+    mu_w, sd_w = S.predict(X, y, Z, Xs, ls, os_, s2, c)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_w, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(sd.cpu().numpy(), sd_w, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sparse_gp_at_reference_size_vs_oracle():
+    """n = 150 000 training rows (the cap of gp_trainer.py:55), 16 features, m = 400 inducing points (the k-fold
+    default, kfold_mutations_main.py:73)."""
+    import torch
+    dev = torch.device("cuda:0")
+    X, y, Z = _problem(150_000, 400, 16, 5)
+    X, Z = X * 0.35, Z * 0.35
+    ls, os_, s2, c = 1.2, 0.7, 0.3, 0.02
+    gp = _model(X, y, Z, ls, os_, s2, c, dev)
+    with torch.no_grad():
+        got = gp.neg_bound_per_point().item()
+    want = -S.bound_woodbury(X, y, Z, ls, os_, s2, c) / len(y)
+    assert abs(got - want) <= 1e-9 * abs(want), (got, want)
+    Xs = np.random.default_rng(10).normal(size=(3000, 16)) * 0.35
+    mu, sd = gp.predict(torch.as_tensor(Xs, dtype=torch.float64, device=dev))
+    mu_w, sd_w = S.predict(X, y, Z, Xs, ls, os_, s2, c)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_w, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(sd.cpu().numpy(), sd_w, rtol=1e-6, atol=1e-9)

@@ -184,3 +184,49 @@ def test_run_element_region_model_end_to_end(_gpu, tmp_path):
     # the reference's key guard (transfer_tools.py:1020-1021): PCAWG_cds scaling needs the PCAWG_cds model
     with pytest.raises(AssertionError):
         tt.run_element_region_model(str(mut), str(bed), path, "my_elts", scale_by_expectation=False, scale_type="PCAWG_cds")
+
+
+def test_run_element_region_model_default_mode_matches_reference(tmp_path, monkeypatch, capsys):
+    """The route `DigDriver.py elementDriver` takes when no scale option is given (scale_by_expectation=True,
+    transfer_tools.py:989-1017): synonymous scale factor on blacklist-filtered de-duplicated rows, uniform indel factor with
+    the reference's no-op CGC exclusion of the mutation frame, then the statistics block.  Golden: the reference function
+    itself (tests/golden/make_golden.py::gen_run_element_expectation) with the panel, the frames and the bedtools
+    tabulation handed in as fixtures; the same fixtures are used here (panel through --panel-dir's mechanism)."""
+    from conftest import GOLDEN
+    from digdriver_amd.data_tools import mutation_tools
+    from digdriver_amd.driver_model import transfer_tools
+    from digdriver_amd.io import mapfile
+    g = np.load(os.path.join(GOLDEN, "run_element_expectation_golden.npz"), allow_pickle=False)
+    gg = np.load(os.path.join(GOLDEN, "gene_stats_golden.npz"), allow_pickle=False)
+    genes = pd.DataFrame(gg["frame_vals"], columns=[str(c) for c in gg["frame_cols"]])
+    genes.insert(0, "GENE", [str(x) for x in gg["genes"]])
+    genes.insert(0, "CHROM", gg["frame_chrom"])
+    elts = pd.DataFrame(g["elt_vals"], columns=[str(c) for c in g["elt_cols"]])
+    elts.insert(0, "ELT", [str(x) for x in g["elt_names"]])
+    elts["FLAG"] = elts.FLAG.astype(bool)
+    for ext in (".map", ".h5"):                    # the directory mirror and the reference's HDF5 container
+        pre = str(tmp_path / ("pre" + ext))
+        mapfile.write_frame(pre, "genic_model", genes)
+        mapfile.write_frame(pre, "myelts", elts)
+        panel_dir = tmp_path / "panels"
+        panel_dir.mkdir(exist_ok=True)
+        (panel_dir / "genes_CGC_ALL.txt").write_text("\n".join(str(x) for x in g["panel"]) + "\n")
+        tab = pd.DataFrame(g["tab_vals"], columns=["OBS_SAMPLES", "OBS_SNV", "OBS_INDEL"], index=pd.Index([str(x) for x in g["tab_index"]], name="ELT"))
+        monkeypatch.setattr(mutation_tools, "tabulate_mutations_in_element", lambda *a, **k: (tab.copy(), [str(x) for x in g["blacklist"]]))
+        monkeypatch.setattr(transfer_tools, "_PANEL_DIRS", [str(panel_dir)])
+        want = pd.DataFrame(g["out_vals"], columns=[str(c) for c in g["out_cols"]], index=[str(x) for x in g["out_index"]])
+        for fused in (False, True):
+            got = transfer_tools.run_element_region_model(os.path.join(GOLDEN, "gene_mutations.tsv"), "unused.bed", pre, "myelts",
+                                                          scale_by_expectation=True, fused=fused)
+            assert list(got.columns) == list(want.columns) and list(got.index) == list(want.index)
+            for col in want.columns:
+                tol = 1e-6 if col.startswith("PVAL") else 1e-12
+                rel_close(got[col].values.astype(float), want[col].values, rtol=tol)
+    out = capsys.readouterr().out
+    assert "scaling by expected number of mutations" in out and "INDEL scale factor is: 1.80183481391" in out
+    # a missing panel names the file and where it was looked for
+    monkeypatch.setattr(transfer_tools, "_PANEL_DIRS", [str(tmp_path / "nowhere")])
+    monkeypatch.setenv("DIG_DATA_DIR", str(tmp_path / "nowhere2"))
+    with pytest.raises(FileNotFoundError) as err:
+        transfer_tools.gene_panel("CGC_ALL")
+    assert "genes_CGC_ALL.txt" in str(err.value) and "nowhere" in str(err.value) and "--panel-dir" in str(err.value)
