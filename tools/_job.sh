@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02q
-python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/r02q/pytest.log
+mkdir -p gpurun_out/r02r
+python -m pytest tests/test_gpu_fullsize.py tests/test_gp_oracle.py -m gpu -x -q 2>&1 | tail -40 > gpurun_out/r02r/pytest.log
