@@ -64,6 +64,52 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(const S* __re
     }
 }
 
+// Track SUBSET (a track-selection file, dataset_generator.py:57-80), row-major output.  The plain kernel above issues one
+// index load, one scattered source load and one scalar store per value.  Here a wave takes one (bin, position) row:
+// the whole source row is copied to LDS with coalesced loads, every lane then assembles FOUR consecutive outputs from
+// LDS (the track list is read once per lane and kept in registers for the kernel's lifetime: the selection does not change
+// from row to row) and writes them with one vector store.  Needs T <= kSubsetMaxT and T_sel % 4 == 0 with a 16-byte
+// aligned output; anything else takes the plain kernel.
+__device__ __forceinline__ void store_vec4(float* p, float a, float b, float c, float d);
+__device__ __forceinline__ void store_vec4(__hip_bfloat16* p, float a, float b, float c, float d);
+constexpr int kSubsetMaxT = 2048;
+constexpr int kSubsetMaxVec = 8;          // vectors of four outputs per lane: T_sel <= 2048
+
+template <typename S, typename D>
+__global__ __launch_bounds__(kGatherBlock) void gather_rows_subset_kernel(const S* __restrict__ x, int64_t L, int64_t T,
+                                                                          const int64_t* __restrict__ rows, int64_t B,
+                                                                          const int32_t* __restrict__ tracks, int64_t T_sel,
+                                                                          D* __restrict__ out)
+{
+    __shared__ float s_row[kGatherBlock / 64][kSubsetMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kGatherBlock >> 6;
+    float* row = s_row[wave];
+    const int n_vec = (int)(T_sel >> 2);
+    int4 sel[kSubsetMaxVec];
+#pragma unroll
+    for (int v = 0; v < kSubsetMaxVec; ++v) {
+        const int q = lane + 64 * v;
+        sel[v] = q < n_vec ? *reinterpret_cast<const int4*>(tracks + 4 * q) : make_int4(0, 0, 0, 0);
+    }
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const int64_t src0 = rows[b] * L * T;
+        const int64_t dst0 = b * L * T_sel;
+        for (int64_t l = wave; l < L; l += nw) {
+            const S* xs = x + src0 + l * T;
+            for (int64_t t = lane; t < T; t += 64) row[t] = load_as_float<S>(xs, t);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the row is in LDS (one wave: no s_barrier needed)
+            D* od = out + dst0 + l * T_sel;
+#pragma unroll
+            for (int v = 0; v < kSubsetMaxVec; ++v) {
+                const int q = lane + 64 * v;
+                if (q < n_vec) store_vec4(od + 4 * q, row[sel[v].x], row[sel[v].y], row[sel[v].z], row[sel[v].w]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // All tracks selected (tracks == NULL), row-major output: a bin is ONE contiguous block of L * T values on both sides, so
 // the gather is a batched block copy with conversion.  Four values per lane and access (8-byte loads of i16, 16-byte
 // of f32; 8-byte stores of bf16, 16-byte of f32), kBlockUnroll independent accesses per lane in flight.
@@ -235,6 +281,11 @@ static int launch_gather(const void* x, int64_t n_total, int64_t L, int64_t T, c
         const int gy = (int)std::min<int64_t>(B, 65535);
         hipLaunchKernelGGL((gather_block_kernel<S, D>), dim3(chunks, gy), dim3(kGatherBlock), 0, stream, (const S*)x, L * T,
                            rows, B, (D*)out);
+    } else if (!transpose_out && tracks && T <= kSubsetMaxT && (T_sel & 3) == 0 && T_sel > 0 && T_sel <= 256 * kSubsetMaxVec &&
+               ((uintptr_t)out & 15) == 0 && ((uintptr_t)tracks & 15) == 0) {
+        int grid = (int)std::min<int64_t>(B, (int64_t)cu_count() * 8);
+        hipLaunchKernelGGL((gather_rows_subset_kernel<S, D>), dim3(grid), dim3(kGatherBlock), 0, stream, (const S*)x, L, T, rows,
+                           B, tracks, T_sel, (D*)out);
     } else if (!transpose_out) {
         int grid = (int)std::min<int64_t>(B, (int64_t)cu_count() * 8);
         hipLaunchKernelGGL((gather_rows_kernel<S, D>), dim3(grid), dim3(kGatherBlock), 0, stream, (const S*)x, L, T, rows,

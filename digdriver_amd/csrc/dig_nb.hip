@@ -92,6 +92,7 @@ struct ElementStatsArgs {
 #endif
 };
 
+constexpr int kMaxDevices = 64;
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
 
 struct PairRaw {
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     // The last workgroup to finish leaves the header cleared (every workgroup read the count before it got here), so a
     // later statistics-only call on this workspace needs no memset in front of it (DIG_PIPE_WORKLIST_CLEAN).
     if (tid == 0) {
-        __threadfence();
+        // (no __threadfence() here: at device scope it writes the XCD's L2 back -- buffer_wbl2 -- and nothing needs it:
+        //  every workgroup read the count at its start, the counter below is a device-scope atomic)
         if (atomicAdd(&a.worklist[1], 1u) == gridDim.x - 1) {
             a.worklist[0] = 0;
             a.worklist[1] = 0;
@@ -896,44 +898,44 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
     const int grid = (int)want_blocks;
     if (wl) {
-        // persistent grid: exactly as many blocks as are resident at once
-        static int resident[3] = {0, 0, 0};
+        // Persistent grids: as many workgroups as are resident at once.  The occupancy figures are cached per (device,
+        // kernel form): a process may drive several GPUs.
         const int which = fused ? 2 : (mu_indel ? 1 : 0);
-        if (!resident[which]) {
-            int per_cu = 0;
-            if (which == 2)
-                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false, true>, kBlock, 0));
-            else if (which == 1)
-                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<true, false>, kBlock, 0));
-            else
-                DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_stream_kernel<false, false>, kBlock, 0));
-            resident[which] = per_cu > 0 ? per_cu : 4;
-        }
-        // Resident blocks per CU: the pass is bound by VALU issue, not by latency hiding -- 4 to 7 blocks per CU perform
-        // within 3 % -- and slightly fewer than the maximum measured best (fewer waves contend for the scalar unit and the
-        // instruction cache): 6 for the plain form, 5 for the fused-rates form.
-        const int sgrid = grid_for(E * C, kBlock, std::min(resident[which], which == 2 ? 5 : 6));
-        if (which == 2 && stream_form() == 1) {
-            static const int tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
-            if (tickets == 1024) {
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
-            } else if (tickets == 256) {
-                static int res_t = 0;
-                if (!res_t) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_t, (element_stats_stream_fused_kernel<256, true>), 256, 0));
-                const int g = grid_for(E * C, 256, std::min(std::max(res_t, 1), stream_blocks_per_cu(8)));
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, true>), dim3(g), dim3(256), 0, s, a);
-            } else {
-                static int res_f = 0;
-                if (!res_f) DIG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&res_f, (element_stats_stream_fused_kernel<256, false>), kBlock, 0));
-                const int g = grid_for(E * C, kBlock, std::min(std::max(res_f, 1), stream_blocks_per_cu(8)));
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, false>), dim3(g), dim3(kBlock), 0, s, a);
+        static int resident[kMaxDevices][4] = {};
+        int dev_id = 0;
+        DIG_HIP_TRY(hipGetDevice(&dev_id));
+        DIG_REQUIRE(dev_id >= 0 && dev_id < kMaxDevices, "device index below 64");
+        auto occupancy = [&](int slot, auto kernel, int block) -> int {
+            int& r = resident[dev_id][slot];
+            if (!r) {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+                r = per_cu;
             }
-        } else if (which == 2)
-            hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(sgrid), dim3(kBlock), 0, s, a);
-        else if (which == 1)
-            hipLaunchKernelGGL((element_stats_stream_kernel<true, false>), dim3(sgrid), dim3(kBlock), 0, s, a);
-        else
-            hipLaunchKernelGGL((element_stats_stream_kernel<false, false>), dim3(sgrid), dim3(kBlock), 0, s, a);
+            return r;
+        };
+        static const int form = stream_form(), tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
+        if (which == 2 && form == 1 && tickets == 1024) {
+            // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
+            hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+        } else if (which == 2 && form == 1 && tickets == 256) {
+            const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, true>, 256), stream_blocks_per_cu(8)));
+            hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, true>), dim3(g), dim3(256), 0, s, a);
+        } else if (which == 2 && form == 1) {
+            const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, false>, 256), stream_blocks_per_cu(8)));
+            hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, false>), dim3(g), dim3(256), 0, s, a);
+        } else if (which == 2) {
+            const int g = grid_for(E * C, kBlock, std::min(occupancy(2, element_stats_stream_kernel<false, true>, kBlock), 5));
+            hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(g), dim3(kBlock), 0, s, a);
+        } else if (which == 1) {
+            // (the two-stage forms are bound by VALU issue, not by latency hiding: slightly fewer than the maximum of
+            //  resident workgroups measured best -- fewer waves contend for the scalar unit and the instruction cache)
+            const int g = grid_for(E * C, kBlock, std::min(occupancy(1, element_stats_stream_kernel<true, false>, kBlock), 6));
+            hipLaunchKernelGGL((element_stats_stream_kernel<true, false>), dim3(g), dim3(kBlock), 0, s, a);
+        } else {
+            const int g = grid_for(E * C, kBlock, std::min(occupancy(0, element_stats_stream_kernel<false, false>, kBlock), 6));
+            hipLaunchKernelGGL((element_stats_stream_kernel<false, false>), dim3(g), dim3(kBlock), 0, s, a);
+        }
     } else
         hipLaunchKernelGGL(element_stats_single_pass_kernel, dim3(grid), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
