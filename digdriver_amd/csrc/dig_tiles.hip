@@ -15,7 +15,7 @@
 //      16-bit counters, no atomics: the counter column belongs to the lane); the region histogram H = sum over tiles;
 //   3. T[c] = sum_ctx H[ctx] S[c][ctx] (the reference's np.sum over positions, regrouped by context);
 //   4. pt[c][tile] = (sum_ctx h[ctx][tile] S[c][ctx]) / T[c]: lane = tile, the 64 x C table is read as LDS broadcasts
-//      (one address per wave), sixteen cohort accumulators in registers per sweep of the histogram column.
+//      (one address per wave), twenty cohort accumulators in registers per sweep of the histogram column, two cohorts per 16-byte LDS read.
 // What bounds it: the FP64 multiply-adds of step 4 (2 x 64 x C flops per tile: 4.7 kflop at C = 37 against 25 bytes of
 // genome) -- FP64 VALU, not HBM; the outputs are 8 C bytes per tile.  binsize == 1 (tile = position) skips the
 // histograms: pt = S[c][ctx] / T[c].  Rounding differs from the reference's per-position normalise-then-sum by a few
@@ -28,7 +28,7 @@
 namespace dig {
 
 constexpr int kTileBlock = 256;
-constexpr int kTileCohorts = 16;          // cohort accumulators per sweep
+constexpr int kTileCohorts = 20;          // cohort accumulators per sweep of the histogram column (37 cohorts: 20 + 17); even
 constexpr int kTileMaxWords = 1536;       // packed words staged per pass: 12 288 bases (a 10-kb bin and its neighbours)
 
 struct TileRegion {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
     __shared__ uint32_t s_words[kTileMaxWords + 2];
     __shared__ unsigned short s_hist[64][kTileBlock];          // h[ctx][tile of the chunk]
     __shared__ unsigned s_H[64];
-    __shared__ double s_S[kTileCohorts][64];
+    __shared__ __attribute__((aligned(16))) double s_S[64][kTileCohorts];      // [context][cohort of the group]: two cohorts per 16-byte LDS read
     __shared__ double s_T[kTileCohorts];
     const int tid = threadIdx.x;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
@@ -141,18 +141,21 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
             for (int64_t c0 = 0; c0 < C; c0 += kTileCohorts) {
                 const int nc = (int)(C - c0 < kTileCohorts ? C - c0 : kTileCohorts);
                 __syncthreads();
-                for (int i = tid; i < nc * 64; i += kTileBlock) s_S[i >> 6][i & 63] = s_prob[(c0 + (i >> 6)) * 64 + (i & 63)];
+                for (int i = tid; i < kTileCohorts * 64; i += kTileBlock) {
+                    const int c = i >> 6, x = i & 63;
+                    s_S[x][c] = c < nc ? s_prob[(c0 + c) * 64 + x] : 0.0;
+                }
                 __syncthreads();
                 if (tid < nc) {
                     double T = 0.0;
-                    for (int x = 0; x < 64; ++x) T = fma((double)s_H[x], s_S[tid][x], T);
+                    for (int x = 0; x < 64; ++x) T = fma((double)s_H[x], s_S[x][tid], T);
                     s_T[tid] = T;
                 }
                 __syncthreads();
                 if (SINGLE) {
                     for (int c = 0; c < nc; ++c) {
                         double v = nan;
-                        if (live) v = (ctx_single < 64 ? s_S[c][ctx_single] : 0.0) / s_T[c];
+                        if (live) v = (ctx_single < 64 ? s_S[ctx_single][c] : 0.0) / s_T[c];
                         if (t < n_tiles) __builtin_nontemporal_store(v, &pt[((c0 + c) * R + r) * n_tiles + t]);
                     }
                 } else {
@@ -162,10 +165,15 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
                     if (live) {
                         for (int x = 0; x < 64; ++x) {
                             const unsigned h = s_hist[x][tid];
-                            if (__any(h != 0)) {                 // (a wave of tiles without this context skips 16 multiply-adds)
+                            if (__any(h != 0)) {                 // (a wave of tiles without this context skips the row)
                                 const double hv = (double)h;
+                                const double2* row = reinterpret_cast<const double2*>(&s_S[x][0]);      // broadcast reads
 #pragma unroll
-                                for (int c = 0; c < kTileCohorts; ++c) acc[c] = fma(hv, s_S[c][x], acc[c]);
+                                for (int c = 0; c < kTileCohorts; c += 2) {
+                                    const double2 sv = row[c >> 1];
+                                    acc[c] = fma(hv, sv.x, acc[c]);
+                                    acc[c + 1] = fma(hv, sv.y, acc[c + 1]);
+                                }
                             }
                         }
                     }

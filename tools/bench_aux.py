@@ -48,6 +48,13 @@ def main():
                                            "ms": dt * 1e3, "bins_per_s": B / dt, "algorithmic_GBps": by / dt / 1e9,
                                            "frac_hbm_peak": by / dt / HBM_PEAK})
         del x
+    # a track-selection file (dataset_generator.py:57-80): 512 of the 735 tracks, row-major output
+    sel512 = torch.sort(torch.randperm(T, device=dev, generator=g)[:512]).values.to(torch.int32)
+    for odt in ("bf16", "f32"):
+        dt = timeit(lambda: engine.gather_bins(x16, rows, sel512, out_dtype=odt, transpose=False))
+        by = B * L * (T * 2 + 512 * (2 if odt == "bf16" else 4))
+        out["gather_bins"].append({"in": "i16", "out": odt, "channels_first": False, "tracks": 512, "bins": B, "L": L, "T": T, "ms": dt * 1e3,
+                                   "bins_per_s": B / dt, "algorithmic_GBps": by / dt / 1e9, "frac_hbm_peak": by / dt / HBM_PEAK})
     del x16
     torch.cuda.empty_cache()
     # ---- a18: per-base tiles, 50-bp tiles of 10-kb bins (200 tiles per bin), C cohorts ------------------------------
@@ -97,6 +104,26 @@ def main():
     out["count_contexts"] = [{"windows": nwin, "window_bp": window, "bases": nbases, "ms": dt * 1e3,
                               "bases_per_s": nbases / dt, "algorithmic_GBps": by / dt / 1e9,
                               "frac_hbm_peak": by / dt / HBM_PEAK, "total_counted": int(res.sum(dtype=torch.int64).item())}]
+    # ---- a18 front half: tile probabilities of every 10-kb bin of the genome for 37 cohorts (BASELINE configs[4]) -----
+    S = torch.rand((37, 64), device=dev, generator=g, dtype=torch.float64) * 1e-2
+    chunk = 36_000                                          # bins per call (the outputs of the whole genome are 17 GB)
+    pt = first = nval = None
+
+    def run_tiles():
+        nonlocal pt, first, nval
+        for s0 in range(0, nwin, chunk):
+            pt, first, nval = engine.base_tile_probs(genome, chroms[s0:s0 + chunk], starts[s0:s0 + chunk], starts[s0:s0 + chunk] + window,
+                                                     S, 50, n_tiles=200, device=dev)
+    dt = timeit(run_tiles, n=2, warm=1)
+    tiles = nwin * 200
+    out["base_tile_probs"] = [{"bins": nwin, "tiles_per_bin": 200, "cohorts": 37, "tile_cohort_values": tiles * 37, "ms": dt * 1e3,
+                               "tile_cohort_values_per_s": tiles * 37 / dt, "flops": 2.0 * 64 * 37 * tiles,
+                               "fp64_TFLOPs": 2.0 * 64 * 37 * tiles / dt / 1e12, "frac_fp64_vector_peak": 2.0 * 64 * 37 * tiles / dt / 78.6e12,
+                               "algorithmic_bytes": nbases * 0.5 + tiles * 37 * 8.0,
+                               "algorithmic_GBps": (nbases * 0.5 + tiles * 37 * 8.0) / dt / 1e9,
+                               "frac_hbm_peak": (nbases * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK}]
+    del pt, first, nval
+    torch.cuda.empty_cache()
     # ---- f1: mutation x element-block interval join (dig_overlap_join_count / fill) ----------------------------------
     del words, res
     torch.cuda.empty_cache()
