@@ -133,6 +133,21 @@ def committed_traffic(kernel_prefixes):
     return (tot or None), os.path.basename(files[-1])
 
 
+def committed_valu_frac(kernel_substr):
+    """FP64-VALU utilisation of a kernel from the committed PMC summary (profiles/rNN_valu.json): cycles its SIMDs spent
+    issuing VALU instructions (SQ_ACTIVE_INST_VALU, quad-cycles, / 1024 SIMDs) over the kernel's cycles (GRBM_GUI_ACTIVE,
+    summed over the 8 XCDs).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d["kernels"].items():
+        if kernel_substr in k and v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE"):
+            return (v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0), os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
+
+
 def algorithmic_bytes(E, C, nbar_ov):
     """SURVEY 8d definitions (unfused)."""
     acc = E * (784 + 260 * nbar_ov) + E * C * (21 * nbar_ov + 32)
@@ -473,7 +488,7 @@ def main():
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms, "launches_timed": n}
 
         stage_names = {
-            "statistics": "dig_element_pipeline statistics stage: element_stats_stream_kernel<fused rates> + "
+            "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel + "
                           "element_stats_slow_kernel (one launch each, back to back)",
             "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
             "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64)"}
@@ -492,6 +507,11 @@ def main():
         step_roof = roof("step = dig_scale_factors || dig_element_pipeline (both streams, overlapped)", d_bytes, ms_step,
                          ["acc_region", "acc_dot", "element_stats_", "suffstats", "scale_factors"], args.steps)
         dominant_roof = stage_roofs["statistics"] or step_roof
+        if dominant_roof is stage_roofs["statistics"] and default_shape:
+            # SURVEY 8d asks for both figures of this kernel: the HBM fraction above and the FP64-VALU utilisation of its
+            # streaming pass (what actually bounds it)
+            vf, src = committed_valu_frac("element_stats_stream")
+            dominant_roof["valu_frac"], dominant_roof["valu_frac_source"] = vf, src
         res = {
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
@@ -513,7 +533,7 @@ def main():
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
                 "main stream": "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
-                               "acc_dot_mfma_kernel, element_stats_stream_kernel<fused rates>, element_stats_slow_kernel",
+                               "acc_dot_mfma_kernel, element_stats_stream_fused_kernel, element_stats_slow_kernel",
                 "side stream": "scale factors of the coming steps, free-running (own buffers and event per step): "
                                "suffstats_chunk_stage1, suffstats_chunk_stage2 (+ all-gather of the chunk sums when N > 1), "
                                "scale_factors_chunked_kernel",
