@@ -187,6 +187,249 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core form of the tile probabilities (binsize >= 2, at most 256 tiles and 12 280 tiled positions per region,
+// cohorts in chunks of 48): pt[c][tile] = (sum_ctx S[c][ctx] h[ctx][tile]) / T[c] is a [C x 64] x [64 x tiles] FP64
+// product per region.  v_mfma_f64_16x16x4_f64 has the FP64 vector rate on gfx950 and -- measured: the kernel's time is
+// the SUM of its matrix and vector instruction time, whatever the occupancy -- shares the issue with the vector ALU,
+// so the design minimises vector instructions around the 624 MFMAs of a region:
+//   * A = S (16 cohorts x 4 contexts per instruction) lives in REGISTERS for the whole kernel (48 doubles per lane: the
+//     table is the same for every region), lane 16 k + i holds S[c0 + 16 m + i][context of histogram row 4 ks + k]; the
+//     rows are in the order the walk produces them (first base in the low bits: b0 + 4 b1 + 16 b2);
+//   * B = h: lane 16 k + j reads h[4 ks + k][16 n + j] as one ds_read_u16 and converts it; the histogram rows are
+//     272 counters apart so that the four k-rows of an operand fall into disjoint LDS banks;
+//   * D[i][j] sits in lane 16 (i % 4) + j, register i / 4: sixteen consecutive tiles of one cohort per quarter wave --
+//     128 contiguous bytes per non-temporal store;
+//   * histograms: lane = tile walks its packed bases a WORD at a time: the eight 4-bit codes are squeezed to a 16-bit
+//     string of 2-bit bases, joined to the two bases before them, and every context is one bit-field extract -- about
+//     four instructions per base, one of them a ds_add_u32 without return (two 16-bit counters per dword).  A word with
+//     a non-ACGT code, or one that straddles the tile's ends, takes the guarded form of the same routine (wave-uniform
+//     choice);
+//   * H = row sums of h, added as packed 16-bit pairs (no pair can overflow: a row sums to at most the 12 280 tiled
+//     positions), + the positions behind the last tile, if any; T[c] from the A registers and H, per wave; the
+//     quotient is a multiplication by 1 / T[c] (one division per cohort and region instead of one per tile).
+// Work split: (cohort tile m, tile group n) pairs, n = (wave + m) mod 4 step 4 -- 10 / 9 / 10 / 10 pairs for
+// 3 x 13.  Sum order differs from the vector form (groups of four contexts inside the MFMA): 1e-15 relative.
+typedef double tile_double4 __attribute__((ext_vector_type(4)));
+constexpr int kTmStride = 272;                 // 16-bit counters per histogram row (256 tiles + 16 of padding)
+constexpr int kTmStride32 = kTmStride / 2;
+constexpr int kTmChunk = 48;                   // cohorts per launch
+#ifndef DIG_TM_OCC
+#define DIG_TM_OCC 2                           // workgroups per CU (register budget 256)
+#endif
+
+// One packed word of a tile's walk: contexts centred on nibbles centre0 .. centre0 + 7 (centre0 = 8 word - 1).
+template <bool GUARD>
+__device__ __forceinline__ void tile_word(unsigned w, unsigned& carry, unsigned& icarry, int centre0, int lo, int hi,
+                                          unsigned* col, unsigned inc)
+{
+    unsigned x = w & 0x33333333u;                                  // 2-bit bases, squeezed: base n at bits 2 n
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0xFFFFu;
+    const unsigned win = (x << 4) | carry;                         // the two bases before the word, then its eight
+    carry = win >> 16;
+    unsigned iwin = 0;
+    if (GUARD) {
+        unsigned f = ((w >> 2) | (w >> 3)) & 0x11111111u;          // non-ACGT flags, squeezed: base n at bit n
+        f = (f | (f >> 3)) & 0x03030303u;
+        f = (f | (f >> 6)) & 0x000F000Fu;
+        f = (f | (f >> 12)) & 0xFFu;
+        iwin = (f << 2) | icarry;
+        icarry = iwin >> 8;
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const unsigned ctx = (win >> (2 * n)) & 63u;
+        unsigned add = inc;
+        if (GUARD) {
+            const int centre = centre0 + n;
+            add = (centre >= lo && centre < hi && ((iwin >> n) & 7u) == 0u) ? inc : 0u;
+        }
+        atomicAdd(col + ctx * kTmStride32, add);
+    }
+}
+
+#ifdef DIG_TM_TIMING                            // developer build: cycles per phase (wave 0 of every workgroup), tools/tile_variant_bench.py
+__device__ unsigned long long g_tm_prof[8];
+#define TM_MARK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); tm_acc[k] += now_ - tm_last; tm_last = now_; } } while (0)
+#else
+#define TM_MARK(k) do {} while (0)
+#endif
+
+template <int MT>
+__global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_kernel(
+    const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
+    const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
+    const int64_t* __restrict__ reg_end, int64_t R, const double* __restrict__ s_prob, int64_t C, int c0, int binsize, int n_tiles,
+    double* __restrict__ pt, int64_t* __restrict__ first_pos, int32_t* __restrict__ n_valid)
+{
+    __shared__ uint32_t s_words[kTileMaxWords + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist32[64 * kTmStride32];
+    __shared__ unsigned s_H[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const unsigned short* s_hist16 = reinterpret_cast<const unsigned short*>(s_hist32);
+
+    double A[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int64_t c = c0 + 16 * m + li;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int row = 4 * ks + lk;                                    // histogram row = b0 + 4 b1 + 16 b2 (walk order) ...
+            const int ctx = ((row & 3) << 4) | (row & 12) | (row >> 4);     // ... of context 16 b0 + 4 b1 + b2
+            A[m][ks] = c < C ? s_prob[c * 64 + ctx] : 0.0;
+        }
+    }
+    const int n_groups = (n_tiles + 15) >> 4;
+    const int64_t cohort_stride = R * n_tiles;                 // elements between two cohorts of pt
+    const int64_t tiled = (int64_t)n_tiles * binsize;
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the A registers are in -- otherwise their first use inside the loop
+                                               // waits on the counter, i.e. also for the stores of the previous region
+
+#ifdef DIG_TM_TIMING
+    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_last = __builtin_readcyclecounter();
+#endif
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const TileRegion reg = tile_region(chrom_off, chrom_len, reg_chrom[r], reg_start[r], reg_end[r]);
+        const int64_t tiles_valid = (reg.n_pos + binsize - 1) / binsize;
+        const int nv = (int)(tiles_valid < n_tiles ? tiles_valid : n_tiles);
+        const int n_cov = (int)(reg.n_pos < tiled ? reg.n_pos : tiled);        // positions that belong to a tile
+        if (tid == 0) {
+            first_pos[r] = reg.first;
+            n_valid[r] = nv;
+        }
+        {
+            uint4* z = reinterpret_cast<uint4*>(s_hist32);
+            for (int i = tid; i < 64 * kTmStride32 / 4; i += kTileBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const int64_t ga = reg.g0 - 1;                      // left neighbour of the first position
+        const int64_t w0 = (ga >> 3) + 1;
+        const int64_t g_lds0 = (w0 - 1) << 3;
+        {
+            const int nw = (int)(((ga + n_cov + 1) >> 3) + 1 - w0 + 1);
+            for (int i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+        }
+        TM_MARK(0);
+        __syncthreads();
+        TM_MARK(1);
+        // ---- per-tile context histograms ----
+        {
+            const bool live = tid < nv;
+            const int tp = tid * binsize;
+            int cnt = binsize;
+            if (cnt > n_cov - tp) cnt = n_cov - tp;
+            const int lo = live ? (int)(ga - g_lds0) + 1 + tp : 0;          // centres [lo, hi) in staged nibble coordinates
+            const int hi = live ? lo + cnt : 0;
+            const int w_last = live ? hi >> 3 : -1;                        // word of the right neighbour of the last position
+            unsigned carry = 0, icarry = 0;
+            const unsigned inc = 1u << (16 * (tid & 1));
+            unsigned* col = s_hist32 + (tid >> 1);
+            for (int wi = live ? (lo - 1) >> 3 : 0;; ++wi) {
+                const bool go = wi <= w_last;
+                if (!__any(go)) break;
+                const unsigned w = go ? s_words[wi] : 0u;
+                const int centre0 = 8 * wi - 1;
+                const bool plain = centre0 >= lo && centre0 + 7 < hi && (w & 0xCCCCCCCCu) == 0u && icarry == 0u;
+                if (__all(plain || !go)) {                     // (wave-uniform: the middle words of every tile)
+                    if (go) tile_word<false>(w, carry, icarry, centre0, lo, hi, col, inc);
+                } else if (go) {
+                    tile_word<true>(w, carry, icarry, centre0, lo, hi, col, inc);
+                }
+            }
+        }
+        TM_MARK(2);
+        __syncthreads();
+        TM_MARK(3);
+        // ---- H[ctx] = sum over the tiles: lane = (row of the wave's sixteen, quarter of the row) ----
+        {
+            const int x = 16 * wave + li;
+            const uint4* rowp = reinterpret_cast<const uint4*>(s_hist32 + x * kTmStride32 + 32 * lk);
+            unsigned sum = 0;                                   // two 16-bit sums side by side
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 v = rowp[j];
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (lane < 16) s_H[x] = (sum & 0xffffu) + (sum >> 16);
+        }
+        if (reg.n_pos > n_cov) {                              // positions behind the last tile count for the normalisation only
+            __syncthreads();
+            const int64_t pos_per_pass = (int64_t)(kTileMaxWords - 1) * 8;
+            for (int64_t p0 = n_cov; p0 < reg.n_pos; p0 += pos_per_pass) {
+                const int64_t np = reg.n_pos - p0 < pos_per_pass ? reg.n_pos - p0 : pos_per_pass;
+                const int64_t gb = reg.g0 + p0 - 1;
+                const int64_t wb0 = (gb >> 3) + 1;
+                const int64_t nw = ((gb + np + 1) >> 3) + 1 - wb0 + 1;
+                __syncthreads();
+                for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(wb0 + i < n_words ? wb0 + i : n_words - 1)];
+                __syncthreads();
+                const int64_t gl = (wb0 - 1) << 3;
+                for (int64_t j = tid; j < np; j += kTileBlock) {
+                    const int64_t g = reg.g0 + p0 + j;
+                    const unsigned a = tile_base(s_words, g - 1, gl), b = tile_base(s_words, g, gl), c = tile_base(s_words, g + 1, gl);
+                    if (!((a | b | c) & 12u)) atomicAdd(&s_H[a + 4 * b + 16 * c], 1u);       // (row order of this kernel)
+                }
+            }
+        }
+        TM_MARK(4);
+        __syncthreads();
+        TM_MARK(5);
+        // ---- 1 / T[c] (every wave for itself: no exchange), moved into the lane layout of D once per region ----
+        double rt[MT][4];
+        {
+            double t[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) t[m] = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double hv = (double)s_H[4 * ks + lk];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) t[m] = fma(hv, A[m][ks], t[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                t[m] += __shfl_xor(t[m], 16, 64);
+                t[m] += __shfl_xor(t[m], 32, 64);
+                const double inv = 1.0 / t[m];                 // lane i (any k) holds cohort 16 m + i
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rt[m][q] = __shfl(inv, 4 * q + lk, 64);     // D register q: cohort 16 m + 4 q + k
+            }
+        }
+        // ---- the product ----
+        double* const out_lane = pt + ((int64_t)(c0 + lk) * R + r) * n_tiles + li;       // cohort c0 + k, tile i
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            for (int n = (wave + m) & 3; n < n_groups; n += 4) {
+                tile_double4 acc = {0.0, 0.0, 0.0, 0.0};
+                const unsigned short* hp = s_hist16 + lk * kTmStride + 16 * n + li;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[m][ks], (double)hp[4 * ks * kTmStride], acc, 0, 0, 0);
+                const int t = 16 * n + li;
+                if (t < n_tiles) {
+                    double* o = out_lane + 16 * n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + 16 * m + 4 * q + lk < C)
+                            __builtin_nontemporal_store(t < nv ? acc[q] * rt[m][q] : nan, o + (16 * m + 4 * q) * cohort_stride);
+                }
+            }
+        }
+        TM_MARK(6);
+        __syncthreads();
+        TM_MARK(7);
+    }
+#ifdef DIG_TM_TIMING
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_tm_prof[k], tm_acc[k]);
+#endif
+}
+
 __global__ __launch_bounds__(256) void tile_mut_counts_kernel(const int32_t* __restrict__ pair_mut, const int32_t* __restrict__ pair_reg,
                                                               int64_t n_pairs, const int64_t* __restrict__ mut_start,
                                                               const int32_t* __restrict__ mut_cohort, const int64_t* __restrict__ first_pos,
@@ -210,6 +453,17 @@ using namespace dig;
 
 extern "C" {
 
+#ifdef DIG_TM_TIMING
+int dig_debug_tile_profile(unsigned long long* out8)
+{
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tm_prof), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tm_prof), z, sizeof(z)));
+    return DIG_OK;
+}
+#endif
+
 int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int64_t* chrom_off, const int64_t* chrom_len,
                         int n_chrom, const int32_t* reg_chrom, const int64_t* reg_start, const int64_t* reg_end, int64_t R,
                         const double* s_prob, int64_t C, int binsize, int64_t n_tiles, double* pt, int64_t* first_pos,
@@ -222,6 +476,28 @@ int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int
                 "non-null pointers");
     DIG_REQUIRE(C == 0 || n_tiles == 0 || (s_prob && pt), "s_prob and pt");
     DIG_REQUIRE(binsize <= (kTileMaxWords - 1) * 8, "binsize at most 12 280 positions");
+    static const bool classic = []() {
+        const char* e = getenv("DIG_TILES_FORM");        // developer switch: "classic" forces the vector-FMA kernel
+        return e && e[0] == 'c';
+    }();
+    const bool mfma = !classic && binsize >= 2 && n_tiles >= 1 && n_tiles <= kTileBlock && C >= 1 &&
+                      n_tiles * binsize <= (int64_t)(kTileMaxWords - 1) * 8;
+    if (mfma) {
+        const int grid = grid_for(R * kTileBlock, kTileBlock, DIG_TM_OCC);
+        for (int64_t c0 = 0; c0 < C; c0 += kTmChunk) {
+            const int mt = (int)(((C - c0 < kTmChunk ? C - c0 : kTmChunk) + 15) / 16);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words, chrom_off,
+                                   chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, (int)c0, binsize, (int)n_tiles, pt,
+                                   first_pos, n_valid);
+            };
+            if (mt == 3) go(base_tile_probs_mfma_kernel<3>);
+            else if (mt == 2) go(base_tile_probs_mfma_kernel<2>);
+            else go(base_tile_probs_mfma_kernel<1>);
+        }
+        DIG_HIP_TRY(hipGetLastError());
+        return DIG_OK;
+    }
     const int grid = grid_for(R * kTileBlock, kTileBlock, 4);
     if (binsize == 1)
         hipLaunchKernelGGL((base_tile_probs_kernel<true>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,

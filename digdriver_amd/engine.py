@@ -39,13 +39,21 @@ def _t(x, dtype, device):
 _WS_CACHE = {}
 
 
-def _workspace(kind, E, C, dev):
-    """Cached device scratch (a torch uint8 tensor, 256-byte aligned by the caching allocator)."""
+def _workspace(kind, E, C, dev, private=False):
+    """Device scratch for one launch sequence (a torch uint8 tensor, 256-byte aligned by the caching allocator).
+
+    The one-shot entry points share a cached buffer per (kind, device, STREAM): launches on one stream are ordered, so they
+    may reuse it; two callers overlapping the same operation on two streams get two buffers.  Plan objects
+    (`private=True`) own theirs for their lifetime -- their launches may be enqueued on any stream, any number of steps
+    ahead."""
     import torch
     need = _lib.workspace_bytes(kind, E, C)
     if need <= 0:
         return None, 0
-    key = (kind, dev.index if dev.index is not None else torch.cuda.current_device())
+    if private:
+        return torch.empty(need, dtype=torch.uint8, device=dev), need
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (kind, idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -321,7 +329,7 @@ class PipelinePlan:
         self.dev = dev
         self.acc = out_acc if out_acc is not None else alloc_accumulate_outputs(self.E, self.C, 1, dev)
         self.stats = out_stats if out_stats is not None else torch.empty((len(ES_PLANES), self.E, self.C), dtype=f64, device=dev)
-        self.ws, self.wsb = _workspace("pipeline", self.E, self.C, dev)
+        self.ws, self.wsb = _workspace("pipeline", self.E, self.C, dev, private=True)
         if self.ws is None:
             raise _lib.DigHipError("dig_element_pipeline: problem too large for the fused path (E * C >= 2^32 - 1)")
         p = _lib.dev_ptr
@@ -350,7 +358,7 @@ class ScaleFactorPlan:
         self.keep = [_t(bin_mu, torch.float64, dev), _t(bin_flag, torch.uint8, dev), _t(n_snv_obs, torch.float64, dev),
                      _t(n_ind_obs, torch.float64, dev)]
         self.N, self.C = self.keep[0].shape
-        self.ws, self.wsb = _workspace("suffstats", self.N, self.C, dev)
+        self.ws, self.wsb = _workspace("suffstats", self.N, self.C, dev, private=True)
         p = _lib.dev_ptr
         self._args = [p(self.keep[0]), p(self.keep[1]), self.N, self.C, p(self.keep[2]), p(self.keep[3])]
         self._ws = p(self.ws)
