@@ -564,6 +564,171 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
     return nb_midp_upper_slow(k, alpha, p);
 }
 
+// ---- mid-p statistic by the FOUR lanes of a quad (the compacted pass of the statistics block) ----------------------
+// The serial slow path above walks the recurrence from 0 to k and then on into the tail: 500 counts = 4 500 dependent
+// FP64 instructions in ONE lane, and the compacted pass lasted as long as its longest lane.  Here a test is anchored at
+// k and only the side of the distribution that is short is summed, as a series RELATIVE to pmf(k), in blocks of 64
+// terms split over the four lanes of a quad (sixteen terms per lane):
+//   r_k = (alpha + k) x / (k + 1) < 1  (k at or above the mode):  0.5 pmf(k) + P(X > k) = pmf(k) (0.5 + sum_{m>=1} prod_{i<m} r_{k+i})
+//   otherwise                                                  :  1 - pmf(k) (0.5 + sum_{m>=1} prod_{i<=m} 1 / r_{k-i})   (ends at j = 0)
+// Both series fall monotonically (alpha > 1: the ratios move away from 1; alpha <= 1: r < x < 1 always and only the
+// first form occurs).  A lane runs the scaled recurrence over its sixteen ratios (products of numerators N and
+// denominators D apart, B = running sum times D: no division inside), the lanes' products are combined by an
+// inclusive scan and the sums by a butterfly, both as quad-permute DPP moves (no LDS traffic); a block is the last one
+// when the geometric bound of the remainder, last term x rho / (1 - rho), is below 2^-54 of the sum.
+// pmf(k): the streaming pass hands it over when it has it (a count <= kSmallK whose direct form cancelled: the usual
+// case); otherwise p^alpha times the product of the ratios below k (counts up to 64: one block), or scipy's own formula
+// with the three lgamma terms from Stirling's series on three lanes of the quad (a count of 500 would take eight
+// product blocks, and the 37 pairs of a large element reach the pass together: its waves set the length of the kernel).  Anything unusual (arguments outside the support, a series still open after
+// kQuadBlocks blocks: heavy tails with alpha << 1) goes to the scalar nb_midp_upper, which keeps scipy's semantics.
+// Every lane of the quad must call with the same arguments; the result is the same in all four.
+constexpr int kQuadTerms = 16;         // terms per lane and block
+constexpr int kQuadBlocks = 64;        // 4 096 terms
+
+__device__ inline double nb_midp_upper(double k, double alpha, double p);
+
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// quad_perm selectors: lane i reads lane sel[i]
+constexpr int kQuadUp1 = 0 | (0 << 2) | (1 << 4) | (2 << 6);     // i - 1 (lane 0 itself)
+constexpr int kQuadUp2 = 0 | (0 << 2) | (0 << 4) | (1 << 6);     // i - 2
+constexpr int kQuadLast = 3 | (3 << 2) | (3 << 4) | (3 << 6);
+constexpr int kQuadXor1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
+constexpr int kQuadXor2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
+constexpr int kQuadLane0 = 0, kQuadLane1 = 1 | (1 << 2) | (1 << 4) | (1 << 6), kQuadLane2 = 2 | (2 << 2) | (2 << 4) | (2 << 6);
+
+// inclusive scan of a product over the four lanes of a quad; every lane returns the total, `excl` the product of the lanes below
+__device__ __forceinline__ double quad_scan_product(double P, int sub, double& excl)
+{
+    double v = quad_perm<kQuadUp1>(P);
+    if (sub >= 1) P *= v;
+    v = quad_perm<kQuadUp2>(P);
+    if (sub >= 2) P *= v;
+    excl = quad_perm<kQuadUp1>(P);
+    if (sub == 0) excl = 1.0;
+    return quad_perm<kQuadLast>(P);
+}
+
+// log Gamma(z) for z > 0: arguments below 16 are shifted up by 16 (Gamma(z) = Gamma(z + 16) / (z (z + 1) ... (z + 15))),
+// then Stirling's series with five correction terms (the first one left out, 691 / (360360 z^11), is 1e-16 at z = 16).
+// Absolute error ~ 2e-16 max(1, z log z): the size of the rounding of its leading term.
+__device__ __forceinline__ double lgamma_stirling(double z)
+{
+    const bool small = z < 16.0;
+    double shift = 1.0, zz = z;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            shift *= zz;
+            zz += 1.0;
+        }
+    }
+    const double r = 1.0 / zz, r2 = r * r;
+    const double corr = r * fma(r2, fma(r2, fma(r2, fma(r2, 1.0 / 1188.0, -1.0 / 1680.0), 1.0 / 1260.0), -1.0 / 360.0), 1.0 / 12.0);
+    double v = (zz - 0.5) * fast_log_normal(zz) - zz + 0.91893853320467274178 + corr;
+    if (small) v -= fast_log_normal(shift);
+    return v;
+}
+
+// pmf_k < 0: not known.
+__device__ inline double nb_midp_upper_quad(double k, double alpha, double p, double pmf_k, int sub)
+{
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    if (!(alpha > 0.0 && alpha < inf && p >= 2.2250738585072014e-308 && p < 1.0 && k >= 0.0 && k < 4.0e15 && floor(k) == k))
+        return nb_midp_upper(k, alpha, p);
+    const double x = 1.0 - p;
+    const double ax = alpha * x;
+    double tk = pmf_k;
+    if (!(tk >= 0.0)) {
+        const double lp = fast_log_normal(p);
+        const double lp0 = alpha * lp;
+        if (k <= 64.0 && lp0 > -690.0) {
+            // pmf(k) = p^alpha prod_{j<k} (alpha + j) x / (j + 1): one block; at most 1 / p^alpha < e^690 on the way
+            double j = (double)(sub * kQuadTerms);
+            double N = 1.0, D = 1.0;
+#pragma unroll
+            for (int s = 0; s < kQuadTerms; ++s) {
+                const bool in = j < k;
+                const double num = in ? fma(j, x, ax) : 1.0;
+                j += 1.0;
+                N *= num;
+                D *= in ? j : 1.0;
+            }
+            double excl;
+            tk = fast_exp_neg(lp0) * quad_scan_product(N / D, sub, excl);
+        } else if (alpha < 1.0e8) {
+            // log pmf(k) = lgamma(k + alpha) - lgamma(k + 1) - lgamma(alpha) + alpha log p + k log(1 - p)  (scipy nbinom._logpmf),
+            // the three lgamma terms on three lanes of the quad
+            const double lg = lgamma_stirling(sub == 0 ? k + alpha : sub == 1 ? k + 1.0 : alpha);
+            const double coeff = quad_perm<kQuadLane0>(lg) - quad_perm<kQuadLane1>(lg) - quad_perm<kQuadLane2>(lg);
+            const double lx = x >= 0.5 ? fast_log_normal(x) : log1p(-p);
+            tk = exp(coeff + lp0 + k * lx);
+        } else {
+            return nb_midp_upper(k, alpha, p);
+        }
+    }
+    const bool upper = (alpha + k) * x < k + 1.0;
+    double base = 1.0, V = 0.0;
+    bool converged = false;
+    for (int blk = 0; blk < kQuadBlocks && !converged; ++blk) {
+        const double m0 = (double)(blk * 4 * kQuadTerms + sub * kQuadTerms);      // ratios m0 .. m0 + 15 of the series
+        double N = 1.0, D = 1.0, B = 0.0;
+        if (upper) {
+            double j = k + m0;
+#pragma unroll
+            for (int s = 0; s < kQuadTerms; ++s) {
+                const double num = fma(j, x, ax);          // (alpha + j) x
+                j += 1.0;                                   // den = j + 1
+                N *= num;
+                D *= j;
+                B = fma(B, j, N);
+            }
+        } else {
+            double j = k - m0;                              // ratio j / ((alpha + j - 1) x), none below j = 1
+#pragma unroll
+            for (int s = 0; s < kQuadTerms; ++s) {
+                const bool in = j >= 1.0;
+                const double num = in ? j : 0.0;
+                j -= 1.0;
+                const double den = in ? fma(j, x, ax) : 1.0;
+                N *= num;
+                D *= den;
+                B = fma(B, den, N);
+            }
+        }
+        const double rD = 1.0 / D;
+        double E;
+        const double tot = quad_scan_product(N * rD, sub, E);       // product of the block's ratios; E: of the lanes below
+        double c = E * (B * rD);                                    // the lane's terms relative to the block's first factor
+        c += quad_perm<kQuadXor1>(c);
+        c += quad_perm<kQuadXor2>(c);
+        V = fma(base, c, V);
+        base *= tot;                                                // = the last term of the block
+        // the ratio num / den that follows the block bounds all later ones:  base rho / (1 - rho) <= 2^-54 (0.5 + V)
+        const double mn = (double)((blk + 1) * 4 * kQuadTerms);
+        double num, den;
+        if (upper) {
+            const double j = k + mn;
+            num = alpha > 1.0 ? fma(j, x, ax) : x;
+            den = alpha > 1.0 ? j + 1.0 : 1.0;
+        } else {
+            const double j = k - mn;                         // next ratio j / ((alpha + j - 1) x)
+            num = j >= 1.0 ? j : 0.0;
+            den = j >= 1.0 ? fma(j - 1.0, x, ax) : 1.0;
+        }
+        converged = num < den && base * num <= (0.5 + V) * 0x1p-54 * (den - num);
+    }
+    if (!converged) return nb_midp_upper(k, alpha, p);
+    const double r = tk * (0.5 + V);
+    return upper ? r : 1.0 - r;
+}
+
 // ---- fast mid-p evaluation for small integer counts sharing (alpha, p) ----------------
 // 1 - S_k - t_k / 2 from the scaled state (A_k, N_k, D_k = k!, k):  t_k = t_0 N_k / D_k,  S_k = t_0 A_k k / D_k.
 // Single definition: both counts of a pair and every entry point go through these exact operations.
@@ -575,7 +740,8 @@ __device__ __forceinline__ double midp_from_state(double A, double N, double D, 
     const double S = (A * k) * rD;
     if (W2 == 0) return 1.0 - S;
     const double t = N * rD;
-    return (1.0 - S) - 0.5 * t;
+    const double res = (1.0 - S) - 0.5 * t;
+    return res >= kDirectMin ? res : -t;          // not accepted: hand pmf(k) on (sign bit set) for the series of the compacted pass
 }
 
 // 1 / k! for k = 0 .. kSmallK, correctly rounded (generated from exact rationals).  The fast recurrence reads it from
@@ -637,7 +803,8 @@ __device__ __forceinline__ double tail_from_state_tab(double A, double N, double
     const double S = (A * k) * rD;
     if (W2 == 0) return 1.0 - S;
     const double t = N * rD;
-    return (1.0 - S) - 0.5 * t;
+    const double res = (1.0 - S) - 0.5 * t;
+    return res >= kDirectMin ? res : -t;          // not accepted: hand pmf(k) on (sign bit set) for the series of the compacted pass
 }
 
 // One step of the scaled recurrence with the running factorial (compacted pass, where D is rescaled on the way).  The
@@ -717,8 +884,9 @@ __device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, 
     const double ra = k1_is_max ? r_max : r_min;   // result for k1
     const double rb = k1_is_max ? r_min : r_max;   // result for k2
     unsigned done = 0;
-    if (e1 && ra >= kDirectMin) { r1 = ra; done |= 1u; }
-    if (e2 && rb >= kDirectMin) { r2 = rb; done |= 2u; }
+    // (an eligible count that is not accepted leaves -pmf(k) in its result: W2 == 1 only, see tail_from_state_tab)
+    if (e1) { r1 = ra; if (ra >= kDirectMin) done |= 1u; }
+    if (e2) { r2 = rb; if (rb >= kDirectMin) done |= 2u; }
     return done;
 }
 

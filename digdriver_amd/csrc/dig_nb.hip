@@ -307,7 +307,9 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
         }
 #endif
         const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
-        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
+        //  cancelled, -2 when it was not eligible at all; no p-value is negative)
+        double pv_snv = -2.0, pv_smp = -2.0, pv_ind = -2.0, dummy = 0.0;
         const unsigned d1 = nb_fast2_counts<1>(cur.k_snv, cur.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_fast2_counts<1>(cur.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
 #ifdef DIG_DEV_ABLATE
@@ -370,6 +372,9 @@ struct StageBin {            // tile t+1
 // shares the waves of a SIMD finish one after the other (the arbiter issues oldest-first): rocprofv3 shows an average wave
 // lifetime of 68 % of the kernel's duration with the VALU 85 % busy while waves are resident -- the tail, where a SIMD is
 // down to one or two waves, is where the pass loses its time.  With a shared queue all waves of a CU end together.
+#ifndef DIG_ES_XCD
+#define DIG_ES_XCD 1
+#endif
 template <int TB, bool TICKETS>
 __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
@@ -396,6 +401,12 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         unsigned t = 0;
         if (lane == 0) t = atomicAdd(&s_ticket, 1u);
         t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+#if DIG_ES_XCD
+        // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the group that shares an L2).  A tile is 64
+        // pairs = 1.7 elements at 37 cohorts, so neighbouring tiles read the same bin rows: the 8 groups take runs of
+        // gridDim / 8 consecutive tiles instead of every 8th tile (the grid still sweeps the arrays as one window).
+        if ((gridDim.x & 7u) == 0u) return ((int64_t)t * 8 + (blockIdx.x & 7u)) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
         return (int64_t)t * gridDim.x + blockIdx.x;
     };
     int64_t tile_ptr = 0;                             // TICKETS: tile the last pointer fetch was for
@@ -507,7 +518,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         w.k_snv = cur.k_snv; w.k_smp = cur.k_smp; w.k_ind = cur.k_ind;
         w.q0 = w.q1 = 0; w.c = cur.c;
         const PairInputs q = prepare_pair(w, false);
-        double pv_snv = 0.0, pv_smp = 0.0, pv_ind = 0.0, dummy = 0.0;
+        // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
+        //  cancelled, -2 when it was not eligible at all; no p-value is negative)
+        double pv_snv = -2.0, pv_smp = -2.0, pv_ind = -2.0, dummy = 0.0;
         const unsigned d1 = nb_fast2_counts<1>(w.k_snv, w.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_fast2_counts<1>(w.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
         const bool slow = ((d1 != 3u) || (d2 != 1u)) && live;
@@ -532,80 +545,79 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     if (parked) park_flush(a.worklist, park, parked, lane);
 }
 
-// Pass 2: the compacted slow pairs.  Three lanes of a quad per pair (lane & 3: 0 = SNV, 1 = SAMPLE, 2 = INDEL), lane
-// 0 combines.  Most of the pass is the k-step recurrence of pairs with counts above kSmallK, and a wave runs until
-// its longest lane is done, so every workgroup first orders its 256 pairs by count (descending, 16-wide buckets in
-// LDS): the 16 pairs of a wave then have similar counts and the wave's loop length is close to its lanes' mean
-// instead of the maximum over arbitrary pairs (measured: 39 -> 31 us on the bench workload).
-constexpr int kSlowBlock = 1024;
-constexpr int kSlowPairs = kSlowBlock / 4;
-constexpr int kSlowBuckets = 64;
+// Pass 2: the compacted slow pairs.  Pass 1 left every test it could not finish NEGATIVE in its p-value plane (counts
+// above kSmallK, p^alpha out of range, or a p-value below kDirectMin where 1 - CDF cancels: -pmf(k) then) and the values
+// of the others in place.  A wave takes eight pairs per round; their open tests (at most 24) are compacted through LDS
+// and evaluated sixteen at a time, ONE QUAD PER TEST (nb_midp_upper_quad: the series is split over the lanes, so a count
+// of 500 costs a few hundred dependent instructions instead of 4 500); then one lane per pair combines SNV and indel and
+// writes the four p-value planes.  Rounds 1 and 2 of this kernel gave a test one lane and sorted the pairs of a
+// workgroup by count: 30 us whatever the number of pairs, the length of its longest lane.
+constexpr int kSlowBlock = 256;
+constexpr int kSlowWaves = kSlowBlock / 64;
+constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
 
 __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementStatsArgs a)
 {
-    __shared__ unsigned s_hist[kSlowBuckets], s_perm[kSlowPairs];
+    // per pair: [0..2] the three p-value slots (pass 1's values, then the finished ones), [3..5] the counts,
+    // [6] alpha, [7] p, [8] alpha of the indel test, [9] its p
+    __shared__ double s_pair[kSlowWaves][kSlowPairsPerWave][10];
+    __shared__ unsigned s_list[kSlowWaves][48];
     nb_tables_init();
     const int64_t n = a.E * a.C;
     const unsigned count = (unsigned)min((int64_t)a.worklist[0], n);   // (never more entries than pairs, whatever the header holds)
-    const int tid = threadIdx.x, role = tid & 3, lane = tid & 63, quad = tid >> 2;
-    if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist (header [0] is cleared below)
-    // pairs per workgroup and round: all of kSlowPairs when there is enough work, fewer when the worklist is short, so
-    // that every CU gets a share
-    const unsigned per = min((unsigned)kSlowPairs, max(16u, (count + gridDim.x - 1) / gridDim.x));
-    for (unsigned base = blockIdx.x * per; base < count; base += gridDim.x * per) {
-        const unsigned n_live = min(per, count - base);
-        if (tid < kSlowBuckets) s_hist[tid] = 0;
-        __syncthreads();
-        unsigned item = 0, within = 0;
-        int bucket = 0;
-        if (tid < (int)n_live) {
-            item = a.worklist[kWorkHeader + base + tid];
-            const int key = max(a.obs_snv[item], a.obs_samples[item]);
-            bucket = kSlowBuckets - 1 - min(max(key, 0) >> 4, kSlowBuckets - 1);     // large counts first
-            within = atomicAdd(&s_hist[bucket], 1u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = lane >> 2, sub = lane & 3;
+    if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist
+    const unsigned n_waves = gridDim.x * kSlowWaves;
+    for (unsigned base = (blockIdx.x * kSlowWaves + wave) * kSlowPairsPerWave; base < count; base += n_waves * kSlowPairsPerWave) {
+        // ---- the first lanes: one pair each: its inputs, and which of its three tests are open (sign bit set) ----
+        const bool owner = lane < kSlowPairsPerWave && base + lane < count;
+        int64_t item = 0;
+        unsigned open = 0;
+        if (owner) {
+            item = a.worklist[kWorkHeader + base + lane];
+            const double v1 = a.out[1 * n + item], v2 = a.out[2 * n + item], v5 = a.out[5 * n + item];
+            const PairInputs q = load_pair(a, item);
+            double* sp = s_pair[wave][lane];
+            sp[0] = v1; sp[1] = v2; sp[2] = v5;
+            sp[3] = q.k_snv; sp[4] = q.k_smp; sp[5] = q.k_ind;
+            sp[6] = q.alpha; sp[7] = q.p; sp[8] = q.alpha_i; sp[9] = q.p_i;
+            open = (__double_as_longlong(v1) < 0 ? 1u : 0u) | (__double_as_longlong(v2) < 0 ? 2u : 0u) |
+                   (__double_as_longlong(v5) < 0 ? 4u : 0u);
         }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned run = 0;
-            for (int k = 0; k < kSlowBuckets; ++k) {
-                const unsigned c = s_hist[k];
-                s_hist[k] = run;
-                run += c;
-            }
+        // bit 16 role + slot of W <-> test (role, pair slot)
+        const unsigned long long W = ((unsigned long long)__ballot(open & 1u) & 0xffffull) |
+                                     (((unsigned long long)__ballot(open & 2u) & 0xffffull) << 16) |
+                                     (((unsigned long long)__ballot(open & 4u) & 0xffffull) << 32);
+        const int n_tests = __popcll(W);
+        if (lane < 48 && ((W >> lane) & 1ull)) s_list[wave][__popcll(W & ((1ull << lane) - 1ull))] = (unsigned)lane;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are in
+        __builtin_amdgcn_wave_barrier();
+        // ---- the open tests, sixteen at a time, one quad each ----
+        for (int t0 = 0; t0 < n_tests; t0 += 16) {
+            const int t = t0 + quad;
+            const bool active = t < n_tests;
+            const unsigned bit = s_list[wave][active ? t : 0];
+            const int role = (int)(bit >> 4), slot = (int)(bit & 15u);
+            const double* sp = s_pair[wave][slot];
+            const double marker = sp[role];                     // -pmf(k), or -2: pmf(k) not known
+            const double k = sp[3 + role];
+            const double al = sp[role == 2 ? 8 : 6], pp = sp[role == 2 ? 9 : 7];
+            const double pv = nb_midp_upper_quad(k, al, pp, marker == -2.0 ? -1.0 : -marker, sub);
+            if (active && sub == 0) s_pair[wave][slot][role] = pv;     // (nobody else reads this test's slot)
         }
-        __syncthreads();
-        if (tid < (int)n_live) s_perm[s_hist[bucket] + within] = item;
-        __syncthreads();
-        const bool live = quad < (int)n_live;
-        double pv = 0.0;
-        int64_t i = 0;
-        if (live) {
-            i = s_perm[quad];
-            const PairInputs q = load_pair(a, i);
-            const double k = role == 0 ? q.k_snv : role == 1 ? q.k_smp : q.k_ind;
-            const double al = role == 2 ? q.alpha_i : q.alpha;
-            const double pp = role == 2 ? q.p_i : q.p;
-            if (role < 3) pv = nb_midp_upper(k, al, pp);      // same device function as every other entry point
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- the first lanes: combine and write ----
+        if (owner) {
+            const double* sp = s_pair[wave][lane];
+            const double pv_snv = sp[0], pv_smp = sp[1], pv_ind = sp[2];
+            a.out[1 * n + item] = pv_snv;
+            a.out[2 * n + item] = pv_smp;
+            a.out[5 * n + item] = pv_ind;
+            a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
         }
-        const double pv_smp = __shfl(pv, (lane & ~3) + 1, 64);
-        const double pv_ind = __shfl(pv, (lane & ~3) + 2, 64);
-        if (live && role == 0) {
-            a.out[1 * n + i] = pv;
-            a.out[2 * n + i] = pv_smp;
-            a.out[5 * n + i] = pv_ind;
-            a.out[6 * n + i] = fisher_combine_fast(pv, pv_ind);
-        }
-        __syncthreads();
-    }
-    // The last workgroup to finish leaves the header cleared (every workgroup read the count before it got here), so a
-    // later statistics-only call on this workspace needs no memset in front of it (DIG_PIPE_WORKLIST_CLEAN).
-    if (tid == 0) {
-        // (no __threadfence() here: at device scope it writes the XCD's L2 back -- buffer_wbl2 -- and nothing needs it:
-        //  every workgroup read the count at its start, the counter below is a device-scope atomic)
-        if (atomicAdd(&a.worklist[1], 1u) == gridDim.x - 1) {
-            a.worklist[0] = 0;
-            a.worklist[1] = 0;
-        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // (s_pair / s_list are rewritten in the next round)
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -940,7 +952,14 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         hipLaunchKernelGGL(element_stats_single_pass_kernel, dim3(grid), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
     if (wl) {
-        hipLaunchKernelGGL(element_stats_slow_kernel, dim3(grid_for(E * C / 2 + 1, kSlowBlock, 1)), dim3(kSlowBlock), 0, s, a);
+        // (the worklist length is only known on the device: a grid that covers 1 % of the pairs in one round, at least one
+        //  workgroup per CU, and rounds beyond that)
+        const int64_t slow_pairs = std::max<int64_t>(E * C / 100, 1);
+        const int slow_grid = (int)std::min<int64_t>(std::max<int64_t>((slow_pairs + kSlowWaves * kSlowPairsPerWave - 1) / (kSlowWaves * kSlowPairsPerWave), 1), (int64_t)cu_count() * 8);
+        hipLaunchKernelGGL(element_stats_slow_kernel, dim3(slow_grid), dim3(kSlowBlock), 0, s, a);
+        // (the header keeps the count: the next launch sequence clears it in front -- context kernel or memset node.  "The
+        //  last workgroup clears behind itself" costs one device-scope atomic per workgroup on ONE address, 13 ns each:
+        //  18 us for this grid, measured.)
         DIG_HIP_TRY(hipGetLastError());
     }
     return DIG_OK;

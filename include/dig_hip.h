@@ -169,8 +169,8 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
 #define DIG_PIPE_STATISTICS 4 /* MU, SIGMA, R_OBS, FLAG and the seven statistics planes */
 #define DIG_PIPE_ALL 7
 /* A call WITHOUT the CONTEXTS stage clears the worklist header of the statistics stage with a memset node of its own.
- * OR this flag into `stages` to skip that node when the caller knows the header is clear: after a CONTEXTS call, or
- * after any completed STATISTICS call, on the same workspace (the compacted pass clears the header behind itself). */
+ * OR this flag into `stages` to skip that node when the caller knows the header is clear: after a CONTEXTS call on the
+ * same workspace with no STATISTICS call since (a statistics stage leaves the length of its worklist in the header). */
 #define DIG_PIPE_WORKLIST_CLEAN 8
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,

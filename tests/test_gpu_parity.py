@@ -153,14 +153,23 @@ def test_element_stats_vs_oracle_random_cohorts(torch_dev):
     want = O.element_stats(mu, sigma, pi, pii[:, None], k1, k2, k3, cj[None, :], cji[None, :], mu_indel=mui, sigma_indel=sgi)
     for name in engine.ES_PLANES:
         rel_close(got[name], want[name], RTOL)
-    # worklist (two-pass) and inline (single-pass) modes give identical bits
+    # worklist (two-pass) and inline (single-pass) modes: identical bits for every test the streaming pass resolves; the
+    # tests it leaves open are summed by eight lanes in the compacted pass and by one lane inline -- same value, another
+    # order of additions
     import torch
     dev = torch.device("cuda:0")
     tt = lambda v: torch.as_tensor(v, device=dev)
     a = engine.element_stats(tt(mu), tt(sigma), tt(pi), tt(pii), tt(k1), tt(k2), tt(k3), tt(cj), tt(cji))
     b = engine.element_stats(tt(mu), tt(sigma), tt(pi), tt(pii), tt(k1), tt(k2), tt(k3), tt(cj), tt(cji), use_workspace=False)
+    n_equal = 0
     for name in engine.ES_PLANES:
-        assert torch.equal(a[name], b[name]) or np.array_equal(a[name].cpu().numpy(), b[name].cpu().numpy(), equal_nan=True), name
+        x, y = a[name].cpu().numpy(), b[name].cpu().numpy()
+        if name.startswith("PVAL"):
+            rel_close(x, y, 1e-6)                               # (the inline form accepts 1 - CDF down to 1e-6: up to 2e-7 of cancellation)
+            n_equal += int((x == y).sum())
+        else:
+            assert np.array_equal(x, y, equal_nan=True), name
+    assert n_equal > 0.9 * 4 * E * C                       # (the open tests are a small minority)
     # empty problem is a no-op
     r = engine.element_stats(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0), np.zeros((0, 3), np.int32),
                              np.zeros((0, 3), np.int32), np.zeros((0, 3), np.int32), np.ones(3), np.ones(3))
