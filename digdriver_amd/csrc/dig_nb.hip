@@ -952,10 +952,21 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         hipLaunchKernelGGL(element_stats_single_pass_kernel, dim3(grid), dim3(kBlock), 0, s, a);
     DIG_HIP_TRY(hipGetLastError());
     if (wl) {
-        // (the worklist length is only known on the device: a grid that covers 1 % of the pairs in one round, at least one
-        //  workgroup per CU, and rounds beyond that)
+        // (the worklist length is only known on the device: a grid that covers 1 % of the pairs in one round, but never more
+        //  workgroups than are resident at once -- the waves of a second batch would start when the first ones end and
+        //  double the length of a kernel whose waves all live equally long: 18 against 12 us, measured)
         const int64_t slow_pairs = std::max<int64_t>(E * C / 100, 1);
-        const int slow_grid = (int)std::min<int64_t>(std::max<int64_t>((slow_pairs + kSlowWaves * kSlowPairsPerWave - 1) / (kSlowWaves * kSlowPairsPerWave), 1), (int64_t)cu_count() * 8);
+        static int slow_resident[kMaxDevices] = {};
+        int slow_dev = 0;
+        DIG_HIP_TRY(hipGetDevice(&slow_dev));
+        DIG_REQUIRE(slow_dev >= 0 && slow_dev < kMaxDevices, "device index below 64");
+        if (!slow_resident[slow_dev]) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, element_stats_slow_kernel, kSlowBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            slow_resident[slow_dev] = per_cu;
+        }
+        const int slow_grid = (int)std::min<int64_t>(std::max<int64_t>((slow_pairs + kSlowWaves * kSlowPairsPerWave - 1) / (kSlowWaves * kSlowPairsPerWave), 1),
+                                                     (int64_t)cu_count() * slow_resident[slow_dev]);
         hipLaunchKernelGGL(element_stats_slow_kernel, dim3(slow_grid), dim3(kSlowBlock), 0, s, a);
         // (the header keeps the count: the next launch sequence clears it in front -- context kernel or memset node.  "The
         //  last workgroup clears behind itself" costs one device-scope atomic per workgroup on ONE address, 13 ns each:
