@@ -462,7 +462,7 @@ def main():
         bool(torch.equal(ref_acc["MU"], out_acc["MU"])) and bool(torch.equal(ref_acc["P"], out_acc["P"]))
     if not same:
         raise SystemExit("bench: the overlapped step loop and the sequential evaluation disagree")
-    ws = engine._WS_CACHE.get(("pipeline", dev.index))
+    ws = getattr(pipe, "ws", None)                            # the plan's own workspace
     slow_frac = None
     if ws is not None:
         off = (_lib.workspace_bytes("accumulate", E, C) + 255) // 256 * 256

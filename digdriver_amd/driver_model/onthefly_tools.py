@@ -51,13 +51,13 @@ def DIG_onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed=None, region_str=None,
 def _onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed, scale_factor, scale_factor_indel, scale_type,
               scale_by_expectation, max_muts_per_sample, max_muts_per_elt_per_sample, skip_pvals, all_cosmic,
               strict_reference):
-    print('Tabulating mutations')
+    transfer_tools._say('Tabulating mutations')
     df_mut_tab, blacklist = mutation_tools.tabulate_mutations_in_element(
         f_mut, f_elts_bed, bed12=True, drop_duplicates=True, all_elements=True, max_muts_per_sample=max_muts_per_sample,
         max_muts_per_elt_per_sample=max_muts_per_elt_per_sample, return_blacklist=True)
     run = transfer_tools.CohortRun(f_mut, f_pretrained)          # the scale-factor rules are shared with elementDriver
     if scale_by_expectation:
-        print('scaling by expected number of mutations')
+        transfer_tools._say('scaling by expected number of mutations')
         coding = run.coding_rows()
         coding = coding.loc[~coding.SAMPLE.isin(blacklist)]
         cj = run.synonymous_scale(run.gene_model(), coding, dedup=True)                                        # :44-50
@@ -65,7 +65,7 @@ def _onthefly(f_pretrained, f_mut, f_fasta, f_elts_bed, scale_factor, scale_fact
     elif scale_factor:
         cj, cj_indel = scale_factor, scale_factor_indel
     else:
-        print('Calculating scale factor')
+        transfer_tools._say('Calculating scale factor')
         cj, cj_indel = run.genome_scale(scale_type)
 
     genome = sequence_tools.load_genome(f_fasta)

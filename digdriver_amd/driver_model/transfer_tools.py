@@ -39,6 +39,11 @@ _COSMIC_EXTRA = ['CDKN2A.p14arf', 'CDKN2A.p16INK4a']          # added to the CGC
 _PANEL_DIRS = []
 
 
+
+def _say(message):
+    """Progress lines on stdout, worded as the reference words them (scripts that parse its log keep working)."""
+    print(message, flush=True)
+
 def set_panel_dir(path):
     """Directory searched FIRST for genes_<name>.txt (the --panel-dir option of scripts/DigDriver.py)."""
     if path and path not in _PANEL_DIRS:
@@ -176,11 +181,11 @@ class CohortRun:
         rows = self.unique_rows()
         rows = rows.loc[~rows.SAMPLE.isin(blacklist)]
         rows = rows.loc[~rows.ANNOT.isin(['Noncoding', 'Synonymous', 'Essential_Splice'])]
-        print(self.f_mut, rows.shape)
+        _say(self.f_mut, rows.shape)
         rows = rows.loc[rows.GENE.isin(counted_genes)]
         if by_sample:
             n_pre = self.attrs['N_SAMPLE_{}'.format(panel)]
-            print(rows.SAMPLE.nunique(), n_pre)
+            _say(rows.SAMPLE.nunique(), n_pre)
             return rows.SAMPLE.nunique() / n_pre
         return len(rows) / self.attrs['N_MUT_{}'.format(panel)]
 
@@ -363,7 +368,7 @@ def element_statistics_block(df_model, cj, cj_indel, skip_pvals=False):
                                   mu_indel=_f64(df_model, 'MU_INDEL'), sigma_indel=_f64(df_model, 'SIGMA_INDEL'))
     wanted = ['PVAL_SNV_BURDEN', 'PVAL_SAMPLE_BURDEN']
     if with_indels:
-        print("\tCalculating indel burden p-values")
+        _say("\tCalculating indel burden p-values")
         wanted += ['THETA_INDEL', 'EXP_INDEL', 'PVAL_INDEL_BURDEN', 'PVAL_MUT_BURDEN']
     for name in wanted:
         df_model[name] = planes[name][:, 0]
@@ -374,10 +379,10 @@ def _gene_statistics(df_model, burden=True, indel=True, all_cosmic=None, announc
     df_model = gene_expected_muts_nb(df_model)
     if burden:
         if announce:
-            print("\tCalculating burden p-values")
+            _say("\tCalculating burden p-values")
         df_model = gene_pvalue_burden_nb_by_sample(gene_pvalue_burden_nb(df_model))
     if indel and df_model.OBS_INDEL.sum() != 0:
-        print("\tCalculating indel burden p-values")
+        _say("\tCalculating indel burden p-values")
         df_model = combine_snv_indel(gene_pvalue_indel(df_model, all_cosmic=all_cosmic), 'PVAL_TRUNC_BURDEN')
     return df_model
 
@@ -397,20 +402,20 @@ def run_gene_model(f_mut, f_h5_genemodel, scale_by_sample=False, pval_burden_nb=
     rows = mutation_tools.filter_hypermut_samples(rows, max_muts_per_sample)
     counts = mutation_tools.mutations_per_gene(rows, max_muts_per_gene_per_sample=max_muts_per_gene_per_sample)
     if scale_by_expectation:
-        print('scaling by expected synonymous mutations (excluding TP53)')
+        _say('scaling by expected synonymous mutations (excluding TP53)')
         cj = run.synonymous_scale(model, rows)
     elif scale_factor:
         cj = scale_factor
     else:
         cj = run.ratio_scale(rows, 'sample' if scale_by_sample else 'exome')
-    print("\tScaling factor is: {}".format(cj))
+    _say("\tScaling factor is: {}".format(cj))
     return _gene_statistics(transfer_gene_model(rows, counts, model, cj), burden=pval_burden_nb, all_cosmic=all_cosmic)
 
 
 def run_target_model(f_mut, f_h5_genemodel, scale_by_sample=False, panel="MSK_341", max_muts_per_sample=3e9,
                      max_muts_per_gene_per_sample=3e9, drop_synonymous=True, cgc_genes=False, scale_factor=None):
     """transfer_tools.py:876-967: genes of a sequencing panel; the scale factor counts the cohort inside the panel."""
-    print(panel)
+    _say(panel)
     panel_genes = gene_panel(panel)
     tested = gene_panel(cgc_genes) if cgc_genes else panel_genes
     run = CohortRun(f_mut, f_h5_genemodel)
@@ -422,9 +427,9 @@ def run_target_model(f_mut, f_h5_genemodel, scale_by_sample=False, panel="MSK_34
     counts = mutation_tools.mutations_per_gene(rows, max_muts_per_gene_per_sample=max_muts_per_gene_per_sample)
     model = run.gene_model()
     model = model.loc[model.index.isin(tested)]
-    print(len(model))
+    _say(len(model))
     cj = scale_factor if scale_factor else run.panel_scale(panel, panel_genes, blacklist, scale_by_sample)
-    print("\tScaling factor is: {}".format(cj))
+    _say("\tScaling factor is: {}".format(cj))
     df_model = transfer_gene_model(rows, counts, model, cj)
     return _gene_statistics(df_model.loc[df_model.index.isin(tested)], indel=False, announce=False)
 
@@ -436,12 +441,12 @@ def run_element_region_model(f_mut, f_bed, f_h5_pretrain, pretrain_key, scale_fa
     (element_statistics_block) instead of the reference's column-by-column sequence; results are identical."""
     run = CohortRun(f_mut, f_h5_pretrain)
     model = load_pretrained_model(f_h5_pretrain, key=pretrain_key, restrict_cols=True)
-    print('Tabulating mutations')
+    _say('Tabulating mutations')
     table, blacklist = mutation_tools.tabulate_mutations_in_element(
         f_mut, f_bed, bed12=True, drop_duplicates=True, max_muts_per_sample=max_muts_per_sample,
         max_muts_per_elt_per_sample=max_muts_per_elt_per_sample, return_blacklist=True)
     if scale_by_expectation:
-        print('scaling by expected number of mutations')
+        _say('scaling by expected number of mutations')
         genes = run.gene_model()
         rows = run.coding_rows()
         rows = rows.loc[~rows.SAMPLE.isin(blacklist)]
@@ -460,12 +465,12 @@ def run_element_region_model(f_mut, f_bed, f_h5_pretrain, pretrain_key, scale_fa
     elif scale_factor:
         cj, cj_indel = scale_factor, scale_factor_indel
     else:
-        print('Calculating scale factor')
+        _say('Calculating scale factor')
         cj, cj_indel = run.genome_scale(scale_type)
-    print("\tScale factor is: {}".format(cj))
-    print("\tINDEL scale factor is: {}".format(cj_indel))
+    _say("\tScale factor is: {}".format(cj))
+    _say("\tINDEL scale factor is: {}".format(cj_indel))
     df_model = transfer_element_model_with_indels(table, model, cj)
-    print('Calculating statistics')
+    _say('Calculating statistics')
     if fused:
         return element_statistics_block(df_model, cj, cj_indel, skip_pvals=skip_pvals)
     df_model = element_expected_muts_nb(df_model)
@@ -473,7 +478,7 @@ def run_element_region_model(f_mut, f_bed, f_h5_pretrain, pretrain_key, scale_fa
         return df_model
     df_model = element_pvalue_burden_nb_by_sample(element_pvalue_burden_nb(df_model))
     if df_model.OBS_INDEL.sum() != 0:
-        print("\tCalculating indel burden p-values")
+        _say("\tCalculating indel burden p-values")
         df_model = combine_snv_indel(element_pvalue_indel(df_model, cj_indel), 'PVAL_SNV_BURDEN')
     return df_model
 
@@ -486,18 +491,18 @@ def run_sites_region_model(f_mut, f_sites, f_h5_pretrain, pretrain_key, scale_fa
     run = CohortRun(f_mut, f_h5_pretrain)
     model = load_pretrained_model(f_h5_pretrain, key=pretrain_key, restrict_cols=True)
     if scale_by_expectation:
-        print('scaling by expected synonymous mutations (excluding TP53)')
+        _say('scaling by expected synonymous mutations (excluding TP53)')
         cj = run.synonymous_scale(run.gene_model(), mutation_tools.read_mutation_file(f_mut, drop_duplicates=False))
     elif scale_factor:
         cj = scale_factor
     elif scale_type == 'MSK_230':
-        print('Scaling by samples in MSK 230 gene subset.')
+        _say('Scaling by samples in MSK 230 gene subset.')
         cj = run.panel_scale('MSK_230', gene_panel('MSK_230'), (), by_sample=True)
     else:
-        print('Calculating scale factor')
+        _say('Calculating scale factor')
         cj = run.genome_scale(scale_type)[0]
-    print("\tScale factor is: {}".format(cj))
-    print('Tabulating mutations')
+    _say("\tScale factor is: {}".format(cj))
+    _say('Tabulating mutations')
     df_model = transfer_element_model(mutation_tools.tabulate_sites_in_element(f_sites, f_mut), model, cj, use_chrom=False)
-    print('Calculating statistics')
+    _say('Calculating statistics')
     return element_pvalue_burden_nb_by_sample(element_pvalue_burden_nb(element_expected_muts_nb(df_model)))
