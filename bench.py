@@ -274,10 +274,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    saved_stdout = None
     if rank != 0:
         # only rank 0 reports: whatever the other ranks' libraries write to stdout (RCCL's banner) must not land after
         # rank 0's JSON line
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    elif world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
+        # rank 0: RCCL prints its version banner to the C stdout; send everything written to descriptor 1 while the
+        # job runs to stderr, and give the descriptor back for the one JSON line at the end
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     # The global problem and this rank's shard of it (at N = 1 the shard is the whole problem)
@@ -558,6 +565,10 @@ def main():
         dist.destroy_process_group()
     import ctypes
     ctypes.CDLL(None).fflush(None)
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(res), flush=True)
 

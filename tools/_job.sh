@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT/gpurun_out
-mkdir -p $R/full
-timeout 1700 python -m pytest tests -q -m gpu -x > $R/full/pytest_gpu.log 2>&1
-echo "pytest exit $?" >> $R/full/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $R/full/smoke.log 2>&1
-tail -4 $R/full/pytest_gpu.log; tail -2 $R/full/smoke.log
-python bench.py --cpu-sample 0 > $R/full/bench1000.json 2> $R/full/bench1000.err; cat $R/full/bench1000.json | cut -c1-900
-python bench.py --cpu-sample 0 --steps 20 --warmup 5 > $R/full/bench20.json 2> $R/full/bench20.err; cat $R/full/bench20.json | cut -c1-700
+R=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $R/dist
+BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $R/dist/b1.json 2> $R/dist/b1.err; echo rc=$?; cut -c1-400 $R/dist/b1.json; tail -3 $R/dist/b1.err
+BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --mode strong > $R/dist/b2.json 2> $R/dist/b2.err; echo rc=$?; cut -c1-300 $R/dist/b2.json; tail -3 $R/dist/b2.err
