@@ -250,3 +250,17 @@ def run_gp(device, train_tup, val_tup, heldout_tup, n_runs=5, n_iter=50, n_induc
     means = np.mean([r['gp_mean'] for r in results], axis=0)                      # gp_trainer.py:247-261
     stds = np.mean([r['gp_std'] for r in results], axis=0)
     return results, means, stds
+
+
+def compute_pretrained(path, label, runs_num, held_key='held-out'):
+    """GPTrainer.compute_pretrained (gp_trainer.py:247-261) on a results container: the held-out set of `label` with the
+    mean over the first `runs_num` GP runs of the predicted mean and standard deviation.
+    Returns (chr_locs, mappability, quantiles, y_true, means, stds)."""
+    from ...io import mapfile
+    base = '{}/{}/'.format(label, held_key)
+    keys = set(mapfile.list_keys(path, base.rstrip('/')))
+    assert 'chr_locs' in keys, 'Cannot compute pretrained model with no saved held-out set. Existing fields are: {}'.format(sorted(keys))
+    get = lambda k: np.asarray(mapfile.read_array(path, base + k))
+    means = np.mean([get('{}/mean'.format(i)) for i in range(int(runs_num))], axis=0)
+    stds = np.mean([get('{}/std'.format(i)) for i in range(int(runs_num))], axis=0)
+    return get('chr_locs'), get('mappability'), get('quantiles'), get('y_true'), means, stds

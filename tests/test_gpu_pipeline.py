@@ -145,6 +145,46 @@ def test_kfold_training_writes_results_regionmodel_reads(tmp_path):
     assert r > 0.5, r
 
 
+def test_single_split_training_writes_pretrained_map(tmp_path):
+    """a6 / f4, the mutations_main route: two reruns of CNN training + GP calibration on a tiny synthetic track matrix;
+    every rerun writes gp_results_run{r}.h5 in GPTrainer.save_results' layout, the held-out windows accumulate in
+    <label>.Pretrained.h5:region_params (a real HDF5 frame), the summaries are written, and the calibrated
+    predictions correlate with the labels."""
+    import glob
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.region_model import mutations_main as mm
+    rng = np.random.default_rng(6)
+    N, L, T = 900, 100, 6
+    base = rng.uniform(0, 1, (N, 1, T))
+    x = np.round(np.clip(base + 0.15 * rng.normal(size=(N, L, T)), 0, 1), 2) * 100
+    y = np.rint(40 * base[:, 0, 0] + 25 * base[:, 0, 1] ** 2 + rng.normal(0, 1.0, N) + 5).clip(0)
+    data = str(tmp_path / "train.map")
+    mapfile.write_array(data, "x_data", x.astype(np.float32))
+    mapfile.write_array(data, "idx", np.stack([1 + np.arange(N) // 300, (np.arange(N) % 300) * 10000, (np.arange(N) % 300 + 1) * 10000], 1))
+    mapfile.write_array(data, "mappability", rng.uniform(0.3, 1.0, N))
+    mapfile.write_array(data, "COHORT_A", y)
+    args = mm.get_cmd_arguments("-c COHORT_A -d %s -o %s -m 0.5 -cq 0.999 -e 4 -b 64 -gp 2 -re 2 -nd 100 -nt 30 -gd 0.5 -sm -st --seed 2"
+                                % (data, tmp_path))
+    out_dir = mm.main(args)
+    for r in (0, 1):
+        f = os.path.join(out_dir, "gp_results_run%d.h5" % r)
+        keys = set(mapfile.list_keys(f, "COHORT_A/held-out"))
+        assert {"nn_features", "y_true", "chr_locs", "mappability", "quantiles", "0", "1"} <= keys
+        assert {"mean", "std", "params"} <= set(mapfile.list_keys(f, "COHORT_A/val/0"))
+        assert 0.0 <= float(mapfile.read_attrs(f, "COHORT_A/held-out/1")["R2"]) <= 1.0
+        assert os.path.exists(os.path.join(out_dir, "best_model_%d.pt" % r)) and os.path.exists(os.path.join(out_dir, "preds_%d.h5" % r))
+    df = mapfile.read_frame(os.path.join(out_dir, "COHORT_A.Pretrained.h5"), "region_params")
+    n_ho = len(np.load(os.path.join(out_dir, "ho_indices_0.npy")))
+    assert list(df.columns) == mm.OutputGenerator.pretrained_cols and len(df) == 2 * n_ho       # the held-out set, once per rerun
+    assert set(df.FOLD.unique()) == {0.0, 1.0} and (df.FLAG == 0).all() and (df.STD > 0).all()
+    assert np.corrcoef(df.Y_TRUE.values, df.Y_PRED.values)[0, 1] > 0.5
+    acc = float(open(os.path.join(out_dir, "COHORT_A_pretrained_accuracy.txt")).read())
+    assert 0.25 < acc <= 1.0
+    summ = open(os.path.join(out_dir, "COHORT_A_gp_runs_summary.csv")).read().splitlines()
+    assert summ[0] == "fold,gp_run,nn_acc,val_acc,test_acc" and len(summ) == 5
+    assert len(glob.glob(os.path.join(out_dir, "run_*"))) == 2                                  # run_params.txt, run_accuracies.csv
+
+
 def test_scale_factors_local_equals_two_step_form():
     """dig_scale_factors_local == dig_scale_suffstats + dig_scale_factors(world = 1), bit for bit."""
     import torch

@@ -245,3 +245,88 @@ def test_kfold_results_on_reference_fold_files(expected):
     assert got.FLAG.dtype == bool and got.CHROM.dtype.kind == "i"
     p = os.path.join(GOLD, "kfold_genuine", "gp_results_fold_0.h5")
     assert set(mapfile.read_attrs(p, "Synthetic-Cohort/held-out/1")) == {"R2", "loss"}
+
+
+def test_compute_pretrained_matches_reference_method():
+    """GPTrainer.compute_pretrained (gp_trainer.py:247-261) of the reference, run with h5py on the committed fold files
+    (tests/golden/make_pretrained_golden.py), against the map-file version the single-split route uses."""
+    from digdriver_amd.region_model.trainers import gp_trainer
+    with open(os.path.join(GOLD, "compute_pretrained_golden.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 6
+    for key, want in cases.items():
+        fn, runs = key.split(":")
+        got = gp_trainer.compute_pretrained(os.path.join(GOLD, "kfold_genuine", fn), want["cohort"], int(runs))
+        for g, name in zip(got, ("chr_locs", "mapps", "quants", "y_true", "means", "stds")):
+            np.testing.assert_array_equal(np.asarray(g, float), np.asarray(want[name], float), err_msg=key + " " + name)
+
+
+def test_store_pretrained_accumulates_sorted_frame(tmp_path):
+    """OutputGenerator.store_pretrained (mutations_main.py:148-172): the held-out windows of every rerun join the label's
+    frame, which is written position-sorted into <label>.Pretrained.h5:region_params with the reference's columns; the
+    accuracy file holds the squared Pearson r of the unflagged rows."""
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.region_model import mutations_main as mm
+    from digdriver_amd.region_model.predict import r2_score
+    args = mm.get_cmd_arguments("-c COH -d none -o %s -gp 2 -re 2" % tmp_path)
+    og = mm.OutputGenerator(args, "cpu", str(tmp_path))
+    rng = np.random.default_rng(0)
+    blocks = []
+    for fold in range(2):
+        n = 7
+        locs = np.stack([rng.integers(1, 4, n), rng.integers(0, 50, n) * 10000, np.zeros(n, int)], 1)
+        locs[:, 2] = locs[:, 1] + 10000
+        y, m, s = rng.poisson(20, n).astype(float), rng.uniform(5, 40, n), rng.uniform(1, 5, n)
+        mp, q = rng.uniform(0.7, 1, n), rng.uniform(0, 1, n)
+        og.store_pretrained("COH", locs, mp, q, y, m, s, fold, is_flagged=(fold == 1))
+        blocks.append((locs, y, m, s, mp, q, fold))
+    df = mapfile.read_frame(str(tmp_path / "COH.Pretrained.h5"), "region_params")
+    assert list(df.columns) == mm.OutputGenerator.pretrained_cols and len(df) == 14
+    key = df.CHROM.values * 1e9 + df.START.values
+    assert (np.diff(key) >= 0).all()                                      # sorted by CHROM, START
+    assert set(df.FOLD.unique()) == {0.0, 1.0} and set(df.FLAG[df.FOLD == 1].unique()) == {1.0}
+    locs, y, m = blocks[0][0], blocks[0][1], blocks[0][2]
+    want_acc = r2_score(y, m)                                              # only fold 0 is unflagged
+    assert abs(float(open(tmp_path / "COH_pretrained_accuracy.txt").read()) - want_acc) < 1e-12
+    row = df[(df.CHROM == locs[0, 0]) & (df.START == locs[0, 1]) & (df.FOLD == 0)].iloc[0]
+    assert row.Y_TRUE == y[0] and row.Y_PRED == m[0] and row.END == locs[0, 2]
+
+
+def test_single_split_generator_splits(tmp_path):
+    """DatasetGenerator (dataset_generator.py:115-193): the held-out set comes off first (random share, chromosome tails
+    or a file of windows), train / validation splits are redrawn per call."""
+    import types
+    from digdriver_amd.io import mapfile
+    from digdriver_amd.region_model import mutations_main as mm
+    rng = np.random.default_rng(1)
+    N = 400
+    chrom = np.repeat([1, 2, 3, 4], 100)
+    idx = np.stack([chrom, np.tile(np.arange(100), 4) * 10000, np.tile(np.arange(100), 4) * 10000 + 10000], 1)
+    data = str(tmp_path / "d.map")
+    mapfile.write_array(data, "x_data", rng.integers(0, 100, (N, 4, 3)).astype(np.float32))
+    mapfile.write_array(data, "idx", idx)
+    mapp = rng.uniform(0.5, 1.0, N)
+    mapfile.write_array(data, "mappability", mapp)
+    y = rng.poisson(30, N).astype(float)
+    mapfile.write_array(data, "COH", y)
+
+    def make(extra):
+        return mm.SplitData(mm.get_cmd_arguments("-c COH -d %s -o %s -m 0.7 -cq 0.99 %s" % (data, tmp_path, extra)), "cpu")
+    d = make("-hr 0.25 --seed 3")
+    kept = set(d.idxs) | set(d.heldout_idxs)
+    assert not (set(d.idxs) & set(d.heldout_idxs)) and all(mapp[i] >= 0.7 for i in kept)
+    assert len(d.heldout_idxs) == len(kept) - int(0.75 * len(kept))
+    tr, va = d.get_datasets()
+    tr2, _ = d.get_datasets()
+    assert set(tr) | set(va) == set(d.idxs) and len(va) == len(d.idxs) - int(0.8 * len(d.idxs)) and not np.array_equal(tr, tr2)
+    c = make("-s chr -hr 0.2")
+    for ch in (1, 2, 3, 4):                                                # the tail of every chromosome is held out
+        rows = np.sort([i for i in (set(c.idxs) | set(c.heldout_idxs)) if chrom[i] == ch])
+        cut = int(0.8 * len(rows))
+        assert set(rows[cut:]) <= set(c.heldout_idxs) and set(rows[:cut]) <= set(c.idxs)
+    pick = [i for i in sorted(kept)][:5]
+    hf = tmp_path / "held.tsv"
+    hf.write_text("CHROM\tSTART\tEND\tY_TRUE\tY_PRED\tSTD\tPVAL\tRANK\n" +
+                  "\n".join("%d\t%d\t%d\t%s\t0\t0\t0\t0" % (idx[i, 0], idx[i, 1], idx[i, 2], y[i]) for i in pick) + "\n")
+    h = make("-u %s" % hf)
+    assert list(h.heldout_idxs) == pick and not (set(pick) & set(h.idxs)) and len(h.idxs) == len(kept) - 5
