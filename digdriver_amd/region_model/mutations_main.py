@@ -35,6 +35,11 @@ from .trainers import gp_trainer
 from .trainers.nn_trainer import NNTrainer
 
 
+def _say(*message):
+    """Progress lines on stdout, worded as the reference words them."""
+    print(*message, flush=True)
+
+
 def get_cmd_arguments(text=None):
     ap = argparse.ArgumentParser(description='single-split CNN + GP region model (MI355X build)')
     ap.add_argument('-c', '--cancer-id', required=True, nargs='*', type=str, dest='label_ids',
@@ -75,7 +80,7 @@ class SplitData:
     train / validation split per call of get_datasets."""
 
     def __init__(self, args, device):
-        print('Loading data and labels from file {}...'.format(args.data_file))
+        _say('Loading data and labels from file {}...'.format(args.data_file))
         self.locs = np.asarray(mapfile.read_array(args.data_file, 'idx'))
         self.mapp = np.asarray(mapfile.read_array(args.data_file, 'mappability'), float)
         self.labels = [np.asarray(mapfile.read_array(args.data_file, l), float) for l in args.label_ids]
@@ -94,23 +99,22 @@ class SplitData:
         self.rng = np.random.default_rng(args.seed)
         self.val_ratio, self.split_method = args.val_ratio, args.split_method
         if args.heldout_file is not None:
-            print('Using predefined held-out samples from {}'.format(args.heldout_file))
+            _say('Using predefined held-out samples from {}'.format(args.heldout_file))
             self.idxs, self.heldout_idxs = self.extract_heldout_set(np.asarray(idxs), args.heldout_file)
         else:
             self.idxs, self.heldout_idxs = self.split(np.asarray(idxs), args.heldout_ratio, 'held-out')
-        print('Input data is of size: {}'.format(self.store.shape(len(self.idxs))))
-
+        _say('Input data is of size: {}'.format(self.store.shape(len(self.idxs))))
     def split(self, idxs, ratio, what):
         if self.split_method == 'random':                               # split_randomly, dataset_generator.py:82-88
             idxs = self.rng.permutation(idxs)
             cut = int((1 - ratio) * len(idxs))
-            print('Splitting {} data at random to {} and {} samples'.format(what, cut, len(idxs) - cut))
+            _say('Splitting {} data at random to {} and {} samples'.format(what, cut, len(idxs) - cut))
             return idxs[:cut], idxs[cut:]
         if self.split_method == 'chr':
             # split_by_chromosome (:90-101): the last `ratio` of every chromosome's bins.  (The reference returns the
             # POSITIONS inside `idxs` instead of the bins at those positions -- the same thing only when no bin was
             # filtered out; the bins are returned here.)
-            print('Splitting {} data by chromosome...'.format(what))
+            _say('Splitting {} data by chromosome...'.format(what))
             chrom = self.locs[idxs, 0]
             head, tail = [], []
             for c in np.unique(chrom):
@@ -137,7 +141,7 @@ class SplitData:
             assert i in inside, "Expected the following to be in the data set, but wasn't found \n{}".format(r)
             inside.discard(i)
             held.append(i)
-        print('Heldout {} windows.'.format(len(held)))
+        _say('Heldout {} windows.'.format(len(held)))
         return np.asarray([i for i in idxs if int(i) in inside], int), np.asarray(held, int)
 
     def get_datasets(self):
@@ -181,7 +185,7 @@ class OutputGenerator:
                             df.sort_values(by=['CHROM', 'START']).reset_index(drop=True))
         ok = df.FLAG.values == 0
         acc = r2_score(df.Y_TRUE.values[ok], df.Y_PRED.values[ok])
-        print('Overall unflagged pretrained accuracy after fold {} is: {}'.format(fold + 1, acc))
+        _say('Overall unflagged pretrained accuracy after fold {} is: {}'.format(fold + 1, acc))
         with open(self.acc_path.format(lbl), 'w') as f:
             f.write(str(acc))
         self.pretrained_dict[lbl] = df
@@ -194,7 +198,7 @@ class OutputGenerator:
             run_gp_fold(self.args, self.device, path, self.args.label_ids, train, val, ho, nn_scores,
                         seed=self.args.seed + 31 * fold)
         except AssertionError as exc:
-            print('GP run failed: {}'.format(exc))
+            _say('GP run failed: {}'.format(exc))
             return False
         for l, lbl in enumerate(self.args.label_ids):
             scores = self.score_dict[lbl]
@@ -205,9 +209,9 @@ class OutputGenerator:
                 scores.loc[(fold, (prefix + '_' if prefix else '') + str(j)), :] = [float(nn_scores[l]), val_r2, ho_r2]
             scores.to_csv(os.path.join(self.out_dir, '{}_gp_runs_summary.csv'.format(lbl)))
             chr_locs, mapps, quants, y_true, means, stds = gp_trainer.compute_pretrained(path, lbl, self.args.run_gaussian)
-            print('Fold {} pretrained model R2: {}'.format(str(fold + 1) + ('_' + prefix if prefix else ''), r2_score(y_true, means)))
-            print('GP fold results summary:')
-            print(scores)
+            _say('Fold {} pretrained model R2: {}'.format(str(fold + 1) + ('_' + prefix if prefix else ''), r2_score(y_true, means)))
+            _say('GP fold results summary:')
+            _say(scores)
             self.store_pretrained(lbl, chr_locs, mapps, quants, y_true, means, stds, fold, is_flagged=len(prefix) > 0)
         return True
 
@@ -229,12 +233,12 @@ def main(input_args=None):
         raise SystemExit("attention maps, the 'fc' network and autoregressive features are not built (CNN + GP route only)")
     labels_str = '-'.join(args.label_ids)
     out_dir = os.path.join(args.out_dir, labels_str, str(datetime.now()))
-    print('Generating prediction for cancer types: {}'.format(args.label_ids))
+    _say('Generating prediction for cancer types: {}'.format(args.label_ids))
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     device = torch.device('cuda', torch.cuda.current_device())
     out_pred = OutputGenerator(args, device, out_dir)
     if args.save_model or args.save_training or args.run_gaussian:
-        print("Saving results under: '{}'".format(out_dir))
+        _say("Saving results under: '{}'".format(out_dir))
         os.makedirs(out_dir)
         with open(os.path.join(out_dir, 'run_params.txt'), 'w') as f:
             for k, v in vars(args).items():
@@ -247,37 +251,37 @@ def main(input_args=None):
     while r < args.nn_reruns and re < args.max_nn_reruns:
         train_rows, val_rows = data.get_datasets()                      # a new split per (re)run, mutations_main.py:324-326
         shape = data.store.shape(len(train_rows))
-        print('Using {} predictors for prediction.'.format(shape[2]))
-        print('Setting model and optimizers for run {}/{}...'.format(r + 1, args.nn_reruns))
+        _say('Using {} predictors for prediction.'.format(shape[2]))
+        _say('Setting model and optimizers for run {}/{}...'.format(r + 1, args.nn_reruns))
         torch.manual_seed(args.seed + 1000 * r + 10 * re)
         model = SimpleMultiTaskResNet(shape, C)
         trainer = NNTrainer(model, optim.Adam(model.parameters(), lr=1e-3, amsgrad=False), nn.MSELoss(), args.bs, args.label_ids,
                             data.store, train_rows, val_rows, data.labels, device, seed=args.seed + 7919 * r + re)
         best = dict(accs=np.zeros(C))
         for epoch in range(1, args.epochs + 1):
-            print('Running epoch {}/{}'.format(epoch, args.epochs))
+            _say('Running epoch {}/{}'.format(epoch, args.epochs))
             _, train_accs, tr_feat, _, tr_true = trainer.train(epoch, r)
             _, val_accs, va_feat, _, va_true, _ = trainer.test(epoch, r)
             live = [int((np.abs(f).mean(axis=0) > 0).sum()) for f in tr_feat]
             if np.mean(val_accs) > np.mean(best['accs']) and all(n > 1 for n in live):      # :365-376
-                print('Changing run model since best R2 was {} compared to previous {}'.format(np.mean(val_accs), np.mean(best['accs'])))
+                _say('Changing run model since best R2 was {} compared to previous {}'.format(np.mean(val_accs), np.mean(best['accs'])))
                 best = dict(accs=np.asarray(val_accs), train_accs=train_accs, model=copy.deepcopy(trainer.model),
                             train=dict(feat=tr_feat, lbls=tr_true, meta=data.meta(trainer.last_train_rows)),
                             val=dict(feat=va_feat, lbls=va_true, meta=data.meta(val_rows)))
         if 'model' not in best:                                          # no epoch qualified: treated like a failed GP
             re += 1
-            print('No epoch with a positive validation r2 and live features! Rerunning NN, attempt {}/{}'.format(re + 1, args.max_nn_reruns))
+            _say('No epoch with a positive validation r2 and live features! Rerunning NN, attempt {}/{}'.format(re + 1, args.max_nn_reruns))
             continue
-        print('Best validation accuracy for run {}/{} was: {}.'.format(r + 1, args.nn_reruns, np.mean(best['accs'])))
-        print('Running best model over {} held-out set samples...'.format(len(ho_rows)))
+        _say('Best validation accuracy for run {}/{} was: {}.'.format(r + 1, args.nn_reruns, np.mean(best['accs'])))
+        _say('Running best model over {} held-out set samples...'.format(len(ho_rows)))
         ho_preds, ho_true, ho_feat, ho_accs = out_pred.predict(best['model'], data.store, ho_rows, data.labels)
-        print('Model held-out accuracy: {}'.format(ho_accs))
+        _say('Model held-out accuracy: {}'.format(ho_accs))
         for j, l in enumerate(args.label_ids):
             accs_df.loc[r, 'Train_{}'.format(l)] = best['train_accs'][j]
             accs_df.loc[r, 'Va_{}'.format(l)] = best['accs'][j]
             accs_df.loc[r, 'Held-out_{}'.format(l)] = ho_accs[j]
         if args.save_model:
-            print('Saving model and held-out indices from run {} to {}...'.format(r, out_dir))
+            _say('Saving model and held-out indices from run {} to {}...'.format(r, out_dir))
             np.save(os.path.join(out_dir, 'ho_indices_{}'.format(r)), ho_rows)
             torch.save(best['model'].state_dict(), os.path.join(out_dir, 'best_model_{}.pt'.format(r)))
         if args.save_training:
@@ -288,18 +292,18 @@ def main(input_args=None):
             gp_succeed = out_pred.run_gp('gp_results_run{}.h5'.format(r), best['train'], best['val'], ho, best['accs'], r)
         if args.run_gaussian > 0 and not gp_succeed:
             re += 1
-            print('GP run failed! Rerunning NN, attempt {}/{}'.format(re + 1, args.max_nn_reruns))
+            _say('GP run failed! Rerunning NN, attempt {}/{}'.format(re + 1, args.max_nn_reruns))
         else:
             r, re = r + 1, 0
     assert args.run_gaussian < 1 or gp_succeed, 'GP failed at run {} after {} NN reruns'.format(r, re)
     if args.save_training:
         accs_df.to_csv(os.path.join(out_dir, 'run_accuracies.csv'))
-    print('Results summary for {} runs:\n {}'.format(args.nn_reruns, accs_df.describe()))
-    print('Done!')
+    _say('Results summary for {} runs:\n {}'.format(args.nn_reruns, accs_df.describe()))
+    _say('Done!')
     return out_dir
 
 
 if __name__ == '__main__':
     t0 = datetime.now()
     main()
-    print('Time elapsed: {}'.format(datetime.now() - t0))
+    _say('Time elapsed: {}'.format(datetime.now() - t0))
