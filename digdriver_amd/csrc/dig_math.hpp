@@ -870,12 +870,20 @@ template <int W2>
 __device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, bool e2, bool two, double alpha, double p,
                                                  double& r1, double& r2)
 {
-    if (!(p >= 2.2250738585072014e-308)) return 0u;   // subnormal p: leave it to the general path
+    // A count that is not resolved leaves a NEGATIVE value in its result for the compacted pass of the statistics block:
+    // -pmf(k) when the direct form cancelled (tail_from_state_tab, W2 == 1), -2 when the recurrence never ran for it.
+    if (!(p >= 2.2250738585072014e-308)) {   // subnormal p: leave it to the general path
+        r1 = r2 = -2.0;
+        return 0u;
+    }
     const double lp0 = alpha * fast_log_normal(p);
     const double k1d = e1 ? k1 : -1.0, k2d = e2 ? k2 : -1.0;
     // the lane's loop ends at the larger count; only the smaller one needs recording on the way
     const double kmax = fmax(k1d, k2d), kmin = fmin(k1d, k2d);
-    if (!(lp0 > fast_lp0_min(kmax))) return 0u;
+    if (!(lp0 > fast_lp0_min(kmax))) {
+        r1 = r2 = -2.0;
+        return 0u;
+    }
     const double x = 1.0 - p;
     double r_min = 0.0, r_max = 0.0;
     if (two) nb_fast_recurrence<W2, true>(kmin, kmax, alpha, x, lp0, r_min, r_max);
@@ -884,9 +892,10 @@ __device__ __forceinline__ unsigned nb_fast2_run(double k1, double k2, bool e1, 
     const double ra = k1_is_max ? r_max : r_min;   // result for k1
     const double rb = k1_is_max ? r_min : r_max;   // result for k2
     unsigned done = 0;
-    // (an eligible count that is not accepted leaves -pmf(k) in its result: W2 == 1 only, see tail_from_state_tab)
-    if (e1) { r1 = ra; if (ra >= kDirectMin) done |= 1u; }
-    if (e2) { r2 = rb; if (rb >= kDirectMin) done |= 2u; }
+    r1 = e1 ? ra : -2.0;
+    r2 = e2 ? rb : -2.0;
+    if (e1 && ra >= kDirectMin) done |= 1u;
+    if (e2 && rb >= kDirectMin) done |= 2u;
     return done;
 }
 
@@ -910,7 +919,10 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
     const bool e1 = (want & 1u) && !(done & 1u) && k1 >= 0.0 && k1 <= (double)kSmallK && floor(k1) == k1;
     const bool e2 = (want & 2u) && !(done & 2u) && k2 >= 0.0 && k2 <= (double)kSmallK && floor(k2) == k2;
     if (!(e1 || e2)) return done & want;
-    done |= nb_fast2_run<W2>(k1, k2, e1, e2, (want & 2u) != 0u, alpha, p, r1, r2);
+    double t1 = 0.0, t2 = 0.0;                  // (the run writes both results; a count settled above keeps its value)
+    done |= nb_fast2_run<W2>(k1, k2, e1, e2, (want & 2u) != 0u, alpha, p, t1, t2);
+    if (e1) r1 = t1;
+    if (e2) r2 = t2;
     return done & want;
 }
 
@@ -921,9 +933,11 @@ template <int W2>
 __device__ __forceinline__ unsigned nb_fast2_counts(int k1, int k2, bool two, double alpha, double p, double& r1,
                                                     double& r2)
 {
-    if (!(alpha > 0.0 && alpha < __longlong_as_double(0x7ff0000000000000LL) && p > 0.0 && p < 1.0)) return 0u;
     const bool e1 = k1 >= 0 && k1 <= kSmallK, e2 = two && k2 >= 0 && k2 <= kSmallK;
-    if (!(e1 || e2)) return 0u;
+    if (!(alpha > 0.0 && alpha < __longlong_as_double(0x7ff0000000000000LL) && p > 0.0 && p < 1.0) || !(e1 || e2)) {
+        r1 = r2 = -2.0;                      // (see nb_fast2_run)
+        return 0u;
+    }
     return nb_fast2_run<W2>((double)k1, (double)k2, e1, e2, two, alpha, p, r1, r2);
 }
 

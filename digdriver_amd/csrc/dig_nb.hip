@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
         const PairInputs q = prepare_pair(cur, HAS_INDEL_PARAMS);
         // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
         //  cancelled, -2 when it was not eligible at all; no p-value is negative)
-        double pv_snv = -2.0, pv_smp = -2.0, pv_ind = -2.0, dummy = 0.0;
+        double pv_snv, pv_smp, pv_ind, dummy;
         const unsigned d1 = nb_fast2_counts<1>(cur.k_snv, cur.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_fast2_counts<1>(cur.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
 #ifdef DIG_DEV_ABLATE
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         const PairInputs q = prepare_pair(w, false);
         // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
         //  cancelled, -2 when it was not eligible at all; no p-value is negative)
-        double pv_snv = -2.0, pv_smp = -2.0, pv_ind = -2.0, dummy = 0.0;
+        double pv_snv, pv_smp, pv_ind, dummy;
         const unsigned d1 = nb_fast2_counts<1>(w.k_snv, w.k_smp, true, q.alpha, q.p, pv_snv, pv_smp);
         const unsigned d2 = nb_fast2_counts<1>(w.k_ind, 0, false, q.alpha_i, q.p_i, pv_ind, dummy);
         const bool slow = ((d1 != 3u) || (d2 != 1u)) && live;
