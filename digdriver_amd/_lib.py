@@ -62,6 +62,8 @@ _SIGNATURES = {
     "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
+    "dig_rbf_from_gram": [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp],
+    "dig_rbf_backward": [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp],
 }
 
 # entry points that return a byte count (int64) instead of a status
@@ -71,6 +73,7 @@ _SIZE_QUERIES = {
     "dig_scale_suffstats_workspace": [_i64, _i64],
     "dig_element_pipeline_workspace": [_i64, _i64],
     "dig_scale_suffstats_chunked_workspace": [_vp, _int, _i64],
+    "dig_rbf_backward_partials": [_i64, _i64],
 }
 
 ABI_VERSION = 2          # include/dig_hip.h: DIG_ABI_VERSION

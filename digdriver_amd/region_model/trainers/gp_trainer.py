@@ -26,16 +26,17 @@ def _softplus_inv(v):
     return math.log(math.expm1(v))
 
 
-def _lower_solve(L, B):
+def _lower_solve(L, B, scale=None):
     """L^-1 B for a lower-triangular [m, m] factor and a wide [m, n] right-hand side.  With n in the hundreds of thousands
     (the 150 000-row training cap of gp_trainer.py:55) rocBLAS' trsm cannot allocate its workspace
     (HIPBLAS_STATUS_ALLOC_FAILED); the m x m inverse is formed by one small triangular solve instead and applied as a
     GEMM, which is also what the MFMA units are good at.  m <= a few thousand and the factor carries jitter, so the
     explicit inverse is harmless in FP64."""
     if B.shape[-1] <= 4096:
-        return torch.linalg.solve_triangular(L, B, upper=False)
+        out = torch.linalg.solve_triangular(L, B, upper=False)
+        return out if scale is None else out * scale
     Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
-    return _WideMatmul.apply(Linv, B)
+    return _WideMatmul.apply(Linv if scale is None else Linv * scale, B)
 
 
 def _outer_wide(X, Y, chunks=64):
@@ -85,6 +86,46 @@ class _CrossTerm(torch.autograd.Function):
         return da, db
 
 
+class _RbfCross(torch.autograd.Function):
+    """outputscale * exp(-|a_i - b_j|^2 / (2 lengthscale^2)) for the [m, d] inducing points a and a long [n, d] b that needs
+    no gradient (the training rows): one GEMM for the squared distances and ONE pass over the m x n matrix
+    (dig_rbf_from_gram, in place on the Gram matrix); the backward is one pass too (dig_rbf_backward: W = g o K with the
+    sums the scalar gradients need) plus the wide product W b.  From torch's elementwise operators the same took about
+    ten passes over 0.5 GB each way -- half of a fit's time (rocprofv3: 474 launches per Adam step)."""
+
+    @staticmethod
+    def forward(ctx, a, b, lengthscale, outputscale):
+        from ... import _lib
+        ls, os_ = float(lengthscale), float(outputscale)
+        K = (a @ b.T).contiguous()
+        a2, b2 = (a * a).sum(-1).contiguous(), (b * b).sum(-1).contiguous()
+        with torch.cuda.device(a.device):
+            _lib.call("dig_rbf_from_gram", _lib.dev_ptr(K), _lib.dev_ptr(a2), _lib.dev_ptr(b2), K.shape[0], K.shape[1], ls, os_,
+                      _lib.stream_ptr())
+        ctx.save_for_backward(a, b, K)
+        ctx.scalars = (ls, os_)
+        return K
+
+    @staticmethod
+    def backward(ctx, g):
+        from ... import _lib
+        a, b, K = ctx.saved_tensors
+        ls, os_ = ctx.scalars
+        m, n = K.shape
+        g = g.contiguous()
+        W = torch.empty_like(K)
+        chunks = (n + 1023) // 1024
+        part = torch.empty((m, chunks, 2), dtype=K.dtype, device=K.device)
+        with torch.cuda.device(K.device):
+            _lib.call("dig_rbf_backward", _lib.dev_ptr(g), _lib.dev_ptr(K), m, n, ls, os_, _lib.dev_ptr(W), _lib.dev_ptr(part),
+                      _lib.stream_ptr())
+        rows = part[:, :, 0].sum(1)                                        # rowsum(W)
+        da = (_outer_wide(W, b.T.contiguous()) - rows[:, None] * a) / (ls * ls) if ctx.needs_input_grad[0] else None
+        d_ls = part[:, :, 1].sum() / ls ** 3 if ctx.needs_input_grad[2] else None
+        d_os = rows.sum() / os_ if ctx.needs_input_grad[3] else None
+        return da, None, d_ls, d_os
+
+
 class SparseGP(torch.nn.Module):
     """SGPR with learnable inducing locations."""
 
@@ -102,6 +143,8 @@ class SparseGP(torch.nn.Module):
     noise = property(lambda self: torch.nn.functional.softplus(self.raw_noise) + 1e-4)
 
     def kernel(self, a, b):
+        if a.is_cuda and a.dtype == torch.float64 and b.shape[0] >= 8192 and not b.requires_grad:
+            return _RbfCross.apply(a, b, self.lengthscale, self.outputscale)
         d2 = (a * a).sum(-1, keepdim=True) - 2.0 * _CrossTerm.apply(a, b) + (b * b).sum(-1)[None, :]
         return self.outputscale * torch.exp(-0.5 * d2.clamp_min(0.0) / self.lengthscale ** 2)
 
@@ -111,8 +154,10 @@ class SparseGP(torch.nn.Module):
         Kmm = self.kernel(Z, Z) + _JITTER * self.outputscale.detach() * torch.eye(m, dtype=Z.dtype, device=Z.device)
         L = torch.linalg.cholesky(Kmm)
         sig = torch.sqrt(self.noise)
-        A = _lower_solve(L, self.kernel(Z, X)) / sig        # [m, n]
-        B = torch.eye(m, dtype=Z.dtype, device=Z.device) + _outer_wide(A, A)
+        A = _lower_solve(L, self.kernel(Z, X), scale=1.0 / sig)        # [m, n]; the 1 / sigma rides on the m x m factor
+        AAt = _outer_wide(A, A)
+        self._trace_aat = torch.diagonal(AAt).sum()                    # = (A * A).sum() without another pass over m x n
+        B = torch.eye(m, dtype=Z.dtype, device=Z.device) + AAt
         LB = torch.linalg.cholesky(B)
         r = self.train_y - self.mean_const
         c = torch.linalg.solve_triangular(LB, (A @ r)[:, None], upper=False)[:, 0] / sig
@@ -125,7 +170,7 @@ class SparseGP(torch.nn.Module):
         s2 = self.noise
         bound = (-0.5 * n * math.log(2 * math.pi) - torch.log(torch.diagonal(LB)).sum() - 0.5 * n * torch.log(s2)
                  - 0.5 * (r @ r) / s2 + 0.5 * (c @ c)
-                 - 0.5 * n * self.outputscale / s2 + 0.5 * (A * A).sum())
+                 - 0.5 * n * self.outputscale / s2 + 0.5 * self._trace_aat)
         return -bound / n
 
     @torch.no_grad()
