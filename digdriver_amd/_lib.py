@@ -62,7 +62,7 @@ _SIGNATURES = {
     "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
-    "dig_rbf_from_gram": [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp],
+    "dig_rbf_cross": [_vp, _vp, _i64, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "dig_rbf_backward": [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp],
 }
 

@@ -46,6 +46,11 @@ def _outer_wide(X, Y, chunks=64):
     m, n = X.shape
     if n < 8192:
         return X @ Y.T
+    if n % chunks:                                        # a chunk count that divides n: padding copies both operands
+        for cand in range(96, 31, -1):
+            if n % cand == 0:
+                chunks = cand
+                break
     pad = (-n) % chunks
     if pad:
         X = torch.nn.functional.pad(X, (0, pad))
@@ -86,10 +91,28 @@ class _CrossTerm(torch.autograd.Function):
         return da, db
 
 
+class _GramAndProject(torch.autograd.Function):
+    """(A A^T, A r) for the wide [m, n] factor A and the residual r [n].  As separate torch operators the backward costs a
+    second long-dimension GEMM (the two operands of A A^T are the same tensor), three copies and two additions over the
+    m x n matrix; by symmetry it is ONE product and one rank-1 update in place:  dA = (G + G^T) A + g (x) r."""
+
+    @staticmethod
+    def forward(ctx, A, r):
+        ctx.save_for_backward(A, r)
+        return _outer_wide(A, A), A @ r
+
+    @staticmethod
+    def backward(ctx, gB, gv):
+        A, r = ctx.saved_tensors
+        dA = (gB + gB.T) @ A
+        dA.addr_(gv, r)
+        dr = A.T @ gv if ctx.needs_input_grad[1] else None
+        return dA, dr
+
+
 class _RbfCross(torch.autograd.Function):
     """outputscale * exp(-|a_i - b_j|^2 / (2 lengthscale^2)) for the [m, d] inducing points a and a long [n, d] b that needs
-    no gradient (the training rows): one GEMM for the squared distances and ONE pass over the m x n matrix
-    (dig_rbf_from_gram, in place on the Gram matrix); the backward is one pass too (dig_rbf_backward: W = g o K with the
+    no gradient (the training rows): ONE pass writing the m x n matrix straight from the points (dig_rbf_cross); the backward is one pass too (dig_rbf_backward: W = g o K with the
     sums the scalar gradients need) plus the wide product W b.  From torch's elementwise operators the same took about
     ten passes over 0.5 GB each way -- half of a fit's time (rocprofv3: 474 launches per Adam step)."""
 
@@ -97,11 +120,11 @@ class _RbfCross(torch.autograd.Function):
     def forward(ctx, a, b, lengthscale, outputscale):
         from ... import _lib
         ls, os_ = float(lengthscale), float(outputscale)
-        K = (a @ b.T).contiguous()
-        a2, b2 = (a * a).sum(-1).contiguous(), (b * b).sum(-1).contiguous()
+        a, b = a.contiguous(), b.contiguous()
+        K = torch.empty((a.shape[0], b.shape[0]), dtype=a.dtype, device=a.device)
         with torch.cuda.device(a.device):
-            _lib.call("dig_rbf_from_gram", _lib.dev_ptr(K), _lib.dev_ptr(a2), _lib.dev_ptr(b2), K.shape[0], K.shape[1], ls, os_,
-                      _lib.stream_ptr())
+            _lib.call("dig_rbf_cross", _lib.dev_ptr(a), _lib.dev_ptr(b), a.shape[0], b.shape[0], a.shape[1], ls, os_,
+                      _lib.dev_ptr(K), _lib.stream_ptr())
         ctx.save_for_backward(a, b, K)
         ctx.scalars = (ls, os_)
         return K
@@ -143,7 +166,7 @@ class SparseGP(torch.nn.Module):
     noise = property(lambda self: torch.nn.functional.softplus(self.raw_noise) + 1e-4)
 
     def kernel(self, a, b):
-        if a.is_cuda and a.dtype == torch.float64 and b.shape[0] >= 8192 and not b.requires_grad:
+        if a.is_cuda and a.dtype == torch.float64 and b.shape[0] >= 8192 and not b.requires_grad and a.shape[1] <= 32:
             return _RbfCross.apply(a, b, self.lengthscale, self.outputscale)
         d2 = (a * a).sum(-1, keepdim=True) - 2.0 * _CrossTerm.apply(a, b) + (b * b).sum(-1)[None, :]
         return self.outputscale * torch.exp(-0.5 * d2.clamp_min(0.0) / self.lengthscale ** 2)
@@ -155,12 +178,12 @@ class SparseGP(torch.nn.Module):
         L = torch.linalg.cholesky(Kmm)
         sig = torch.sqrt(self.noise)
         A = _lower_solve(L, self.kernel(Z, X), scale=1.0 / sig)        # [m, n]; the 1 / sigma rides on the m x m factor
-        AAt = _outer_wide(A, A)
+        r = self.train_y - self.mean_const
+        AAt, Ar = _GramAndProject.apply(A, r)
         self._trace_aat = torch.diagonal(AAt).sum()                    # = (A * A).sum() without another pass over m x n
         B = torch.eye(m, dtype=Z.dtype, device=Z.device) + AAt
         LB = torch.linalg.cholesky(B)
-        r = self.train_y - self.mean_const
-        c = torch.linalg.solve_triangular(LB, (A @ r)[:, None], upper=False)[:, 0] / sig
+        c = torch.linalg.solve_triangular(LB, Ar[:, None], upper=False)[:, 0] / sig
         return L, A, LB, r, c
 
     def neg_bound_per_point(self):

@@ -316,13 +316,13 @@ int dig_tiled_nb_test_host(const double *pt, int pt_per_cohort, const int32_t *k
 
 /* ---- RBF cross-covariance of the sparse-GP calibration (gp_trainer.py:28-45: ScaleKernel(RBFKernel) between the m
  * inducing points and the n training rows) as single passes over the m x n matrix ----------------------------------- *
- * dig_rbf_from_gram: IN PLACE on the Gram matrix G = Z X^T (f64 [m, n], row-major):
- *   G[i][j] <- outputscale * exp(-max(a2[i] + b2[j] - 2 G[i][j], 0) / (2 lengthscale^2)),  a2 = |z_i|^2 [m], b2 = |x_j|^2 [n].
+ * dig_rbf_cross: K[i][j] = outputscale * exp(-|z_i - x_j|^2 / (2 lengthscale^2)), Z f64 [m, d], X f64 [n, d], d <= 32,
+ *   K f64 [m, n] row-major.
  * dig_rbf_backward: W = g o K and, per row and 1024-column chunk, partial[row][chunk] = {sum W, sum W d2}
  *   (dig_rbf_backward_partials(m, n) doubles; summed by the caller: d outputscale = sum W / outputscale,
  *   d lengthscale = sum W d2 / lengthscale^3, dZ = (W X - rowsum(W) o Z) / lengthscale^2). */
-int dig_rbf_from_gram(double *G, const double *a2, const double *b2, int64_t m, int64_t n, double lengthscale,
-                      double outputscale, void *stream);
+int dig_rbf_cross(const double *Z, const double *X, int64_t m, int64_t n, int64_t d, double lengthscale, double outputscale,
+                  double *K, void *stream);
 int64_t dig_rbf_backward_partials(int64_t m, int64_t n);
 int dig_rbf_backward(const double *g, const double *K, int64_t m, int64_t n, double lengthscale, double outputscale,
                      double *W, double *partial, void *stream);
