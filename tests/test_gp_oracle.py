@@ -124,3 +124,32 @@ def test_sparse_gp_at_reference_size_vs_oracle():
     mu_w, sd_w = S.predict(X, y, Z, Xs, ls, os_, s2, c)
     np.testing.assert_allclose(mu.cpu().numpy(), mu_w, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(sd.cpu().numpy(), sd_w, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_rbf_cross_kernels_vs_numpy_and_autograd():
+    """dig_rbf_cross / dig_rbf_backward (csrc/dig_gp.hip) through the autograd function the SGPR uses: the values against
+    numpy's direct RBF, the gradients against torch autograd of the elementwise formulation (every feature count the
+    dispatch covers at its ends, a ragged n, rows past one 16-row group)."""
+    import torch
+    from digdriver_amd.region_model.trainers import gp_trainer as G
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    for m, n, d in ((37, 9001, 16), (5, 8192, 1), (130, 8200, 32)):
+        Z = torch.tensor(rng.normal(size=(m, d)), device=dev, requires_grad=True)
+        X = torch.tensor(rng.normal(size=(n, d)), device=dev)
+        ls = torch.tensor(0.9 + 0.2 * d ** 0.5, device=dev, dtype=torch.float64, requires_grad=True)
+        osc = torch.tensor(1.7, device=dev, dtype=torch.float64, requires_grad=True)
+        K = G._RbfCross.apply(Z, X, ls, osc)
+        zn, xn = Z.detach().cpu().numpy(), X.cpu().numpy()
+        d2 = ((zn[:, None, :] - xn[None, :, :]) ** 2).sum(-1)
+        np.testing.assert_allclose(K.detach().cpu().numpy(), 1.7 * np.exp(-0.5 * d2 / float(ls.detach()) ** 2), rtol=1e-13, atol=1e-300)
+        g = torch.tensor(rng.normal(size=(m, n)), device=dev)
+        (K * g).sum().backward()
+        got = [Z.grad.clone(), ls.grad.clone(), osc.grad.clone()]
+        for t in (Z, ls, osc):
+            t.grad = None
+        ref = osc * torch.exp(-0.5 * ((Z[:, None, :] - X[None, :, :]) ** 2).sum(-1) / ls ** 2)
+        (ref * g).sum().backward()
+        for a, b in zip(got, (Z.grad, ls.grad, osc.grad)):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-12)
