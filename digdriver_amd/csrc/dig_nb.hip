@@ -562,19 +562,25 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     // [6] alpha, [7] p, [8] alpha of the indel test, [9] its p
     __shared__ double s_pair[kSlowWaves][kSlowPairsPerWave][10];
     __shared__ unsigned s_list[kSlowWaves][48];
-    nb_tables_init();
     const int64_t n = a.E * a.C;
-    const unsigned count = (unsigned)min((int64_t)a.worklist[0], n);   // (never more entries than pairs, whatever the header holds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = lane >> 2, sub = lane & 3;
-    if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist
     const unsigned n_waves = gridDim.x * kSlowWaves;
-    for (unsigned base = (blockIdx.x * kSlowWaves + wave) * kSlowPairsPerWave; base < count; base += n_waves * kSlowPairsPerWave) {
+    const unsigned base0 = (blockIdx.x * kSlowWaves + wave) * kSlowPairsPerWave;
+    // the length of the worklist and this wave's first entries are requested together, in front of the table set-up: one
+    // round trip instead of three (an entry past the end is stale and never used; n pairs bound the list's capacity)
+    const unsigned count_raw = a.worklist[0];
+    unsigned first_item = 0;
+    if (lane < kSlowPairsPerWave && (int64_t)(base0 + lane) < n) first_item = a.worklist[kWorkHeader + base0 + lane];
+    nb_tables_init();
+    const unsigned count = (unsigned)min((int64_t)count_raw, n);   // (never more entries than pairs, whatever the header holds)
+    if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist
+    for (unsigned base = base0; base < count; base += n_waves * kSlowPairsPerWave) {
         // ---- the first lanes: one pair each: its inputs, and which of its three tests are open (sign bit set) ----
         const bool owner = lane < kSlowPairsPerWave && base + lane < count;
         int64_t item = 0;
         unsigned open = 0;
         if (owner) {
-            item = a.worklist[kWorkHeader + base + lane];
+            item = base == base0 ? first_item : a.worklist[kWorkHeader + base + lane];
             const double v1 = a.out[1 * n + item], v2 = a.out[2 * n + item], v5 = a.out[5 * n + item];
             const PairInputs q = load_pair(a, item);
             double* sp = s_pair[wave][lane];
