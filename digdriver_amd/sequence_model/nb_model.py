@@ -171,27 +171,44 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=1, n_down=1, b
                                 np.asarray(sigma_lst, float)[None, :], muts.CHROM.astype(str).values, muts.START.values,
                                 muts.END.values, np.zeros(len(muts), np.int32), binsize=binsize, device=device)
     host = {k: v.cpu().numpy() for k, v in res.items()}
-    first, nval = host["first_pos"], host["n_valid"]
+    first, nval = host["first_pos"], host["n_valid"].astype(np.int64)
     n_pos = np.minimum(ends, np.array([g.lengths[i] for i in g.chrom_index(chroms)]) - 1) - first
-    rows = []
-    for r in range(len(idx)):
-        nt = int(nval[r])
-        t = np.arange(nt)
-        lo = first[r] + t * binsize
-        hi = np.minimum(lo + binsize, first[r] + n_pos[r]) - 1
-        rows.append(pd.DataFrame({
-            "CHROM": float(idx[r, 0]), "POS": (lo + hi) / 2.0 if binsize > 1 else lo.astype(float),
-            "OBS": host["k"][0, r, :nt].astype(float), "EXP": host["exp"][0, r, :nt], "PVAL": host["pval"][0, r, :nt],
-            "Pi": host["pt"][0, r, :nt], "MU": float(mu_lst[r]), "SIGMA": float(sigma_lst[r]),
-            "REGION": "{}:{}-{}".format(idx[r, 0], idx[r, 1], idx[r, 2])}))
     cols = ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi", "MU", "SIGMA", "REGION"]
-    return pd.concat(rows, ignore_index=True)[cols] if rows else pd.DataFrame(columns=cols)
+    if len(idx) == 0 or nval.sum() == 0:
+        return pd.DataFrame(columns=cols)
+    # all regions at once (the reference appends one block per region): region of every tile, tile number inside it
+    reg = np.repeat(np.arange(len(idx)), nval)
+    t = np.arange(nval.sum()) - np.repeat(np.cumsum(nval) - nval, nval)
+    lo = first[reg] + t * binsize
+    hi = np.minimum(lo + binsize, (first + n_pos)[reg]) - 1
+    take = lambda a: a[0][reg, t]
+    labels = np.array(["{}:{}-{}".format(c, s_, e) for c, s_, e in idx], dtype=object)
+    return pd.DataFrame({
+        "CHROM": idx[reg, 0].astype(float), "POS": (lo + hi) / 2.0 if binsize > 1 else lo.astype(float),
+        "OBS": take(host["k"]).astype(float), "EXP": take(host["exp"]), "PVAL": take(host["pval"]), "Pi": take(host["pt"]),
+        "MU": np.asarray(mu_lst, float)[reg], "SIGMA": np.asarray(sigma_lst, float)[reg], "REGION": labels[reg]})[cols]
 
 
 def get_q_vals(pvals_lst):
     """nb_model.py:340-342: Benjamini-Hochberg q-values, statsmodels.stats.multitest.fdrcorrection(pvals)[1] (method
     'indep'): q_(i) = min_{j >= i} p_(j) n / j in ascending order of p, capped at 1.  NaNs propagate the way the sort
     places them (last)."""
+    if type(pvals_lst).__module__.startswith("torch") and pvals_lst.is_cuda:
+        # device form for whole-genome tile sets (57.6 M p-values per cohort): the same IEEE operations in the same order
+        # (p / (rank / n), reverse running minimum, cap), so the same bits as the host form and as statsmodels
+        import torch
+        p = pvals_lst.reshape(-1).to(torch.float64)
+        n = p.numel()
+        if n == 0:
+            return p.clone()
+        ps, order = torch.sort(p, stable=True)
+        # (the divisor as a DEVICE tensor: torch turns a division by a host scalar into a multiplication by its reciprocal)
+        q = ps / (torch.arange(1, n + 1, device=p.device, dtype=torch.float64) / torch.full((), float(n), device=p.device, dtype=torch.float64))
+        q = torch.flip(torch.cummin(torch.flip(q, [0]), 0).values, [0])
+        q = torch.clamp(q, max=1.0)
+        out = torch.empty_like(q)
+        out[order] = q
+        return out.reshape(pvals_lst.shape)
     p = np.asarray(pvals_lst, dtype=np.float64)
     n = p.size
     if n == 0:

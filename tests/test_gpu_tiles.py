@@ -143,3 +143,19 @@ def test_full_size_configs4_properties():
     p = 1.0 / (pt.reshape(-1)[flat] * theta + 1.0)
     want = nb_model.nb_pvalue_exact(k.reshape(-1)[flat].double(), alpha, p)
     assert torch.equal(pval.reshape(-1)[flat], want)
+
+
+def test_q_values_on_the_device_equal_the_host_form():
+    """get_q_vals on a CUDA tensor (whole-genome tile sets) == the host form, which is pinned to statsmodels
+    (tests/golden/qvals_golden.json): same operations in the same order, same bits; ties and NaNs included."""
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    rng = np.random.default_rng(8)
+    p = rng.uniform(size=200_003) ** 3
+    p[rng.integers(0, p.size, 500)] = p[rng.integers(0, p.size, 500)]            # ties
+    p[:7] = [0.0, 1.0, 1e-300, 0.5, 0.5, 1.0, 0.0]
+    want = nb_model.get_q_vals(p)
+    got = nb_model.get_q_vals(torch.as_tensor(p, device="cuda:0")).cpu().numpy()
+    assert np.array_equal(got, want)
+    q2 = nb_model.get_q_vals(torch.as_tensor(p.reshape(-1, 1), device="cuda:0"))
+    assert q2.shape == (p.size, 1) and np.array_equal(q2.cpu().numpy()[:, 0], want)
