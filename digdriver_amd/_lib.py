@@ -76,7 +76,7 @@ _SIZE_QUERIES = {
     "dig_rbf_backward_partials": [_i64, _i64],
 }
 
-ABI_VERSION = 2          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 3          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

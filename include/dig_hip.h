@@ -34,7 +34,7 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 2   /* 2: + join, contexts, scale factors, pipeline entry points */
+#define DIG_ABI_VERSION 3   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes; a statistics stage leaves its worklist length in the header */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
