@@ -362,16 +362,24 @@ def main():
     # Per-stage durations are sampled INSIDE the timed loop: on every 8th step one stage (contexts, dot or statistics) is
     # bracketed by two HIP events on the main stream.  An event record is a barrier packet (~6 us), so each step carries at
     # most one pair and seven steps in eight carry none (< 1 % of the loop time).
-    SAMPLE_EVERY = 8
+    # (short runs -- the driver's 20 steps -- bracket the dominant stage on every 4th step, 5 samples instead of 2, and the
+    #  two smaller stages in turn on another: one bracket on every second step, about 1 % of the loop)
+    SAMPLE_EVERY = 8 if args.steps >= 100 else 4
     sample_slot = {1: "contexts", 3: "dot", 5: "statistics"}
     samples = {"contexts": [], "dot": [], "statistics": []}
     sampling = [False]
 
     # every event of the run exists before the loop starts (HIP creates the object behind a torch event at its first
     # record, and a growing pool of them costs a one-off stall of tens of milliseconds at some point of the loop)
-    n_sample_events = 2 * (3 * ((args.steps + args.warmup) // SAMPLE_EVERY + 2))
+    n_sample_events = 2 * (4 * ((args.steps + args.warmup) // SAMPLE_EVERY + 2))
     sample_events = [torch.cuda.Event(enable_timing=True) for _ in range(n_sample_events)]
     for e in side_done + sample_events:
+        e.record(main_stream)
+    torch.cuda.synchronize()
+
+    THROTTLE_EVERY = 16
+    throttle_events = [torch.cuda.Event() for _ in range(8)]
+    for e in throttle_events:
         e.record(main_stream)
     torch.cuda.synchronize()
 
@@ -393,12 +401,23 @@ def main():
         t = step_no[0]
         step_no[0] += 1
         b = t % RING
+        # The host enqueues a step in 0.05 ms, the GPU takes 0.23: unchecked, the host runs hundreds of steps ahead, the
+        # HIP queue fills up, and the runtime then blocks the enqueue until the backlog has drained COMPLETELY -- 32 ms
+        # in a 200-step run, with the GPU idle at the end of it (BENCH_TRACE=1 shows the enqueue times).  One event on
+        # the main stream every 16 steps (a 5 us packet: 0.1 %) keeps the host between 32 and 48 steps ahead instead.
+        if t % THROTTLE_EVERY == 0:
+            k = t // THROTTLE_EVERY
+            throttle_events[k % len(throttle_events)].record(main_stream)
+            if k >= 3:
+                throttle_events[(k - 3) % len(throttle_events)].synchronize()
         while queued[0] < t + 1:                 # this step's (first call only) and the next step's scale factors
             queued[0] += 1
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
         main_stream.wait_event(side_done[b])
         which = sample_slot.get(t % SAMPLE_EVERY) if sampling[0] else None
+        if sampling[0] and SAMPLE_EVERY == 4:                  # short runs: statistics on steps 1 mod 4, dot / contexts in turn on 3 mod 4
+            which = "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
         if which is None:
             pipe.run(cj, cji, stages=7, stream=main_stream)
         else:
@@ -435,6 +454,12 @@ def main():
             break
     torch.cuda.synchronize()
     settle_ms = (time.perf_counter() - t_settle) * 1e3
+    # Python's cyclic collector must not run inside the loop: a full collection over the process's objects (torch, numpy,
+    # thousands of events and closures) takes 30-40 ms -- 150 steps' worth of GPU time; with K = 200 it used to land in the
+    # timed region every time (BENCH_TRACE=1: one 38 ms enqueue), with K = 20 or 1000 it did not.
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -446,12 +471,22 @@ def main():
     t0 = time.perf_counter()
     ev_begin.record(main_stream)
     sampling[0] = True
+    trace = [] if os.environ.get("BENCH_TRACE") == "1" else None      # developer switch: host time of every enqueue
     for _ in range(args.steps):
+        if trace is not None:
+            t1 = time.perf_counter()
         step()
+        if trace is not None:
+            trace.append(time.perf_counter() - t1)
     sampling[0] = False
     ev_end.record(main_stream)
+    if trace is not None and rank == 0:
+        top = sorted(range(len(trace)), key=lambda i: -trace[i])[:6]
+        print("BENCH_TRACE longest enqueues (step, ms):", [(i, round(trace[i] * 1e3, 3)) for i in top], "median ms",
+              round(sorted(trace)[len(trace) // 2] * 1e3, 4), file=sys.stderr)
     host_enqueue_s = time.perf_counter() - t0        # the host's share: enqueueing K steps (it must stay below dt)
     barrier()
+    gc.enable()
     dt = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
