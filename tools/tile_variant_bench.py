@@ -27,7 +27,7 @@ def child(ref_path, write_ref):
     words[0] = 0x44444444
     words[-1] = 0x44444444
     words[5000:5400] = 0x44444444                            # a run of N across several tiles
-    words[20001] = 0x33334333                                # single N bases
+    words[min(20001, words.numel() - 2)] = 0x33334333           # single N bases
     words[1250 * 7:1250 * 8] = 0x44444444                    # a whole bin of N (T = 0)
     genome = PackedGenome(["chr1"], [0], [nbases], np.zeros(2, np.uint32))
     genome._dev[(dev.type, dev.index)] = (words, torch.zeros(1, dtype=torch.int64, device=dev),
