@@ -188,7 +188,9 @@ def _chunk_worker(rank, world, port, tmp):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_chunked_scale_factors_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_chunked_scale_factors_gloo(tmp_path, world):
+    """(world 4: every rank owns 16 of the 64 canonical chunks; the scale factors still have the single-process bits)"""
     port = _free_port()
-    mp.spawn(_chunk_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_chunk_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(tmp_path / "chunk_ok.npy")
