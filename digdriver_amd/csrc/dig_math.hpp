@@ -323,6 +323,71 @@ __device__ __forceinline__ double fast_log(double x)
     return fast_log_normal(x);
 }
 
+// log Gamma(z) for z > 0: arguments below 16 are shifted up by 16 (Gamma(z) = Gamma(z + 16) / (z (z + 1) ... (z + 15))),
+// then Stirling's series with five correction terms (the first one left out, 691 / (360360 z^11), is 1e-16 at z = 16).
+// Absolute error ~ 2e-16 max(1, z log z): the size of the rounding of its leading term.
+__device__ __forceinline__ double lgamma_stirling(double z)
+{
+    const bool small = z < 16.0;
+    double shift = 1.0, zz = z;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            shift *= zz;
+            zz += 1.0;
+        }
+    }
+    const double r = 1.0 / zz, r2 = r * r;
+    const double corr = r * fma(r2, fma(r2, fma(r2, fma(r2, 1.0 / 1188.0, -1.0 / 1680.0), 1.0 / 1260.0), -1.0 / 360.0), 1.0 / 12.0);
+    double v = (zz - 0.5) * fast_log_normal(zz) - zz + 0.91893853320467274178 + corr;
+    if (small) v -= fast_log_normal(shift);
+    return v;
+}
+
+// ---- pmf of the negative binomial without cancellation (Loader's saddle-point form, as R's dnbinom) ------------------
+// scipy's nbinom._logpmf -- lgamma(k + n) - lgamma(k + 1) - lgamma(n) + n log p + k log1p(-p) -- subtracts numbers of the
+// size of k log k: at k ~ 10^6 its double-precision value is off by 2e-6 (measured against 50-digit arithmetic), whatever
+// the quality of lgamma.  Here  pmf(k) = n / (n + k) * dbinom_raw(n, n + k, p, 1 - p)  with
+//   dbinom_raw(x, N, p, q) = exp(stirlerr(N) - stirlerr(x) - stirlerr(N - x) - bd0(x, N p) - bd0(N - x, N q)) sqrt(N / (2 pi x (N - x)))
+//   stirlerr(z) = lgamma(z + 1) - ((z + 1/2) log z - z + log sqrt(2 pi))        (the Stirling series from z = 16 on)
+//   bd0(x, M)   = x log(x / M) + M - x                                           (a series in (x - M) / (x + M) near x = M)
+// every term is small when the pmf is not: 3e-10 worst case over n in [1e-3, 1e7], means in [1e-3, 3e6], counts from five
+// standard deviations below the mean to twenty above (the lgamma form: 1.8e-6).  k >= 0 integer, n > 0 finite, 0 < p < 1.
+__device__ __forceinline__ double stirlerr_dev(double z)
+{
+    if (z >= 16.0) {
+        const double r = 1.0 / z, r2 = r * r;
+        return r * fma(-r2, fma(-r2, fma(-r2, fma(-r2, 1.0 / 1188.0, 1.0 / 1680.0), 1.0 / 1260.0), 1.0 / 360.0), 1.0 / 12.0);
+    }
+    return lgamma_stirling(z + 1.0) - (z + 0.5) * fast_log_normal(z) + z - 0.91893853320467274178;
+}
+
+__device__ inline double bd0_dev(double x, double M)
+{
+    const double d = x - M;
+    if (fabs(d) < 0.1 * (x + M)) {
+        const double v = d / (x + M), v2 = v * v;
+        double s = d * v, ej = 2.0 * x * v;
+        for (int j = 1; j < 1000; ++j) {
+            ej *= v2;
+            const double s1 = s + ej / (double)(2 * j + 1);
+            if (s1 == s) return s1;
+            s = s1;
+        }
+        return s;
+    }
+    return x * fast_log_normal(x / M) + M - x;
+}
+
+__device__ inline double nb_pmf_saddle(double k, double n, double p)
+{
+    if (k == 0.0) return exp(n * fast_log_normal(p));
+    const double q = 1.0 - p, N = k + n;
+    const double lc = stirlerr_dev(N) - stirlerr_dev(n) - stirlerr_dev(k) - bd0_dev(n, N * p) - bd0_dev(k, N * q);
+    const double lf = 1.83787706640934548356 + fast_log_normal(n) + log1p(-n / N);          // log(2 pi n (N - n) / N)
+    return (n / N) * exp(lc - 0.5 * lf);
+}
+
 // ---- continued fraction for I_x(a,b) (fast for x < (a+1)/(a+b+2)) -------------------
 __device__ inline double betacf(double a, double b, double x)
 {
@@ -525,11 +590,11 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
     }
     // (3) lgamma + continued fraction for whatever is left
     if (todo & 1u) {
-        const double pmfk = exp(nbinom_logpmf_unchecked(k1, alpha, p));
+        const double pmfk = nb_pmf_saddle(k1, alpha, p);
         r1 = (1.0 - 0.5 * W2) * pmfk + nb_upper_tail_from_pmf(k1, alpha, p, x, pmfk);
     }
     if (todo & 2u) {
-        const double pmfk = exp(nbinom_logpmf_unchecked(k2, alpha, p));
+        const double pmfk = nb_pmf_saddle(k2, alpha, p);
         r2 = (1.0 - 0.5 * W2) * pmfk + nb_upper_tail_from_pmf(k2, alpha, p, x, pmfk);
     }
 }
@@ -577,9 +642,9 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
 // inclusive scan and the sums by a butterfly, both as quad-permute DPP moves (no LDS traffic); a block is the last one
 // when the geometric bound of the remainder, last term x rho / (1 - rho), is below 2^-54 of the sum.
 // pmf(k): the streaming pass hands it over when it has it (a count <= kSmallK whose direct form cancelled: the usual
-// case); otherwise p^alpha times the product of the ratios below k (counts up to 64: one block), or scipy's own formula
-// with the three lgamma terms from Stirling's series on three lanes of the quad (a count of 500 would take eight
-// product blocks, and the 37 pairs of a large element reach the pass together: its waves set the length of the kernel).  Anything unusual (arguments outside the support, a series still open after
+// case); otherwise p^alpha times the product of the ratios below k (counts up to 64: one block), or Loader's saddle-point
+// form (nb_pmf_saddle: a count of 500 would take eight product blocks, and the 37 pairs of a large element reach the
+// pass together: its waves set the length of the kernel).  Anything unusual (arguments outside the support, a series still open after
 // kQuadBlocks blocks: heavy tails with alpha << 1) goes to the scalar nb_midp_upper, which keeps scipy's semantics.
 // Every lane of the quad must call with the same arguments; the result is the same in all four.
 constexpr int kQuadTerms = 16;         // terms per lane and block
@@ -615,27 +680,6 @@ __device__ __forceinline__ double quad_scan_product(double P, int sub, double& e
     return quad_perm<kQuadLast>(P);
 }
 
-// log Gamma(z) for z > 0: arguments below 16 are shifted up by 16 (Gamma(z) = Gamma(z + 16) / (z (z + 1) ... (z + 15))),
-// then Stirling's series with five correction terms (the first one left out, 691 / (360360 z^11), is 1e-16 at z = 16).
-// Absolute error ~ 2e-16 max(1, z log z): the size of the rounding of its leading term.
-__device__ __forceinline__ double lgamma_stirling(double z)
-{
-    const bool small = z < 16.0;
-    double shift = 1.0, zz = z;
-    if (small) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            shift *= zz;
-            zz += 1.0;
-        }
-    }
-    const double r = 1.0 / zz, r2 = r * r;
-    const double corr = r * fma(r2, fma(r2, fma(r2, fma(r2, 1.0 / 1188.0, -1.0 / 1680.0), 1.0 / 1260.0), -1.0 / 360.0), 1.0 / 12.0);
-    double v = (zz - 0.5) * fast_log_normal(zz) - zz + 0.91893853320467274178 + corr;
-    if (small) v -= fast_log_normal(shift);
-    return v;
-}
-
 // pmf_k < 0: not known.
 __device__ inline double nb_midp_upper_quad(double k, double alpha, double p, double pmf_k, int sub)
 {
@@ -662,15 +706,8 @@ __device__ inline double nb_midp_upper_quad(double k, double alpha, double p, do
             }
             double excl;
             tk = fast_exp_neg(lp0) * quad_scan_product(N / D, sub, excl);
-        } else if (alpha < 1.0e8) {
-            // log pmf(k) = lgamma(k + alpha) - lgamma(k + 1) - lgamma(alpha) + alpha log p + k log(1 - p)  (scipy nbinom._logpmf),
-            // the three lgamma terms on three lanes of the quad
-            const double lg = lgamma_stirling(sub == 0 ? k + alpha : sub == 1 ? k + 1.0 : alpha);
-            const double coeff = quad_perm<kQuadLane0>(lg) - quad_perm<kQuadLane1>(lg) - quad_perm<kQuadLane2>(lg);
-            const double lx = x >= 0.5 ? fast_log_normal(x) : log1p(-p);
-            tk = exp(coeff + lp0 + k * lx);
         } else {
-            return nb_midp_upper(k, alpha, p);
+            tk = nb_pmf_saddle(k, alpha, p);        // no cancellation at any count (scipy's own lgamma form loses 2e-6 at k ~ 1e6)
         }
     }
     const bool upper = (alpha + k) * x < k + 1.0;
@@ -796,7 +833,7 @@ __device__ __forceinline__ void nb_tables_init()
 // 1 - S_k - (W2/2) t_k from the scaled state (A_k, N_k) with 1/k! from the table:  t_k = t_0 N_k / k!,
 // S_k = t_0 A_k k / k!.
 template <int W2>
-__device__ __forceinline__ double tail_from_state_tab(double A, double N, double k, double t0)
+__device__ __forceinline__ double tail_from_state_tab(double A, double N, double k, double t0, double thr = kDirectMin)
 {
 #pragma clang fp contract(off)
     const double rD = t0 * g_inv_factorial[(int)k];
@@ -804,7 +841,7 @@ __device__ __forceinline__ double tail_from_state_tab(double A, double N, double
     if (W2 == 0) return 1.0 - S;
     const double t = N * rD;
     const double res = (1.0 - S) - 0.5 * t;
-    return res >= kDirectMin ? res : -t;          // not accepted: hand pmf(k) on (sign bit set) for the series of the compacted pass
+    return res >= thr ? res : -t;          // not accepted: hand pmf(k) on (sign bit set) for the series of the compacted pass
 }
 
 // One step of the scaled recurrence with the running factorial (compacted pass, where D is rescaled on the way).  The
@@ -842,7 +879,7 @@ __device__ __forceinline__ double fast_lp0_min(double kmax) { return kmax <= 64.
 //   operations with no memory access and no division; the trip count is tested on the FP64 counter itself.
 template <int W2, bool TWO>
 __device__ __forceinline__ void nb_fast_recurrence(double kmin, double kmax, double alpha, double x, double lp0,
-                                                   double& r_min, double& r_max)
+                                                   double& r_min, double& r_max, double thr = kDirectMin)
 {
     const double t0 = fast_exp_neg_core(lp0);                    // -400 < lp0 <= 0 here
     double N = 1.0, A = 0.0, u = alpha * x, jj = 0.0;
@@ -854,7 +891,7 @@ __device__ __forceinline__ void nb_fast_recurrence(double kmin, double kmax, dou
             pmf_scaled_step_nofact(A, N, u, jj, x);
         }
         if (jj < kmin) pmf_scaled_step_nofact(A, N, u, jj, x);
-        r_min = tail_from_state_tab<W2>(A, N, jj, t0);
+        r_min = tail_from_state_tab<W2>(A, N, jj, t0, thr);
     }
     const double kmax_m1 = kmax - 1.0;
     while (jj < kmax_m1) {
@@ -862,7 +899,7 @@ __device__ __forceinline__ void nb_fast_recurrence(double kmin, double kmax, dou
         pmf_scaled_step_nofact(A, N, u, jj, x);
     }
     if (jj < kmax) pmf_scaled_step_nofact(A, N, u, jj, x);
-    r_max = tail_from_state_tab<W2>(A, N, jj, t0);
+    r_max = tail_from_state_tab<W2>(A, N, jj, t0, thr);
 }
 
 // Shared tail of the two front ends below: e1 / e2 say which counts are eligible for the fast recurrence.
