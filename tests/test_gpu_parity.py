@@ -176,6 +176,30 @@ def test_element_stats_vs_oracle_random_cohorts(torch_dev):
     assert r["EXP_SNV"].shape == (0, 3)
 
 
+def test_element_stats_wide_range_vs_oracle():
+    """Far outside the fixtures: rates 1e-2 .. 1e5, dispersion alpha 1e-2 .. 1e6, counts from four standard deviations below
+    the mean to fourteen above (up to 2e6) -- the compacted pass's series, its saddle-point pmf and the scalar fallbacks
+    (heavy tails at alpha << 1, counts beyond the recurrence) all inside the 1e-6 contract (tools/stress_stats.py is the
+    multi-seed form of this test; scipy's own lgamma form of the pmf would be off by 2e-6 at counts of 1e6)."""
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(21)
+    E, C = 2500, 37
+    mean = 10 ** rng.uniform(-2, 5, (E, C))
+    alpha = 10 ** rng.uniform(-2, 6, (E, C))
+    mu, sigma = mean, mean / np.sqrt(alpha)
+    sd = np.sqrt(mean * (1 + mean / alpha))
+    k1 = np.clip(np.rint(mean + rng.uniform(-4, 14, (E, C)) * sd), 0, 2e6).astype(np.int32)
+    k2 = np.clip(np.rint(k1 * rng.uniform(0.5, 1.0, (E, C))), 0, None).astype(np.int32)
+    k3 = np.clip(np.rint(mean + rng.uniform(-3, 8, (E, C)) * sd), 0, 2e6).astype(np.int32)
+    one = np.ones((E, C))
+    got = engine.element_stats(mu, sigma, one, np.ones(E), k1, k2, k3, np.ones(C), np.ones(C))
+    want = O.element_stats(mu, sigma, one, np.ones((E, 1)), k1, k2, k3, np.ones((1, C)), np.ones((1, C)))
+    for name in engine.ES_PLANES:
+        rel_close(got[name], want[name], RTOL)
+
+
+
 # ---------------------------------------------------------------------------------------
 # per-element accumulation vs the reference's own loops (goldens)
 # ---------------------------------------------------------------------------------------
