@@ -505,7 +505,7 @@ __device__ __forceinline__ unsigned nb_midp_upper_fast2(double k1, double k2, un
 // k > kSmallK, p^alpha underflows, or the p-value is < kDirectMin (1 - CDF would cancel).
 constexpr int kRecurK = 2048;   // direct summation limit of the slow pass
 
-__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x);
+__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x, double ax);
 template <int W2 = 1>
 __device__ __forceinline__ double midp_from_state(double A, double N, double D, double k, double t0);
 
@@ -542,12 +542,13 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
         const double klo = (el1 && el2) ? fmin(k1, k2) : (el1 ? k1 : k2);
         const double khi = (el1 && el2) ? fmax(k1, k2) : klo;
         const int n_phase = (el1 || el2) ? ((el1 && el2 && k1 != k2) ? 2 : 1) : 0;
-        double N = 1.0, A = 0.0, D = 1.0, u = alpha * x, jj = 0.0;
+        const double ax = alpha * x;
+        double N = 1.0, A = 0.0, D = 1.0, u = ax, jj = 0.0;
         for (int phase = 0; phase < n_phase; ++phase) {
             const double k = phase == 0 ? klo : khi;
             while (jj < k) {
                 const double stop = fmin(k, jj + 16.0);
-                while (jj < stop) pmf_scaled_step(A, N, D, u, jj, x);
+                while (jj < stop) pmf_scaled_step(A, N, D, u, jj, x, ax);
                 const int e = -__builtin_amdgcn_frexp_exp(D);
                 D = ldexp(D, e);
                 N = ldexp(N, e);
@@ -564,8 +565,8 @@ __device__ inline void nb_midp_upper_slow2(double k1, double k2, unsigned want, 
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
                         Nt *= ut;                // N_{j+1}
-                        ut += x;
                         jt += 1.0;
+                        ut = fma(jt, x, ax);     // (not ut += x: see pmf_scaled_step)
                         Dt *= jt;                // D_{j+1}
                         B = fma(B, jt, Nt);      // B_{j+1} = B_j (j+1) + N_{j+1}
                         H *= jt;                 // keeps 0.5 t_k on the same scale
@@ -847,14 +848,14 @@ __device__ __forceinline__ double tail_from_state_tab(double A, double N, double
 // One step of the scaled recurrence with the running factorial (compacted pass, where D is rescaled on the way).  The
 // accumulator update A <- A * j + N is issued as the three-address v_fma_f64 (the compiler's v_fmac form needs three
 // register copies per step to keep N alive).
-__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x)
+__device__ __forceinline__ void pmf_scaled_step(double& A, double& N, double& D, double& u, double& jj, double x, double ax)
 {
     double An;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(An) : "v"(A), "v"(jj), "v"(N));
     A = An;                 // A_{j+1} = A_j * j + N_j
     N *= u;                 // N_{j+1}
-    u += x;
     jj += 1.0;
+    u = fma(jj, x, ax);     // (alpha + j) x afresh, one rounding: an incremental u += x lets its errors pile up, k^2 / 2 ulp in N_k
     D *= jj;                // D_{j+1} = (j+1)!
 }
 
@@ -865,8 +866,8 @@ __device__ __forceinline__ void pmf_scaled_step_nofact(double& A, double& N, dou
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(An) : "v"(A), "v"(jj), "v"(N));
     A = An;                 // A_{j+1} = A_j * j + N_j
     N *= u;                 // N_{j+1}
-    u += x;
-    jj += 1.0;
+    u += x;                 // (incremental: its rounding errors add up to ~k^1.5 / 3 ulp in N_k, 5e-14 at k = 128 -- 5e-8 of a
+    jj += 1.0;              //  p-value at the 1e-6 acceptance edge; forming (alpha + j) x afresh costs 2 % of the pass)
 }
 
 // Range of the scaled recurrence: N_k <= k! / t_0 must stay finite, i.e. log(k!) - lp0 < 709.  64! = e^205 allows
@@ -1013,11 +1014,12 @@ __device__ __forceinline__ bool nb_lower_cdf_small(double k, double alpha, doubl
     const double lp0 = alpha * fast_log(p);
     if (!(lp0 > -690.0)) return false;
     const double x = 1.0 - p;
-    double t = fast_exp_neg(lp0), S = t, u = alpha * x, jj = 1.0;
+    const double ax = alpha * x;
+    double t = fast_exp_neg(lp0), S = t, u = ax, jj = 1.0;
     while (jj <= k) {
         t *= u * recip_nr(jj);
         S += t;
-        u += x;
+        u = fma(jj, x, ax);
         jj += 1.0;
     }
     *out = S;
