@@ -209,7 +209,7 @@ static __device__ __constant__ const double kLogTabRom[128][2] = {
     {0x1.038c6b78247fcp+0, -0x1.c317384c75f0dp-7},
     {0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7},
     {0x1.0182436517a37p+0, -0x1.8121214586b02p-8},
-    {0x1.0080402010080p+0, -0x1.0040155d5881ep-9},
+    {0x1.0000000000000p+0, 0x0.0p+0}   /* the bin below 1, [1 - 2^-8, 1): c = 1, so that log x = log1p(x - 1) keeps its RELATIVE accuracy for x -> 1 (log p of a success probability near 1 is multiplied by alpha ~ 1e6) */,
     {0x1.fe01fe01fe020p-1, 0x1.ff00aa2b10ba0p-9},
     {0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7},
     {0x1.f6310aca0dbb5p-1, 0x1.3cea44346a584p-6},
@@ -460,9 +460,19 @@ __device__ inline double betainc(double a, double b, double x)
     if (x == 0.0) return 0.0;
     if (x == 1.0) return 1.0;
     const double y = 1.0 - x;
-    const double lfront = a * log(x) + b * log(y) + lgamma(a + b) - lgamma(a) - lgamma(b);
-    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lfront) * betacf(a, b, x) / a;
-    return 1.0 - exp(lfront) * betacf(b, a, y) / b;
+    // x^a y^b / B(a, b) = a b / (a + b) * dbinom_raw(a, a + b, x, y) in Loader's form (see nb_pmf_saddle): the textbook
+    // a log x + b log y + lgamma(a + b) - lgamma(a) - lgamma(b) cancels numbers of the size of a log a (2e-6 off at a ~ 1e6)
+    double front;
+    if (x >= 2.2250738585072014e-308 && y >= 2.2250738585072014e-308 && a >= 1e-300 && b >= 1e-300 && a < 1e300 && b < 1e300) {
+        const double nn = a + b;
+        const double lc = stirlerr_dev(nn) - stirlerr_dev(a) - stirlerr_dev(b) - bd0_dev(a, nn * x) - bd0_dev(b, nn * y);
+        const double lf = 1.83787706640934548356 + fast_log_normal(a) + log1p(-a / nn);
+        front = (a * (b / nn)) * exp(lc - 0.5 * lf);
+    } else {
+        front = exp(a * log(x) + b * log(y) + lgamma(a + b) - lgamma(a) - lgamma(b));
+    }
+    if (x < (a + 1.0) / (a + b + 2.0)) return front * betacf(a, b, x) / a;
+    return 1.0 - front * betacf(b, a, y) / b;
 }
 
 // scipy.stats.nbinom.pmf(k, n, p)
@@ -472,6 +482,9 @@ __device__ inline double nbinom_pmf(double k, double n, double p)
     if (!(n > 0.0) || !(p > 0.0) || !(p <= 1.0) || isinf(n)) return dnan();
     if (k < 0.0 || floor(k) != k) return 0.0;
     if (p == 1.0) return k == 0.0 ? 1.0 : 0.0;
+    // (scipy's own expression here is lgamma(k + n) - lgamma(k + 1) - lgamma(n) + n log p + k log1p(-p): it cancels k log k,
+    //  2e-6 off at k ~ 1e6; scipy 1.15 evaluates the pmf through boost instead, and so does this -- Loader's form)
+    if (p >= 2.2250738585072014e-308 && k < 4.0e15) return nb_pmf_saddle(k, n, p);
     const double l = lgamma(k + n) - lgamma(k + 1.0) - lgamma(n) + n * log(p) + k * log1p(-p);
     return exp(l);
 }
@@ -1077,6 +1090,8 @@ __device__ inline double nb_exact(double k, double alpha, double p)
 __device__ inline double nb_midp_twosided(double k, double alpha, double p)
 {
     const double mu = alpha * (1.0 - p) / p;
+    if (!(k < mu) && !isnan(k) && !isnan(mu))
+        return nb_midp_upper(k, alpha, p);      // 0.5 pmf(k) + betainc(k + 1, alpha, 1 - p): the statistic of the burden test, by its own routes
     const double pmf = nbinom_pmf(k, alpha, p);
     if (k < mu) {
         if (k > 0.0) return 0.5 * pmf + betainc(alpha, k, p);

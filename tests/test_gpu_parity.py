@@ -176,6 +176,22 @@ def test_element_stats_vs_oracle_random_cohorts(torch_dev):
     assert r["EXP_SNV"].shape == (0, 3)
 
 
+def test_elementwise_entry_points_wide_range_vs_oracle():
+    """nb_pvalue_greater_midp / greater / exact / two-sided mid-p far outside the fixtures (tools/stress_elementwise.py is the
+    multi-seed form): counts up to 2e6, alpha 1e-2 .. 1e6.  scipy's lgamma expressions for the pmf and for the prefactor of
+    the incomplete beta are 2e-6 off at counts of 1e6; the device uses Loader's saddle-point forms."""
+    from digdriver_amd.sequence_model import nb_model as M
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(5)
+    n = 60_000
+    mean = 10 ** rng.uniform(-2, 5, n)
+    alpha = 10 ** rng.uniform(-2, 6, n)
+    p = alpha / (alpha + mean)
+    k = np.clip(np.rint(mean + rng.uniform(-4, 14, n) * np.sqrt(mean / p)), 0, 2e6)
+    for name in ("nb_pvalue_greater_midp", "nb_pvalue_greater", "nb_pvalue_exact", "nb_pvalue_midp"):
+        rel_close(getattr(M, name)(k, alpha, p), getattr(O, name)(k, alpha, p), RTOL)
+
+
 def test_element_stats_wide_range_vs_oracle():
     """Far outside the fixtures: rates 1e-2 .. 1e5, dispersion alpha 1e-2 .. 1e6, counts from four standard deviations below
     the mean to fourteen above (up to 2e6) -- the compacted pass's series, its saddle-point pmf and the scalar fallbacks

@@ -23,6 +23,11 @@ for i in range(128):
     lo = as_double(OFF + (i << 45))
     hi = as_double(OFF + ((i + 1) << 45))
     c = (mp.mpf(lo) + mp.mpf(hi)) / 2
+    if hi == 1.0:
+        # the bin below 1 takes c = 1 instead of its centre: r = z - 1 exactly (|r| <= 2^-8, inside the polynomial's range) and
+        # log z = log1p(r) without the cancellation logc + log1p(r) suffers for z -> 1 (absolute error 1e-18, relative
+        # 1e-12 at z = 1 - 4e-7: the logarithm of a success probability near 1 is multiplied by alpha ~ 1e6)
+        c = mp.mpf(1)
     invc = float(1 / c)
     logc = float(-mp.log(mp.mpf(invc)))
     rows.append((invc, logc))
