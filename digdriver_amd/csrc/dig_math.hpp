@@ -720,8 +720,16 @@ __device__ inline double nb_midp_upper_quad(double k, double alpha, double p, do
             }
             double excl;
             tk = fast_exp_neg(lp0) * quad_scan_product(N / D, sub, excl);
+        } else if (k <= 4096.0 && alpha <= 4096.0) {
+            // log pmf(k) = lgamma(k + alpha) - lgamma(k + 1) - lgamma(alpha) + alpha log p + k log(1 - p)  (scipy nbinom._logpmf), the
+            // three lgamma terms from Stirling's series on three lanes of the quad; at these sizes its terms are below 4e4
+            // and the cancellation costs at most 1e-11 (the usual case of a large element: a count of a few hundred)
+            const double lg = lgamma_stirling(sub == 0 ? k + alpha : sub == 1 ? k + 1.0 : alpha);
+            const double coeff = quad_perm<kQuadLane0>(lg) - quad_perm<kQuadLane1>(lg) - quad_perm<kQuadLane2>(lg);
+            const double lx = x >= 0.5 ? fast_log_normal(x) : log1p(-p);
+            tk = exp(coeff + lp0 + k * lx);
         } else {
-            tk = nb_pmf_saddle(k, alpha, p);        // no cancellation at any count (scipy's own lgamma form loses 2e-6 at k ~ 1e6)
+            tk = nb_pmf_saddle(k, alpha, p);        // no cancellation at any size (the lgamma form loses 2e-6 at k ~ 1e6)
         }
     }
     const bool upper = (alpha + k) * x < k + 1.0;
