@@ -656,9 +656,10 @@ __device__ inline double nb_midp_upper(double k, double alpha, double p)
 // inclusive scan and the sums by a butterfly, both as quad-permute DPP moves (no LDS traffic); a block is the last one
 // when the geometric bound of the remainder, last term x rho / (1 - rho), is below 2^-54 of the sum.
 // pmf(k): the streaming pass hands it over when it has it (a count <= kSmallK whose direct form cancelled: the usual
-// case); otherwise p^alpha times the product of the ratios below k (counts up to 64: one block), or Loader's saddle-point
-// form (nb_pmf_saddle: a count of 500 would take eight product blocks, and the 37 pairs of a large element reach the
-// pass together: its waves set the length of the kernel).  Anything unusual (arguments outside the support, a series still open after
+// case); otherwise p^alpha times the product of the ratios below k (counts up to 64: one block), or, for counts and
+// dispersions up to 4096, the lgamma form with the three Stirling terms on three lanes of the quad (a count of 500 would
+// take eight product blocks, and the 37 pairs of a large element reach the pass together: its waves set the length of
+// the kernel), or Loader's saddle-point form (nb_pmf_saddle) beyond, where the lgamma differences cancel.  Anything unusual (arguments outside the support, a series still open after
 // kQuadBlocks blocks: heavy tails with alpha << 1) goes to the scalar nb_midp_upper, which keeps scipy's semantics.
 // Every lane of the quad must call with the same arguments; the result is the same in all four.
 constexpr int kQuadTerms = 16;         // terms per lane and block
