@@ -533,13 +533,13 @@ def main():
             "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel + "
                           "element_stats_slow_kernel (one launch each, back to back)",
             "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
-            "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64)"}
+            "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64 + v_mfma_f64_4x4x4_f64 for the last 5 cohorts)"}
         stage_roofs = {k: roof(stage_names[k], stage_bytes[k], stage_ms[k], stage_kernels[k], len(samples[k]))
                        for k in ("statistics", "contexts", "dot")}
         if stage_ms["dot"]:
             # the dot stage is bound by the FP64 matrix pipe, not by HBM: SURVEY 8d counts 2 dots x 192 x 2 flops per
-            # (element, cohort); the kernel issues 2/3 of that (the 64 context sums of d_pr are formed once) on 48 of 37
-            # cohort columns
+            # (element, cohort); the kernel issues 2/3 of that (the 64 context sums of d_pr are formed once) on 40 columns for 37
+            # cohorts (two 16-column tiles + two 4-column quads)
             fl = 768.0 * E * C
             stage_roofs["dot"] = {"bound": "mfma", "kernel": stage_names["dot"], "achieved": fl / (stage_ms["dot"] * 1e-3) / 1e12,
                                   "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (stage_ms["dot"] * 1e-3) / 78.6e12,

@@ -220,8 +220,24 @@ constexpr int kMfmaWaves = DIG_MFMA_WAVES;
 constexpr int kMfmaSteps = 64;                // 256 K rows / 4
 constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
 
+// How the (at most 48) cohort columns of a chunk are cut: full 16-column tiles for v_mfma_f64_16x16x4, and, when what is
+// left over is 1..8 columns, one or two QUADS of four columns for v_mfma_f64_4x4x4 (four 4x4 blocks = the same sixteen
+// elements; a quad costs a quarter of a tile's matrix-pipe time, so 37 cohorts pay for 40 columns instead of 48).
+struct ChunkCut {
+    int nt, nq;      // full tiles, tail quads
+};
+__host__ __device__ inline ChunkCut chunk_cut(int C, int chunk)
+{
+    const int rem = C - chunk * 48 < 48 ? C - chunk * 48 : 48;
+    const int full = rem >> 4, r = rem & 15;
+    if (r == 0) return {full, 0};
+    if (r <= 8) return {full, (r + 3) >> 2};
+    return {full + 1, 0};
+}
+
 // tab[chunk][step = 4 t + u][nt][lane] = T[kappa = 16 t + 4 (lane / 16) + u][chunk * 48 + nt * 16 + lane % 16],
 // T = per-context sums (kappa < 64, d_pr[c][3 ctx .. 3 ctx + 2] summed as (a + b) + c) then d_pr[c][kappa - 64].
+// The slot after the full tiles holds the tail quads: entry 16 q + 4 k + j = T[16 t + 4 k + u][first tail column + 4 q + j].
 // (written by the first phase of acc_region_kernel, which precedes the dot kernel on the stream)
 __device__ __forceinline__ void acc_write_mfma_table(const double* __restrict__ d_pr, double* __restrict__ tab, int C,
                                                      int nchunk, int64_t first, int64_t step_)
@@ -230,10 +246,12 @@ __device__ __forceinline__ void acc_write_mfma_table(const double* __restrict__ 
     for (int64_t idx64 = first; idx64 < n; idx64 += step_) {
         const int idx = (int)idx64;
         const int lane = idx & 63, nt = (idx >> 6) % 3, step = (idx / 192) % kMfmaSteps, chunk = idx / (192 * kMfmaSteps);
-        const int kappa = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3);
-        const int c = chunk * kMfmaChunk + nt * 16 + (lane & 15);
+        const ChunkCut cut = chunk_cut(C, chunk);
+        const bool tail = cut.nq > 0 && nt == cut.nt;
+        const int kappa = 16 * (step >> 2) + 4 * (tail ? (lane >> 2) & 3 : lane >> 4) + (step & 3);
+        const int c = chunk * kMfmaChunk + nt * 16 + (tail ? 4 * (lane >> 4) + (lane & 3) : lane & 15);
         double v = 0.0;
-        if (c < C) {
+        if (c < C && (!tail || (lane >> 4) < cut.nq)) {
             const double* d = d_pr + (int64_t)c * 192;
             v = (kappa < 64) ? (d[3 * kappa] + d[3 * kappa + 1]) + d[3 * kappa + 2] : d[kappa - 64];
         }
@@ -382,10 +400,12 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
 //   * denominators (64 context rows) and numerators (192 substitution rows) use separate accumulators; the quotient
 //     and the integer element sizes are formed in registers and written once.
 // =======================================================================================
-template <int NT>
+template <int NT, int NQ>
 __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __restrict__ tab, int step0, int lane,
-                                           double4_t (&acc)[NT], int& isum)
+                                           int toff, double4_t (&acc)[NT > 0 ? NT : 1], double (&accq)[NQ > 0 ? NQ : 1],
+                                           int& isum)
 {
+    constexpr int SL = NT + (NQ > 0 ? 1 : 0);     // LDS slots per step
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int v[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
@@ -393,31 +413,40 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double A = (double)v[u];
-            const double* b = tab + ((step0 + 4 * t + u) * NT) * 64 + lane;
+            const double* b = tab + ((step0 + 4 * t + u) * SL) * 64 + lane;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, b[nt * 64], acc[nt], 0, 0, 0);
+            if constexpr (NQ > 0) {
+                // A[i][k] of block b sits in lane 16 k + 4 b + i: the same register as for the 16-row tile
+                const double* bq = tab + ((step0 + 4 * t + u) * SL + NT) * 64 + toff;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    accq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, bq[q * 16], accq[q], 0, 0, 0);
+            }
         }
     }
 }
 
-template <int NCLASS, int NT>
+template <int NCLASS, int NT, int NQ>
 __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
     const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
     const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
     int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
 {
-    extern __shared__ double tab[];           // [kMfmaSteps][NT][64]
+    extern __shared__ double tab[];           // [kMfmaSteps][SL][64]
+    constexpr int SL = NT + (NQ > 0 ? 1 : 0);
+    constexpr int NTA = NT > 0 ? NT : 1, NQA = NQ > 0 ? NQ : 1;
     {
         // stage this chunk's NT tiles of the pre-swizzled table (global layout: 3 tiles per step); all loads of a
         // thread are issued before its first LDS write
-        constexpr int kTotal = kMfmaSteps * NT * 64;
+        constexpr int kTotal = kMfmaSteps * SL * 64;
         constexpr int kPer = (kTotal + kMfmaWaves * 64 - 1) / (kMfmaWaves * 64);   // doubles per thread
         double v[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int idx = threadIdx.x + k * kMfmaWaves * 64;
-            const int lane_ = idx & 63, nt = (idx >> 6) % NT, step = idx / (NT * 64);
+            const int lane_ = idx & 63, nt = (idx >> 6) % SL, step = idx / (SL * 64);
             v[k] = idx < kTotal ? tab_g[(step * 3 + nt) * 64 + lane_] : 0.0;
         }
 #pragma unroll
@@ -428,6 +457,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
+    const int toff = 4 * kq + (lane & 3);     // B[k][j] of every block of a quad: lane 16 k + 4 b + j
     const int64_t n_tiles = (E + 15) >> 4;
     const int64_t n_waves = (int64_t)gridDim.x * kMfmaWaves;
     constexpr int G = 1 + 3 * NCLASS;         // 16-row groups per tile: contexts, then 3 per mutation class
@@ -457,7 +487,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
         const double* tabw = tab + opaque_zero;
         const int64_t e0 = tile * 16;
         const int64_t tile_next = tile + n_waves;
-        double4_t den[NT];
+        double4_t den[NTA];
+        double denq[NQA];
         int rsum = 0, lsum = 0;
         // group 0: the 64 context rows -> denominators
 #pragma unroll
@@ -469,15 +500,20 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) den[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-        mfma_group<NT>(cur, tabw, 0, lane, den, rsum);                  // sum(region_counts * d_pr), genic_driver_tools.py:361
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) denq[q] = 0.0;
+        mfma_group<NT, NQ>(cur, tabw, 0, lane, toff, den, denq, rsum);                  // sum(region_counts * d_pr), genic_driver_tools.py:361
 #pragma unroll 1
         for (int q = 0; q < NCLASS; ++q) {
             int opaque_zero_q;                                           // (same hoisting guard, per class)
             asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero_q));
             const double* tabq = tabw + opaque_zero_q;
-            double4_t num[NT];
+            double4_t num[NTA];
+            double numq[NQA];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) num[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) numq[qq] = 0.0;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {                                // sum(t_pi * L), :364-366
 #pragma unroll
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
 #pragma unroll
                     for (int t = 0; t < 4; ++t) nxt[t] = pn[4 * t];
                 }
-                mfma_group<NT>(cur, tabq, 16 + 16 * g, lane, num, lsum);
+                mfma_group<NT, NQ>(cur, tabq, 16 + 16 * g, lane, toff, num, numq, lsum);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -498,6 +534,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
                     for (int nt = 0; nt < NT; ++nt) {
                         const int c = c0 + nt * 16 + i;
                         if (c < C) P[(e * NCLASS + q) * C + c] = num[nt][r] / den[nt][r];
+                    }
+                }
+            }
+            if constexpr (NQ > 0) {
+                const int64_t e = e0 + 4 * ((lane >> 2) & 3) + kq;      // D[i][j] of block b: lane 16 i + 4 b + j
+                if (e < E) {
+#pragma unroll
+                    for (int qq = 0; qq < NQ; ++qq) {
+                        const int c = c0 + NT * 16 + 4 * qq + (lane & 3);
+                        if (c < C) P[(e * NCLASS + q) * C + c] = numq[qq] / denq[qq];
                     }
                 }
             }
@@ -546,8 +592,8 @@ static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cu_count(), (n_tiles + kMfmaWaves - 1) / kMfmaWaves));
     for (int ch = 0; ch < w.n48; ++ch) {
         const int c0 = ch * kMfmaChunk;
-        const int nt = (int)std::min<int64_t>(3, (C - c0 + 15) / 16);
-        const size_t lds = (size_t)kMfmaSteps * nt * 64 * sizeof(double);
+        const ChunkCut cut = chunk_cut((int)C, ch);
+        const size_t lds = (size_t)kMfmaSteps * (cut.nt + (cut.nq > 0)) * 64 * sizeof(double);
         const double* tab = w.tab + (int64_t)ch * kMfmaSteps * 3 * 64;
         auto go = [&](auto kern) -> int {
             DIG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -557,9 +603,17 @@ static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_
             return DIG_OK;
         };
         int rc;
-        if (nt == 3) rc = go(acc_dot_mfma_kernel<NCLASS, 3>);
-        else if (nt == 2) rc = go(acc_dot_mfma_kernel<NCLASS, 2>);
-        else rc = go(acc_dot_mfma_kernel<NCLASS, 1>);
+        switch (cut.nt * 3 + cut.nq) {
+        case 9: rc = go(acc_dot_mfma_kernel<NCLASS, 3, 0>); break;
+        case 6: rc = go(acc_dot_mfma_kernel<NCLASS, 2, 0>); break;
+        case 7: rc = go(acc_dot_mfma_kernel<NCLASS, 2, 1>); break;
+        case 8: rc = go(acc_dot_mfma_kernel<NCLASS, 2, 2>); break;
+        case 3: rc = go(acc_dot_mfma_kernel<NCLASS, 1, 0>); break;
+        case 4: rc = go(acc_dot_mfma_kernel<NCLASS, 1, 1>); break;
+        case 5: rc = go(acc_dot_mfma_kernel<NCLASS, 1, 2>); break;
+        case 1: rc = go(acc_dot_mfma_kernel<NCLASS, 0, 1>); break;
+        default: rc = go(acc_dot_mfma_kernel<NCLASS, 0, 2>); break;
+        }
         if (rc) return rc;
     }
     return DIG_OK;
