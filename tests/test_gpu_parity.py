@@ -284,7 +284,7 @@ def test_accumulate_tiled_and_genic_golden(torch_dev):
     assert np.array_equal(r["FLAG"][:, 0], v[:, col["FLAG"]].astype(np.int32))
 
 
-@pytest.mark.parametrize("C", [1, 37, 64, 70])
+@pytest.mark.parametrize("C", [1, 5, 12, 20, 33, 37, 48, 64, 70, 104])
 def test_accumulate_vs_oracle_multi_cohort(torch_dev, C):
     import torch
     from bench import make_workload
