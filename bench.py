@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--mode", choices=["sharded", "strong", "replicas"], default="sharded",
                     help="how N > 1 ranks divide the work (see the module docstring); all three are configs[2] at N = 1")
+    ap.add_argument("--contexts-on", choices=["main", "side"], default="main",
+                    help="stream of the pipeline's context stage (it depends on the step's inputs only, like the scale factors)")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed: the sequential evaluation the loop is checked against is repeated for this long before "
                          "the W warm-up steps (brings the GPU out of its idle power state; 0 = evaluate once)")
@@ -339,9 +341,21 @@ def main():
     step_no = [0]
 
     # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
-    pipe = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
-                               td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
-                               td["obs_indel"], out_acc=out_acc, out_stats=out_stats)
+    # --contexts-on side: the context stage of a step (strand-permuted context counts of the elements + the dot kernel's
+    # parameter table: inputs only) runs on the side stream behind that step's scale factors, up to 32 steps ahead of the
+    # main stream, which is left with the dot kernel and the statistics.  What the stage writes must then exist once per
+    # step in flight: a ring of plans, each with its own workspace (30 MB) and its own R_SIZE column; all other outputs
+    # are written by the main stream and shared.
+    ctx_side = args.contexts_on == "side"
+    PLAN_RING = 32 if ctx_side else 1
+
+    def make_plan(k):
+        acc_k = out_acc if k == 0 else dict(out_acc, R_SIZE=torch.empty_like(out_acc["R_SIZE"]))
+        return engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                   td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                                   td["obs_indel"], out_acc=acc_k, out_stats=out_stats)
+    pipes = [make_plan(k) for k in range(PLAN_RING)]
+    pipe = pipes[0]
     # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
     # exchanges nothing (its plan has world = 1)
     exchange = use_dist and (sharded or world == 1)
@@ -356,6 +370,14 @@ def main():
         cj_out = cj_outs[b]
         with torch.cuda.stream(side_stream):
             scale_plan.run(cj_out[0], cj_out[1], stream=side_stream)
+            if ctx_side:
+                # plan t % 32 was last used by step t - 32: the main stream's throttle event of step t - 16 (recorded
+                # in front of that step) says that everything up to step t - 17 has run
+                if t % THROTTLE_EVERY == 0 and t >= PLAN_RING:
+                    side_stream.wait_event(throttle_events[(t // THROTTLE_EVERY - 1) % len(throttle_events)])
+                which = sample_which(t)
+                staged("contexts", which, lambda: pipes[t % PLAN_RING].run(cj_out[0], cj_out[1], stages=1, stream=side_stream),
+                       side_stream)
             side_done[b].record(side_stream)
 
     queued = [-1]      # last step whose scale factors have been enqueued
@@ -383,18 +405,28 @@ def main():
         e.record(main_stream)
     torch.cuda.synchronize()
 
-    def staged(name, which, fn):
+    def staged(name, which, fn, stream=None):
         if which != name:
             return fn()
+        stream = stream or main_stream
         a, b_ = sample_events.pop(), sample_events.pop()
-        a.record(main_stream)
+        a.record(stream)
         fn()
-        b_.record(main_stream)
+        b_.record(stream)
         samples[name].append((a, b_))
+
+    def sample_which(t):
+        """The stage bracketed on step t (None: no bracket)."""
+        if not sampling[0]:
+            return None
+        if SAMPLE_EVERY == 4:       # short runs: statistics on steps 1 mod 4, dot / contexts in turn on 3 mod 4
+            return "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
+        return sample_slot.get(t % SAMPLE_EVERY)
 
     def step():
         # One step = wait for this step's scale factors (side stream, normally long done) + ONE dig_element_pipeline
-        # call on the main stream: context kernel, dot kernel, statistics stream pass, compacted pass, back to back.  On
+        # call on the main stream: context kernel (unless --contexts-on side put it behind the scale factors), dot kernel,
+        # statistics stream pass, compacted pass, back to back.  On
         # the sampled steps the call is split into its stages so that one of them can be bracketed by events.  All
         # outputs of accumulation and statistics are written every step; every step computes its own scale factors
         # from the bin tables.
@@ -415,15 +447,20 @@ def main():
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
         main_stream.wait_event(side_done[b])
-        which = sample_slot.get(t % SAMPLE_EVERY) if sampling[0] else None
-        if sampling[0] and SAMPLE_EVERY == 4:                  # short runs: statistics on steps 1 mod 4, dot / contexts in turn on 3 mod 4
-            which = "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
-        if which is None:
-            pipe.run(cj, cji, stages=7, stream=main_stream)
+        which = sample_which(t)
+        plan = pipes[t % PLAN_RING]
+        if ctx_side:
+            if which in (None, "contexts"):
+                plan.run(cj, cji, stages=2 | 4 | 8, stream=main_stream)
+            else:
+                staged("dot", which, lambda: plan.run(cj, cji, stages=2, stream=main_stream))
+                staged("statistics", which, lambda: plan.run(cj, cji, stages=4 | 8, stream=main_stream))
+        elif which is None:
+            plan.run(cj, cji, stages=7, stream=main_stream)
         else:
-            staged("contexts", which, lambda: pipe.run(cj, cji, stages=1, stream=main_stream))    # context kernel
-            staged("dot", which, lambda: pipe.run(cj, cji, stages=2, stream=main_stream))         # dot kernel
-            staged("statistics", which, lambda: pipe.run(cj, cji, stages=4 | 8, stream=main_stream))  # statistics (header cleared by the stages=1 call)
+            staged("contexts", which, lambda: plan.run(cj, cji, stages=1, stream=main_stream))    # context kernel
+            staged("dot", which, lambda: plan.run(cj, cji, stages=2, stream=main_stream))         # dot kernel
+            staged("statistics", which, lambda: plan.run(cj, cji, stages=4 | 8, stream=main_stream))  # statistics (header cleared by the stages=1 call)
 
     def barrier():
         torch.cuda.synchronize()
@@ -568,22 +605,26 @@ def main():
                                               "elements in all, about %d per GPU), all-gather of the per-cohort chunk sums every step",
                                     "replicas": "%d-bin genome replicated on each of %d GPUs, %d cohorts, %d elements in all (%d per GPU), "
                                                 "no exchange"}[args.mode] % (args.bins, world, C, E_total, E_total // world),
-                       "mode": args.mode, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
+                       "mode": args.mode, "contexts_on": args.contexts_on, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
                        "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if args.mode != "replicas" else "replicas x%d" % world},
             "roofline": dominant_roof,
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
-                "main stream": "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
-                               "acc_dot_mfma_kernel, element_stats_stream_fused_kernel, element_stats_slow_kernel",
-                "side stream": "scale factors of the coming steps, free-running (own buffers and event per step): "
+                "main stream": ("one dig_element_pipeline call per step (stages DOT | STATISTICS): acc_dot_mfma_kernel, "
+                                "element_stats_stream_fused_kernel, element_stats_slow_kernel" if ctx_side else
+                                "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
+                                "acc_dot_mfma_kernel, element_stats_stream_fused_kernel, element_stats_slow_kernel"),
+                "side stream": "what depends on a step's inputs only, for the coming steps (own buffers and event per step): "
                                "suffstats_chunk_stage1, suffstats_chunk_stage2 (+ all-gather of the chunk sums when N > 1), "
-                               "scale_factors_chunked_kernel",
+                               "scale_factors_chunked_kernel" +
+                               (", then the pipeline's CONTEXTS stage of that step (acc_region_kernel; a ring of 32 "
+                                "workspaces, at most 32 steps ahead of the main stream)" if ctx_side else ""),
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
-            "kernel_timing": "HIP events on the main stream (the stream the kernels are launched on): `roofline` and "
-                             "`roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` brackets "
-                             "all %d timed steps (side-stream reduction overlapped); rocprofv3 per-kernel averages of the "
-                             "same command: profiles/" % (SAMPLE_EVERY, args.steps),
+            "kernel_timing": "HIP events on the stream a stage is launched on (statistics and dot: main; contexts: %s): "
+                             "`roofline` and `roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` "
+                             "brackets all %d timed steps on the main stream (side-stream work overlapped); rocprofv3 per-kernel "
+                             "averages of the same command: profiles/" % (args.contexts_on, SAMPLE_EVERY, args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle,

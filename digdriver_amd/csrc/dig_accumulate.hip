@@ -217,6 +217,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // waves per workgroup (one workgroup per CU: the table takes <= 96 KB LDS): three per SIMD hide the LDS / HBM waits better
 // than two (127.7 -> 124.2 us per accumulate call); four would cap the kernel at 128 VGPRs and spill
 constexpr int kMfmaWaves = DIG_MFMA_WAVES;
+#ifndef DIG_MFMA_MINBLOCKS
+#define DIG_MFMA_MINBLOCKS 1
+#endif
 constexpr int kMfmaSteps = 64;                // 256 K rows / 4
 constexpr int kMfmaChunk = 48;                // cohorts per launch (3 B tiles)
 
@@ -429,7 +432,7 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 }
 
 template <int NCLASS, int NT, int NQ>
-__global__ __launch_bounds__(kMfmaWaves * 64, 1) void acc_dot_mfma_kernel(
+__global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_mfma_kernel(
     const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
     const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
     int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
