@@ -265,6 +265,11 @@ def main():
                     help="how N > 1 ranks divide the work (see the module docstring); all three are configs[2] at N = 1")
     ap.add_argument("--contexts-on", choices=["main", "side"], default="main",
                     help="stream of the pipeline's context stage (it depends on the step's inputs only, like the scale factors)")
+    ap.add_argument("--side-lead", type=int, default=0,
+                    help="the side stream starts the scale factors of step t when the main stream has finished step "
+                         "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
+    ap.add_argument("--settle-passes", type=int, default=100,
+                    help="untimed passes in the loop's two-stream form at the end of the settle phase")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed: the sequential evaluation the loop is checked against is repeated for this long before "
                          "the W warm-up steps (brings the GPU out of its idle power state; 0 = evaluate once)")
@@ -338,6 +343,7 @@ def main():
     main_stream = torch.cuda.current_stream(dev)
     side_stream = torch.cuda.Stream(device=dev, priority=-1)     # own hardware queue even when RCCL holds streams too
     side_done = [torch.cuda.Event() for _ in range(RING)]   # scale factors of a step are ready
+    main_done = [torch.cuda.Event() for _ in range(RING)]   # the main stream has finished a step (paces the side stream)
     step_no = [0]
 
     # argument marshalling once, outside the loop (a step is then a handful of ctypes calls: the host stays ahead)
@@ -369,6 +375,8 @@ def main():
         b = t % RING
         cj_out = cj_outs[b]
         with torch.cuda.stream(side_stream):
+            if args.side_lead > 0 and t >= args.side_lead:
+                side_stream.wait_event(main_done[(t - args.side_lead) % RING])
             scale_plan.run(cj_out[0], cj_out[1], stream=side_stream)
             if ctx_side:
                 # plan t % 32 was last used by step t - 32: the main stream's throttle event of step t - 16 (recorded
@@ -395,7 +403,7 @@ def main():
     # record, and a growing pool of them costs a one-off stall of tens of milliseconds at some point of the loop)
     n_sample_events = 2 * (4 * ((args.steps + args.warmup) // SAMPLE_EVERY + 2))
     sample_events = [torch.cuda.Event(enable_timing=True) for _ in range(n_sample_events)]
-    for e in side_done + sample_events:
+    for e in side_done + main_done + sample_events:
         e.record(main_stream)
     torch.cuda.synchronize()
 
@@ -461,6 +469,8 @@ def main():
             staged("contexts", which, lambda: plan.run(cj, cji, stages=1, stream=main_stream))    # context kernel
             staged("dot", which, lambda: plan.run(cj, cji, stages=2, stream=main_stream))         # dot kernel
             staged("statistics", which, lambda: plan.run(cj, cji, stages=4 | 8, stream=main_stream))  # statistics (header cleared by the stages=1 call)
+        if args.side_lead > 0:
+            main_done[b].record(main_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -472,6 +482,16 @@ def main():
     # --settle-ms.  A fresh process starts from the GPU's idle power state and a cold TLB / L2: with W = 5 warm-up
     # steps (1.5 ms of GPU time) the first timed steps ran 10-15 % slower than the sustained rate (BENCH_r01: 0.301 ms
     # at --steps 20 against 0.27-0.29 ms at --steps 1000).  This is setup work, not a step: no timed step depends on it.
+    # Python's cyclic collector must not run inside the loop: a full collection over the process's objects (torch, numpy,
+    # thousands of events and closures) takes 30-40 ms -- 150 steps' worth of GPU time; with K = 200 it used to land in the
+    # timed region every time (BENCH_TRACE=1: one 38 ms enqueue), with K = 20 or 1000 it did not.  It is collected and
+    # switched off HERE, in front of the settle phase: between the settle phase and the first warm-up step it left the GPU
+    # idle for 40 ms, and the first ~30 steps after such a pause run up to 15 % slower (rocprofv3 kernel trace of a
+    # W = 40 run: stream pass 137 -> 154 us, dot kernel 55 -> 74 us at steps 8-22 of the loop, back to normal by step 34;
+    # the barrier in front of the timed region, 0.2 ms, does not do that).
+    import gc
+    gc.collect()
+    gc.disable()
     seq_cj = torch.empty(C, dtype=torch.float64, device=dev)
     seq_cji = torch.empty(C, dtype=torch.float64, device=dev)
     scale_plan.run(seq_cj, seq_cji)                  # (a collective when the bins are sharded: every rank is here)
@@ -490,13 +510,20 @@ def main():
         if (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms:
             break
     torch.cuda.synchronize()
+    # ... and the side stream with it: the sequential evaluation above never touches the side stream's hardware queue, and
+    # the first ~15 steps after its first use run 10 % slower (BENCH_TRACE=1: statistics-stage brackets of 196 us at timed
+    # steps 5-13 of a W = 5 run against 170-177 before and after; with W = 50 none).  A fixed number of untimed passes in
+    # the loop's own form (the same count on every rank: the side stream's all-gather is a collective).
+    reh_cj, reh_cji = torch.empty_like(seq_cj), torch.empty_like(seq_cji)
+    reh_ev = torch.cuda.Event()
+    for _ in range(args.settle_passes):
+        with torch.cuda.stream(side_stream):
+            scale_plan.run(reh_cj, reh_cji, stream=side_stream)
+            reh_ev.record(side_stream)
+        main_stream.wait_event(reh_ev)
+        pipe.run(seq_cj, seq_cji, stages=7, stream=main_stream)
+    torch.cuda.synchronize()
     settle_ms = (time.perf_counter() - t_settle) * 1e3
-    # Python's cyclic collector must not run inside the loop: a full collection over the process's objects (torch, numpy,
-    # thousands of events and closures) takes 30-40 ms -- 150 steps' worth of GPU time; with K = 200 it used to land in the
-    # timed region every time (BENCH_TRACE=1: one 38 ms enqueue), with K = 20 or 1000 it did not.
-    import gc
-    gc.collect()
-    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -531,6 +558,9 @@ def main():
         dt = float(tmax.item())
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
     stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
+    if trace is not None and rank == 0:
+        print("BENCH_TRACE statistics-stage samples (us):", [round(a.elapsed_time(b_) * 1e3, 1) for a, b_ in samples["statistics"]][:40],
+              file=sys.stderr)
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
     torch.cuda.synchronize()
@@ -627,7 +657,7 @@ def main():
                              "averages of the same command: profiles/" % (args.contexts_on, SAMPLE_EVERY, args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
-            "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle,
+            "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle, "two_stream_passes": args.settle_passes,
                                "what": "the sequential evaluation the loop is checked against, repeated before the warm-up steps"},
         }
         if args.cpu_sample > 0 and world == 1:
