@@ -372,12 +372,19 @@ struct StageBin {            // tile t+1
 // shares the waves of a SIMD finish one after the other (the arbiter issues oldest-first): rocprofv3 shows an average wave
 // lifetime of 68 % of the kernel's duration with the VALU 85 % busy while waves are resident -- the tail, where a SIMD is
 // down to one or two waves, is where the pass loses its time.  With a shared queue all waves of a CU end together.
+#ifdef DIG_ES_TIMING
+// developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
+__device__ unsigned long long g_es_t0[1024], g_es_t1[1024];
+#endif
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
 #endif
 template <int TB, bool TICKETS>
 __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
+#ifdef DIG_ES_TIMING
+    if (threadIdx.x == 0) g_es_t0[blockIdx.x & 1023] = wall_clock64();
+#endif
     __shared__ unsigned park_all[TB / 64][kParkCap];
     __shared__ unsigned s_ticket;
     if (TICKETS && threadIdx.x == 0) s_ticket = 0;
@@ -543,6 +550,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         DIG_STREAM_STORE(&a.out[6 * n + i], pv_mut);
     }
     if (parked) park_flush(a.worklist, park, parked, lane);
+#ifdef DIG_ES_TIMING
+    if (lane == 0) atomicMax(&g_es_t1[blockIdx.x & 1023], (unsigned long long)wall_clock64());
+#endif
 }
 
 // Pass 2: the compacted slow pairs.  Pass 1 left every test it could not finish NEGATIVE in its p-value plane (counts
@@ -746,6 +756,19 @@ static int host_nb3(const double* k, const double* alpha, const double* p, doubl
 using namespace dig;
 
 extern "C" {
+
+#ifdef DIG_ES_TIMING
+int dig_debug_es_timing(unsigned long long* out2048)
+{
+    DIG_HIP_TRY(hipDeviceSynchronize());
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out2048, HIP_SYMBOL(dig::g_es_t0), 1024 * sizeof(unsigned long long)));
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out2048 + 1024, HIP_SYMBOL(dig::g_es_t1), 1024 * sizeof(unsigned long long)));
+    static unsigned long long z[1024] = {};
+    DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dig::g_es_t1), z, sizeof(z)));
+    return DIG_OK;
+}
+#endif
+
 
 int dig_nb_midp_upper(const double* k, const double* alpha, const double* p, double* out, int64_t n, void* stream)
 {

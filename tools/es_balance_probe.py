@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""When do the workgroups of the statistics stream pass finish?  (developer probe; needs a -DDIG_ES_TIMING build)
+
+    DIG_HIP_LIB=.../es_timing.so python tools/es_balance_probe.py
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_workload          # noqa: E402
+from digdriver_amd import _lib, engine   # noqa: E402
+
+dev = torch.device("cuda:0")
+E, C = 120091, 37
+w = make_workload(288000, E, C, seed=3)
+td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"],
+                           td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+s = torch.cuda.current_stream(dev)
+lib = _lib.load()
+fn = lib.dig_debug_es_timing
+fn.argtypes = [ctypes.c_void_p]
+buf = np.zeros(2048, np.uint64)
+for _ in range(50):
+    plan.run(td["cj"], td["cj_indel"], stages=7, stream=s)
+torch.cuda.synchronize()
+fn(buf.ctypes.data)
+for rep in range(3):
+    plan.run(td["cj"], td["cj_indel"], stages=7, stream=s)
+    torch.cuda.synchronize()
+    fn(buf.ctypes.data)
+    t0, t1 = buf[:256].astype(np.int64), buf[1024:1280].astype(np.int64)
+    base = t0.min()
+    start = (t0 - base) / 100.0          # us
+    end = (t1 - base) / 100.0
+    print("starts: min %.1f max %.1f | ends: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f us | mean idle at the end %.1f us"
+          % (start.min(), start.max(), end.min(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max(),
+             (end.max() - end).mean()))
+    byx = [(end[x::8].mean(), end[x::8].max()) for x in range(8)]
+    print("  per XCD (mean, max):", " ".join("%.0f/%.0f" % b for b in byx))
