@@ -688,6 +688,67 @@ def gen_cnn():
              first_conv_w_sum=np.float64(net.conv11.weight.double().sum().item()))
 
 
+# ----------------------------------------------------------------------------
+# (vi-b) one CNN training epoch + evaluation through the reference's NNTrainer (nn_trainer.py:17-141)
+# ----------------------------------------------------------------------------
+def gen_nn_training():
+    """A seeded SimpleMultiTaskResNet (weights regenerated from the seed by the test), ten training and four validation
+    bins, batch size 4 (3 batches: 4, 4, 2), one NNTrainer.train epoch (Adam 1e-3, summed per-task MSE, train-mode
+    BatchNorm, features captured DURING the epoch) followed by NNTrainer.test.  The DataLoader's shuffle order is
+    recovered from the labels the trainer returns (they are distinct) and stored, so that the other side can visit
+    the bins in the same order."""
+    import importlib.util
+    import torch
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    cnn = load("ref_cnn_t", "DIGDriver/region_model/nets/cnn_predictors.py")
+    ref_tr = load("ref_nn_trainer", "DIGDriver/region_model/trainers/nn_trainer.py")
+    T, L, C, n_train, n_val, bs = 6, 100, 2, 10, 4, 4
+    gx = torch.Generator().manual_seed(6)
+    x = torch.round(torch.rand(n_train + n_val, L, T, generator=gx), decimals=2) * 100
+    labels = torch.rand(C, n_train + n_val, generator=gx) * 10
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, rows):
+            self.rows = rows
+
+        def __len__(self):
+            return len(self.rows)
+
+        def __getitem__(self, i):
+            r = self.rows[i]
+            return x[r], [labels[c][r] for c in range(C)]
+
+    torch.manual_seed(5)
+    net = cnn.SimpleMultiTaskResNet((n_train, L, T), C)
+    w0 = np.float64(net.conv11.weight.double().sum().item())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, amsgrad=False)
+    trainer = ref_tr.NNTrainer(net, opt, torch.nn.MSELoss(), bs, ["a", "b"], DS(list(range(n_train))),
+                               DS(list(range(n_train, n_train + n_val))), torch.device("cpu"))
+    torch.manual_seed(7)                       # the shuffle of the epoch
+    # cnn_predictors.py:148,153,158 add the residual IN PLACE to a ReLU output that ReLU's backward has saved: torch 2.x
+    # refuses the backward pass ("modified by an inplace operation").  allow_mutation_on_saved_tensors keeps a copy of
+    # the saved tensor as it was, i.e. the gradient of the network as written; nothing of the reference is changed.
+    with torch.autograd.graph.allow_mutation_on_saved_tensors():
+        tl, ta, feats, preds, true = trainer.train(1, 0, print_interval=100)   # (:76 divides by int(batches * interval / 100))
+    lab0 = labels[0].numpy()
+    order = np.array([int(np.argmin(np.abs(lab0 - v))) for v in true[0]])
+    assert sorted(order.tolist()) == list(range(n_train))
+    vl, va, vfeats, vpreds, vtrue, _ = trainer.test(1, 0)
+    save_npz("nn_training_golden.npz", x=x.numpy(), labels=labels.numpy(), shape=np.array([T, L, C, n_train, n_val, bs]),
+             first_conv_w_sum_before=w0, order=order, train_losses=tl, train_accs=ta,
+             train_features=np.stack([np.stack(f) for f in feats]), train_preds=np.array(preds),
+             val_losses=np.array([float(v) for v in vl]), val_accs=va, val_features=np.stack(vfeats), val_preds=np.array(vpreds),
+             first_conv_w_sum_after=np.float64(net.conv11.weight.double().sum().item()),
+             fc_w_sum_after=np.float64(sum(p.double().sum().item() for n_, p in net.named_parameters() if n_.startswith("fc") or "fc" in n_)),
+             bn_running_mean_sum=np.float64(sum(m.running_mean.double().sum().item() for m in net.modules()
+                                                if isinstance(m, torch.nn.BatchNorm1d))))
+
+
 class _FakeFasta:
     """pysam.FastaFile look-alike over an in-memory genome: fetch(chrom, start, end) returns the stored text
     (case preserved), truncated at the end of the chromosome like pysam does."""
@@ -919,6 +980,9 @@ def main():
     if "--only-run-element" in sys.argv:
         gen_run_element_expectation()
         return
+    if "--only-nn-training" in sys.argv:
+        gen_nn_training()
+        return
     gen_nb_midp()
     gen_nb_exact()
     gen_element_stats()
@@ -929,6 +993,7 @@ def main():
     gen_mutation_tools()
     gen_sequence_model(df_empty)
     gen_cnn()
+    gen_nn_training()
     gen_contexts()
     gen_sites()
     gen_tiled()

@@ -227,3 +227,45 @@ def test_sgpr_long_dimension_products_match_plain_matmuls():
     assert torch.allclose(torch.autograd.grad(c1.sin().sum(), Z)[0], torch.autograd.grad(c2.sin().sum(), Z)[0], rtol=1e-10, atol=1e-8)
     L = torch.linalg.cholesky(torch.eye(m, dtype=torch.float64) * 3 + 0.1 * (S.detach() @ S.detach().T))
     assert torch.allclose(G._lower_solve(L, X.detach()), torch.linalg.solve_triangular(L, X.detach(), upper=False), rtol=1e-10, atol=1e-10)
+
+
+def test_nn_trainer_epoch_matches_reference_trainer():
+    """One NNTrainer.train epoch + NNTrainer.test against the reference's own trainer (nn_trainer.py:40-141) run on the
+    same seeded network, bins and visiting order (tests/golden/make_golden.py::gen_nn_training): summed per-task MSE,
+    Adam(1e-3), train-mode BatchNorm, a last batch of two, features captured during the epoch, then eval-mode scores."""
+    from torch import nn, optim
+    from digdriver_amd.region_model.trainers.nn_trainer import NNTrainer
+    d = np.load(os.path.join(GOLDEN, "nn_training_golden.npz"))
+    T, L, C, n_train, n_val, bs = [int(v) for v in d["shape"]]
+    x = torch.tensor(d["x"])
+
+    class Store:                                   # BinTrackStore's interface on the CPU
+        def batch(self, rows, channels_first=True, out_dtype="f32"):
+            b = x[torch.as_tensor(np.asarray(rows), dtype=torch.long)]
+            return b.transpose(1, 2).contiguous() if channels_first else b
+
+    class Order:                                   # the reference DataLoader's shuffle, as recorded
+        def permutation(self, rows):
+            assert sorted(np.asarray(rows).tolist()) == list(range(n_train))
+            return d["order"].copy()
+
+    torch.manual_seed(5)
+    net = SimpleMultiTaskResNet((n_train, L, T), C)
+    assert net.conv11.weight.double().sum().item() == float(d["first_conv_w_sum_before"])
+    tr = NNTrainer(net, optim.Adam(net.parameters(), lr=1e-3, amsgrad=False), nn.MSELoss(), bs, ["a", "b"], Store(),
+                   np.arange(n_train), np.arange(n_train, n_train + n_val), list(d["labels"]), torch.device("cpu"))
+    tr.rng = Order()
+    losses, accs, feats, preds, true = tr.train(1)
+    np.testing.assert_array_equal(tr.last_train_rows, d["order"])
+    np.testing.assert_allclose(np.stack(true), d["labels"][:, d["order"]], rtol=0, atol=0)
+    np.testing.assert_allclose(losses, d["train_losses"], rtol=2e-4)
+    np.testing.assert_allclose(accs, d["train_accs"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(np.stack(preds), d["train_preds"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(np.stack(feats), d["train_features"], rtol=2e-3, atol=2e-3)   # (16 ReLU outputs per bin: some sit at the kink)
+    assert abs(net.conv11.weight.double().sum().item() - float(d["first_conv_w_sum_after"])) < 2e-3
+    bn_sum = sum(m.running_mean.double().sum().item() for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d))
+    assert abs(bn_sum - float(d["bn_running_mean_sum"])) < 1e-2 * max(1.0, abs(float(d["bn_running_mean_sum"])))
+    vl, va, vfeats, vpreds, vtrue, _ = tr.test(1)
+    np.testing.assert_allclose(vl, d["val_losses"], rtol=5e-3)
+    np.testing.assert_allclose(np.stack(vpreds), d["val_preds"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(np.stack(vfeats), d["val_features"], rtol=5e-3, atol=5e-3)
