@@ -349,6 +349,33 @@ class PipelinePlan:
         return self.acc, self.stats
 
 
+class PlanRing:
+    """Several PipelinePlans -- one per batch in flight, each with its own outputs and workspace -- taking turns on as
+    many streams.  A pass is a chain of four dependent kernels (contexts -> dot -> stream pass -> compacted pass) and each
+    of them leaves part of the chip idle while it ramps up and while its last waves finish; with two passes over
+    different batches in flight the kernels of one fill those gaps of the other: 186 us per pass against 207 us one
+    after the other on an MI355X at the whole-genome x 37-cohort size (tools/overlap_probe.py).  The caller keeps the
+    order of the passes on ONE plan (they share a stream); passes on different plans are independent."""
+
+    def __init__(self, plans, streams=None):
+        import torch
+        self.plans = list(plans)
+        assert self.plans, "at least one plan"
+        dev = self.plans[0].dev
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(device=dev) for _ in self.plans]
+        assert len(self.streams) == len(self.plans)
+
+    def run(self, k, cj, cj_indel):
+        """Enqueue pass k on plan k mod len(plans); returns that plan's (accumulation outputs, statistics planes), valid
+        once the plan's stream has been synchronised."""
+        j = k % len(self.plans)
+        return self.plans[j].run(cj, cj_indel, stream=self.streams[j])
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+
 class ScaleFactorPlan:
     """dig_scale_factors_local with cached arguments (see PipelinePlan)."""
 

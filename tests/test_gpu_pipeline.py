@@ -199,3 +199,36 @@ def test_scale_factors_local_equals_two_step_form():
         tot2 = engine.scale_suffstats(mu, fl)
         cj2, cji2 = engine.scale_factors_from_parts(torch.stack([tot2, ns, ni]).unsqueeze(0).contiguous())
         assert torch.equal(tot, tot2) and torch.equal(cj, cj2) and torch.equal(cji, cji2)
+
+
+def test_plan_ring_two_batches_in_flight():
+    """engine.PlanRing: two batches (different elements, observations and scale factors) alternating on two streams give,
+    pass for pass, the bits of the same plans run one after the other on one stream."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from bench import make_workload
+    torch_dev = torch.device("cuda:0")
+    from digdriver_amd import engine
+    plans, cjs = [], []
+    for seed, E in ((21, 3000), (22, 4100)):
+        w = make_workload(n_bins=5000, n_elements=E, n_cohorts=37, seed=seed)
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        plans.append(engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                         td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                                         td["obs_indel"]))
+        cjs.append((td["cj"], td["cj_indel"]))
+    want = []
+    for plan, (cj, cji) in zip(plans, cjs):            # one after the other, current stream
+        acc, st = plan.run(cj, cji)
+        torch.cuda.synchronize()
+        want.append(({k: v.clone() for k, v in acc.items()}, st.clone()))
+        st.fill_(-5.0)
+        acc["P"].fill_(-5.0)
+    ring = engine.PlanRing(plans)
+    for k in range(6):
+        ring.run(k, *cjs[k % 2])
+    ring.synchronize()
+    for plan, (acc_w, st_w) in zip(plans, want):
+        assert torch.equal(torch.nan_to_num(plan.stats, nan=-7.0), torch.nan_to_num(st_w, nan=-7.0))
+        for name in acc_w:
+            assert torch.equal(plan.acc[name], acc_w[name]), name
