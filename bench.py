@@ -434,7 +434,7 @@ def main():
     def step():
         # One step = wait for this step's scale factors (side stream, normally long done) + ONE dig_element_pipeline
         # call on the main stream: context kernel (unless --contexts-on side put it behind the scale factors), dot kernel,
-        # statistics stream pass, compacted pass, back to back.  On
+        # statistics stream pass (which finishes its own slow pairs), back to back.  On
         # the sampled steps the call is split into its stages so that one of them can be bracketed by events.  All
         # outputs of accumulation and statistics are written every step; every step computes its own scale factors
         # from the bin tables.
@@ -575,7 +575,8 @@ def main():
     slow_frac = None
     if ws is not None:
         off = (_lib.workspace_bytes("accumulate", E, C) + 255) // 256 * 256
-        slow_frac = float(ws[off + 8:off + 12].view(torch.int32)[0].item()) / (E * C)    # header [2]: length of the last worklist
+        hdr = ws[off:off + 16].view(torch.int32)     # header [2] + [3]: pairs finished from the worklist / from the LDS queues
+        slow_frac = float(int(hdr[2].item()) + int(hdr[3].item())) / (E * C)
 
     if rank == 0:
         units = float(E_total) * C * args.steps
@@ -597,8 +598,8 @@ def main():
                     "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms, "launches_timed": n}
 
         stage_names = {
-            "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel + "
-                          "element_stats_slow_kernel (one launch each, back to back)",
+            "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel (one launch: the "
+                          "stream pass and, at the end of every workgroup, the pairs it could not finish in passing)",
             "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
             "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64 + v_mfma_f64_4x4x4_f64 for the last 5 cohorts)"}
         stage_roofs = {k: roof(stage_names[k], stage_bytes[k], stage_ms[k], stage_kernels[k], len(samples[k]))
@@ -642,9 +643,9 @@ def main():
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
                 "main stream": ("one dig_element_pipeline call per step (stages DOT | STATISTICS): acc_dot_mfma_kernel, "
-                                "element_stats_stream_fused_kernel, element_stats_slow_kernel" if ctx_side else
+                                "element_stats_stream_fused_kernel" if ctx_side else
                                 "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
-                                "acc_dot_mfma_kernel, element_stats_stream_fused_kernel, element_stats_slow_kernel"),
+                                "acc_dot_mfma_kernel, element_stats_stream_fused_kernel"),
                 "side stream": "what depends on a step's inputs only, for the coming steps (own buffers and event per step): "
                                "suffstats_chunk_stage1, suffstats_chunk_stage2 (+ all-gather of the chunk sums when N > 1), "
                                "scale_factors_chunked_kernel" +

@@ -372,6 +372,77 @@ struct StageBin {            // tile t+1
 // shares the waves of a SIMD finish one after the other (the arbiter issues oldest-first): rocprofv3 shows an average wave
 // lifetime of 68 % of the kernel's duration with the VALU 85 % busy while waves are resident -- the tail, where a SIMD is
 // down to one or two waves, is where the pass loses its time.  With a shared queue all waves of a CU end together.
+// ---- pass 2 inside the fused stream pass ---------------------------------------------------------------------------
+// The pairs a wave cannot finish (0.8 % on the bench workload) go into a QUEUE OF RECORDS in the workgroup's LDS -- the
+// three p-value slots as pass 1 left them, the counts and the two parameter pairs: everything pass 2 needs, nothing is
+// read back from memory.  When the workgroup has run out of tiles its 16 waves empty the queue together, eight pairs
+// per wave and round, with the quad series of the compacted pass, and overwrite their markers.  (Finishing them in the
+// wave that found them was measured first: +30 us -- the 37 pairs of a large element park together, in ONE wave, and
+// that wave then runs five rounds on its own while its SIMD waits for it.)  A queue that is full (more than
+// kQueueCap parked pairs in one workgroup: 6 % of its pairs) overflows into the workgroup's OWN segment of the global
+// worklist (pair indices only), which the same workgroup works off after its queue in the manner of the compacted kernel
+// -- it reads back what its own waves wrote, through its own L1: no other workgroup is involved.  No kernel follows.
+#ifndef DIG_ES_INWAVE
+#define DIG_ES_INWAVE 1
+#endif
+constexpr int kQueueCap = 1024;        // records per workgroup
+constexpr int kRecDoubles = 11;        // [0..2] p-value slots, [3..5] counts, [6] alpha, [7] p, [8] [9] the indel pair, [10] pair index
+__shared__ double g_queue[kQueueCap * kRecDoubles];
+__shared__ unsigned g_queue_list[16][48];
+__shared__ unsigned g_queue_len, g_queue_next, g_ovf_len, g_ovf_next;
+constexpr int kSlowBlock = 256;
+constexpr int kSlowWaves = kSlowBlock / 64;
+constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
+constexpr int kOverflowSlack = 64 * 1024;      // entries behind the n of the worklist: each workgroup's segment is rounded up to whole tiles
+__device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsigned* __restrict__ items, unsigned base,
+                                           unsigned count, bool have_first, unsigned first_item, double (*sp_all)[10],
+                                           unsigned* list, int64_t n);
+
+// one round: the records [base, base + batch) of the queue (fewer at its end; batch <= 16), by one wave
+__device__ __forceinline__ void queue_round(int wave, int base, int batch, int count, double* __restrict__ out, int64_t n)
+{
+    const int lane = threadIdx.x & 63, quad = lane >> 2, sub = lane & 3;
+    unsigned* list = g_queue_list[wave];
+    const bool owner = lane < batch && base + lane < count;
+    double* mine = g_queue + (base + (lane & 15)) * kRecDoubles;
+    unsigned open = 0;
+    if (owner)
+        open = (__double_as_longlong(mine[0]) < 0 ? 1u : 0u) | (__double_as_longlong(mine[1]) < 0 ? 2u : 0u) |
+               (__double_as_longlong(mine[2]) < 0 ? 4u : 0u);
+    // bit 16 role + slot of W <-> test (role, pair slot)
+    const unsigned long long W = ((unsigned long long)__ballot(open & 1u) & 0xffffull) |
+                                 (((unsigned long long)__ballot(open & 2u) & 0xffffull) << 16) |
+                                 (((unsigned long long)__ballot(open & 4u) & 0xffffull) << 32);
+    const int n_tests = __popcll(W);
+    if (lane < 48 && ((W >> lane) & 1ull)) list[__popcll(W & ((1ull << lane) - 1ull))] = (unsigned)lane;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are in
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < n_tests; t0 += 16) {             // sixteen open tests at a time, one quad each
+        const int t = t0 + quad;
+        const bool active = t < n_tests;
+        const unsigned bit = list[active ? t : 0];
+        const int role = (int)(bit >> 4), slot = (int)(bit & 15u);
+        double* sp = g_queue + (base + slot) * kRecDoubles;
+        const double marker = sp[role];                     // -pmf(k), or -2: pmf(k) not known
+        const double k = sp[3 + role];
+        const double al = sp[role == 2 ? 8 : 6], pp = sp[role == 2 ? 9 : 7];
+        const double pv = nb_midp_upper_quad(k, al, pp, marker == -2.0 ? -1.0 : -marker, sub);
+        if (active && sub == 0) sp[role] = pv;              // (nobody else reads this test's slot)
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (owner) {
+        const int64_t item = __double_as_longlong(mine[10]);
+        const double pv_snv = mine[0], pv_smp = mine[1], pv_ind = mine[2];
+        out[1 * n + item] = pv_snv;
+        out[2 * n + item] = pv_smp;
+        out[5 * n + item] = pv_ind;
+        out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // (the list is rewritten in the next round)
+    __builtin_amdgcn_wave_barrier();
+}
+
 #ifdef DIG_ES_TIMING
 // developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
 __device__ unsigned long long g_es_t0[1024], g_es_t1[1024];
@@ -388,6 +459,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     __shared__ unsigned park_all[TB / 64][kParkCap];
     __shared__ unsigned s_ticket;
     if (TICKETS && threadIdx.x == 0) s_ticket = 0;
+#if DIG_ES_INWAVE
+    if (TB == 1024 && TICKETS && threadIdx.x == 0) g_queue_len = g_queue_next = g_ovf_len = g_ovf_next = 0;
+#endif
     nb_tables_init();
     unsigned* park = park_all[threadIdx.x >> 6];
     const int64_t n = a.E * a.C;
@@ -486,8 +560,20 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     int64_t tile_n1 = tile_ptr;
     StageBin bin_c = fetch_bin(in_c);
     unsigned parked = 0;   // wave-uniform
+    // the wave's parked pair indices leave LDS for the global worklist; the in-kernel form keeps one segment per workgroup
+    // (ceil(tiles per workgroup) x 64 entries: it cannot overflow)
+    const bool own_segment = DIG_ES_INWAVE && TB == 1024 && TICKETS;
+    unsigned* segment = a.worklist + kWorkHeader + (own_segment ? (int64_t)blockIdx.x * (((n_tiles + gridDim.x - 1) / gridDim.x) << 6) : 0);
+    auto flush = [&](unsigned count) -> unsigned {
+        if (!own_segment) return park_flush(a.worklist, park, count, lane);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&g_ovf_len, count);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        for (unsigned j = lane; j < count; j += 64) segment[base + j] = park[j];
+        return 0;
+    };
     for (; tile < n_tiles; tile = TICKETS ? tile_n1 : tile + n_waves) {
-        if (parked > (unsigned)(kParkCap - 64)) parked = park_flush(a.worklist, park, parked, lane);
+        if (parked > (unsigned)(kParkCap - 64)) parked = flush(parked);
         const bool live = tile * 64 + lane < n;
         const StageIn cur = in_c;
         const StageBin bin = bin_c;
@@ -534,8 +620,26 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         double pv_mut = 0.0;
         if (!slow) pv_mut = fisher_combine_fast(pv_snv, pv_ind);
         bin_c = fetch_bin(in_c);         // tile t+1: bin rates (requested BEFORE this tile's stores)
-        const unsigned long long m = __ballot(slow);
-        if (slow) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
+        unsigned long long m = __ballot(slow);
+#if DIG_ES_INWAVE
+        if (TB == 1024 && TICKETS && m) {                   // into the workgroup's queue; what does not fit goes the old way
+            const unsigned cnt = (unsigned)__popcll(m);
+            unsigned qb = 0;
+            if (lane == 0) qb = atomicAdd(&g_queue_len, cnt);
+            qb = (unsigned)__builtin_amdgcn_readfirstlane((int)qb);
+            const unsigned slot = qb + (unsigned)__popcll(m & lanes_below);
+            const bool fits = slot < (unsigned)kQueueCap;
+            if (slow && fits) {
+                double* r = g_queue + slot * kRecDoubles;
+                r[0] = pv_snv; r[1] = pv_smp; r[2] = pv_ind;
+                r[3] = q.k_snv; r[4] = q.k_smp; r[5] = q.k_ind;
+                r[6] = q.alpha; r[7] = q.p; r[8] = q.alpha_i; r[9] = q.p_i;
+                r[10] = __longlong_as_double((long long)i);
+            }
+            m = __ballot(slow && !fits);
+        }
+#endif
+        if (slow && ((m >> lane) & 1ull)) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
         parked += (unsigned)__popcll(m);
         DIG_STREAM_STORE(&a.mu_w[i], w.mu);
         DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
@@ -549,7 +653,39 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         DIG_STREAM_STORE(&a.out[5 * n + i], pv_ind);
         DIG_STREAM_STORE(&a.out[6 * n + i], pv_mut);
     }
-    if (parked) park_flush(a.worklist, park, parked, lane);
+    if (parked) flush(parked);
+#if DIG_ES_INWAVE
+    if (TB == 1024 && TICKETS) {
+        __syncthreads();                                    // every wave of the workgroup is out of tiles: the queue is complete
+        const int total = (int)min(g_queue_len, (unsigned)kQueueCap);
+        if (threadIdx.x == 0 && total) atomicAdd(&a.worklist[3], (unsigned)total);     // diagnostic: pairs finished here
+        // one round per wave while the queue holds up to 256 records (the usual case: 143 on the bench workload), rounds
+        // of sixteen beyond
+        const int batch = min(16, max(1, (total + TB / 64 - 1) / (TB / 64)));
+        for (;;) {
+            unsigned b = 0;
+            if (lane == 0) b = atomicAdd(&g_queue_next, (unsigned)batch);
+            b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+            if ((int)b >= total) break;
+            queue_round((int)(threadIdx.x >> 6), (int)b, batch, total, a.out, n);
+        }
+        const unsigned ovf = g_ovf_len;                     // (final since the barrier above)
+        if (ovf) {
+            // the pairs the queue had no room for: their indices are in this workgroup's segment, their markers in the
+            // planes -- written by this workgroup's waves, all of which have passed the barrier (vmcnt(0) in front of it)
+            __syncthreads();                                // the queue's LDS is free: 80 doubles per wave of it become the pair buffers
+            if (threadIdx.x == 0) atomicAdd(&a.worklist[2], ovf);
+            double (*sp)[10] = reinterpret_cast<double (*)[10]>(g_queue + (threadIdx.x >> 6) * (kSlowPairsPerWave * 10));
+            for (;;) {
+                unsigned b = 0;
+                if (lane == 0) b = atomicAdd(&g_ovf_next, (unsigned)kSlowPairsPerWave);
+                b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= ovf) break;
+                slow_round(a, segment, b, ovf, false, 0u, sp, g_queue_list[threadIdx.x >> 6], n);
+            }
+        }
+    }
+#endif
 #ifdef DIG_ES_TIMING
     if (lane == 0) atomicMax(&g_es_t1[blockIdx.x & 1023], (unsigned long long)wall_clock64());
 #endif
@@ -562,9 +698,64 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 // of 500 costs a few hundred dependent instructions instead of 4 500); then one lane per pair combines SNV and indel and
 // writes the four p-value planes.  Rounds 1 and 2 of this kernel gave a test one lane and sorted the pairs of a
 // workgroup by count: 30 us whatever the number of pairs, the length of its longest lane.
-constexpr int kSlowBlock = 256;
-constexpr int kSlowWaves = kSlowBlock / 64;
-constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
+
+// One round of pass 2 on listed pairs: the pairs items[base .. base + 8) (fewer at the end of the list), by one wave.
+// sp: 8 x 10 doubles and list: 48 dwords of LDS owned by the wave.
+__device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsigned* __restrict__ items, unsigned base,
+                                           unsigned count, bool have_first, unsigned first_item, double (*sp_all)[10],
+                                           unsigned* list, int64_t n)
+{
+    const int lane = threadIdx.x & 63, quad = lane >> 2, sub = lane & 3;
+    // ---- the first lanes: one pair each: its inputs, and which of its three tests are open (sign bit set) ----
+    const bool owner = lane < kSlowPairsPerWave && base + lane < count;
+    int64_t item = 0;
+    unsigned open = 0;
+    if (owner) {
+        item = have_first ? first_item : items[base + lane];
+        const double v1 = a.out[1 * n + item], v2 = a.out[2 * n + item], v5 = a.out[5 * n + item];
+        const PairInputs q = load_pair(a, item);
+        double* sp = sp_all[lane];
+        sp[0] = v1; sp[1] = v2; sp[2] = v5;
+        sp[3] = q.k_snv; sp[4] = q.k_smp; sp[5] = q.k_ind;
+        sp[6] = q.alpha; sp[7] = q.p; sp[8] = q.alpha_i; sp[9] = q.p_i;
+        open = (__double_as_longlong(v1) < 0 ? 1u : 0u) | (__double_as_longlong(v2) < 0 ? 2u : 0u) |
+               (__double_as_longlong(v5) < 0 ? 4u : 0u);
+    }
+    // bit 16 role + slot of W <-> test (role, pair slot)
+    const unsigned long long W = ((unsigned long long)__ballot(open & 1u) & 0xffffull) |
+                                 (((unsigned long long)__ballot(open & 2u) & 0xffffull) << 16) |
+                                 (((unsigned long long)__ballot(open & 4u) & 0xffffull) << 32);
+    const int n_tests = __popcll(W);
+    if (lane < 48 && ((W >> lane) & 1ull)) list[__popcll(W & ((1ull << lane) - 1ull))] = (unsigned)lane;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are in
+    __builtin_amdgcn_wave_barrier();
+    // ---- the open tests, sixteen at a time, one quad each ----
+    for (int t0 = 0; t0 < n_tests; t0 += 16) {
+        const int t = t0 + quad;
+        const bool active = t < n_tests;
+        const unsigned bit = list[active ? t : 0];
+        const int role = (int)(bit >> 4), slot = (int)(bit & 15u);
+        const double* sp = sp_all[slot];
+        const double marker = sp[role];                     // -pmf(k), or -2: pmf(k) not known
+        const double k = sp[3 + role];
+        const double al = sp[role == 2 ? 8 : 6], pp = sp[role == 2 ? 9 : 7];
+        const double pv = nb_midp_upper_quad(k, al, pp, marker == -2.0 ? -1.0 : -marker, sub);
+        if (active && sub == 0) sp_all[slot][role] = pv;     // (nobody else reads this test's slot)
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- the first lanes: combine and write ----
+    if (owner) {
+        const double* sp = sp_all[lane];
+        const double pv_snv = sp[0], pv_smp = sp[1], pv_ind = sp[2];
+        a.out[1 * n + item] = pv_snv;
+        a.out[2 * n + item] = pv_smp;
+        a.out[5 * n + item] = pv_ind;
+        a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // (sp / list are rewritten in the next round)
+    __builtin_amdgcn_wave_barrier();
+}
 
 __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementStatsArgs a)
 {
@@ -573,7 +764,7 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     __shared__ double s_pair[kSlowWaves][kSlowPairsPerWave][10];
     __shared__ unsigned s_list[kSlowWaves][48];
     const int64_t n = a.E * a.C;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = lane >> 2, sub = lane & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned n_waves = gridDim.x * kSlowWaves;
     const unsigned base0 = (blockIdx.x * kSlowWaves + wave) * kSlowPairsPerWave;
     // the length of the worklist and this wave's first entries are requested together, in front of the table set-up: one
@@ -584,57 +775,8 @@ __global__ __launch_bounds__(kSlowBlock) void element_stats_slow_kernel(ElementS
     nb_tables_init();
     const unsigned count = (unsigned)min((int64_t)count_raw, n);   // (never more entries than pairs, whatever the header holds)
     if (blockIdx.x == 0 && tid == 0) a.worklist[2] = count;      // diagnostic: length of the last worklist
-    for (unsigned base = base0; base < count; base += n_waves * kSlowPairsPerWave) {
-        // ---- the first lanes: one pair each: its inputs, and which of its three tests are open (sign bit set) ----
-        const bool owner = lane < kSlowPairsPerWave && base + lane < count;
-        int64_t item = 0;
-        unsigned open = 0;
-        if (owner) {
-            item = base == base0 ? first_item : a.worklist[kWorkHeader + base + lane];
-            const double v1 = a.out[1 * n + item], v2 = a.out[2 * n + item], v5 = a.out[5 * n + item];
-            const PairInputs q = load_pair(a, item);
-            double* sp = s_pair[wave][lane];
-            sp[0] = v1; sp[1] = v2; sp[2] = v5;
-            sp[3] = q.k_snv; sp[4] = q.k_smp; sp[5] = q.k_ind;
-            sp[6] = q.alpha; sp[7] = q.p; sp[8] = q.alpha_i; sp[9] = q.p_i;
-            open = (__double_as_longlong(v1) < 0 ? 1u : 0u) | (__double_as_longlong(v2) < 0 ? 2u : 0u) |
-                   (__double_as_longlong(v5) < 0 ? 4u : 0u);
-        }
-        // bit 16 role + slot of W <-> test (role, pair slot)
-        const unsigned long long W = ((unsigned long long)__ballot(open & 1u) & 0xffffull) |
-                                     (((unsigned long long)__ballot(open & 2u) & 0xffffull) << 16) |
-                                     (((unsigned long long)__ballot(open & 4u) & 0xffffull) << 32);
-        const int n_tests = __popcll(W);
-        if (lane < 48 && ((W >> lane) & 1ull)) s_list[wave][__popcll(W & ((1ull << lane) - 1ull))] = (unsigned)lane;
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are in
-        __builtin_amdgcn_wave_barrier();
-        // ---- the open tests, sixteen at a time, one quad each ----
-        for (int t0 = 0; t0 < n_tests; t0 += 16) {
-            const int t = t0 + quad;
-            const bool active = t < n_tests;
-            const unsigned bit = s_list[wave][active ? t : 0];
-            const int role = (int)(bit >> 4), slot = (int)(bit & 15u);
-            const double* sp = s_pair[wave][slot];
-            const double marker = sp[role];                     // -pmf(k), or -2: pmf(k) not known
-            const double k = sp[3 + role];
-            const double al = sp[role == 2 ? 8 : 6], pp = sp[role == 2 ? 9 : 7];
-            const double pv = nb_midp_upper_quad(k, al, pp, marker == -2.0 ? -1.0 : -marker, sub);
-            if (active && sub == 0) s_pair[wave][slot][role] = pv;     // (nobody else reads this test's slot)
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // ---- the first lanes: combine and write ----
-        if (owner) {
-            const double* sp = s_pair[wave][lane];
-            const double pv_snv = sp[0], pv_smp = sp[1], pv_ind = sp[2];
-            a.out[1 * n + item] = pv_snv;
-            a.out[2 * n + item] = pv_smp;
-            a.out[5 * n + item] = pv_ind;
-            a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // (s_pair / s_list are rewritten in the next round)
-        __builtin_amdgcn_wave_barrier();
-    }
+    for (unsigned base = base0; base < count; base += n_waves * kSlowPairsPerWave)
+        slow_round(a, a.worklist + kWorkHeader, base, count, base == base0, first_item, s_pair[wave], s_list[wave], n);
 }
 
 // Generic form: any shape, one item per thread and grid-stride step, everything recomputed per item.
@@ -870,7 +1012,7 @@ int64_t dig_element_stats_workspace(int64_t E, int64_t C)
     if (E < 0 || C < 0) return 0;
     const int64_t n = E * C;
     if (n >= (int64_t)0xffffffffu) return 0;   // 32-bit worklist indices; larger problems run single-pass
-    return (int64_t)sizeof(unsigned) * (kWorkHeader + n);
+    return (int64_t)sizeof(unsigned) * (kWorkHeader + n + kOverflowSlack);
 }
 
 }  // extern "C"
@@ -935,6 +1077,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;
 #endif
     if (wl && !worklist_already_zero) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
+    bool finished_in_wave = false;
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
     DIG_REQUIRE(want_blocks <= 0x7fffffff, "E * C too large for one launch");
     const int grid = (int)want_blocks;
@@ -958,7 +1101,9 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         static const int form = stream_form(), tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
         if (which == 2 && form == 1 && tickets == 1024) {
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
+            DIG_REQUIRE(!DIG_ES_INWAVE || cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
             hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            finished_in_wave = DIG_ES_INWAVE != 0;
         } else if (which == 2 && form == 1 && tickets == 256) {
             const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, true>, 256), stream_blocks_per_cu(8)));
             hipLaunchKernelGGL((element_stats_stream_fused_kernel<256, true>), dim3(g), dim3(256), 0, s, a);
@@ -984,6 +1129,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         // (the worklist length is only known on the device: a grid that covers 1 % of the pairs in one round, but never more
         //  workgroups than are resident at once -- the waves of a second batch would start when the first ones end and
         //  double the length of a kernel whose waves all live equally long: 18 against 12 us, measured)
+        if (finished_in_wave) return DIG_OK;      // the fused stream pass finishes its own slow pairs
         const int64_t slow_pairs = std::max<int64_t>(E * C / 100, 1);
         static int slow_resident[kMaxDevices] = {};
         int slow_dev = 0;

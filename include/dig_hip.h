@@ -104,8 +104,9 @@ int dig_normal_params_to_gamma_host(const double *mu, const double *sigma, doubl
  * 709-727): call it once per mutation class with that class's Pi_* / OBS_* / N_SAMP_*.
  * workspace: optional device scratch of at least dig_element_stats_workspace(E, C) bytes.  With it the
  * rare expensive tests (k > 64 or p-value < 1e-3: lgamma + continued fraction) are compacted into a
- * worklist and finished by a second, dense launch; with workspace == NULL they are resolved inline
- * (same results, more wave divergence).  The function never allocates. */
+ * worklist and finished by a second, dense launch (dig_element_pipeline's fused statistics kernel keeps them in LDS
+ * and finishes them itself); with workspace == NULL they are resolved inline (same results, more wave divergence).
+ * The function never allocates. */
 int64_t dig_element_stats_workspace(int64_t E, int64_t C);
 int dig_element_stats(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
                       const double *pi_sum, const double *pi_indel, int pi_indel_per_cohort, const int32_t *obs_snv,
@@ -170,7 +171,8 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
 #define DIG_PIPE_ALL 7
 /* A call WITHOUT the CONTEXTS stage clears the worklist header of the statistics stage with a memset node of its own.
  * OR this flag into `stages` to skip that node when the caller knows the header is clear: after a CONTEXTS call on the
- * same workspace with no STATISTICS call since (a statistics stage leaves the length of its worklist in the header). */
+ * same workspace with no STATISTICS call since (a statistics stage leaves counts in the header: dword 2 the pairs it
+ * finished from the global worklist, dword 3 the pairs the fused stream pass finished from its workgroups' LDS queues). */
 #define DIG_PIPE_WORKLIST_CLEAN 8
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,

@@ -593,6 +593,32 @@ def test_element_pipeline_equals_separate_calls(torch_dev):
             assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
 
 
+def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
+    """The fused stream pass finishes its unfinished pairs itself: through the workgroup's LDS queue (1024 records) and, beyond
+    that, through the workgroup's own segment of the worklist.  With every SNV count raised past the recurrence's range
+    almost every pair takes that route and every workgroup overflows its queue; the result must still be the bits of the
+    two separate calls (whose statistics kernel is the two-kernel form)."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    for (nb, E, C, seed, bump) in ((20000, 20000, 37, 31, 300), (9000, 12000, 37, 32, 0)):
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        td["obs_snv"] += bump
+        td["obs_samples"] += bump // 2
+        acc = engine.accumulate_elements(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                         td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"])
+        st = engine.element_stats(acc["MU"], acc["SIGMA"], acc["P"].view(E, C), acc["P_INDEL"], td["obs_snv"], td["obs_samples"],
+                                  td["obs_indel"], td["cj"], td["cj_indel"])
+        acc2, st2 = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                            td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"],
+                                            td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"])
+        for j, name in enumerate(engine.ES_PLANES):
+            a, b = st[name], st2[j]
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (name, bump)
+        assert torch.isfinite(st2[1]).all() and (st2[1] >= 0).all() and (st2[6] >= 0).all()      # no marker left behind
+
+
 def test_pipeline_with_more_than_2_to_24_bins(torch_dev):
     """Bin rows beyond 2^24: the statistics stream pass then leaves its 24-bit multiply-add for 64-bit offsets.  Pipeline
     against the two separate calls (bit-identical) and against the oracle on the bins the elements touch."""
