@@ -696,7 +696,7 @@ __device__ __forceinline__ double quad_scan_product(double P, int sub, double& e
 }
 
 // pmf_k < 0: not known.
-__device__ inline double nb_midp_upper_quad(double k, double alpha, double p, double pmf_k, int sub)
+__device__ __forceinline__ double nb_midp_upper_quad(double k, double alpha, double p, double pmf_k, int sub)
 {
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     if (!(alpha > 0.0 && alpha < inf && p >= 2.2250738585072014e-308 && p < 1.0 && k >= 0.0 && k < 4.0e15 && floor(k) == k))
