@@ -356,6 +356,7 @@ struct StagePtr {            // tile t+2
 };
 struct StageIn {             // tile t+1
     int32_t idx[kPre];
+    double mu, sg, mu_i, sg_i;   // (GIVEN form only: the pair's parameters as handed in)
     double pi_s, pi_i, cj, cji;
     int k_snv, k_smp, k_ind;
     int64_t q0;
@@ -450,7 +451,10 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024];
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
 #endif
-template <int TB, bool TICKETS>
+// GIVEN = 0: dig_element_pipeline (the rate sums of a pair are formed here from the bin tables and written out);
+// GIVEN = 1 / 2: dig_element_stats (mu / sigma handed in per pair; 2: separate indel parameters) -- the same pipeline,
+// tickets and in-kernel second pass without the CSR and bin stages.
+template <int TB, bool TICKETS, int GIVEN = 0>
 __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
 #ifdef DIG_ES_TIMING
@@ -503,8 +507,11 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         s.i = (uint32_t)(past ? n - 1 : iu);
         s.e = (uint32_t)(past ? a.E - 1 : eu);
         s.c = past ? C32 - 1 : cu;
-        s.q0 = a.ov_ptr[s.e];
-        s.q1 = a.ov_ptr[s.e + 1];
+        if (GIVEN == 0) {
+            s.q0 = a.ov_ptr[s.e];
+            s.q1 = a.ov_ptr[s.e + 1];
+        } else
+            s.q0 = s.q1 = 0;
         if (!TICKETS) {
             iu += step_pairs;
             eu += step_e;
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         return s;
     };
     // every element's CSR range lies inside [0, nnz); with an empty CSR the index loads replay ov_ptr[0] (= 0: row 0)
-    const int64_t nnz = a.ov_ptr[a.E];
+    const int64_t nnz = GIVEN == 0 ? a.ov_ptr[a.E] : 0;
     const int32_t* oi_base = nnz > 0 ? a.ov_idx : reinterpret_cast<const int32_t*>(a.ov_ptr);
     const int64_t oi_last = nnz > 0 ? nnz - 1 : 0;
     auto fetch_in = [&](const StagePtr& s) {
@@ -526,9 +533,18 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         r.nb = (uint32_t)(s.q1 - s.q0);
         r.i = s.i;
         r.c = s.c;
+        if (GIVEN == 0) {
 #pragma unroll
-        for (int j = 0; j < kPre; ++j)      // unconditional (the memory counter stays exact): bins past the pair's last replay a valid entry
-            r.idx[j] = oi_base[min(s.q0 + j, oi_last)];
+            for (int j = 0; j < kPre; ++j)      // unconditional (the memory counter stays exact): bins past the pair's last replay a valid entry
+                r.idx[j] = oi_base[min(s.q0 + j, oi_last)];
+        } else {
+            r.mu = a.mu[s.i];
+            r.sg = a.sigma[s.i];
+            if (GIVEN == 2) {
+                r.mu_i = a.mu_indel[s.i];
+                r.sg_i = a.sigma_indel[s.i];
+            }
+        }
         r.pi_s = a.pi_sum[s.i];
         r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
         r.k_snv = a.obs_snv[s.i];
@@ -540,6 +556,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     };
     auto fetch_bin = [&](const StageIn& r) {
         StageBin b;
+        if (GIVEN != 0) return b;
 #pragma unroll
         for (int j = 0; j < kPre; ++j) {
             const int64_t o = a.small_index ? (int64_t)(__umul24((uint32_t)r.idx[j], C32) + r.c)
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         // rate sums (genic_driver_tools.py:262-271)
         double mu = 0.0, var = 0.0;
         int robs = 0, flag = 0;
+        if (GIVEN == 0) {
 #pragma unroll
         for (int j = 0; j < kPre; ++j) {      // (bins past the pair's last were fetched from a replayed row: skipped here)
             if ((uint32_t)j < cur.nb) {
@@ -604,13 +622,23 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
                 flag |= (a.bin_flag[o] != 0);
             }
         }
+        }
         PairRaw w;
-        w.mu = w.mu_i = mu;
-        w.sigma = w.sigma_i = sqrt(var);
+        if (GIVEN == 0) {
+            w.mu = w.mu_i = mu;
+            w.sigma = w.sigma_i = sqrt(var);
+        } else {
+            w.mu = w.mu_i = cur.mu;
+            w.sigma = w.sigma_i = cur.sg;
+            if (GIVEN == 2) {
+                w.mu_i = cur.mu_i;
+                w.sigma_i = cur.sg_i;
+            }
+        }
         w.pi_s = cur.pi_s; w.pi_i = cur.pi_i; w.cj = cur.cj; w.cji = cur.cji;
         w.k_snv = cur.k_snv; w.k_smp = cur.k_smp; w.k_ind = cur.k_ind;
         w.q0 = w.q1 = 0; w.c = cur.c;
-        const PairInputs q = prepare_pair(w, false);
+        const PairInputs q = prepare_pair(w, GIVEN == 2);
         // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
         //  cancelled, -2 when it was not eligible at all; no p-value is negative)
         double pv_snv, pv_smp, pv_ind, dummy;
@@ -641,10 +669,12 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #endif
         if (slow && ((m >> lane) & 1ull)) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
         parked += (unsigned)__popcll(m);
-        DIG_STREAM_STORE(&a.mu_w[i], w.mu);
-        DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
-        DIG_STREAM_STORE(&a.r_obs[i], robs);
-        DIG_STREAM_STORE(&a.flag[i], flag);
+        if (GIVEN == 0) {
+            DIG_STREAM_STORE(&a.mu_w[i], w.mu);
+            DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
+            DIG_STREAM_STORE(&a.r_obs[i], robs);
+            DIG_STREAM_STORE(&a.flag[i], flag);
+        }
         DIG_STREAM_STORE(&a.out[0 * n + i], q.exp_snv);
         DIG_STREAM_STORE(&a.out[1 * n + i], pv_snv);
         DIG_STREAM_STORE(&a.out[2 * n + i], pv_smp);
@@ -1099,6 +1129,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
             return r;
         };
         static const int form = stream_form(), tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
+        static const int given_form = getenv("DIG_ES_GIVEN_FORM") ? atoi(getenv("DIG_ES_GIVEN_FORM")) : 1;
         if (which == 2 && form == 1 && tickets == 1024) {
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
             DIG_REQUIRE(!DIG_ES_INWAVE || cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
@@ -1113,6 +1144,15 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         } else if (which == 2) {
             const int g = grid_for(E * C, kBlock, std::min(occupancy(2, element_stats_stream_kernel<false, true>, kBlock), 5));
             hipLaunchKernelGGL((element_stats_stream_kernel<false, true>), dim3(g), dim3(kBlock), 0, s, a);
+        } else if (which != 2 && DIG_ES_INWAVE && given_form) {
+            // dig_element_stats on the pipelined kernel of dig_element_pipeline (one 1024-thread workgroup per CU, tickets,
+            // second pass inside): DIG_ES_GIVEN_FORM=0 keeps round 1's two-stage kernels + the compacted kernel
+            DIG_REQUIRE(cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
+            if (which == 1)
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 2>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            else
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 1>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            finished_in_wave = true;
         } else if (which == 1) {
             // (the two-stage forms are bound by VALU issue, not by latency hiding: slightly fewer than the maximum of
             //  resident workgroups measured best -- fewer waves contend for the scalar unit and the instruction cache)

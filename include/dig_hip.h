@@ -104,8 +104,8 @@ int dig_normal_params_to_gamma_host(const double *mu, const double *sigma, doubl
  * 709-727): call it once per mutation class with that class's Pi_* / OBS_* / N_SAMP_*.
  * workspace: optional device scratch of at least dig_element_stats_workspace(E, C) bytes.  With it the
  * rare expensive tests (k > 64 or p-value < 1e-3: lgamma + continued fraction) are compacted into a
- * worklist and finished by a second, dense launch (dig_element_pipeline's fused statistics kernel keeps them in LDS
- * and finishes them itself); with workspace == NULL they are resolved inline (same results, more wave divergence).
+ * queue in LDS and finished by the same kernel at the end of each workgroup (what does not fit there goes through the
+ * workspace); with workspace == NULL they are resolved inline (same results, more wave divergence).
  * The function never allocates. */
 int64_t dig_element_stats_workspace(int64_t E, int64_t C);
 int dig_element_stats(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
