@@ -391,6 +391,11 @@ constexpr int kRecDoubles = 11;        // [0..2] p-value slots, [3..5] counts, [
 __shared__ double g_queue[kQueueCap * kRecDoubles];
 __shared__ unsigned g_queue_list[16][48];
 __shared__ unsigned g_queue_len, g_queue_next, g_ovf_len, g_ovf_next;
+#ifndef DIG_ES_DRAIN_TESTS
+#define DIG_ES_DRAIN_TESTS 1
+#endif
+__shared__ unsigned g_tests[3 * kQueueCap];      // the open tests of the queue: record * 4 + role
+__shared__ unsigned g_n_tests, g_next_test;
 constexpr int kSlowBlock = 256;
 constexpr int kSlowWaves = kSlowBlock / 64;
 constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
@@ -446,7 +451,7 @@ __device__ __forceinline__ void queue_round(int wave, int base, int batch, int c
 
 #ifdef DIG_ES_TIMING
 // developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
-__device__ unsigned long long g_es_t0[1024], g_es_t1[1024];
+__device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_b1[1024];
 #endif
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     __shared__ unsigned s_ticket;
     if (TICKETS && threadIdx.x == 0) s_ticket = 0;
 #if DIG_ES_INWAVE
-    if (TB == 1024 && TICKETS && threadIdx.x == 0) g_queue_len = g_queue_next = g_ovf_len = g_ovf_next = 0;
+    if (TB == 1024 && TICKETS && threadIdx.x == 0) g_queue_len = g_queue_next = g_ovf_len = g_ovf_next = g_n_tests = g_next_test = 0;
 #endif
     nb_tables_init();
     unsigned* park = park_all[threadIdx.x >> 6];
@@ -686,9 +691,65 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     if (parked) flush(parked);
 #if DIG_ES_INWAVE
     if (TB == 1024 && TICKETS) {
+#ifdef DIG_ES_TIMING
+        if (lane == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicMin(&g_es_b0[blockIdx.x & 1023], now);
+            atomicMax(&g_es_b1[blockIdx.x & 1023], now);
+        }
+#endif
         __syncthreads();                                    // every wave of the workgroup is out of tiles: the queue is complete
         const int total = (int)min(g_queue_len, (unsigned)kQueueCap);
         if (threadIdx.x == 0 && total) atomicAdd(&a.worklist[3], (unsigned)total);     // diagnostic: pairs finished here
+#if DIG_ES_DRAIN_TESTS
+        // The queue is taken apart TEST by test, not pair by pair: the workgroups that end last are the ones with the most
+        // records (probe: 14-18 us from the barrier to the end against a median of 8), and with whole pairs dealt to
+        // the waves a wave with sixteen pairs runs three rounds of sixteen quads while its neighbours run two.
+        // (a) one thread per record lists the record's open tests; (b) the waves draw sixteen tests at a time, one quad
+        // each, and put the p-value back into the record; (c) one thread per record combines and writes the four planes.
+        if (total) {
+            const int rec = (int)threadIdx.x;               // TB == kQueueCap
+            double* r = g_queue + rec * kRecDoubles;
+            unsigned open = 0;
+            if (rec < total)
+                open = (__double_as_longlong(r[0]) < 0 ? 1u : 0u) | (__double_as_longlong(r[1]) < 0 ? 2u : 0u) |
+                       (__double_as_longlong(r[2]) < 0 ? 4u : 0u);
+            const unsigned long long b0 = __ballot(open & 1u), b1 = __ballot(open & 2u), b2 = __ballot(open & 4u);
+            const unsigned c0 = (unsigned)__popcll(b0), c1 = (unsigned)__popcll(b1), c2 = (unsigned)__popcll(b2);
+            unsigned tb = 0;
+            if (lane == 0 && c0 + c1 + c2) tb = atomicAdd(&g_n_tests, c0 + c1 + c2);
+            tb = (unsigned)__builtin_amdgcn_readfirstlane((int)tb);
+            if (open & 1u) g_tests[tb + (unsigned)__popcll(b0 & lanes_below)] = (unsigned)rec * 4u;
+            if (open & 2u) g_tests[tb + c0 + (unsigned)__popcll(b1 & lanes_below)] = (unsigned)rec * 4u + 1u;
+            if (open & 4u) g_tests[tb + c0 + c1 + (unsigned)__popcll(b2 & lanes_below)] = (unsigned)rec * 4u + 2u;
+            __syncthreads();
+            const unsigned n_tests = g_n_tests;
+            const int quad = lane >> 2, sub = lane & 3;
+            for (;;) {
+                unsigned t0 = 0;
+                if (lane == 0) t0 = atomicAdd(&g_next_test, 16u);
+                t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)t0);
+                if (t0 >= n_tests) break;
+                const bool active = t0 + (unsigned)quad < n_tests;
+                const unsigned id = g_tests[active ? t0 + (unsigned)quad : t0];
+                const int role = (int)(id & 3u);
+                double* sp = g_queue + (id >> 2) * kRecDoubles;
+                const double marker = sp[role];             // -pmf(k), or -2: pmf(k) not known
+                const double pv = nb_midp_upper_quad(sp[3 + role], sp[role == 2 ? 8 : 6], sp[role == 2 ? 9 : 7],
+                                                     marker == -2.0 ? -1.0 : -marker, sub);
+                if (active && sub == 0) sp[role] = pv;      // (nobody else reads this slot before the barrier)
+            }
+            __syncthreads();
+            if (rec < total) {
+                const int64_t item = __double_as_longlong(r[10]);
+                const double pv_snv = r[0], pv_smp = r[1], pv_ind = r[2];
+                a.out[1 * n + item] = pv_snv;
+                a.out[2 * n + item] = pv_smp;
+                a.out[5 * n + item] = pv_ind;
+                a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+            }
+        }
+#else
         // one round per wave while the queue holds up to 256 records (the usual case: 143 on the bench workload), rounds
         // of sixteen beyond
         const int batch = min(16, max(1, (total + TB / 64 - 1) / (TB / 64)));
@@ -699,6 +760,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             if ((int)b >= total) break;
             queue_round((int)(threadIdx.x >> 6), (int)b, batch, total, a.out, n);
         }
+#endif
         const unsigned ovf = g_ovf_len;                     // (final since the barrier above)
         if (ovf) {
             // the pairs the queue had no room for: their indices are in this workgroup's segment, their markers in the
@@ -937,6 +999,13 @@ int dig_debug_es_timing(unsigned long long* out2048)
     DIG_HIP_TRY(hipMemcpyFromSymbol(out2048 + 1024, HIP_SYMBOL(dig::g_es_t1), 1024 * sizeof(unsigned long long)));
     static unsigned long long z[1024] = {};
     DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dig::g_es_t1), z, sizeof(z)));
+    // [2048, 3072): first, [3072, 4096): last arrival of a wave at the workgroup's end-of-tiles barrier
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out2048 + 2048, HIP_SYMBOL(dig::g_es_b0), 1024 * sizeof(unsigned long long)));
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out2048 + 3072, HIP_SYMBOL(dig::g_es_b1), 1024 * sizeof(unsigned long long)));
+    DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dig::g_es_b1), z, sizeof(z)));
+    static unsigned long long big[1024];
+    for (auto& v : big) v = ~0ull;
+    DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dig::g_es_b0), big, sizeof(big)));
     return DIG_OK;
 }
 #endif

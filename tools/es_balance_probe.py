@@ -25,7 +25,7 @@ s = torch.cuda.current_stream(dev)
 lib = _lib.load()
 fn = lib.dig_debug_es_timing
 fn.argtypes = [ctypes.c_void_p]
-buf = np.zeros(2048, np.uint64)
+buf = np.zeros(4096, np.uint64)
 for _ in range(50):
     plan.run(td["cj"], td["cj_indel"], stages=7, stream=s)
 torch.cuda.synchronize()
@@ -43,3 +43,9 @@ for rep in range(3):
              (end.max() - end).mean()))
     byx = [(end[x::8].mean(), end[x::8].max()) for x in range(8)]
     print("  per XCD (mean, max):", " ".join("%.0f/%.0f" % b for b in byx))
+    b0, b1 = (buf[2048:2304].astype(np.int64) - base) / 100.0, (buf[3072:3328].astype(np.int64) - base) / 100.0
+    print("  within a workgroup: first wave out of tiles %.1f, last %.1f (spread %.1f), then %.1f us to the end (means over workgroups)"
+          % (b0.mean(), b1.mean(), (b1 - b0).mean(), (end - b1).mean()))
+    late = np.argsort(-end)[:8]
+    print("  the eight last workgroups: end", np.round(end[late], 1), "last wave out of tiles", np.round(b1[late], 1), "then", np.round((end - b1)[late], 1))
+    print("  from the barrier to the end, all workgroups: p10 %.1f median %.1f p90 %.1f max %.1f us" % tuple(np.percentile(end - b1, [10, 50, 90, 100])))
