@@ -619,6 +619,19 @@ def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
         assert torch.isfinite(st2[1]).all() and (st2[1] >= 0).all() and (st2[6] >= 0).all()      # no marker left behind
 
 
+def test_one_kernel_statistics_equal_round_one_two_kernel_form():
+    """The pipelined statistics kernel (stream pass + the workgroup's own second pass) against round 1's two-stage kernel +
+    compacted kernel, which DIG_ES_GIVEN_FORM=0 keeps behind dig_element_stats: random shapes and parking rates, bit for
+    bit (tools/fuzz_pipeline.py in a process of its own: the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIG_ES_GIVEN_FORM="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pipeline.py"), "80", "7"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_pipeline_with_more_than_2_to_24_bins(torch_dev):
     """Bin rows beyond 2^24: the statistics stream pass then leaves its 24-bit multiply-add for 64-bit offsets.  Pipeline
     against the two separate calls (bit-identical) and against the oracle on the bins the elements touch."""
