@@ -376,8 +376,8 @@ struct StageBin {            // tile t+1
 // ---- pass 2 inside the fused stream pass ---------------------------------------------------------------------------
 // The pairs a wave cannot finish (0.8 % on the bench workload) go into a QUEUE OF RECORDS in the workgroup's LDS -- the
 // three p-value slots as pass 1 left them, the counts and the two parameter pairs: everything pass 2 needs, nothing is
-// read back from memory.  When the workgroup has run out of tiles its 16 waves empty the queue together, eight pairs
-// per wave and round, with the quad series of the compacted pass, and overwrite their markers.  (Finishing them in the
+// read back from memory.  When the workgroup has run out of tiles its 16 waves empty the queue together, test by test
+// (sixteen per draw, one quad each), with the quad series of the compacted pass, and overwrite their markers.  (Finishing them in the
 // wave that found them was measured first: +30 us -- the 37 pairs of a large element park together, in ONE wave, and
 // that wave then runs five rounds on its own while its SIMD waits for it.)  A queue that is full (more than
 // kQueueCap parked pairs in one workgroup: 6 % of its pairs) overflows into the workgroup's OWN segment of the global
@@ -390,10 +390,7 @@ constexpr int kQueueCap = 1024;        // records per workgroup
 constexpr int kRecDoubles = 11;        // [0..2] p-value slots, [3..5] counts, [6] alpha, [7] p, [8] [9] the indel pair, [10] pair index
 __shared__ double g_queue[kQueueCap * kRecDoubles];
 __shared__ unsigned g_queue_list[16][48];
-__shared__ unsigned g_queue_len, g_queue_next, g_ovf_len, g_ovf_next;
-#ifndef DIG_ES_DRAIN_TESTS
-#define DIG_ES_DRAIN_TESTS 1
-#endif
+__shared__ unsigned g_queue_len, g_ovf_len, g_ovf_next;
 __shared__ unsigned g_tests[3 * kQueueCap];      // the open tests of the queue: record * 4 + role
 __shared__ unsigned g_n_tests, g_next_test;
 constexpr int kSlowBlock = 256;
@@ -403,51 +400,6 @@ constexpr int kOverflowSlack = 64 * 1024;      // entries behind the n of the wo
 __device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsigned* __restrict__ items, unsigned base,
                                            unsigned count, bool have_first, unsigned first_item, double (*sp_all)[10],
                                            unsigned* list, int64_t n);
-
-// one round: the records [base, base + batch) of the queue (fewer at its end; batch <= 16), by one wave
-__device__ __forceinline__ void queue_round(int wave, int base, int batch, int count, double* __restrict__ out, int64_t n)
-{
-    const int lane = threadIdx.x & 63, quad = lane >> 2, sub = lane & 3;
-    unsigned* list = g_queue_list[wave];
-    const bool owner = lane < batch && base + lane < count;
-    double* mine = g_queue + (base + (lane & 15)) * kRecDoubles;
-    unsigned open = 0;
-    if (owner)
-        open = (__double_as_longlong(mine[0]) < 0 ? 1u : 0u) | (__double_as_longlong(mine[1]) < 0 ? 2u : 0u) |
-               (__double_as_longlong(mine[2]) < 0 ? 4u : 0u);
-    // bit 16 role + slot of W <-> test (role, pair slot)
-    const unsigned long long W = ((unsigned long long)__ballot(open & 1u) & 0xffffull) |
-                                 (((unsigned long long)__ballot(open & 2u) & 0xffffull) << 16) |
-                                 (((unsigned long long)__ballot(open & 4u) & 0xffffull) << 32);
-    const int n_tests = __popcll(W);
-    if (lane < 48 && ((W >> lane) & 1ull)) list[__popcll(W & ((1ull << lane) - 1ull))] = (unsigned)lane;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are in
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < n_tests; t0 += 16) {             // sixteen open tests at a time, one quad each
-        const int t = t0 + quad;
-        const bool active = t < n_tests;
-        const unsigned bit = list[active ? t : 0];
-        const int role = (int)(bit >> 4), slot = (int)(bit & 15u);
-        double* sp = g_queue + (base + slot) * kRecDoubles;
-        const double marker = sp[role];                     // -pmf(k), or -2: pmf(k) not known
-        const double k = sp[3 + role];
-        const double al = sp[role == 2 ? 8 : 6], pp = sp[role == 2 ? 9 : 7];
-        const double pv = nb_midp_upper_quad(k, al, pp, marker == -2.0 ? -1.0 : -marker, sub);
-        if (active && sub == 0) sp[role] = pv;              // (nobody else reads this test's slot)
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (owner) {
-        const int64_t item = __double_as_longlong(mine[10]);
-        const double pv_snv = mine[0], pv_smp = mine[1], pv_ind = mine[2];
-        out[1 * n + item] = pv_snv;
-        out[2 * n + item] = pv_smp;
-        out[5 * n + item] = pv_ind;
-        out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // (the list is rewritten in the next round)
-    __builtin_amdgcn_wave_barrier();
-}
 
 #ifdef DIG_ES_TIMING
 // developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
@@ -469,7 +421,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     __shared__ unsigned s_ticket;
     if (TICKETS && threadIdx.x == 0) s_ticket = 0;
 #if DIG_ES_INWAVE
-    if (TB == 1024 && TICKETS && threadIdx.x == 0) g_queue_len = g_queue_next = g_ovf_len = g_ovf_next = g_n_tests = g_next_test = 0;
+    if (TB == 1024 && TICKETS && threadIdx.x == 0) g_queue_len = g_ovf_len = g_ovf_next = g_n_tests = g_next_test = 0;
 #endif
     nb_tables_init();
     unsigned* park = park_all[threadIdx.x >> 6];
@@ -701,7 +653,6 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         __syncthreads();                                    // every wave of the workgroup is out of tiles: the queue is complete
         const int total = (int)min(g_queue_len, (unsigned)kQueueCap);
         if (threadIdx.x == 0 && total) atomicAdd(&a.worklist[3], (unsigned)total);     // diagnostic: pairs finished here
-#if DIG_ES_DRAIN_TESTS
         // The queue is taken apart TEST by test, not pair by pair: the workgroups that end last are the ones with the most
         // records (probe: 14-18 us from the barrier to the end against a median of 8), and with whole pairs dealt to
         // the waves a wave with sixteen pairs runs three rounds of sixteen quads while its neighbours run two.
@@ -749,18 +700,6 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
                 a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
             }
         }
-#else
-        // one round per wave while the queue holds up to 256 records (the usual case: 143 on the bench workload), rounds
-        // of sixteen beyond
-        const int batch = min(16, max(1, (total + TB / 64 - 1) / (TB / 64)));
-        for (;;) {
-            unsigned b = 0;
-            if (lane == 0) b = atomicAdd(&g_queue_next, (unsigned)batch);
-            b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
-            if ((int)b >= total) break;
-            queue_round((int)(threadIdx.x >> 6), (int)b, batch, total, a.out, n);
-        }
-#endif
         const unsigned ovf = g_ovf_len;                     // (final since the barrier above)
         if (ovf) {
             // the pairs the queue had no room for: their indices are in this workgroup's segment, their markers in the
