@@ -351,10 +351,10 @@ class PipelinePlan:
 
 class PlanRing:
     """Several PipelinePlans -- one per batch in flight, each with its own outputs and workspace -- taking turns on as
-    many streams.  A pass is a chain of four dependent kernels (contexts -> dot -> stream pass -> compacted pass) and each
-    of them leaves part of the chip idle while it ramps up and while its last waves finish; with two passes over
-    different batches in flight the kernels of one fill those gaps of the other: 186 us per pass against 207 us one
-    after the other on an MI355X at the whole-genome x 37-cohort size (tools/overlap_probe.py).  The caller keeps the
+    many streams.  A pass is a chain of dependent kernels (contexts -> dot -> statistics) and each of them leaves part of
+    the chip idle while it ramps up and while its last waves finish; with two passes over different batches in flight
+    the kernels of one fill those gaps of the other: 188 us per pass against 193 us one after the other on an MI355X at
+    the whole-genome x 37-cohort size (tools/overlap_probe.py; 186 against 207 while the pass still had a fourth kernel).  The caller keeps the
     order of the passes on ONE plan (they share a stream); passes on different plans are independent."""
 
     def __init__(self, plans, streams=None):
