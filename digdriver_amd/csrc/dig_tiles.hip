@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void tile_mut_counts_kernel(const int32_t* __r
                                                               int64_t n_pairs, const int64_t* __restrict__ mut_start,
                                                               const int32_t* __restrict__ mut_cohort, const int64_t* __restrict__ first_pos,
                                                               const int32_t* __restrict__ n_valid, int binsize, int64_t n_tiles, int64_t R,
-                                                              int32_t* __restrict__ k)
+                                                              int64_t C, int32_t* __restrict__ k)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += stride) {
@@ -443,7 +443,9 @@ __global__ __launch_bounds__(256) void tile_mut_counts_kernel(const int32_t* __r
         if (off < 0) continue;
         const int64_t t = off / binsize;
         if (t >= n_valid[r]) continue;
-        atomicAdd(&k[((int64_t)mut_cohort[m] * R + r) * n_tiles + t], 1);
+        const int64_t c = mut_cohort[m];
+        if ((uint64_t)c >= (uint64_t)C) continue;                  // a cohort id outside [0, C) has no plane to count in
+        atomicAdd(&k[(c * R + r) * n_tiles + t], 1);
     }
 }
 
@@ -521,7 +523,7 @@ int dig_tile_mut_counts(const int32_t* pair_mut, const int32_t* pair_reg, int64_
     if (n_pairs == 0) return DIG_OK;
     DIG_REQUIRE(pair_mut && pair_reg && mut_start && mut_cohort, "non-null pair / mutation arrays");
     hipLaunchKernelGGL(tile_mut_counts_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream, pair_mut, pair_reg,
-                       n_pairs, mut_start, mut_cohort, first_pos, n_valid, binsize, n_tiles, R, k);
+                       n_pairs, mut_start, mut_cohort, first_pos, n_valid, binsize, n_tiles, R, C, k);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

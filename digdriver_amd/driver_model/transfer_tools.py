@@ -40,9 +40,9 @@ _PANEL_DIRS = []
 
 
 
-def _say(message):
+def _say(*message):
     """Progress lines on stdout, worded as the reference words them (scripts that parse its log keep working)."""
-    print(message, flush=True)
+    print(*message, flush=True)
 
 def set_panel_dir(path):
     """Directory searched FIRST for genes_<name>.txt (the --panel-dir option of scripts/DigDriver.py)."""

@@ -628,12 +628,20 @@ class ChunkedScaleFactorPlan:
             raise _lib.DigHipError("dig_scale_suffstats_chunked failed (%d): %s" % (rc, _lib.last_error()))
         return self.part
 
+    def _on(self, stream):
+        """Context in which torch's own work (copies, the collective) lands on `stream` -- the kernels of this plan take the
+        stream as an argument, torch's operations take the CURRENT stream, and the two must be the same queue."""
+        import contextlib
+        import torch
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
     def finish(self, all_parts, cj, cj_indel, out_sum=None, stream=None):
         """all_parts [world, n_own + 2, C] (rank order = chunk order) -> scale factors on this rank."""
         p = _lib.dev_ptr
         if self.world > 1:
-            self.sums.view(self.world, self.n_own, self.C).copy_(all_parts[:, :self.n_own])
-            self.obs.copy_(all_parts[:, self.n_own:])
+            with self._on(stream):
+                self.sums.view(self.world, self.n_own, self.C).copy_(all_parts[:, :self.n_own])
+                self.obs.copy_(all_parts[:, self.n_own:])
             sums, obs = self.sums, self.obs
         else:
             sums, obs = all_parts[0, :self.n_own], all_parts[0, self.n_own:]
@@ -644,12 +652,14 @@ class ChunkedScaleFactorPlan:
             raise _lib.DigHipError("dig_scale_factors_chunked failed (%d): %s" % (rc, _lib.last_error()))
 
     def run(self, cj, cj_indel, out_sum=None, stream=None):
-        """Enqueue on `stream` (default: torch's current stream; with a process group the collective runs there too)."""
+        """Enqueue on `stream` (default: torch's current stream).  With a process group the all-gather and the copies that
+        unpack it are issued with `stream` made current, so they are ordered with the two kernels around them."""
         import torch.distributed as dist
         assert self.world in (1, self.dist_world), "run() needs the process group the plan was built for"
         part = self.enqueue_part(stream)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.all, part, group=self.group)
+            with self._on(stream):
+                dist.all_gather_into_tensor(self.all, part, group=self.group)
             self.finish(self.all, cj, cj_indel, out_sum, stream)
         else:
             self.finish(part.unsqueeze(0), cj, cj_indel, out_sum, stream)

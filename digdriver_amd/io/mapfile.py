@@ -291,6 +291,8 @@ def list_keys(path, key=""):
 
 def has_key(path, key):
     if _is_h5(path):
+        if os.fspath(path) in _PENDING:
+            return key in _PENDING[os.fspath(path)]
         return os.path.exists(path) and key in _h5_tree(path)
     s = _safe(key)
     return os.path.exists(os.path.join(path, "A." + s + ".npy")) or os.path.exists(os.path.join(path, "F." + s + ".json"))

@@ -206,15 +206,16 @@ def initialize_nonc_data(f_nonc_data, f_genome_counts, window, n_up=1, n_down=1)
     substitution index and window_{w}/full_window_si_{index,values}."""
     from ..io import mapfile
     key = 'window_{}'.format(window)
-    if not mapfile.has_key(f_nonc_data, 'substitution_idx'):
-        mapfile.write_array(f_nonc_data, 'substitution_idx', np.array(mk_trans_idx(n_up=n_up, n_down=n_down, collapse=False)))
-    if not (mapfile.has_key(f_nonc_data, key + '/full_window_si_index') and
-            mapfile.has_key(f_nonc_data, key + '/full_window_si_values')):
-        idx = mapfile.read_array(f_genome_counts, 'idx')
-        genome_df = mapfile.read_frame(f_genome_counts, 'all_window_genome_counts')
-        assert int(str(genome_df.index[0]).split('-')[-1]) == window      # the counts must be on this window size (:476)
-        mapfile.write_array(f_nonc_data, key + '/full_window_si_values', genome_df.values.astype(np.int64))
-        mapfile.write_array(f_nonc_data, key + '/full_window_si_index', idx)
+    with mapfile.batch(f_nonc_data):
+        if not mapfile.has_key(f_nonc_data, 'substitution_idx'):
+            mapfile.write_array(f_nonc_data, 'substitution_idx', np.array(mk_trans_idx(n_up=n_up, n_down=n_down, collapse=False)))
+        if not (mapfile.has_key(f_nonc_data, key + '/full_window_si_index') and
+                mapfile.has_key(f_nonc_data, key + '/full_window_si_values')):
+            idx = mapfile.read_array(f_genome_counts, 'idx')
+            genome_df = mapfile.read_frame(f_genome_counts, 'all_window_genome_counts')
+            assert int(str(genome_df.index[0]).split('-')[-1]) == window      # the counts must be on this window size (:476)
+            mapfile.write_array(f_nonc_data, key + '/full_window_si_values', genome_df.values.astype(np.int64))
+            mapfile.write_array(f_nonc_data, key + '/full_window_si_index', idx)
 
 
 def preprocess_nonc(f_nonc_bed, f_nonc_data, f_pretrained, L_contexts, save_key, window):
@@ -235,13 +236,14 @@ def preprocess_nonc(f_nonc_bed, f_nonc_data, f_pretrained, L_contexts, save_key,
     L = np.zeros((E, 192))
     np.add.at(L, owner, L_contexts.loc[keys].values)
     base = 'window_{}/{}/'.format(window, save_key)
-    mapfile.write_array(f_nonc_data, base + 'names', df_elts.ELT.values.astype(str))
-    mapfile.write_array(f_nonc_data, base + 'chrom', chrom)
-    mapfile.write_array(f_nonc_data, base + 'strand', df_elts.STRAND.astype(str).values)
-    mapfile.write_array(f_nonc_data, base + 'blk_ptr', blk_ptr)
-    mapfile.write_array(f_nonc_data, base + 'blk_start', blk_start)
-    mapfile.write_array(f_nonc_data, base + 'blk_end', blk_end)
-    mapfile.write_array(f_nonc_data, base + 'L', np.rint(L).astype(np.int32))
+    with mapfile.batch(f_nonc_data):                 # one rewrite of the container instead of one per key
+        mapfile.write_array(f_nonc_data, base + 'names', df_elts.ELT.values.astype(str))
+        mapfile.write_array(f_nonc_data, base + 'chrom', chrom)
+        mapfile.write_array(f_nonc_data, base + 'strand', df_elts.STRAND.astype(str).values)
+        mapfile.write_array(f_nonc_data, base + 'blk_ptr', blk_ptr)
+        mapfile.write_array(f_nonc_data, base + 'blk_start', blk_start)
+        mapfile.write_array(f_nonc_data, base + 'blk_end', blk_end)
+        mapfile.write_array(f_nonc_data, base + 'L', np.rint(L).astype(np.int32))
 
 
 def preprocess_sites(f_sites, f_nonc_data, f_pretrained, save_key, window):
@@ -277,10 +279,11 @@ def preprocess_sites(f_sites, f_nonc_data, f_pretrained, save_key, window):
         blk_ptr.append(len(bs))
         Ls.append(L)
     base = 'window_{}/{}/'.format(window, save_key)
-    mapfile.write_array(f_nonc_data, base + 'names', np.array(names))
-    mapfile.write_array(f_nonc_data, base + 'chrom', np.array(chroms, np.int32))
-    mapfile.write_array(f_nonc_data, base + 'strand', np.array(strands))
-    mapfile.write_array(f_nonc_data, base + 'blk_ptr', np.array(blk_ptr, np.int64))
-    mapfile.write_array(f_nonc_data, base + 'blk_start', np.array(bs, np.int64))
-    mapfile.write_array(f_nonc_data, base + 'blk_end', np.array(be, np.int64))
-    mapfile.write_array(f_nonc_data, base + 'L', np.stack(Ls) if Ls else np.zeros((0, 192), np.int32))
+    with mapfile.batch(f_nonc_data):                 # one rewrite of the container instead of one per key
+        mapfile.write_array(f_nonc_data, base + 'names', np.array(names))
+        mapfile.write_array(f_nonc_data, base + 'chrom', np.array(chroms, np.int32))
+        mapfile.write_array(f_nonc_data, base + 'strand', np.array(strands))
+        mapfile.write_array(f_nonc_data, base + 'blk_ptr', np.array(blk_ptr, np.int64))
+        mapfile.write_array(f_nonc_data, base + 'blk_start', np.array(bs, np.int64))
+        mapfile.write_array(f_nonc_data, base + 'blk_end', np.array(be, np.int64))
+        mapfile.write_array(f_nonc_data, base + 'L', np.stack(Ls) if Ls else np.zeros((0, 192), np.int32))

@@ -211,7 +211,8 @@ int dig_scale_factors_chunked(const double *chunk_sums, int n_chunks, const doub
  *       normalise-then-np.sum order.
  * dig_tile_mut_counts: k i32 [C, R, n_tiles] (cleared by the call) from (mutation, region) pairs as produced by
  *   dig_overlap_join_count/fill with the regions as blocks: a pair counts when the mutation's START is one of the
- *   region's positions (value_counts of START, nb_model.py:135-136,160-163). */
+ *   region's positions (value_counts of START, nb_model.py:135-136,160-163); pairs whose mut_cohort is outside [0, C)
+ *   are skipped. */
 int dig_base_tile_probs(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off, const int64_t *chrom_len,
                         int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start, const int64_t *reg_end, int64_t R,
                         const double *s_prob, int64_t C, int binsize, int64_t n_tiles, double *pt, int64_t *first_pos,

@@ -44,10 +44,11 @@ def count_genome_context(args):
     df = sequence_tools.count_contexts_in_bed(args.fasta, df_bed, n_up=1, n_down=1)
     idx = df_bed.iloc[:, 0:3].values
     print('Saving context counts to {}'.format(args.fout))
-    mapfile.write_frame(args.fout, 'genome_counts', df.sum(axis=0).to_frame('COUNT'))
-    mapfile.write_frame(args.fout, 'all_window_genome_counts', df)
-    mapfile.write_array(args.fout, 'idx', idx.astype(np.int32))
-    mapfile.write_attrs(args.fout, n_up=1, n_down=1, collapse=0)
+    with mapfile.batch(args.fout):
+        mapfile.write_frame(args.fout, 'genome_counts', df.sum(axis=0).to_frame('COUNT'))
+        mapfile.write_frame(args.fout, 'all_window_genome_counts', df)
+        mapfile.write_array(args.fout, 'idx', idx.astype(np.int32))
+        mapfile.write_attrs(args.fout, n_up=1, n_down=1, collapse=0)
 
 
 def initialize_data(args):

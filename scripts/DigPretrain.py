@@ -47,10 +47,11 @@ def pretrain_region_model(args):
     df = region_model_tools.kfold_results(args.kfold_dir, args.cohort_name, key=args.key)
     if os.path.exists(args.outputFile) and not args.append:
         raise SystemExit("{} exists; pass --append to add to it.".format(args.outputFile))
-    mapfile.write_array(args.outputFile, 'idx', idx_all.astype(np.int32))
-    mapfile.write_array(args.outputFile, 'mappability', mapp.astype(np.float32))
-    mapfile.write_attrs(args.outputFile, cohort_name=args.cohort_name, mappability_threshold=args.map_thresh)
-    mapfile.write_frame(args.outputFile, 'region_params', df)
+    with mapfile.batch(args.outputFile):
+        mapfile.write_array(args.outputFile, 'idx', idx_all.astype(np.int32))
+        mapfile.write_array(args.outputFile, 'mappability', mapp.astype(np.float32))
+        mapfile.write_attrs(args.outputFile, cohort_name=args.cohort_name, mappability_threshold=args.map_thresh)
+        mapfile.write_frame(args.outputFile, 'region_params', df)
     if args.fmut:
         print('Adding mutation counts...')
         count_training_mutations(args)
@@ -93,8 +94,9 @@ def pretrain_sequence_model(args):
     print('Training sequence model')
     f192, f64 = sequence_tools.train_sequence_model(idx[keep], df_mut, S_genome)
     print('Saving sequence models to {}'.format(args.output_h5))
-    mapfile.write_frame(args.output_h5, 'sequence_model_192', f192)
-    mapfile.write_frame(args.output_h5, 'sequence_model_64', f64)
+    with mapfile.batch(args.output_h5):
+        mapfile.write_frame(args.output_h5, 'sequence_model_192', f192)
+        mapfile.write_frame(args.output_h5, 'sequence_model_64', f64)
 
 
 def pretrain_genic_model(args):

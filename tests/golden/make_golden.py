@@ -850,6 +850,37 @@ def gen_run_element_expectation():
     print("wrote run_element_expectation_golden.npz", out.shape)
 
 
+def gen_run_target():
+    """run_target_model (transfer_tools.py:876-967): the reference function itself on tests/golden/gene_mutations.tsv, once
+    per scale rule (mutations in the panel, samples in the panel, manual).  The packaged panel file
+    (pkg_resources.resource_stream) and the pretrained map (pd.read_hdf + h5py attrs) are handed in as fixtures."""
+    import io as _io
+    g = np.load(os.path.join(HERE, "gene_stats_golden.npz"), allow_pickle=False)
+    genes = [str(x) for x in g["genes"]]
+    frame = pd.DataFrame(g["frame_vals"], columns=[str(c) for c in g["frame_cols"]])
+    frame.insert(0, "GENE", genes)
+    frame.insert(0, "CHROM", g["frame_chrom"])
+    for c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+        frame[c] = frame[c].astype(int)
+    _HDF_FRAMES[("mem://target.h5", "genic_model")] = frame
+    attrs = {"N_MUT_PANELX": 1234, "N_MUT_SAMPLE_PANELX": 987, "N_SAMPLE_PANELX": 211}
+    _H5_FILES["mem://target.h5"] = {"__attrs__": attrs}
+    panel = ["G%d" % i for i in range(0, 400, 2)] + ["TP53", "NOT_IN_MODEL"]
+    sys.modules["pkg_resources"].resource_stream = lambda pkg, name: _io.BytesIO(("\n".join(panel) + "\n").encode())
+    ref_tt.pkg_resources = sys.modules["pkg_resources"]
+    outs = {}
+    for tag, kw in (("mut", {}), ("sample", dict(scale_by_sample=True)), ("manual", dict(scale_factor=0.37)),
+                    ("capped", dict(max_muts_per_sample=170, max_muts_per_gene_per_sample=3, drop_synonymous=False))):
+        with np.errstate(all="ignore"):
+            out = ref_tt.run_target_model(os.path.join(HERE, "gene_mutations.tsv"), "mem://target.h5", panel="PANELX", **kw)
+        num = [c for c in out.columns if c != "CHROM"]
+        outs[tag + "_index"] = np.array(out.index).astype(str)
+        outs[tag + "_cols"] = np.array(num).astype(str)
+        outs[tag + "_vals"] = out[num].values.astype(float)
+    save_npz("run_target_golden.npz", panel=np.array(panel), attr_names=np.array(list(attrs)), attr_vals=np.array(list(attrs.values())),
+             **outs)
+
+
 class _FakeTabix:
     """pysam.TabixFile look-alike over in-memory mutation rows (chrom, start, end, ref, alt, id): fetch(chrom, start,
     end) yields the tab-joined rows overlapping [start, end), as tabix does for 0-based half-open bed intervals."""
@@ -980,6 +1011,9 @@ def main():
     if "--only-run-element" in sys.argv:
         gen_run_element_expectation()
         return
+    if "--only-run-target" in sys.argv:
+        gen_run_target()
+        return
     if "--only-nn-training" in sys.argv:
         gen_nn_training()
         return
@@ -998,6 +1032,7 @@ def main():
     gen_sites()
     gen_tiled()
     gen_run_element_expectation()
+    gen_run_target()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

@@ -18,6 +18,9 @@ Outputs (all small, data only):
 """
 import json
 import os
+import sys
+
+sys.dont_write_bytecode = True            # nothing may be written under /root/reference
 
 import numpy
 numpy.typeDict = numpy.sctypeDict          # see the docstring

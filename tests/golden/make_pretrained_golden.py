@@ -8,6 +8,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True            # importing the reference must not leave .pyc files under /root/reference
+
 import h5py
 import numpy as np
 

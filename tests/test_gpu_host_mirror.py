@@ -230,3 +230,49 @@ def test_run_element_region_model_default_mode_matches_reference(tmp_path, monke
     with pytest.raises(FileNotFoundError) as err:
         transfer_tools.gene_panel("CGC_ALL")
     assert "genes_CGC_ALL.txt" in str(err.value) and "nowhere" in str(err.value) and "--panel-dir" in str(err.value)
+
+
+def test_run_target_model_matches_reference(_gpu, tmp_path, monkeypatch, capsys):
+    """`DigDriver.py targetDriver` (transfer_tools.py:876-967): panel genes, the three scale rules -- mutations inside the
+    panel (CohortRun.panel_scale, the default), samples inside the panel, manual -- and the capped / keep-synonymous form.
+    Golden: the reference function itself (tests/golden/make_golden.py::gen_run_target) on tests/golden/gene_mutations.tsv."""
+    from digdriver_amd.driver_model import transfer_tools as tt
+    from digdriver_amd.io import mapfile
+    g = np.load(os.path.join(GOLDEN, "run_target_golden.npz"), allow_pickle=False)
+    gg = np.load(os.path.join(GOLDEN, "gene_stats_golden.npz"), allow_pickle=False)
+    genes = pd.DataFrame(gg["frame_vals"], columns=[str(c) for c in gg["frame_cols"]])
+    for c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+        genes[c] = genes[c].astype(np.int64)
+    genes.insert(0, "GENE", [str(x) for x in gg["genes"]])
+    genes.insert(0, "CHROM", gg["frame_chrom"])
+    panel_dir = tmp_path / "panels"
+    panel_dir.mkdir()
+    (panel_dir / "genes_PANELX.txt").write_text("\n".join(str(x) for x in g["panel"]) + "\n")
+    (panel_dir / "genes_MSK_230.txt").write_text("\n".join(str(x) for x in g["panel"]) + "\n")
+    monkeypatch.setattr(tt, "_PANEL_DIRS", [str(panel_dir)])
+    attrs = {str(k): int(v) for k, v in zip(g["attr_names"], g["attr_vals"])}
+    mut = os.path.join(GOLDEN, "gene_mutations.tsv")
+    for ext in (".map", ".h5"):
+        pre = str(tmp_path / ("target" + ext))
+        mapfile.write_frame(pre, "genic_model", genes)
+        mapfile.write_attrs(pre, N_SAMPLE_MSK_230=attrs["N_SAMPLE_PANELX"], **attrs)
+        for tag, kw in (("mut", {}), ("sample", dict(scale_by_sample=True)), ("manual", dict(scale_factor=0.37)),
+                        ("capped", dict(max_muts_per_sample=170, max_muts_per_gene_per_sample=3, drop_synonymous=False))):
+            got = tt.run_target_model(mut, pre, panel="PANELX", **kw)
+            cols = [str(c) for c in g[tag + "_cols"]]
+            assert list(got.index) == [str(x) for x in g[tag + "_index"]], tag
+            assert [c for c in got.columns if c != "CHROM"] == cols, tag
+            vals = g[tag + "_vals"]
+            for i, c in enumerate(cols):
+                col = got[c].values.astype(float)
+                if c.startswith(("OBS_", "N_SAMP_")) or c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+                    assert np.array_equal(col, vals[:, i]), (tag, c)
+                else:
+                    rel_close(col, vals[:, i], 1e-6)
+        # the sites route's 'MSK_230' rule goes through the same counting (transfer_tools.py:1131-1149): samples inside the
+        # panel over the pretrained cohort's
+        run = tt.CohortRun(mut, pre)
+        by_sample = run.panel_scale('MSK_230', tt.gene_panel('MSK_230'), (), by_sample=True)
+        assert by_sample == 300 / attrs["N_SAMPLE_PANELX"]
+    out = capsys.readouterr().out
+    assert "Scaling factor is: 1.4218009478672986" in out and "300 211" in out       # the reference's own log lines
