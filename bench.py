@@ -265,6 +265,9 @@ def main():
                     help="how N > 1 ranks divide the work (see the module docstring); all three are configs[2] at N = 1")
     ap.add_argument("--contexts-on", choices=["main", "side"], default="main",
                     help="stream of the pipeline's context stage (it depends on the step's inputs only, like the scale factors)")
+    ap.add_argument("--form", choices=["auto", "general"], default="auto",
+                    help="auto: the plan checks L once (plan time) for the three-fold context repetition of sequence_tools.py:560-564 "
+                         "and runs the 64-context form of the accumulation when it holds; general: the 192-substitution form")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -359,7 +362,7 @@ def main():
         acc_k = out_acc if k == 0 else dict(out_acc, R_SIZE=torch.empty_like(out_acc["R_SIZE"]))
         return engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
-                                   td["obs_indel"], out_acc=acc_k, out_stats=out_stats)
+                                   td["obs_indel"], out_acc=acc_k, out_stats=out_stats, compact=args.form == "auto")
     pipes = [make_plan(k) for k in range(PLAN_RING)]
     pipe = pipes[0]
     # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
@@ -428,8 +431,12 @@ def main():
         if not sampling[0]:
             return None
         if SAMPLE_EVERY == 4:       # short runs: statistics on steps 1 mod 4, dot / contexts in turn on 3 mod 4
-            return "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
-        return sample_slot.get(t % SAMPLE_EVERY)
+            which = "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
+        else:
+            which = sample_slot.get(t % SAMPLE_EVERY)
+        if which == "contexts" and pipe.compact:       # the compact form has no context kernel: contexts + dot are one launch
+            which = "dot"
+        return which
 
     def step():
         # One step = wait for this step's scale factors (side stream, normally long done) + ONE dig_element_pipeline
@@ -496,14 +503,17 @@ def main():
     seq_cji = torch.empty(C, dtype=torch.float64, device=dev)
     scale_plan.run(seq_cj, seq_cji)                  # (a collective when the bins are sharded: every rank is here)
     t_settle = time.perf_counter()
-    ref_acc = ref_stats = None
+    # (a plan of its own -- own outputs, own workspace, the same form of the accumulation as the loop's plans -- run in
+    #  stream order on the main stream, nothing overlapped)
+    seq_plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
+                                   td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
+                                   td["obs_indel"], compact=args.form == "auto")
+    assert seq_plan.compact == pipe.compact
+    ref_acc, ref_stats = seq_plan.acc, seq_plan.stats
     n_settle = 0
     settle_cj, settle_cji = seq_cj, seq_cji
     while True:
-        ref_acc, ref_stats = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
-                                                     td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"],
-                                                     td["obs_snv"], td["obs_samples"], td["obs_indel"], settle_cj, settle_cji,
-                                                     out_acc=ref_acc, out_stats=ref_stats)
+        seq_plan.run(settle_cj, settle_cji, stages=7, stream=main_stream)
         n_settle += 1
         if n_settle % 16 == 0:
             torch.cuda.synchronize()
@@ -585,6 +595,8 @@ def main():
         # SURVEY 8d's algorithmic bytes, split by the stage that moves them (the three parts add up to b_acc + b_stat):
         stage_bytes = {"contexts": E * (260.0 * nbar + 4), "dot": E * 780.0 + 8.0 * E * C,
                        "statistics": E * C * (21.0 * nbar + 24 + 100)}
+        if pipe.compact:            # one launch does the work of both accumulation stages (SURVEY's unfused count is kept)
+            stage_bytes["dot"] += stage_bytes["contexts"]
         stage_kernels = {"contexts": ["acc_region"], "dot": ["acc_dot"], "statistics": ["element_stats_"]}
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37) and world == 1
 
@@ -601,7 +613,10 @@ def main():
             "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel (one launch: the "
                           "stream pass and, at the end of every workgroup, the pairs it could not finish in passing)",
             "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
-            "dot": "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64 + v_mfma_f64_4x4x4_f64 for the last 5 cohorts)"}
+            "dot": ("dig_element_pipeline accumulation (contexts + dot in one launch): acc_dot_ctx_kernel, the 64-context form for "
+                    "context-repeated L -- checked and compacted to [E, 64] ONCE at plan time (dig_element_pipeline_prepare), "
+                    "not per step; v_mfma_f64_16x16x4_f64 + v_mfma_f64_4x4x4_f64 for the last 5 cohorts") if pipe.compact else
+                   "dig_element_pipeline dot stage: acc_dot_mfma_kernel (v_mfma_f64_16x16x4_f64 + v_mfma_f64_4x4x4_f64 for the last 5 cohorts)"}
         stage_roofs = {k: roof(stage_names[k], stage_bytes[k], stage_ms[k], stage_kernels[k], len(samples[k]))
                        for k in ("statistics", "contexts", "dot")}
         if stage_ms["dot"]:
@@ -642,7 +657,12 @@ def main():
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
             "operations": {
-                "main stream": ("one dig_element_pipeline call per step (stages DOT | STATISTICS): acc_dot_mfma_kernel, "
+                "accumulation_form": ("compact: L repeats every context count three times (sequence_tools.py:560-564), verified on the "
+                                      "device and compacted to [E, 64] at plan time; contexts + dot = acc_dot_ctx_kernel (K = 128)"
+                                      if pipe.compact else "general: 192 substitution columns, acc_region_kernel + acc_dot_mfma_kernel (K = 256)"),
+                "main stream": ("one dig_element_pipeline call per step: acc_dot_ctx_kernel (contexts + dot), "
+                                "element_stats_stream_fused_kernel" if pipe.compact else
+                                "one dig_element_pipeline call per step (stages DOT | STATISTICS): acc_dot_mfma_kernel, "
                                 "element_stats_stream_fused_kernel" if ctx_side else
                                 "one dig_element_pipeline call per step: acc_region_kernel (contexts + table), "
                                 "acc_dot_mfma_kernel, element_stats_stream_fused_kernel"),

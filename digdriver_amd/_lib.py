@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_hip.so")
 
 DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
+DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS, DIG_PIPE_WORKLIST_CLEAN, DIG_PIPE_COMPACT_L = 1, 2, 4, 8, 16
 ES_PLANES = ("EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "THETA_INDEL", "EXP_INDEL",
              "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN")
 
@@ -51,6 +52,7 @@ _SIGNATURES = {
     "dig_scale_factors_chunked": [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
+    "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -76,7 +78,7 @@ _SIZE_QUERIES = {
     "dig_rbf_backward_partials": [_i64, _i64],
 }
 
-ABI_VERSION = 3          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 4          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

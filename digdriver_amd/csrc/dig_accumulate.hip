@@ -20,6 +20,7 @@
 //   * blockIdx -> element-group mapping is XCD-aware: workgroups that share an XCD (b % 8) walk one contiguous
 //     eighth of the genome-ordered element list, so shared bin rows stay in that XCD's L2.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "dig_common.hpp"
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
 
         double mu = 0.0, var = 0.0;
         int robs = 0, flag = 0, rsize = 0, lsum = 0;
+        unsigned class_has_zero = 0;      // bit q: some L[e, q, j] == 0 (wave-uniform)
         if (active) {
             const int64_t q0 = a.ov_ptr[e], q1 = a.ov_ptr[e + 1];
             int rc = 0;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
                 const int v = Le[r * 64 + lane];
                 st[r * 64 + lane] = (double)v;
                 lsum += v;
+                if (__any(v == 0)) class_has_zero |= 1u << (r / 3);
             }
             lsum = wave_sum_i32(lsum);
         }
@@ -165,7 +168,10 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
                         n2 = fma(Ls[j + 2], dprT[(j + 2) * Cc + lane], n2);
                         n3 = fma(Ls[j + 3], dprT[(j + 3) * Cc + lane], n3);
                     }
-                    a.P[(e * NCLASS + q) * a.C + col] = ((n0 + n1) + (n2 + n3)) / denom;
+                    // (denominator 0: the reference forms t_pi = d_pr / 0 = inf first, and inf * 0 is NaN -- see fix_zero_denominators)
+                    const double numer = (denom == 0.0 && ((class_has_zero >> q) & 1u)) ? __longlong_as_double(0x7ff8000000000000ll)
+                                                                                        : (n0 + n1) + (n2 + n3);
+                    a.P[(e * NCLASS + q) * a.C + col] = numer / denom;
                 }
             }
             if (lane == 0 && a.c0 == 0) {
@@ -406,13 +412,14 @@ __global__ __launch_bounds__(kRegionBlock) void acc_region_kernel(
 template <int NT, int NQ>
 __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __restrict__ tab, int step0, int lane,
                                            int toff, double4_t (&acc)[NT > 0 ? NT : 1], double (&accq)[NQ > 0 ? NQ : 1],
-                                           int& isum)
+                                           int& isum, int& anyzero)
 {
     constexpr int SL = NT + (NQ > 0 ? 1 : 0);     // LDS slots per step
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int v[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
         isum += (a[t].x + a[t].y) + (a[t].z + a[t].w);
+        anyzero |= (a[t].x == 0) | (a[t].y == 0) | (a[t].z == 0) | (a[t].w == 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double A = (double)v[u];
@@ -428,6 +435,43 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
                     accq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, bq[q * 16], accq[q], 0, 0, 0);
             }
         }
+    }
+}
+
+// sum(region_counts * d_pr) == 0 (an element whose bins hold no countable context, or no bin at all): the reference forms
+// t_pi = d_pr / 0 = inf FIRST and then sum(t_pi * L) (genic_driver_tools.py:361-366), which is NaN as soon as one L[j] is 0
+// (inf * 0) and inf otherwise; numerator / 0 alone would say inf in both cases.  `lzero`: this lane's slices of the row's L
+// hold a zero.  The numerators of such rows are replaced so that the quotient that follows gives the reference's value.
+// Rare: one wave-uniform test per tile in front of it.
+template <int NT, int NQ>
+__device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT > 0 ? NT : 1], const double (&denq)[NQ > 0 ? NQ : 1],
+                                                      double4_t (&num)[NT > 0 ? NT : 1], double (&numq)[NQ > 0 ? NQ : 1],
+                                                      int lzero, int lane)
+{
+    bool z = false;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z |= den[nt][r] == 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) z |= denq[q] == 0.0;
+    if (!__any(z)) return;
+    lzero |= __shfl_xor(lzero, 16, 64);                                  // the four k-lanes of a row together hold the row
+    lzero |= __shfl_xor(lzero, 32, 64);
+    const int kq = lane >> 4;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                        // D[i][j]: row 4 r + kq
+        const int rowzero = __shfl(lzero, 4 * r + kq, 64);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (den[nt][r] == 0.0 && rowzero) num[nt][r] = nan;
+    }
+    if constexpr (NQ > 0) {
+        const int rowzero = __shfl(lzero, 4 * ((lane >> 2) & 3) + kq, 64);   // D[i][j] of block b: row 4 b + i
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (denq[q] == 0.0 && rowzero) numq[q] = nan;
     }
 }
 
@@ -505,7 +549,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
         for (int nt = 0; nt < NT; ++nt) den[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < NQ; ++q) denq[q] = 0.0;
-        mfma_group<NT, NQ>(cur, tabw, 0, lane, toff, den, denq, rsum);                  // sum(region_counts * d_pr), genic_driver_tools.py:361
+        int unused_zero = 0;
+        mfma_group<NT, NQ>(cur, tabw, 0, lane, toff, den, denq, rsum, unused_zero);     // sum(region_counts * d_pr), genic_driver_tools.py:361
 #pragma unroll 1
         for (int q = 0; q < NCLASS; ++q) {
             int opaque_zero_q;                                           // (same hoisting guard, per class)
@@ -517,6 +562,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
             for (int nt = 0; nt < NT; ++nt) num[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int qq = 0; qq < NQ; ++qq) numq[qq] = 0.0;
+            int lzero = 0;                                               // some L[e, q, j] == 0 (this lane's slices)
 #pragma unroll
             for (int g = 0; g < 3; ++g) {                                // sum(t_pi * L), :364-366
 #pragma unroll
@@ -527,8 +573,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
 #pragma unroll
                     for (int t = 0; t < 4; ++t) nxt[t] = pn[4 * t];
                 }
-                mfma_group<NT, NQ>(cur, tabq, 16 + 16 * g, lane, toff, num, numq, lsum);
+                mfma_group<NT, NQ>(cur, tabq, 16 + 16 * g, lane, toff, num, numq, lsum, lzero);
             }
+            fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t e = e0 + 4 * r + kq;                      // D[i][j]: lane 16 (i % 4) + j, register i / 4
@@ -563,6 +610,246 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
             }
         }
         tile = tile_next;
+    }
+}
+
+// =======================================================================================
+// Compact form: context-repeated L (every elementModel / tiledModel / quickDriver set).
+//
+// sequence_tools.py:560-564 builds the L_counts of an element as its 64 trinucleotide context counts, each written to the
+// three substitutions of that context (adjacent in sorted "XYZ>XaZ" order).  Then
+//     sum_j L[e, j] d_pr[c, j] = sum_ctx Lc[e, ctx] d64[c, ctx],   d64[c, ctx] = (d_pr[c, 3 ctx] + d_pr[c, 3 ctx + 1]) + d_pr[c, 3 ctx + 2]
+// -- the numerator runs over the SAME 64 per-context sums the denominator sum(region_counts * d_pr) uses, so the
+// [E x 256] x [256 x C] product collapses to two [E x 64] x [64 x C] products that share their B operand: half the matrix
+// instructions, a quarter of the LDS table (24 KB: built by every workgroup straight from d_pr, no table kernel), and
+// L is read as [E, 64] (compacted once per plan by compact_L_kernel, which also verifies the repetition).
+// The context stage lives in the same kernel: lane (i, k) of a wave gathers the 16-byte slices 4 t + k of the context
+// rows of its element's bins itself (CSR bounds two tiles ahead, bin indices one tile ahead, rows half a tile ahead: the
+// loads of the main path are unconditional so that the memory counter stays exact), sums them as integers and feeds
+// them to the matrix pipe; the '-' strand permutation (sequence_tools.py:633-634) is a register choice: the lane reads
+// slice 4 t' + (3 - k) instead and takes component 3 - t of slice 3 - u where the '+' strand takes component u of slice t
+// (revcomp(16 t + 4 k + u) = 16 (3 - u) + 4 (3 - k) + (3 - t)).  No context rows cross HBM between two kernels any more.
+// =======================================================================================
+#ifndef DIG_CTX_WAVES
+#define DIG_CTX_WAVES 12
+#endif
+constexpr int kCtxWaves = DIG_CTX_WAVES;
+constexpr int kCtxSteps = 16;                 // 64 context rows / 4
+
+__global__ __launch_bounds__(256) void compact_L_kernel(const int32_t* __restrict__ L, int64_t n64, int32_t* __restrict__ Lc,
+                                                        int* __restrict__ mismatch)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int bad = 0;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n64; g += stride) {
+        const int32_t* p = L + 3 * g;                          // [E, 192] = [E * 64, 3]
+        const int a = p[0], b = p[1], c = p[2];
+        Lc[g] = a;
+        bad |= (a != b) | (a != c);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(mismatch, 1);
+}
+
+template <int NT, int NQ>
+__global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
+    const int32_t* __restrict__ bin_ctx, const int64_t* __restrict__ ov_ptr, const int32_t* __restrict__ ov_idx,
+    const uint8_t* __restrict__ strand_minus, const int32_t* __restrict__ Lc, const double* __restrict__ d_pr,
+    const int32_t* __restrict__ gene_length, double* __restrict__ P, int32_t* __restrict__ R_SIZE,
+    int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes,
+    unsigned* __restrict__ zero_dwords, int n_zero)
+{
+    constexpr int SL = NT + (NQ > 0 ? 1 : 0);
+    constexpr int NTA = NT > 0 ? NT : 1, NQA = NQ > 0 ? NQ : 1;
+    __shared__ double tab[kCtxSteps * SL * 64];       // tab[step = 4 t + u][slot][lane], as acc_write_mfma_table lays it out
+
+    // (pipeline only) clear the worklist header of the statistics stage that follows on the stream
+    if (zero_dwords && blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_dwords[threadIdx.x] = 0u;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int toff = 4 * kq + (lane & 3);     // B[k][j] of every block of a quad: lane 16 k + 4 b + j
+    const int64_t n_tiles = (E + 15) >> 4;
+    // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs; the workgroups of one XCD (equal blockIdx % 8) take one
+    // contiguous eighth of the genome-ordered tiles, so that the bin rows neighbouring elements share stay in that L2
+    const int nx = (gridDim.x & 7u) == 0u ? 8 : 1;
+    const int xcd = blockIdx.x % nx, slot_b = blockIdx.x / nx, nslots = gridDim.x / nx;
+    const int64_t per_x = (n_tiles + nx - 1) / nx;
+    const int64_t t_begin = (int64_t)xcd * per_x;
+    const int64_t t_end = t_begin + per_x < n_tiles ? t_begin + per_x : n_tiles;
+    const int64_t stride = (int64_t)nslots * kCtxWaves;
+    int64_t tile = t_begin + (int64_t)wave * nslots + slot_b;    // wave-major: a partial last round is spread over all CUs
+
+    const int4* ctx4 = reinterpret_cast<const int4*>(bin_ctx);
+    const int4* L4 = reinterpret_cast<const int4*>(Lc);
+    // every element's CSR range lies inside [0, nnz); with an empty CSR the index loads replay ov_ptr[0] (= 0: row 0)
+    const int64_t nnz = ov_ptr[E];
+    const int32_t* oi_base = nnz > 0 ? ov_idx : reinterpret_cast<const int32_t*>(ov_ptr);
+    const int64_t oi_last = nnz > 0 ? nnz - 1 : 0;
+
+    struct Bounds { int64_t q0, row; int cnt, minus; };
+    struct Idx { int i0, i1; };
+    struct Rows { int4 a[4], b[4], l[4]; };
+    auto load_bounds = [&](int64_t tile_) {          // tiles / rows past the end replay the last row (never stored)
+        Bounds r;
+        r.row = min(min(tile_, n_tiles - 1) * 16 + i, E - 1);
+        r.q0 = ov_ptr[r.row];
+        r.cnt = (int)(ov_ptr[r.row + 1] - r.q0);
+        r.minus = strand_minus[r.row];
+        return r;
+    };
+    auto load_idx = [&](const Bounds& b) {           // unconditional: bins an element does not have replay a valid entry
+        Idx x;
+        x.i0 = oi_base[min(b.q0, oi_last)];
+        x.i1 = oi_base[min(b.q0 + 1, oi_last)];
+        return x;
+    };
+    auto load_rows = [&](const Bounds& b, const Idx& x) {
+        Rows r;
+        const int kk = b.minus ? 3 - kq : kq;
+        const int4* r0 = ctx4 + (int64_t)x.i0 * 16 + kk;
+        const int4* r1 = ctx4 + (int64_t)x.i1 * 16 + kk;
+        const int4* rl = L4 + b.row * 16 + kq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.a[t] = r0[4 * t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.b[t] = r1[4 * t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.l[t] = rl[4 * t];
+        return r;
+    };
+
+    // pipeline fill (in flight while the table is staged)
+    Bounds b_c = load_bounds(tile), b_n = load_bounds(tile + stride);
+    Idx x_c = load_idx(b_c);
+
+    // stage the B operand: per-context sums of d_pr in the per-lane order of the matrix instructions
+    for (int idx = threadIdx.x; idx < kCtxSteps * SL * 64; idx += kCtxWaves * 64) {
+        const int lane_ = idx & 63, slot = (idx >> 6) % SL, step = idx / (SL * 64);
+        const bool tail = NQ > 0 && slot == NT;
+        const int kappa = 16 * (step >> 2) + 4 * (tail ? (lane_ >> 2) & 3 : lane_ >> 4) + (step & 3);
+        const int c = c0 + slot * 16 + (tail ? 4 * (lane_ >> 4) + (lane_ & 3) : lane_ & 15);
+        double v = 0.0;
+        if (c < C && (!tail || (lane_ >> 4) < NQ)) {
+            const double* d = d_pr + (int64_t)c * 192 + 3 * kappa;
+            v = (d[0] + d[1]) + d[2];
+        }
+        tab[idx] = v;
+    }
+    Rows r_c = load_rows(b_c, x_c);
+    __syncthreads();
+    if (tile >= t_end) return;
+
+    while (tile < t_end) {
+        // (the table reads are invariant across tiles: without the opaque zero the compiler hoists them out of the loop and spills)
+        int opaque_zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+        const double* tabw = tab + opaque_zero;
+        const int64_t e0 = tile * 16;
+        const Bounds b_nn = load_bounds(tile + 2 * stride);      // tile t+2: CSR bounds
+        const Idx x_n = load_idx(b_n);                           // tile t+1: first two bin indices
+        // region counts of the element: sum of its bins' context rows (sequence_tools.py:630-631), integers
+        int rcv[4][4], lv[4][4];
+        {
+            const int m0 = b_c.cnt > 0 ? -1 : 0, m1 = b_c.cnt > 1 ? -1 : 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rcv[t][0] = (r_c.a[t].x & m0) + (r_c.b[t].x & m1);
+                rcv[t][1] = (r_c.a[t].y & m0) + (r_c.b[t].y & m1);
+                rcv[t][2] = (r_c.a[t].z & m0) + (r_c.b[t].z & m1);
+                rcv[t][3] = (r_c.a[t].w & m0) + (r_c.b[t].w & m1);
+                lv[t][0] = r_c.l[t].x; lv[t][1] = r_c.l[t].y; lv[t][2] = r_c.l[t].z; lv[t][3] = r_c.l[t].w;
+            }
+        }
+        if (__any(b_c.cnt > 2)) {                                // elements over more than two bins (multi-block, gene-sized)
+            const int kk = b_c.minus ? 3 - kq : kq;
+            for (int j = 2; j < b_c.cnt; ++j) {
+                const int4* r = ctx4 + (int64_t)ov_idx[b_c.q0 + j] * 16 + kk;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int4 v = r[4 * t];
+                    rcv[t][0] += v.x; rcv[t][1] += v.y; rcv[t][2] += v.z; rcv[t][3] += v.w;
+                }
+            }
+        }
+        double4_t den[NTA], num[NTA];
+        double denq[NQA], numq[NQA];
+#pragma unroll
+        for (int nt = 0; nt < NTA; ++nt) den[nt] = num[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) denq[q] = numq[q] = 0.0;
+        int rsum = 0, lsum = 0, lzero = 0;
+        const bool minus = b_c.minus != 0;
+        auto steps = [&](auto T0) {
+            constexpr int t0 = decltype(T0)::value;
+#pragma unroll
+            for (int t = t0; t < t0 + 2; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int vr = minus ? rcv[3 - u][3 - t] : rcv[t][u];
+                    rsum += rcv[t][u];
+                    lsum += lv[t][u];
+                    lzero |= lv[t][u] == 0;
+                    const double Ar = (double)vr, Al = (double)lv[t][u];
+                    const double* b = tabw + ((4 * t + u) * SL) * 64 + lane;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const double bv = b[nt * 64];
+                        den[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar, bv, den[nt], 0, 0, 0);   // sum(region_counts * d_pr), :361
+                        num[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, bv, num[nt], 0, 0, 0);   // sum(d_pr * L), :364-366
+                    }
+                    if constexpr (NQ > 0) {
+                        const double* bq = tabw + ((4 * t + u) * SL + NT) * 64 + toff;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const double bv = bq[q * 16];
+                            denq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ar, bv, denq[q], 0, 0, 0);
+                            numq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Al, bv, numq[q], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        steps(std::integral_constant<int, 0>{});
+        r_c = load_rows(b_n, x_n);                               // tile t+1: context rows + L (indices have arrived meanwhile)
+        steps(std::integral_constant<int, 2>{});
+        fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t e = e0 + 4 * r + kq;                   // D[i][j]: lane 16 (i % 4) + j, register i / 4
+            if (e < E) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = c0 + nt * 16 + i;
+                    if (c < C) P[e * C + c] = num[nt][r] / den[nt][r];
+                }
+            }
+        }
+        if constexpr (NQ > 0) {
+            const int64_t e = e0 + 4 * ((lane >> 2) & 3) + kq;   // D[i][j] of block b: lane 16 i + 4 b + j
+            if (e < E) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = c0 + NT * 16 + 4 * q + (lane & 3);
+                    if (c < C) P[e * C + c] = numq[q] / denq[q];
+                }
+            }
+        }
+        if (write_sizes) {
+            rsum += __shfl_xor(rsum, 16, 64);
+            rsum += __shfl_xor(rsum, 32, 64);
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            const int64_t e = e0 + i;
+            if (kq == 0 && e < E) {
+                R_SIZE[e] = rsum;                                                    // genic_driver_tools.py:375
+                ELT_SIZE[e] = lsum;                                                  // :380 (sum(L) / 3 with L = 3 x repeated)
+                const double numer = gene_length ? (double)gene_length[e] : (double)lsum;
+                P_INDEL[e] = numer / (double)rsum;                                   // :381 / :159
+            }
+        }
+        b_c = b_n;
+        b_n = b_nn;
+        tile += stride;
     }
 }
 
@@ -680,6 +967,55 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
     if (!(parts & 2)) return DIG_OK;
     return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
                           : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
+}
+
+// Compact form of the dot + context stages (dig_element_pipeline with DIG_PIPE_COMPACT_L): one kernel per 48-cohort chunk.
+int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const uint8_t* strand_minus,
+                              const int32_t* Lc, const int32_t* gene_length, const double* d_pr, double* P, int32_t* R_SIZE,
+                              int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, void* stream, unsigned* zero_dwords,
+                              int n_zero)
+{
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && Lc && d_pr, "non-null inputs");
+    DIG_REQUIRE(P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
+    const int64_t n_tiles = (E + 15) / 16;
+    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cu_count(), (n_tiles + kCtxWaves - 1) / kCtxWaves));
+    if (grid >= 8) grid &= ~7;                 // whole rounds of the 8 XCDs (the walk is XCD-aware when it can be)
+    const int n48 = (int)((C + kMfmaChunk - 1) / kMfmaChunk);
+    for (int ch = 0; ch < n48; ++ch) {
+        const ChunkCut cut = chunk_cut((int)C, ch);
+        auto go = [&](auto kern) -> int {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kCtxWaves * 64), 0, (hipStream_t)stream, bin_ctx, ov_ptr, ov_idx, strand_minus,
+                               Lc, d_pr, gene_length, P, R_SIZE, ELT_SIZE, P_INDEL, E, (int)C, ch * kMfmaChunk, (int)(ch == 0),
+                               ch == 0 ? zero_dwords : nullptr, n_zero);
+            DIG_HIP_TRY(hipGetLastError());
+            return DIG_OK;
+        };
+        int rc;
+        switch (cut.nt * 3 + cut.nq) {
+        case 9: rc = go(acc_dot_ctx_kernel<3, 0>); break;
+        case 6: rc = go(acc_dot_ctx_kernel<2, 0>); break;
+        case 7: rc = go(acc_dot_ctx_kernel<2, 1>); break;
+        case 8: rc = go(acc_dot_ctx_kernel<2, 2>); break;
+        case 3: rc = go(acc_dot_ctx_kernel<1, 0>); break;
+        case 4: rc = go(acc_dot_ctx_kernel<1, 1>); break;
+        case 5: rc = go(acc_dot_ctx_kernel<1, 2>); break;
+        case 1: rc = go(acc_dot_ctx_kernel<0, 1>); break;
+        default: rc = go(acc_dot_ctx_kernel<0, 2>); break;
+        }
+        if (rc) return rc;
+    }
+    return DIG_OK;
+}
+
+// Plan-time: Lc[e, ctx] = L[e, 3 ctx]; *mismatch (device int, cleared here) becomes 1 when some context's three counts differ.
+int compact_L_launch(const int32_t* L, int64_t E, int32_t* Lc, int* mismatch, void* stream)
+{
+    DIG_HIP_TRY(hipMemsetAsync(mismatch, 0, sizeof(int), (hipStream_t)stream));
+    if (E == 0) return DIG_OK;
+    hipLaunchKernelGGL(compact_L_kernel, dim3(grid_for(E * 64, 256)), dim3(256), 0, (hipStream_t)stream, L, E * 64, Lc, mismatch);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
 }
 
 }  // namespace dig

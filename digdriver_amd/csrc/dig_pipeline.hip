@@ -35,6 +35,28 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
                          const int32_t* obs_samples, const int32_t* obs_indel, const double* cj, const double* cj_indel,
                          double* out, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes, void* stream,
                          const FusedRates* fused, int worklist_already_zero);
+int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const uint8_t* strand_minus,
+                              const int32_t* Lc, const int32_t* gene_length, const double* d_pr, double* P, int32_t* R_SIZE,
+                              int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, void* stream, unsigned* zero_dwords,
+                              int n_zero);
+int compact_L_launch(const int32_t* L, int64_t E, int32_t* Lc, int* mismatch, void* stream);
+
+// workspace of dig_element_pipeline: [accumulate: context rows + parameter table][statistics: worklist][compact L + flag]
+struct PipeLayout {
+    int64_t acc_bytes, stats_off, stats_bytes, lc_off, flag_off, bytes;
+};
+static PipeLayout pipe_layout(int64_t E, int64_t C, int64_t acc, int64_t stats)
+{
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    PipeLayout p{};
+    p.acc_bytes = up(acc);
+    p.stats_off = p.acc_bytes;
+    p.stats_bytes = stats;
+    p.lc_off = up(p.stats_off + stats);
+    p.flag_off = up(p.lc_off + E * 64 * (int64_t)sizeof(int32_t));
+    p.bytes = p.flag_off + 256;
+    return p;
+}
 
 }  // namespace dig
 
@@ -50,7 +72,29 @@ int64_t dig_element_pipeline_workspace(int64_t E, int64_t C)
     if (E <= 0 || C <= 0) return 0;
     const int64_t a = dig_accumulate_workspace(E, C), b = dig_element_stats_workspace(E, C);
     if (a <= 0 || b <= 0) return 0;
-    return (a + 255) / 256 * 256 + b;
+    return pipe_layout(E, C, a, b).bytes;
+}
+
+int dig_element_pipeline_prepare(const int32_t* L, int64_t E, int64_t C, void* workspace, int64_t workspace_bytes,
+                                 int* compact_ok, void* stream)
+{
+    DIG_REQUIRE(E >= 0 && C >= 0 && compact_ok, "E, C >= 0, compact_ok non-null");
+    *compact_ok = 0;
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(L, "L non-null");
+    const int64_t need = dig_element_pipeline_workspace(E, C);
+    DIG_REQUIRE(workspace && need > 0 && workspace_bytes >= need,
+                "workspace of at least dig_element_pipeline_workspace(E, C) bytes (E * C must stay below 2^32 - 1)");
+    DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
+    const PipeLayout lay = pipe_layout(E, C, dig_accumulate_workspace(E, C), dig_element_stats_workspace(E, C));
+    int* flag = (int*)((char*)workspace + lay.flag_off);
+    int rc = compact_L_launch(L, E, (int32_t*)((char*)workspace + lay.lc_off), flag, stream);
+    if (rc) return rc;
+    int bad = 1;
+    DIG_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DIG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *compact_ok = bad ? 0 : 1;
+    return DIG_OK;
 }
 
 int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
@@ -62,7 +106,8 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                          int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
     const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
-    stages &= ~DIG_PIPE_WORKLIST_CLEAN;
+    const int compact = (stages & DIG_PIPE_COMPACT_L) != 0 && N >= 1;
+    stages &= ~(DIG_PIPE_WORKLIST_CLEAN | DIG_PIPE_COMPACT_L);
     DIG_REQUIRE(stages >= 1 && stages <= 7, "stages: bit mask of DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS");
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
@@ -71,10 +116,21 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     DIG_REQUIRE(workspace && need > 0 && workspace_bytes >= need,
                 "workspace of at least dig_element_pipeline_workspace(E, C) bytes (E * C must stay below 2^32 - 1)");
     DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
-    const int64_t acc_bytes = (dig_accumulate_workspace(E, C) + 255) / 256 * 256;
+    const PipeLayout lay = pipe_layout(E, C, dig_accumulate_workspace(E, C), dig_element_stats_workspace(E, C));
+    const int64_t acc_bytes = lay.acc_bytes;
     // the first kernel also clears the worklist header of the statistics stage (64 dwords): no separate memset node
     unsigned* wl = (unsigned*)((char*)workspace + acc_bytes);
-    if (stages & 3) {
+    if (compact) {
+        // context-repeated L, compacted by dig_element_pipeline_prepare: contexts + dot are ONE kernel (the DOT stage; a
+        // CONTEXTS-only call has nothing to enqueue)
+        if (stages & DIG_PIPE_DOT) {
+            DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && d_pr && P && R_SIZE && ELT_SIZE && P_INDEL,
+                        "non-null accumulation arguments");
+            int rc = accumulate_compact_launch(bin_ctx, ov_ptr, ov_idx, strand_minus, (const int32_t*)((char*)workspace + lay.lc_off),
+                                               gene_length, d_pr, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, stream, wl, 64);
+            if (rc) return rc;
+        }
+    } else if (stages & 3) {
         int rc = accumulate_launch(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, 1, strand_minus, gene_length,
                                    d_pr, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE, P_INDEL, N, E, C, workspace, acc_bytes,
                                    stream, 0, wl, 64, stages & 3);
@@ -84,10 +140,10 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
     const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index};
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
-                                out, E, C, (char*)workspace + acc_bytes, workspace_bytes - acc_bytes, stream, &f,
+                                out, E, C, (char*)workspace + acc_bytes, lay.stats_bytes, stream, &f,
                                 /* worklist header cleared by the context kernel of THIS call; a statistics-only call
                                    (new scale factors on an existing accumulation) clears it itself */
-                                (stages & 1) != 0 || worklist_clean);
+                                (compact ? (stages & DIG_PIPE_DOT) != 0 : (stages & 1) != 0) || worklist_clean);
 }
 
 }  // extern "C"

@@ -88,6 +88,38 @@ class PackedGenome:
                 raise KeyError("chromosome %r is not in the genome" % c)
         return out
 
+    def slab(self, chroms, starts, ends, margin_words=1):
+        """The part of the genome a set of regions needs -- one rank's bin range of the per-base route (the reference
+        fetches every bin's sequence from the FASTA on its own, sequence_tools.py:21-29; regions are independent).
+        Per chromosome the regions touch: the words from the one holding min(start) - 1 to the one holding max(end) + 1, plus
+        `margin_words` on either side (clipped to the chromosome).  Returns (sub, shift): `sub` is a PackedGenome with the
+        same chromosome names (untouched chromosomes have length 0) in which a true position p of chromosome c sits at
+        p - shift[c]; a region shifted that way gets the same positions, contexts and chromosome-end clipping from the
+        kernels as the true region on the whole genome (shift is 0 or leaves >= 8 bases in front of the first region; the
+        slab ends >= 8 bases behind the last region or at the true chromosome end)."""
+        ci = self.chrom_index(chroms)
+        st, en = np.asarray(starts, np.int64).ravel(), np.asarray(ends, np.int64).ravel()
+        n_chrom = len(self.names)
+        shift, new_len = np.zeros(n_chrom, np.int64), np.zeros(n_chrom, np.int64)
+        pieces, offsets, total = [np.full(1, 0x44444444, np.uint32)], np.zeros(n_chrom, np.int64), 0
+        for c in range(n_chrom):
+            offsets[c] = total
+            sel = ci == c
+            if not sel.any():
+                continue
+            length = int(self.lengths[c])
+            lo = max(0, (int(st[sel].min()) - 1) // 8 * 8 - 8 * margin_words)
+            hi = min(length, (int(en[sel].max()) + 2 + 7) // 8 * 8 + 8 * margin_words)
+            if hi <= lo:
+                continue
+            w0 = 1 + (int(self.offsets[c]) + lo) // 8
+            w1 = 1 + (int(self.offsets[c]) + hi + 7) // 8
+            pieces.append(self.words[w0:w1])
+            shift[c], new_len[c] = lo, hi - lo
+            total += (w1 - w0) * 8
+        pieces.append(np.full(1, 0x44444444, np.uint32))
+        return PackedGenome(self.names, offsets, new_len, np.concatenate(pieces)), shift
+
     def on_device(self, device):
         import torch
         dev = torch.device(device)

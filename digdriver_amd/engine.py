@@ -271,11 +271,17 @@ _NP_DT = {np.dtype(np.float32): _lib.DIG_F32, np.dtype(np.float64): _lib.DIG_F64
 
 
 def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
-                     obs_samples, obs_indel, cj, cj_indel, gene_length=None, out_acc=None, out_stats=None, stages=7):
+                     obs_samples, obs_indel, cj, cj_indel, gene_length=None, out_acc=None, out_stats=None, stages=7, compact=False):
     """accumulate_elements (n_class = 1) + element_stats as one operation on device tensors (dig_element_pipeline):
     the rate sums are formed inside the statistics kernel.  Returns (accumulate dict, statistics tensor [7, E, C]).
-    stages: bit mask 1 = context kernel, 2 = dot kernel, 4 = statistics (7 = all); separate calls must keep that order."""
+    stages: bit mask 1 = context kernel, 2 = dot kernel, 4 = statistics (7 = all); separate calls must keep that order.
+    compact="auto": check L for the three-fold context repetition first (one more pass over L and a stream synchronisation,
+    see PipelinePlan) and run the 64-context form when it holds; a loop over the same element set should keep a PipelinePlan."""
     import torch
+    if compact:
+        plan = PipelinePlan(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv, obs_samples,
+                            obs_indel, out_acc=out_acc, out_stats=out_stats, gene_length=gene_length, compact=compact)
+        return plan.run(_t(cj, torch.float64, plan.dev), _t(cj_indel, torch.float64, plan.dev), stages=stages)
     dev = bin_mu.device
     f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
     bin_mu, bin_std = _t(bin_mu, f64, dev), _t(bin_std, f64, dev)
@@ -311,7 +317,12 @@ class PipelinePlan:
     host time instead of ~60), which keeps the host ahead of a 0.3 ms GPU step.  The tensors are held by the plan."""
 
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
-                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None):
+                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto"):
+        """compact: "auto" (default) checks ONCE, here, on the device whether L repeats every context count three times
+        (sequence_tools.py:560-564: true for every elementModel / tiledModel / quickDriver set) and, if so, runs the
+        64-context form of the accumulation (contexts + dot in one kernel, half the matrix work); False forces the
+        general 192-substitution form.  `self.compact` tells which one runs."""
+        import ctypes
         import torch
         dev = bin_mu.device
         f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
@@ -339,11 +350,19 @@ class PipelinePlan:
                       p(o["P_INDEL"]), p(self.stats), self.N, self.E, self.C]
         self._ws = p(self.ws)
         self._fn = getattr(_lib.load(), "dig_element_pipeline")
+        self.compact = False
+        if compact and self.N >= 1:
+            ok = ctypes.c_int(0)
+            with torch.cuda.device(dev):
+                _lib.call("dig_element_pipeline_prepare", p(L), self.E, self.C, self._ws, self.wsb, ctypes.byref(ok),
+                          _lib.stream_ptr())
+            self.compact = bool(ok.value)
+        self._flags = _lib.DIG_PIPE_COMPACT_L if self.compact else 0
 
     def run(self, cj, cj_indel, stages=7, stream=None):
         """Enqueue the pipeline (or one of its stages) on `stream` (default: torch's current stream)."""
-        rc = self._fn(*self._head, _lib.dev_ptr(cj), _lib.dev_ptr(cj_indel), *self._tail, int(stages), self._ws, self.wsb,
-                      _lib.stream_ptr(stream))
+        rc = self._fn(*self._head, _lib.dev_ptr(cj), _lib.dev_ptr(cj_indel), *self._tail, int(stages) | self._flags, self._ws,
+                      self.wsb, _lib.stream_ptr(stream))
         if rc != 0:
             raise _lib.DigHipError("dig_element_pipeline failed (%d): %s" % (rc, _lib.last_error()))
         return self.acc, self.stats

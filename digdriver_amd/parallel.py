@@ -278,3 +278,132 @@ def chunked_scale_factors_reference(part, n_own, group=None):
     s = sum(p[n_own] for p in parts)
     d = sum(p[n_own + 1] for p in parts)
     return s / e, d / e
+
+
+# ---------------------------------------------------------------------------------------------
+# per-base / tiled route and CNN + GP prediction, sharded by bins (BASELINE configs[4], SURVEY 8e: "bins are independent
+# for a1-a7"; nb_model.py:188-234 is a loop over bins)
+# ---------------------------------------------------------------------------------------------
+def shard_rows(n, rank, world):
+    """Positions [lo, hi) of a list of n bins that rank `rank` of `world` takes: contiguous, genome order kept, so that the
+    concatenation of the ranks' results in rank order IS the single-process result."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def all_gather_rows(t, group=None):
+    """Variable-length row all-gather: the concatenation, in rank order, of every rank's `t` (dim 0), on EVERY rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    pad = torch.zeros((max(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+class ShardedTiles:
+    """One rank of the per-base / tiled NB test sharded by bins (nb_model.py:188-234: one independent iteration per bin).
+
+    Rank r takes the bins shard_rows(R, r, world) of the genome-ordered bin list with their mu / sigma columns, the slab
+    of the packed genome those bins need (PackedGenome.slab: coordinates shifted per chromosome, same positions, contexts
+    and chromosome-end clipping as on the whole genome) and the mutations that start inside the slab.  The three launches
+    (dig_base_tile_probs -> dig_tile_mut_counts -> dig_tiled_nb_test) need nothing from another rank: results have the
+    single-device bits.  The one exchange of the route is the Benjamini-Hochberg pass (get_q_vals, nb_model.py:340-342),
+    which ranks ALL p-values of a cohort: q_values() all-gathers the cohort's valid-tile p-values in rank order (= the
+    single-process frame order) and every rank keeps the q-values of its own tiles."""
+
+    def __init__(self, genome, chroms, starts, ends, s_prob, mu, sigma, mut_chrom, mut_start, mut_end, mut_cohort, binsize,
+                 device, rank, world, group=None):
+        self.rank, self.world, self.group, self.device, self.binsize = int(rank), int(world), group, device, int(binsize)
+        chroms = np.asarray([str(c) for c in chroms])
+        starts, ends = np.asarray(starts, np.int64), np.asarray(ends, np.int64)
+        R = len(chroms)
+        self.R_total = R
+        self.lo, self.hi = shard_rows(R, rank, world)
+        # tiles per bin: the same on every rank (what the longest bin of the WHOLE list needs)
+        self.n_tiles = int(max(1, -(-int((ends - starts).max() if R else 1) // self.binsize)))
+        sl = slice(self.lo, self.hi)
+        self.chroms = chroms[sl]
+        self.genome, self.shift = genome.slab(self.chroms, starts[sl], ends[sl]) if self.hi > self.lo else (genome, None)
+        if self.hi > self.lo:
+            ci = genome.chrom_index(self.chroms)
+            self.reg_shift = self.shift[ci]
+            self.starts, self.ends = starts[sl] - self.reg_shift, ends[sl] - self.reg_shift
+        else:
+            self.reg_shift = np.zeros(0, np.int64)
+            self.starts, self.ends = starts[sl], ends[sl]
+        self.s_prob = np.asarray(s_prob, np.float64)
+        self.C = self.s_prob.shape[0]
+        self.mu = np.ascontiguousarray(np.asarray(mu, np.float64).reshape(self.C, R)[:, sl])
+        self.sigma = np.ascontiguousarray(np.asarray(sigma, np.float64).reshape(self.C, R)[:, sl])
+        # mutations that start inside the slab (a row counts in the tile that holds its START, nb_model.py:160-163)
+        mc = np.asarray(mut_chrom).astype(str)
+        ms, me, co = np.asarray(mut_start, np.int64), np.asarray(mut_end, np.int64), np.asarray(mut_cohort, np.int32)
+        if self.hi > self.lo and len(mc):
+            known = {n.replace("chr", ""): i for i, n in enumerate(genome.names)}
+            mi = np.array([known.get(c.replace("chr", ""), -1) for c in mc])
+            ok = mi >= 0
+            sh = np.where(ok, self.shift[np.maximum(mi, 0)], 0)
+            ln = np.where(ok, self.genome.lengths[np.maximum(mi, 0)], 0)
+            keep = ok & (ms - sh >= 0) & (ms - sh < ln)
+            self.mut = (mc[keep], (ms - sh)[keep], (me - sh)[keep], co[keep])
+        else:
+            self.mut = (mc[:0], ms[:0], me[:0], co[:0])
+        self.result = None
+
+    def run(self):
+        """The rank's tiles: dict of device tensors pval, exp, pt [C, R_r, n_tiles], k i32, first_pos [R_r] (TRUE
+        coordinates), n_valid [R_r]."""
+        import torch
+        from . import engine
+        dev, C, Rr = self.device, self.C, self.hi - self.lo
+        if Rr == 0:
+            z = lambda dt: torch.empty((C, 0, self.n_tiles), dtype=dt, device=dev)
+            self.result = dict(pval=z(torch.float64), exp=z(torch.float64), pt=z(torch.float64), k=z(torch.int32),
+                               first_pos=torch.empty(0, dtype=torch.int64, device=dev), n_valid=torch.empty(0, dtype=torch.int32, device=dev))
+            return self.result
+        pt, first, nval = engine.base_tile_probs(self.genome, self.chroms, self.starts, self.ends, self.s_prob, self.binsize,
+                                                 n_tiles=self.n_tiles, device=dev)
+        mc, ms, me, co = self.mut
+        k = engine.tile_mut_counts(self.genome, self.chroms, self.starts, self.ends, first, nval, mc, ms, me, co, C, self.binsize,
+                                   self.n_tiles)
+        pval, ex = engine.tiled_nb_test(pt, k, torch.as_tensor(self.mu, device=dev), torch.as_tensor(self.sigma, device=dev))
+        self.result = dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first + torch.as_tensor(self.reg_shift, device=dev), n_valid=nval)
+        return self.result
+
+    def valid_pvalues(self, cohort):
+        """The cohort's p-values of the rank's existing tiles, in (bin, tile) order: its rows of the reference's frame."""
+        import torch
+        r = self.result
+        t = torch.arange(self.n_tiles, device=r["pval"].device)[None, :]
+        mask = t < r["n_valid"][:, None]
+        return r["pval"][cohort][mask], mask
+
+    def q_values(self, cohort, gathered=None):
+        """Benjamini-Hochberg q-values (nb_model.get_q_vals) of the rank's tiles of one cohort among the tiles of ALL ranks:
+        [R_r, n_tiles], NaN where a bin has no such tile.  `gathered`: the concatenation of valid_pvalues() of all ranks in
+        rank order when the caller did the exchange (one-device walks); default: all_gather_rows over the process group."""
+        import torch
+        from .sequence_model import nb_model
+        mine, mask = self.valid_pvalues(cohort)
+        counts = all_gather_rows(torch.tensor([mine.numel()], dtype=torch.int64, device=mine.device), self.group) \
+            if gathered is None else None
+        everything = all_gather_rows(mine.contiguous(), self.group) if gathered is None else gathered
+        if gathered is None:
+            before = int(counts[: self.rank].sum().item()) if counts.numel() > 1 else 0
+        else:
+            before = int(self._offset_in(gathered))
+        q_all = nb_model.get_q_vals(everything) if everything.is_cuda else torch.as_tensor(nb_model.get_q_vals(everything.numpy()))
+        out = torch.full(mask.shape, float("nan"), dtype=torch.float64, device=mine.device)
+        out[mask] = q_all[before:before + mine.numel()]
+        return out
+
+    def _offset_in(self, gathered):
+        return getattr(self, "offset", 0)

@@ -34,7 +34,8 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 3   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes; a statistics stage leaves its worklist length in the header */
+#define DIG_ABI_VERSION 4   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+                             * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -174,7 +175,21 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
  * same workspace with no STATISTICS call since (a statistics stage leaves counts in the header: dword 2 the pairs it
  * finished from the global worklist, dword 3 the pairs the fused stream pass finished from its workgroups' LDS queues). */
 #define DIG_PIPE_WORKLIST_CLEAN 8
+/* Context-repeated L (ABI 4).  The reference builds the L_counts of every element / tile / on-the-fly region as its 64
+ * trinucleotide context counts, each written to the three substitutions of that context (sequence_tools.py:560-564): then
+ * sum(t_pi * L) runs over the same 64 per-context sums of d_pr as the denominator sum(region_counts * d_pr), and contexts +
+ * dot become ONE kernel with half the matrix work (acc_dot_ctx_kernel; no acc_region_kernel, no parameter-table pass).
+ *   dig_element_pipeline_prepare  PLAN TIME, once per element set: checks L[e, 3 j] == L[e, 3 j + 1] == L[e, 3 j + 2] for
+ *       every element and context on the device, writes the compact [E, 64] counts into `workspace`, waits for `stream`
+ *       and reports *compact_ok (host int) = 1 / 0.  Genic (n_class = 4) and --f-sites sets give 0.
+ *   DIG_PIPE_COMPACT_L  OR into `stages` of dig_element_pipeline calls on a workspace prepared with compact_ok = 1 for
+ *       this very L.  The CONTEXTS stage is then empty; the DOT stage is the fused kernel and clears the worklist header.
+ *       Denominators are bit-identical to the general form, numerators differ by the rounding of a regrouped sum (P within
+ *       a few ulp; tests/test_gpu_parity.py).  Without the flag the general K = 256 form runs, as before. */
+#define DIG_PIPE_COMPACT_L 16
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
+int dig_element_pipeline_prepare(const int32_t *L, int64_t E, int64_t C, void *workspace, int64_t workspace_bytes,
+                                 int *compact_ok, void *stream);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
                          const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
                          const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,

@@ -194,3 +194,73 @@ def test_chunked_scale_factors_gloo(tmp_path, world):
     port = _free_port()
     mp.spawn(_chunk_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(tmp_path / "chunk_ok.npy")
+
+
+def _tiles_worker(rank, world, port, tmp):
+    """Per-base route sharded by bins (parallel.ShardedTiles) over a real 2-process group, CPU: what a rank would hand to
+    the tile kernels -- its slab of the packed genome, shifted bin coordinates, its mutations -- evaluated with the ORACLE
+    (the checker) equals the oracle on the whole genome for the rank's bins; then the one exchange of the route, the
+    Benjamini-Hochberg pass over all ranks' p-values (all_gather_rows), against the single-process q-values."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_gpu_tiles import _tile_problem
+        from digdriver_amd.sequence_model import nb_model
+        from oracle import dig_oracle as O
+        seqs, genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co = _tile_problem(C=2)
+        C, R, B = 2, len(chroms), 50
+        sh = parallel.ShardedTiles(genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co, B, None, rank, world)
+        assert (sh.lo, sh.hi) == parallel.shard_rows(R, rank, world)
+
+        def decode(g, c):
+            w = g.words
+            nib = np.stack([(w >> np.uint32(4 * k)) & np.uint32(15) for k in range(8)], 1).reshape(-1)[8:]
+            o, n = int(g.offsets[c]), int(g.lengths[c])
+            return "".join("ACGTN"[x] for x in nib[o:o + n])
+
+        slab_seq = {n: decode(sh.genome, i) for i, n in enumerate(sh.genome.names)}
+        T = sh.n_tiles
+        assert T == 20                                           # 1000 positions per bin / 50
+        pval = np.full((C, sh.hi - sh.lo, T), np.nan)
+        nval = np.zeros(sh.hi - sh.lo, np.int32)
+        smc, sms, sme, sco = sh.mut
+        for j in range(sh.hi - sh.lo):
+            name = sh.chroms[j]
+            for c in range(C):
+                here = (smc == name) & (sco == c)
+                got = O.apply_nb_to_region(slab_seq[name], S[c], int(sh.starts[j]), int(sh.ends[j]), sh.mu[c, j], sh.sigma[c, j],
+                                           sms[here], B)
+                there = (mc == name) & (co == c)
+                want = O.apply_nb_to_region(seqs[name].upper(), S[c], int(starts[sh.lo + j]), int(ends[sh.lo + j]), mu[c, sh.lo + j],
+                                            sg[c, sh.lo + j], ms[there], B)
+                for a, b in zip(got, want):
+                    if a is got[1]:
+                        assert np.array_equal(a + sh.reg_shift[j], b)            # positions: shifted back
+                    else:
+                        assert np.array_equal(a, b, equal_nan=True)              # p-values, counts, expectations, pt: same bits
+                pval[c, j, :len(got[0])] = got[0]
+                nval[j] = len(got[0])
+        sh.result = dict(pval=torch.tensor(pval), n_valid=torch.tensor(nval))
+        for fill in (None, 0.5):          # as computed (the all-N bin's NaN p-values make every q NaN, as in statsmodels); NaN-free
+            if fill is not None:
+                sh.result["pval"] = torch.nan_to_num(sh.result["pval"], nan=fill)
+            for c in range(C):
+                q = sh.q_values(c)                                    # the collective
+                mine, mask = sh.valid_pvalues(c)
+                everything = parallel.all_gather_rows(mine)
+                want = nb_model.get_q_vals(everything.numpy())
+                before = int(parallel.all_gather_rows(torch.tensor([mine.numel()]))[:rank].sum())
+                assert np.array_equal(q[mask].numpy(), want[before:before + mine.numel()], equal_nan=True)
+                assert fill is None or np.isfinite(q[mask].numpy()).all()
+                assert torch.isnan(q[~mask]).all()
+        if rank == 0:
+            np.save(os.path.join(tmp, "tiles_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_tiles_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_tiles_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "tiles_ok.npy")

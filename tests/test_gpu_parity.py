@@ -593,6 +593,85 @@ def test_element_pipeline_equals_separate_calls(torch_dev):
             assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
 
 
+def test_compact_pipeline_against_general_form_and_oracle(torch_dev):
+    """Context-repeated L (sequence_tools.py:560-564: every element / tile / on-the-fly set): dig_element_pipeline_prepare +
+    DIG_PIPE_COMPACT_L run contexts + dot as ONE kernel over the 64 per-context sums of d_pr (acc_dot_ctx_kernel).  Against
+    the general 192-substitution form: integer outputs, MU, SIGMA and P_INDEL bit-identical, P within 1e-13 (same
+    denominators, regrouped numerator sum), statistics within the contract; against the oracle: P within 1e-11.  Cohort
+    counts on both sides of the 16-column tiles / 4-column quads / 48-cohort chunks, elements over 0 ... many bins, both
+    strands, E not a multiple of 16, stages as separate calls."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import _lib, engine
+    from oracle import dig_oracle as O
+    for (nb, E, C, seed, mb) in ((3000, 2500, 5, 1, 3), (900, 700, 37, 2, 3), (400, 333, 1, 3, 9), (1200, 1000, 49, 4, 3),
+                                 (500, 450, 17, 5, 6), (300, 260, 104, 6, 3), (200, 7, 48, 7, 3), (64, 1, 37, 8, 1),
+                                 (700, 1601, 40, 9, 12), (50, 16, 8, 10, 2)):
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed, max_blocks=mb)
+        if E > 20:                                        # a few elements without any bin: rates 0, P = 0 / 0
+            ptr = w["ov_ptr"].copy()
+            keep = np.ones(len(w["ov_idx"]), bool)
+            for e in (3, 11, E - 1):
+                keep[ptr[e]:ptr[e + 1]] = False
+            cnt = np.diff(ptr)
+            cnt[[3, 11, E - 1]] = 0
+            w["ov_idx"] = w["ov_idx"][keep]
+            w["ov_ptr"] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+        acc_g, st_g = engine.element_pipeline(*args, td["cj"], td["cj_indel"])
+        plan = engine.PipelinePlan(*args)
+        assert plan.compact, "make_workload repeats every context count three times"
+        acc_c, st_c = plan.run(td["cj"], td["cj_indel"])
+        torch.cuda.synchronize()
+        for k in ("MU", "SIGMA", "R_OBS", "FLAG", "R_SIZE", "ELT_SIZE", "P_INDEL"):
+            assert torch.equal(torch.nan_to_num(acc_g[k].double(), nan=-7.0), torch.nan_to_num(acc_c[k].double(), nan=-7.0)), (k, C)
+        pg, pc = acc_g["P"].cpu().numpy(), acc_c["P"].cpu().numpy()
+        assert (np.isnan(pg) == np.isnan(pc)).all()
+        ok = np.isfinite(pg)
+        assert np.array_equal(pc[~ok & ~np.isnan(pg)], pg[~ok & ~np.isnan(pg)])
+        assert (np.abs(pc[ok] / pg[ok] - 1) <= 1e-13).all(), C
+        sg, sc = st_g.cpu().numpy(), st_c.cpu().numpy()
+        def close(got, ref, tol):                          # rel_close, with infinities (an element without bins) in the same places
+            fin = ~np.isinf(ref)
+            assert np.array_equal(got[~fin], ref[~fin])
+            rel_close(got[fin], ref[fin], tol)
+        for j, name in enumerate(engine.ES_PLANES):
+            close(sc[j], sg[j], 1e-9)
+        want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"], w["ov_idx"],
+                                     w["L"], w["strand_minus"].astype(bool), w["d_pr"])
+        close(pc, want["P"], 1e-11)
+        assert np.array_equal(acc_c["R_SIZE"].cpu().numpy(), want["R_SIZE"])
+        assert np.array_equal(acc_c["ELT_SIZE"].cpu().numpy(), want["ELT_SIZE"])
+        # the stages as separate calls (contexts: nothing to do; dot: the fused kernel; statistics) == one call
+        keep_p, keep_s = acc_c["P"].clone(), st_c.clone()
+        acc_c["P"].fill_(-3.0)
+        st_c.fill_(-3.0)
+        plan.run(td["cj"], td["cj_indel"], stages=1)
+        plan.run(td["cj"], td["cj_indel"], stages=2)
+        plan.run(td["cj"], td["cj_indel"], stages=4 | 8)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(acc_c["P"], nan=-7.0), torch.nan_to_num(keep_p, nan=-7.0))
+        assert torch.equal(torch.nan_to_num(st_c, nan=-7.0), torch.nan_to_num(keep_s, nan=-7.0))
+        # new scale factors on the same accumulation: statistics only (clears the worklist header itself)
+        plan.run(td["cj"] * 2.0, td["cj_indel"] * 0.5, stages=4)
+        _, st_2 = engine.element_pipeline(*args, td["cj"] * 2.0, td["cj_indel"] * 0.5, compact="auto")
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(st_c, nan=-7.0), torch.nan_to_num(st_2, nan=-7.0))
+    # an L that does NOT repeat (genic class columns, --f-sites sets): prepare says so and the general form runs, same bits as before
+    w = make_workload(n_bins=500, n_elements=400, n_cohorts=37, seed=12)
+    w["L"][17, 0, 5] += 1
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+            td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+    plan = engine.PipelinePlan(*args)
+    assert not plan.compact
+    acc_p, st_p = plan.run(td["cj"], td["cj_indel"])
+    acc_g, st_g = engine.element_pipeline(*args, td["cj"], td["cj_indel"])
+    assert torch.equal(acc_p["P"], acc_g["P"]) and torch.equal(torch.nan_to_num(st_p, nan=-7.0), torch.nan_to_num(st_g, nan=-7.0))
+
+
 def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
     """The fused stream pass finishes its unfinished pairs itself: through the workgroup's LDS queue (1024 records) and, beyond
     that, through the workgroup's own segment of the worklist.  With every SNV count raised past the recurrence's range

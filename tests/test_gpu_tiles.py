@@ -159,3 +159,75 @@ def test_q_values_on_the_device_equal_the_host_form():
     assert np.array_equal(got, want)
     q2 = nb_model.get_q_vals(torch.as_tensor(p.reshape(-1, 1), device="cuda:0"))
     assert q2.shape == (p.size, 1) and np.array_equal(q2.cpu().numpy()[:, 0], want)
+
+
+def _tile_problem(seed=3, C=3):
+    """A small genome (three chromosomes of different lengths, N runs, one too short for a whole bin), 1 kb bins in genome
+    order with a ragged last bin per chromosome, mutations of C cohorts incl. rows on a chromosome without bins."""
+    from digdriver_amd.data_tools.genome import PackedGenome
+    rng = np.random.default_rng(seed)
+    seqs = {"chr1": "".join(rng.choice(list("ACGTN"), 23_017, p=[.24, .25, .25, .24, .02])),
+            "chr2": "".join(rng.choice(list("ACGT"), 9_400)), "chr3": "".join(rng.choice(list("ACGT"), 731)),
+            "chrX": "".join(rng.choice(list("ACGT"), 500))}
+    seqs["chr1"] = seqs["chr1"][:5000] + "N" * 1500 + seqs["chr1"][6500:]
+    genome = PackedGenome.from_sequences(seqs)
+    chroms, starts, ends = [], [], []
+    for name in ("chr1", "chr2", "chr3"):
+        for s in range(0, len(seqs[name]), 1000):
+            chroms.append(name)
+            starts.append(s)
+            ends.append(min(s + 1000, len(seqs[name]) + 40))        # the last bin pokes over the chromosome end
+    R = len(chroms)
+    S = rng.uniform(1e-3, 1e-2, (C, 64))
+    mu, sg = rng.uniform(3, 40, (C, R)), rng.uniform(1, 6, (C, R))
+    M = 6000
+    mc = rng.choice(["chr1", "chr2", "chr3", "chrX"], M, p=[.6, .3, .05, .05])
+    ms = np.array([rng.integers(0, len(seqs[c])) for c in mc])
+    me = ms + rng.integers(1, 4, M)
+    co = rng.integers(0, C, M).astype(np.int32)
+    return seqs, genome, np.array(chroms), np.array(starts), np.array(ends), S, mu, sg, mc, ms, me, co
+
+
+def test_sharded_tiles_equal_unsharded_bit_for_bit():
+    """parallel.ShardedTiles (BASELINE configs[4]: the per-base route sharded by bins): the ranks of a 2-, 3- and 8-rank
+    plan, walked one after the other on one device -- each on its own slab of the genome, with shifted coordinates and its
+    own mutations -- reproduce the single-device result bit for bit (pt, k, exp, pval, first positions), and so do the
+    Benjamini-Hochberg q-values formed from the rank-ordered concatenation of the ranks' p-values."""
+    import torch
+    from digdriver_amd import engine, parallel
+    from digdriver_amd.sequence_model import nb_model
+    dev = torch.device("cuda:0")
+    seqs, genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co = _tile_problem()
+    C, R = S.shape[0], len(chroms)
+    whole = engine.tiled_nb_model(genome, chroms, starts, ends, S, mu, sg, mc[mc != "chrX"], ms[mc != "chrX"], me[mc != "chrX"],
+                                  co[mc != "chrX"], binsize=50, device=0)
+    assert int(whole["k"].sum()) > 1000
+    T = whole["pt"].shape[2]
+    valid = torch.arange(T, device=dev)[None, :] < whole["n_valid"][:, None]
+    for world in (2, 3, 8, 40):                               # 40 ranks for 35 bins: some ranks hold no bin at all
+        ranks = [parallel.ShardedTiles(genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co, 50, dev, r, world) for r in range(world)]
+        res = [r.run() for r in ranks]
+        assert sum(len(r.genome.words) for r in ranks if r.hi > r.lo) < len(genome.words) + 6 * world
+        for key in ("pt", "k", "exp", "pval"):
+            got = torch.cat([x[key] for x in res], dim=1)
+            assert got.shape == whole[key].shape
+            a, b = got.double(), whole[key].double()
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (world, key)
+        assert torch.equal(torch.cat([x["first_pos"] for x in res]), whole["first_pos"])
+        assert torch.equal(torch.cat([x["n_valid"] for x in res]), whole["n_valid"])
+        for r_, x in zip(ranks, res):                           # (the all-N bin's NaN p-values would make every q NaN, as in statsmodels)
+            x["pval"] = torch.nan_to_num(x["pval"], nan=0.5)
+        whole_p = torch.nan_to_num(whole["pval"], nan=0.5)
+        for c in range(C):
+            parts = [r.valid_pvalues(c)[0] for r in ranks]
+            allp = torch.cat(parts)
+            assert torch.equal(allp, whole_p[c][valid])                             # = the PVAL column of the reference's frame
+            want = nb_model.get_q_vals(whole_p[c][valid])
+            assert bool(torch.isfinite(want).all())
+            off, got = 0, []
+            for r, p in zip(ranks, parts):
+                r.offset = off
+                q = r.q_values(c, gathered=allp)
+                got.append(q[r.valid_pvalues(c)[1]])
+                off += p.numel()
+            assert torch.equal(torch.cat(got), want), (world, c)
