@@ -407,3 +407,52 @@ class ShardedTiles:
 
     def _offset_in(self, gathered):
         return getattr(self, "offset", 0)
+
+
+def standardisation_stats(X, y, group=None):
+    """Feature means / population standard deviations and label mean / std over the rows of ALL ranks -- what sklearn's
+    StandardScaler and y.mean() / y.std() give the reference on the whole training set (gp_trainer.py:107-120) -- from
+    this rank's rows X [n_r, d], y [n_r]: two passes (sums, then squared deviations from the global means), each ONE
+    rank-ordered sum of d + 2 numbers (all-gather + first-to-last add: the same bits on every rank).  Zero-variance
+    columns keep scale 1.  Returns (mean [d], std [d], y_mean, y_std, n)."""
+    import torch
+    X = torch.as_tensor(np.ascontiguousarray(X), dtype=torch.float64)
+    y = torch.as_tensor(np.ascontiguousarray(y), dtype=torch.float64).reshape(-1)
+    s1 = rank_ordered_sum(torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64), X.sum(0), y.sum().reshape(1)]), group)
+    n = float(s1[0])
+    mean, y_mean = s1[1:-1] / n, s1[-1] / n
+    s2 = rank_ordered_sum(torch.cat([((X - mean) ** 2).sum(0), ((y - y_mean) ** 2).sum().reshape(1)]), group)
+    std = torch.sqrt(s2[:-1] / n)
+    std = torch.where(std == 0, torch.ones_like(std), std)
+    return mean.numpy(), std.numpy(), float(y_mean), float(torch.sqrt(s2[-1] / n)), int(n)
+
+
+def broadcast_state(state, idx_feat, device, comm_device, src=0, group=None, dtype=None):
+    """A fitted GP predictor (dict of tensors, SparseGP.predictor_state) and the kept feature columns from rank `src` to every
+    rank: shapes first (the receivers do not know m or d), then the payload as one flat buffer."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return state, idx_feat
+    keys = ("Z", "L", "LB", "c", "scalars")
+    rank = dist.get_rank(group)
+    dtype = dtype or torch.float64
+    hdr = torch.zeros(3, dtype=torch.int64, device=comm_device)
+    if rank == src:
+        hdr = torch.tensor([state["Z"].shape[0], state["Z"].shape[1], len(idx_feat)], dtype=torch.int64, device=comm_device)
+    dist.broadcast(hdr, src=src, group=group)
+    m, d, nf = (int(v) for v in hdr.tolist())
+    shapes = {"Z": (m, d), "L": (m, m), "LB": (m, m), "c": (m,), "scalars": (4,)}
+    total = sum(int(np.prod(shapes[k])) for k in keys) + nf
+    if rank == src:
+        flat = torch.cat([state[k].reshape(-1).to(torch.float64) for k in keys] +
+                         [torch.as_tensor(np.asarray(idx_feat), dtype=torch.float64, device=state["Z"].device)]).to(comm_device)
+    else:
+        flat = torch.empty(total, dtype=torch.float64, device=comm_device)
+    dist.broadcast(flat, src=src, group=group)
+    out, off = {}, 0
+    for k in keys:
+        cnt = int(np.prod(shapes[k]))
+        out[k] = flat[off:off + cnt].reshape(shapes[k]).to(device=device, dtype=dtype)
+        off += cnt
+    return out, flat[off:off + nf].cpu().numpy().astype(np.int64)

@@ -69,14 +69,20 @@ def split_folds(idxs, k, seed=None):
 class BinTrackStore:
     """x_data [N, L, T] resident on the GPU (torch tensor, fp32 / fp64 / int16) + batch gather."""
 
-    def __init__(self, x_data, selected_tracks=None):
+    def __init__(self, x_data, selected_tracks=None, row_offset=0, row_ranges=None):
+        """row_offset / row_ranges: this store holds the rows [row_offset, row_offset + len(x_data)) of a track matrix that is
+        sharded over ranks by contiguous bin ranges `row_ranges` [(lo, hi)] (predict.predict_sharded sends a bin to the rank
+        that holds it); bin rows handed to batch() are global."""
         self.x = x_data
         self.n_bins, self.length, self.n_tracks_total = x_data.shape
         self.tracks = None if selected_tracks is None else np.asarray(selected_tracks)    # None = all tracks, in order
+        self.row_offset, self.row_ranges = int(row_offset), row_ranges
 
     def shape(self, n):
         return (n, self.length, self.n_tracks_total if self.tracks is None else len(self.tracks))
 
     def batch(self, bin_rows, channels_first=True, out_dtype="f32"):
         """x_data[bin_rows, :, tracks] (mut_dataset.py:76-81) for a batch, optionally as [B, T, L]."""
+        if self.row_offset:
+            bin_rows = np.asarray(bin_rows) - self.row_offset
         return engine.gather_bins(self.x, bin_rows, self.tracks, out_dtype=out_dtype, transpose=channels_first)

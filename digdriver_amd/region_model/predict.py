@@ -40,9 +40,54 @@ def predict(model, store, bin_rows, labels=None, batch_size=2048, fold_bn=True, 
         out, fv, _ = net.forward_gemm(xb.to(dtype)) if use_gemm else net.forward_channels_first(xb.to(dtype))
         preds.append(torch.stack(out).float())
         feats.append(torch.stack(fv).float())
+    if not preds:                                      # an empty bin list (a rank without bins in a sharded run)
+        C = getattr(net, "task_num", None) or len(getattr(net, "heads", [])) or 1
+        preds, feats = [torch.zeros((C, 0), device=dev)], [torch.zeros((C, 0, 16), device=dev)]
     preds = torch.cat(preds, dim=1).cpu().numpy()
     feats = torch.cat(feats, dim=1).cpu().numpy()
     r2 = None
     if labels is not None:
         r2 = np.array([r2_score(np.asarray(labels[c])[bin_rows], preds[c]) for c in range(preds.shape[0])])
     return preds, feats, r2
+
+
+def predict_sharded(model, store, bin_rows, labels=None, batch_size=2048, group=None, rank=None, world=None, **kw):
+    """OutputGenerator.predict (mutations_main.py:121-146) over a process group: the reference scatters every batch over
+    the GPUs of one process (nn.DataParallel, kfold_mutations_main.py:143); here every rank forwards its own share of the
+    bin list and the predictions + 16-d features are all-gathered (rank order) and put back into the order of `bin_rows`,
+    so every rank returns what the single-process call returns: (preds [C, n], features [C, n, 16], r2 [C] or None).
+    Which bins a rank takes: those whose rows of the track matrix it holds when `store` is a shard (store.row_ranges),
+    else a contiguous piece of the list (parallel.shard_rows)."""
+    import torch.distributed as dist
+    from .. import parallel
+    on = dist.is_available() and dist.is_initialized()
+    world = world if world is not None else (dist.get_world_size(group) if on else 1)
+    rank = rank if rank is not None else (dist.get_rank(group) if on else 0)
+    bin_rows = np.asarray(bin_rows)
+    n = len(bin_rows)
+    ranges = getattr(store, "row_ranges", None)
+    if ranges is not None:
+        his = np.array([hi for _, hi in ranges])
+        owner = np.searchsorted(his, bin_rows, side="right")
+    else:
+        owner = np.zeros(n, np.int64)
+        for r in range(world):
+            lo, hi = parallel.shard_rows(n, r, world)
+            owner[lo:hi] = r
+    pos = [np.flatnonzero(owner == r) for r in range(world)]
+    p, f, _ = predict(model, store, bin_rows[pos[rank]], labels=None, batch_size=batch_size, **kw)
+    C = p.shape[0]
+    if world > 1:
+        dev = next(model.parameters()).device if (on and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        flat = torch.cat([torch.as_tensor(p.T, dtype=torch.float32), torch.as_tensor(f.transpose(1, 0, 2).reshape(len(pos[rank]), C * 16),
+                                                                                  dtype=torch.float32)], dim=1).to(dev)
+        everything = parallel.all_gather_rows(flat.contiguous(), group).cpu().numpy()       # rows in rank order
+        order = np.concatenate(pos)
+        full = np.empty_like(everything)
+        full[order] = everything
+        p = np.ascontiguousarray(full[:, :C].T)
+        f = np.ascontiguousarray(full[:, C:].reshape(n, C, 16).transpose(1, 0, 2))
+    r2 = None
+    if labels is not None:
+        r2 = np.array([r2_score(np.asarray(labels[c])[bin_rows], p[c]) for c in range(C)])
+    return p, f, r2

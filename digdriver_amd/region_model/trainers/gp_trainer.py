@@ -210,16 +210,51 @@ class SparseGP(torch.nn.Module):
         return torch.cat(means), torch.cat(stds)
 
 
+    def predictor_state(self):
+        """Everything predict() needs, without the training rows: the inducing points, the two m x m factors, the weight
+        vector and three scalars (a few MB at m = 400) -- what a bin-sharded run broadcasts from the rank that fitted the
+        model ("fit on rank 0 and broadcast")."""
+        with torch.no_grad():
+            L, A, LB, r, c = self._factor()
+            scal = torch.stack([self.lengthscale, self.outputscale, self.noise, self.mean_const]).detach()
+            return dict(Z=self.inducing_points.detach().clone(), L=L.detach(), LB=LB.detach(), c=c.detach(), scalars=scal)
+
+    @staticmethod
+    @torch.no_grad()
+    def predict_from_state(state, x, chunk=65536):
+        """predict() from a predictor_state(): latent mean and standard deviation at x [n, d] (standardised features)."""
+        Z, L, LB, c = state["Z"], state["L"], state["LB"], state["c"]
+        ls, os_, _, mean_const = state["scalars"].unbind(0)
+        means, stds = [], []
+        for s in range(0, x.shape[0], chunk):
+            xs = x[s:s + chunk]
+            d2 = (Z * Z).sum(-1, keepdim=True) - 2.0 * (Z @ xs.T) + (xs * xs).sum(-1)[None, :]
+            K = os_ * torch.exp(-0.5 * d2.clamp_min(0.0) / ls ** 2)
+            t1 = torch.linalg.solve_triangular(L, K, upper=False)
+            t2 = torch.linalg.solve_triangular(LB, t1, upper=False)
+            means.append(mean_const + t2.T @ c)
+            stds.append(torch.sqrt((os_ - (t1 * t1).sum(0) + (t2 * t2).sum(0)).clamp_min(0.0)))
+        if not means:
+            return x.new_zeros(0), x.new_zeros(0)
+        return torch.cat(means), torch.cat(stds)
+
+
 class GPTrainer:
     samp_bound = int(1.5e5)      # gp_trainer.py:55: training-set cap
 
     def __init__(self, device, train_tup, val_tup, heldout_tup=None, n_iter=50, n_inducing=500, seed=None,
-                 dtype=torch.float64):
+                 dtype=torch.float64, stats=None):
+        """stats: (feature means, feature stds, y mean, y std) when they were formed elsewhere -- a bin-sharded run gets them
+        from all ranks' rows by an all-reduce (parallel.standardisation_stats); default: from train_tup (gp_trainer.py:107-120)."""
         self.device, self.n_iter, self.n_inducing, self.dtype = device, n_iter, n_inducing, dtype
         self.org_train_x, self.org_train_y = train_tup[0], train_tup[1]
         self.org_val_x, self.org_val_y = val_tup[0], val_tup[1]
         self.train_meta, self.val_meta = train_tup[2:], val_tup[2:]
-        self.train_x, self.train_y, self.scaler, self.y_mean, self.y_std = self.standardize(train_tup[0], train_tup[1])
+        if stats is not None:
+            self.train_x, self.train_y, self.scaler, self.y_mean, self.y_std = self.standardize(
+                train_tup[0], train_tup[1], (np.asarray(stats[0], float), np.asarray(stats[1], float)), float(stats[2]), float(stats[3]))
+        else:
+            self.train_x, self.train_y, self.scaler, self.y_mean, self.y_std = self.standardize(train_tup[0], train_tup[1])
         self.val_x, self.val_y, _, _, _ = self.standardize(val_tup[0], val_tup[1], self.scaler, self.y_mean, self.y_std)
         self.idx_feat = np.where(np.abs(self.train_x).mean(axis=0) > 0)[0]       # gp_trainer.py:79
         n = self.train_x.shape[0]
@@ -275,7 +310,7 @@ class GPTrainer:
 
     def run(self):
         """gp_trainer.py:173-204 -> (val_res, hld_res) dicts with keys gp_mean, gp_std, r2, loss, params."""
-        model = self.train_model()
+        model = self.model = self.train_model()
         params = np.array([model.lengthscale.item(), model.outputscale.item(), model.noise.item()])
         v_mean, v_std, v_loss = self.predict(model, self.val_x, self.val_y)
         v_r2 = r2_score(self.val_y, v_mean)
@@ -316,6 +351,71 @@ def run_gp(device, train_tup, val_tup, heldout_tup, n_runs=5, n_iter=50, n_induc
             raise AssertionError("GP failed for every inducing-point count")      # kfold_mutations_main.py:228
         results.append(done)
     means = np.mean([r['gp_mean'] for r in results], axis=0)                      # gp_trainer.py:247-261
+    stds = np.mean([r['gp_std'] for r in results], axis=0)
+    return results, means, stds
+
+
+def run_gp_sharded(device, train_tup, val_tup, heldout_tup, group=None, src=0, n_runs=5, n_iter=50, n_inducing=400, gp_reruns=3,
+                   gp_delta=0.03, nn_r2=None, seed=0, dtype=torch.float64):
+    """run_gp for a bin-sharded run: the three tuples hold THIS RANK's rows (features [n_r, d], labels [n_r]).
+      1. standardisation statistics of features and labels over all ranks' training rows: two rank-ordered sums
+         (parallel.standardisation_stats -- the "GP/standardisation" collective: n, sum y, sum y^2, sum x, sum x^2);
+      2. the training rows are all-gathered (<= 150 000 x 16 values) and rank `src` fits the SGPR;
+      3. the fitted predictor (inducing points, two m x m factors, a vector, four scalars) is broadcast;
+      4. every rank predicts mean / std of ITS validation and held-out rows; the R^2 of the retry ladder
+         (mutations_main.py:177-195) is formed from the all-gathered predictions, and `src` takes the retry decision.
+    Returns (results, means, stds) as run_gp does, for the rank's own held-out rows."""
+    import torch.distributed as dist
+    from ... import parallel
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if on else 0
+    tx, ty = np.asarray(train_tup[0], float), np.asarray(train_tup[1], float)
+    mean, std, y_mean, y_std, _ = parallel.standardisation_stats(tx, ty, group)
+    comm = device if (on and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    gather = lambda a: parallel.all_gather_rows(torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=comm), group).cpu().numpy()
+    all_tx, all_ty = gather(tx), gather(ty)
+    vy_all, hy_all = gather(np.asarray(val_tup[1], float)), gather(np.asarray(heldout_tup[1], float))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=device)
+    results = []
+    for run in range(n_runs):
+        m, attempt, done = n_inducing, 0, None
+        while done is None and m > 0:
+            state, idx_feat, failed = None, None, False
+            if rank == src:
+                try:
+                    tr = GPTrainer(device, (all_tx, all_ty), (np.asarray(val_tup[0], float), np.asarray(val_tup[1], float)), None,
+                                   n_iter=n_iter, n_inducing=m, seed=seed + 1000 * run + attempt, dtype=dtype,
+                                   stats=(mean, std, y_mean, y_std))
+                    model = tr.train_model()
+                    state, idx_feat = model.predictor_state(), tr.idx_feat
+                except (RuntimeError, torch.linalg.LinAlgError) as exc:
+                    print('GP attempt failed: {}'.format(exc))
+                    failed = True
+            failed = parallel.broadcast_flag(failed, comm, src, group)
+            if not failed:
+                state, idx_feat = parallel.broadcast_state(state, idx_feat, device, comm, src, group, dtype)
+                out = {}
+                for name, tup in (('val', val_tup), ('held', heldout_tup)):
+                    x = (np.asarray(tup[0], float) - mean) / std
+                    mu_, sd_ = SparseGP.predict_from_state(state, t(x[:, idx_feat]))
+                    out[name] = (mu_.cpu().numpy() * y_std + y_mean, sd_.cpu().numpy() * y_std)
+                params = state["scalars"][:3].cpu().numpy()
+                h_r2 = r2_score(hy_all, gather(out['held'][0]))
+                v_r2 = r2_score(vy_all, gather(out['val'][0]))
+                if nn_r2 is not None and h_r2 - nn_r2 < -gp_delta:
+                    print('GP attempt failed: GP R2 %.4f fell below CNN R2 %.4f' % (h_r2, nn_r2))
+                    failed = True
+            if failed:
+                attempt += 1
+                if attempt >= gp_reruns:
+                    attempt, m = 0, m - 100
+                continue
+            done = dict(GPTrainer.get_results_dict(out['held'][0], out['held'][1], h_r2, float('nan'), params),
+                        val=GPTrainer.get_results_dict(out['val'][0], out['val'][1], v_r2, float('nan'), params))
+        if done is None:
+            raise AssertionError("GP failed for every inducing-point count")
+        results.append(done)
+    means = np.mean([r['gp_mean'] for r in results], axis=0)
     stds = np.mean([r['gp_std'] for r in results], axis=0)
     return results, means, stds
 

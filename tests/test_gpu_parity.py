@@ -638,7 +638,9 @@ def test_compact_pipeline_against_general_form_and_oracle(torch_dev):
             assert np.array_equal(got[~fin], ref[~fin])
             rel_close(got[fin], ref[fin], tol)
         for j, name in enumerate(engine.ES_PLANES):
-            close(sc[j], sg[j], 1e-9)
+            # (an ulp of P moves a p-value that the stream pass takes as 1 - CDF just above its 1e-6 acceptance edge by up to
+            #  ~1e-8: the cancellation the tolerance contract of 1e-6 against scipy already budgets for)
+            close(sc[j], sg[j], 2e-7 if name.startswith("PVAL") else 1e-12)
         want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"], w["ov_idx"],
                                      w["L"], w["strand_minus"].astype(bool), w["d_pr"])
         close(pc, want["P"], 1e-11)
