@@ -264,3 +264,85 @@ def test_sharded_tiles_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_tiles_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "tiles_ok.npy")
+
+
+class _HostStore:
+    """Stand-in for BinTrackStore on CPU (the HIP gather is covered by the -m gpu tests): same interface, numpy gather."""
+
+    def __init__(self, x, row_offset=0, row_ranges=None):
+        self.x, self.row_offset, self.row_ranges = x, row_offset, row_ranges
+
+    def batch(self, bin_rows, channels_first=True, out_dtype="f32"):
+        xb = torch.as_tensor(self.x[np.asarray(bin_rows) - self.row_offset])
+        return xb.transpose(1, 2).contiguous() if channels_first else xb
+
+
+def _predict_worker(rank, world, port, tmp):
+    """predict_sharded (OutputGenerator.predict over a process group) == the single-process predict: replicated store
+    (contiguous pieces of the bin list) and a store sharded by bin ranges (a bin goes to the rank that holds its rows; the
+    bin list is in random order), predictions + 16-d features back in the order of the list on every rank.  Then the GP on
+    sharded features: standardisation statistics by rank-ordered sums, fit on rank 0, broadcast predictor, per-rank
+    prediction == the single-process GPTrainer on all rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_region_and_sequence_models import _golden_net
+        from digdriver_amd.region_model.predict import predict, predict_sharded
+        from digdriver_amd.region_model.trainers import gp_trainer
+        net, d = _golden_net()
+        rng = np.random.default_rng(5)
+        N, L, T = 61, 100, int(d["shape"][2])
+        x = (np.round(rng.uniform(0, 1, (N, L, T)), 2) * 100).astype(np.float32)
+        rows = rng.permutation(N)[:47]
+        labels = [rng.poisson(20, N).astype(float) for _ in range(3)]
+        want_p, want_f, want_r2 = predict(net, _HostStore(x), rows, labels=labels, batch_size=16)
+        got = predict_sharded(net, _HostStore(x), rows, labels=labels, batch_size=16)
+        ranges = [parallel.shard_rows(N, r, world) for r in range(world)]
+        lo, hi = ranges[rank]
+        got2 = predict_sharded(net, _HostStore(x[lo:hi], row_offset=lo, row_ranges=ranges), rows, labels=labels, batch_size=16)
+        for p, f, r2 in (got, got2):
+            assert p.shape == want_p.shape and f.shape == want_f.shape
+            np.testing.assert_allclose(p, want_p, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(f, want_f, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(r2, want_r2, rtol=1e-4, atol=1e-7)
+
+        # ---- GP on sharded rows ----
+        g = np.random.default_rng(6)
+        def make(n):
+            X = g.normal(size=(n, 16)) * g.uniform(0.5, 3, 16) + g.normal(size=16)
+            X[:, 7] = 0.0                                               # an all-zero feature is dropped (gp_trainer.py:79)
+            y = 3.0 + np.sin(X[:, 0]) + 0.5 * X[:, 1] + 0.1 * g.normal(size=n)
+            return X, y
+        train, val, held = make(500), make(120), make(171)
+        cut = lambda tup, r: tuple(a[(len(a) * r) // world + (7 if 0 < r else 0):(len(a) * (r + 1)) // world + (7 if r + 1 < world else 0)] for a in tup)
+        mean, std, ym, ys, n = parallel.standardisation_stats(*cut(train, rank))
+        assert n == 500
+        np.testing.assert_allclose(mean, train[0].mean(0), rtol=1e-12, atol=1e-14)
+        sd = train[0].std(0)
+        np.testing.assert_allclose(std, np.where(sd == 0, 1.0, sd), rtol=1e-12)
+        np.testing.assert_allclose([ym, ys], [train[1].mean(), train[1].std()], rtol=1e-12)
+        both = [torch.empty(16, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, torch.as_tensor(std))
+        assert all(torch.equal(both[0], b) for b in both)                # the same bits on every rank
+        torch.manual_seed(0)
+        res, means, stds = gp_trainer.run_gp_sharded(torch.device("cpu"), cut(train, rank), cut(val, rank), cut(held, rank),
+                                                     n_runs=1, n_iter=12, n_inducing=40, nn_r2=0.2)
+        single = gp_trainer.GPTrainer(torch.device("cpu"), train, val, held, n_iter=12, n_inducing=40)
+        v, h = single.run()
+        mine = cut((h["gp_mean"], h["gp_std"]), rank)
+        np.testing.assert_allclose(means, mine[0], rtol=1e-7)
+        np.testing.assert_allclose(stds, mine[1], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(res[0]["r2"], h["r2"], rtol=1e-8)
+        np.testing.assert_allclose(res[0]["val"]["r2"], v["r2"], rtol=1e-8)
+        assert h["r2"] > 0.1 and len(means) == len(cut(held, rank)[1])
+        if rank == 0:
+            np.save(os.path.join(tmp, "predict_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_predict_and_gp_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_predict_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "predict_ok.npy")

@@ -153,3 +153,41 @@ def test_rbf_cross_kernels_vs_numpy_and_autograd():
         (ref * g).sum().backward()
         for a, b in zip(got, (Z.grad, ls.grad, osc.grad)):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_gp_retry_ladder_follows_the_reference(monkeypatch, capsys):
+    """run_gp's retry ladder (mutations_main.py:177-195): every inducing-point count gets gp_reruns attempts; an attempt fails on
+    a RuntimeError of the fit (:185-188) or when the GP's VALIDATION R^2 is more than gp_delta below the CNN's (:189-191); after
+    gp_reruns failures the count drops by 100 (:194); when it reaches 0 the fold fails (the caller retrains the CNN).  The fit
+    itself is replaced by a script of outcomes: the sequence of inducing-point counts tried is what is checked."""
+    import numpy as np
+    from digdriver_amd.region_model.trainers import gp_trainer
+    script, tried = [], []
+
+    class Scripted:
+        def __init__(self, device, train_tup, val_tup, heldout_tup=None, n_iter=50, n_inducing=500, seed=None, **kw):
+            tried.append(n_inducing)
+
+        def run(self):
+            what = script.pop(0)
+            if what == "error":
+                raise RuntimeError("cholesky: not positive definite")
+            r2 = {"low": 0.40, "ok": 0.48, "good": 0.9}[what]
+            res = lambda: {"gp_mean": np.full(4, r2), "gp_std": np.ones(4), "r2": r2, "loss": 0.0, "params": np.zeros(3)}
+            return res(), res()
+
+    monkeypatch.setattr(gp_trainer, "GPTrainer", Scripted)
+    tup = (np.zeros((4, 2)), np.zeros(4))
+    # run 0: three failures at 400 (error, low R^2, error), two at 300, then R^2 0.48 >= 0.5 - 0.03 passes; run 1: first try
+    script[:] = ["error", "low", "error", "low", "error", "ok", "good"]
+    results, means, stds = gp_trainer.run_gp("cpu", tup, tup, tup, n_runs=2, n_inducing=400, gp_reruns=3, gp_delta=0.03, nn_r2=0.5)
+    assert tried == [400, 400, 400, 300, 300, 300, 400] and not script
+    assert [r["r2"] for r in results] == [0.48, 0.9] and np.allclose(means, (0.48 + 0.9) / 2)
+    assert results[0]["val"]["r2"] == 0.48                              # the validation results of the same fit ride along
+    # every count down to 100 fails three times: the fold fails (kfold_mutations_main.py:228 retrains the CNN)
+    tried.clear()
+    script[:] = ["low"] * 12
+    with pytest.raises(AssertionError):
+        gp_trainer.run_gp("cpu", tup, tup, tup, n_runs=1, n_inducing=400, gp_reruns=3, gp_delta=0.03, nn_r2=0.5)
+    assert tried == [400] * 3 + [300] * 3 + [200] * 3 + [100] * 3
+    assert "failed to reach minimal accuracy of 0.4700" in capsys.readouterr().out
