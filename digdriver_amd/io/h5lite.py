@@ -522,6 +522,7 @@ class _Reader:
 
         if btree not in (UNDEF, UNDEF + self.base_addr):
             walk(btree)
+        walk = None      # the recursive closure refers to itself: without this, `full` (a whole slab of rows) waits for the cyclic collector
         return full.tobytes()
 
     def read_object(self, addr):
@@ -604,8 +605,17 @@ class _Reader:
 
             if self.lazy and desc[0] in ("num", "bool", "str", "enum") and shape:
                 np_dtype = np.dtype(bool) if desc[0] == "bool" else (np.dtype("S%d" % desc[1]) if desc[0] == "str" else desc[1])
-                ds = Dataset(_Lazy(tuple(shape), np_dtype, load,
-                                   lambda lo, hi: load((max(lo, 0), min(hi, shape[0])))), attrs)
+                def rows_(lo, hi):
+                    out = load((max(lo, 0), min(hi, shape[0])))
+                    # the mapped pages just read (compressed chunks) are not needed again by a slab-by-slab reader: hand them
+                    # back, so that a pass over a file larger than host memory keeps a flat resident set
+                    try:
+                        import mmap
+                        self.b.madvise(mmap.MADV_DONTNEED)
+                    except (AttributeError, OSError, ValueError):
+                        pass
+                    return out
+                ds = Dataset(_Lazy(tuple(shape), np_dtype, load, rows_), attrs)
             else:
                 ds = Dataset(load(), attrs)
             ds.bitfield = desc[0] == "bool" and (dtype_msg[0] & 0x0F) == 4     # PyTables boolean: written back as B8

@@ -231,13 +231,25 @@ def read_array_rows(path, key, lo, hi):
         if key not in root:
             raise KeyError("no array %r in %s" % (key, path))
         return root[key].read_rows(lo, hi)
-    return _dir_read_array(path, key)[lo:hi]
+    f = os.path.join(path, "A." + _safe(key) + ".npy")
+    if not os.path.exists(f):
+        raise KeyError("no array %r in %s" % (key, path))
+    return np.array(np.load(f, mmap_mode="r", allow_pickle=False)[lo:hi])       # only the pages of these rows are read
 
 
 def array_shape(path, key):
     if _is_h5(path):
         return tuple(_h5_tree(path)[key].shape)
-    return tuple(_dir_read_array(path, key).shape)
+    f = os.path.join(path, "A." + _safe(key) + ".npy")
+    if not os.path.exists(f):
+        raise KeyError("no array %r in %s" % (key, path))
+    return tuple(np.load(f, mmap_mode="r", allow_pickle=False).shape)
+
+
+def array_dtype(path, key):
+    if _is_h5(path):
+        return np.dtype(_h5_tree(path)[key].dtype)
+    return np.load(os.path.join(path, "A." + _safe(key) + ".npy"), mmap_mode="r", allow_pickle=False).dtype
 
 
 def write_array(path, key, arr, **kw):

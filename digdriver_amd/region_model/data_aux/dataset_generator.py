@@ -66,6 +66,51 @@ def split_folds(idxs, k, seed=None):
     return np.array_split(idxs, k)
 
 
+def load_track_matrix(path, device, key='x_data', slab_bytes=256 << 20, log=None):
+    """The bin x position x track matrix of a training file, resident on `device`, filled SLAB BY SLAB.
+
+    The reference stores x_data (N, L, T) as float64, gzip-chunked (DataExtractor.py:424-426; 169 GB for a whole genome at
+    T = 735) and re-opens the file for every sample (mut_dataset.py:76-81).  Here the matrix lives in HBM as int16 -- track
+    values are around(x, 2) * 100 (DataExtractor.py:220), whose float32 image (what the reference's .float() hands to the
+    network) is an integer that int16 carries exactly, 42 GB -- and the host never holds more than one
+    slab of rows (`slab_bytes` of the on-disk type): rows [lo, hi) are read through the lazy chunk reader
+    (mapfile.read_array_rows), uploaded, checked for exactness and converted ON THE DEVICE.  The first slab that holds a
+    value int16 cannot carry switches the whole matrix to float32 (the int16 rows already filled are converted on the
+    device; nothing is re-read).  Returns a torch tensor [N, L, T] (int16 or float32; float32 / int16 sources keep their type)."""
+    import torch
+    from ...io import mapfile
+    shape = mapfile.array_shape(path, key)
+    assert len(shape) == 3, "x_data must be [bins, positions, tracks]"
+    N, L, T = (int(v) for v in shape)
+    src = mapfile.array_dtype(path, key)
+    rows = max(1, int(slab_bytes) // max(1, L * T * src.itemsize))
+    keep = {np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32}.get(src)
+    out = torch.empty((N, L, T), dtype=keep or torch.int16, device=device)
+    exact = keep is None                      # float64 (or another float) source: try int16 first
+    for lo in range(0, N, rows):
+        hi = min(N, lo + rows)
+        slab = torch.as_tensor(np.ascontiguousarray(mapfile.read_array_rows(path, key, lo, hi))).to(device)
+        if keep is not None:
+            out[lo:hi] = slab
+            continue
+        if exact:
+            # what the network sees in the reference is torch.tensor(x).float() (mut_dataset.py:79): the float32 image of
+            # around(x, 2) * 100, whose float64 form is often one ulp off the integer (0.29 * 100 = 28.999999999999996)
+            s32 = slab.to(torch.float32)
+            r = torch.round(s32)
+            if bool(((r == s32) & (s32.abs() < 32768)).all()):
+                out[lo:hi] = r.to(torch.int16)
+                continue
+            exact = False                      # a non-integer (or too large) value: the matrix becomes float32
+            wide = torch.empty((N, L, T), dtype=torch.float32, device=device)
+            wide[:lo] = out[:lo].to(torch.float32)
+            out = wide
+            if log:
+                log('x_data holds values int16 cannot carry (first in bins {}-{}): keeping float32'.format(lo, hi))
+        out[lo:hi] = slab.to(torch.float32)
+    return out
+
+
 class BinTrackStore:
     """x_data [N, L, T] resident on the GPU (torch tensor, fp32 / fp64 / int16) + batch gather."""
 

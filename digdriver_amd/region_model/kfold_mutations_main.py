@@ -25,7 +25,7 @@ from .. import parallel
 from ..io import mapfile
 from .data_aux import dataset_generator as dg
 from .nets.cnn_predictors import SimpleMultiTaskResNet
-from .predict import predict, r2_score
+from .predict import predict, predict_sharded, r2_score
 from .trainers import gp_trainer
 from .trainers.nn_trainer import NNTrainer
 
@@ -66,16 +66,12 @@ class KFoldData:
         self.labels = [np.asarray(mapfile.read_array(args.data_file, l), float) for l in args.label_ids]
         self.quantiles = dg.rank_quantiles(self.labels[0])
         self.idxs, self.below_mapp = dg.select_bins(self.mapp, self.labels[0], args.mappability, args.count_quantile)
-        x = mapfile.read_array(args.data_file, 'x_data')
-        if x.dtype.kind == 'f' and np.array_equal(x, np.rint(x)) and np.abs(x).max() < 32768:
-            x = x.astype(np.int16)                                   # round(x, 2) * 100 values: exact in int16
-        elif x.dtype == np.float64:
-            x = x.astype(np.float32)
+        x = dg.load_track_matrix(args.data_file, device, log=print)      # slab by slab: int16 in HBM when exact, else float32
         tracks = None
         if args.track_file is not None:
             with open(args.track_file) as f:
                 tracks = dg.load_track_selection(f.readlines())
-        self.store = dg.BinTrackStore(torch.as_tensor(x, device=device), tracks)
+        self.store = dg.BinTrackStore(x, tracks)
         self.folds = dg.split_folds(self.idxs, args.k, seed=args.seed)
         self.val_ratio, self.rng = args.val_ratio, np.random.default_rng(args.seed + 1)
         print('Input data is of size: {}'.format(self.store.shape(len(self.idxs))))
@@ -181,12 +177,19 @@ def main(input_args=None):
             continue
         print('Best overall validation accuracy was: {}.'.format(best['acc']))
         ok = True
+        ho_feat = sub_feat = None
+        sub_rows = np.asarray(data.below_mapp)
+        if args.run_gaussian > 0:
+            # held-out (and sub-threshold) bins: every rank forwards its share of the list, predictions and features are
+            # all-gathered (the reference scatters each batch over the GPUs with nn.DataParallel, kfold_mutations_main.py:143)
+            ho_pred, ho_feat, ho_acc = predict_sharded(best["model"], data.store, ho_rows, labels=data.labels)
+            if args.sub_mapp and len(sub_rows):
+                _, sub_feat, _ = predict_sharded(best["model"], data.store, sub_rows)
         if rank == 0:
             if args.save_model:
                 torch.save(best['model'].state_dict(), os.path.join(out_dir, 'best_model_fold_{}.pt'.format(k)))
                 np.save(os.path.join(out_dir, 'val_indices_fold_{}'.format(k)), val_rows)
             if args.run_gaussian > 0:
-                ho_pred, ho_feat, ho_acc = predict(best["model"], data.store, ho_rows, labels=data.labels)
                 print('Model held-out accuracy: {}'.format(ho_acc))
                 C = len(args.label_ids)
                 ho = dict(feat=[ho_feat[c] for c in range(C)], lbls=[data.labels[c][ho_rows] for c in range(C)],
@@ -197,9 +200,7 @@ def main(input_args=None):
                     scores = run_gp_fold(args, device, os.path.join(out_dir, 'gp_results_fold_{}.h5'.format(k)), args.label_ids,
                                          best['train'], best['val'], ho, best['accs'], seed=args.seed + 31 * k)
                     summary.append(scores)
-                    if args.sub_mapp and len(data.below_mapp):
-                        sub_rows = np.asarray(data.below_mapp)
-                        _, sub_feat, _ = predict(best["model"], data.store, sub_rows)
+                    if sub_feat is not None:
                         sub = dict(feat=[sub_feat[c] for c in range(C)], lbls=[data.labels[c][sub_rows] for c in range(C)],
                                    meta=data.meta(sub_rows))
                         run_gp_fold(args, device, os.path.join(out_dir, 'sub_mapp_results_fold_{}.h5'.format(k)), args.label_ids,

@@ -86,16 +86,12 @@ class SplitData:
         self.labels = [np.asarray(mapfile.read_array(args.data_file, l), float) for l in args.label_ids]
         self.quantiles = dg.rank_quantiles(self.labels[0])
         idxs, _ = dg.select_bins(self.mapp, self.labels[0], args.mappability, args.count_quantile)
-        x = mapfile.read_array(args.data_file, 'x_data')
-        if x.dtype.kind == 'f' and np.array_equal(x, np.rint(x)) and np.abs(x).max() < 32768:
-            x = x.astype(np.int16)                                   # round(x, 2) * 100 values: exact in int16
-        elif x.dtype == np.float64:
-            x = x.astype(np.float32)
+        x = dg.load_track_matrix(args.data_file, device, log=_say)       # slab by slab: int16 in HBM when exact, else float32
         tracks = None
         if args.track_file is not None:
             with open(args.track_file) as f:
                 tracks = dg.load_track_selection(f.readlines())
-        self.store = dg.BinTrackStore(torch.as_tensor(x, device=device), tracks)
+        self.store = dg.BinTrackStore(x, tracks)
         self.rng = np.random.default_rng(args.seed)
         self.val_ratio, self.split_method = args.val_ratio, args.split_method
         if args.heldout_file is not None:

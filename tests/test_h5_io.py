@@ -330,3 +330,61 @@ def test_single_split_generator_splits(tmp_path):
                   "\n".join("%d\t%d\t%d\t%s\t0\t0\t0\t0" % (idx[i, 0], idx[i, 1], idx[i, 2], y[i]) for i in pick) + "\n")
     h = make("-u %s" % hf)
     assert list(h.heldout_idxs) == pick and not (set(pick) & set(h.idxs)) and len(h.idxs) == len(kept) - 5
+
+
+_STREAM_PROBE = r'''
+import resource, sys, os
+sys.path.insert(0, sys.argv[2])
+import numpy as np, torch
+from digdriver_amd.region_model.data_aux import dataset_generator as dg
+from digdriver_amd.io import mapfile
+torch.zeros(1)
+base = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+x = dg.load_track_matrix(sys.argv[1], torch.device(sys.argv[3]), slab_bytes=int(sys.argv[4]))
+peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+rows = mapfile.read_array_rows(sys.argv[1], "x_data", 5, 9)
+print("RESULT", str(x.dtype), tuple(x.shape), base, peak, float(x.double().sum()), bool(np.array_equal(x[5:9].cpu().float().numpy(), rows.astype(np.float32))))   # = torch.tensor(rows).float(), mut_dataset.py:79
+'''
+
+
+def _xdata_file(tmp_path, N, L, T, n_frac=0):
+    import subprocess
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        pytest.skip("the image's second interpreter (h5py 3.3) is not here")
+    path = str(tmp_path / ("x%d.h5" % n_frac))
+    subprocess.check_call([py39, os.path.join(GOLD, "make_xdata_fixture.py"), path, str(N), str(L), str(T), str(n_frac)])
+    return path
+
+
+def test_streaming_track_matrix_loader_keeps_one_slab_on_the_host(tmp_path):
+    """load_track_matrix on a GENUINE h5py file in the reference's layout (x_data float64, gzip, chunked: DataExtractor.py:424-426):
+    the matrix arrives as int16, values exact, and the host's peak resident set grows by the int16 destination (on the CPU
+    device it lives in host memory) plus a few slabs -- NOT by the float64 matrix.  A file with a fractional value near its
+    end becomes float32 without re-reading what was already loaded."""
+    import subprocess
+    import sys
+    N, L, T = 6000, 100, 64                                  # 307 MB as float64, 77 MB as int16
+    f64_bytes = N * L * T * 8
+    path = _xdata_file(tmp_path, N, L, T)
+    slab = 8 << 20
+    out = subprocess.run([sys.executable, "-c", _STREAM_PROBE, path, ROOT, "cpu", str(slab)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0]
+    _, dtype, rest = line.split(" ", 2)
+    shape, tail = rest.split(") ", 1)
+    base_kb, peak_kb, total, same = tail.split()
+    assert dtype == "torch.int16" and shape == "(6000, 100, 64" and same == "True"
+    grown = (int(peak_kb) - int(base_kb)) * 1024
+    # destination (host memory on the CPU device) + the slab in its forms (decoded chunks, assembled rows, float64 / float32 /
+    # int16 tensors) + allocator slack; the float64 matrix itself never exists
+    assert grown < N * L * T * 2 + 10 * slab + (32 << 20), grown
+    assert grown < 0.7 * f64_bytes
+    # the values: compare with h5py's own reading through the lazy reader on a slice (done in the probe) and the total
+    assert abs(float(total) - 50.0 * N * L * T) < 0.01 * 50.0 * N * L * T
+    # a fractional value in the last rows: float32, everything kept
+    path2 = _xdata_file(tmp_path, 300, 100, 16, n_frac=2)
+    out2 = subprocess.run([sys.executable, "-c", _STREAM_PROBE, path2, ROOT, "cpu", str(1 << 20)], capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    line2 = [l for l in out2.stdout.splitlines() if l.startswith("RESULT")][0]
+    assert "torch.float32 (300, 100, 16)" in line2 and line2.endswith("True")
