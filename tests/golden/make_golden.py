@@ -688,6 +688,37 @@ def gen_cnn():
              first_conv_w_sum=np.float64(net.conv11.weight.double().sum().item()))
 
 
+def gen_cnn_735():
+    """The reference network at the whole-genome track count (T = 735, 5 heads): seeded weights and BatchNorm statistics
+    (regenerated from the seeds by the test), 4 bins of x_data-like values (stored as uint8: round(u, 2) * 100), the
+    reference module's own eval-mode outputs and 16-d features."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location(
+        "ref_cnn735", os.path.join(REF, "DIGDriver/region_model/nets/cnn_predictors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    T, L, C, B = 735, 100, 5, 4
+    torch.manual_seed(3)
+    net = mod.SimpleMultiTaskResNet((B, L, T), C)
+    g = torch.Generator().manual_seed(4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    gx = torch.Generator().manual_seed(5)
+    x = torch.round(torch.rand(B, L, T, generator=gx), decimals=2) * 100
+    x = torch.round(x)                                            # exact integers 0..100, as the float32 image of x_data is
+    with torch.no_grad():
+        outs, feats, att = net(x)
+    save_npz("cnn_forward_735_golden.npz", x=x.numpy().astype(np.uint8), shape=np.array([B, L, T, C]),
+             outputs=np.stack([o.numpy() for o in outs]), features=np.stack([f.numpy() for f in feats]),
+             first_conv_w_sum=np.float64(net.conv11.weight.double().sum().item()))
+
+
 # ----------------------------------------------------------------------------
 # (vi-b) one CNN training epoch + evaluation through the reference's NNTrainer (nn_trainer.py:17-141)
 # ----------------------------------------------------------------------------
@@ -1011,6 +1042,9 @@ def main():
     if "--only-run-element" in sys.argv:
         gen_run_element_expectation()
         return
+    if "--only-cnn-735" in sys.argv:
+        gen_cnn_735()
+        return
     if "--only-run-target" in sys.argv:
         gen_run_target()
         return
@@ -1027,6 +1061,7 @@ def main():
     gen_mutation_tools()
     gen_sequence_model(df_empty)
     gen_cnn()
+    gen_cnn_735()
     gen_nn_training()
     gen_contexts()
     gen_sites()

@@ -37,8 +37,9 @@ def test_configs1_whole_genome_cnn_forward_and_burden_test():
     with torch.no_grad():
         xb = x[torch.as_tensor(pick, device=dev)].float()            # [B, L, T], the layout the reference module takes
         want_o, want_f, _ = net(xb)
-    np.testing.assert_allclose(preds[0, pick], want_o[0].cpu().numpy(), rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(feats[0, pick], want_f[0].cpu().numpy(), rtol=2e-3, atol=2e-4)
+    # (fp32 both ways; the reference-seeded golden at T = 735 is tests/test_gpu_pipeline.py::test_cnn_forward_at_735_tracks_...)
+    np.testing.assert_allclose(preds[0, pick], want_o[0].cpu().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(feats[0, pick], want_f[0].cpu().numpy(), rtol=1e-4, atol=2e-5)
     # batch composition must not matter: the same bins in another batch size give the same numbers
     p2, _, _ = predict(net, store, pick, batch_size=32)
     np.testing.assert_allclose(p2[0], preds[0, pick], rtol=1e-4, atol=1e-5)

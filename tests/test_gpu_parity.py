@@ -798,3 +798,31 @@ def test_degenerate_shapes_do_not_crash(torch_dev):
     assert one.sum() == 8                                           # centres 1..12 minus the five windows touching N
     x = torch.zeros((5, 100, 4), dtype=torch.float32, device=dev)
     assert engine.gather_bins(x, torch.zeros(0, dtype=torch.int64, device=dev), torch.arange(4, device=dev)).shape == (0, 100, 4)
+
+
+def test_configs0_chr21_every_element_against_the_oracle(torch_dev):
+    """BASELINE configs[0] (SURVEY 8d cfg 1): chr21 only -- N = 4 812 10-kb bins, ONE cohort, E = 2 000 elements, seed 21 --
+    through dig_element_pipeline (both forms of the accumulation) with EVERY element and every output checked against the
+    oracle: integers bit-exact, rates and P to 1e-12 / 1e-11, the seven statistics planes within the 1e-6 contract."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    w = make_workload(n_bins=4812, n_elements=2000, n_cohorts=1, seed=21)
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+            td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"])
+    want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"], w["ov_idx"], w["L"],
+                                 w["strand_minus"].astype(bool), w["d_pr"])
+    want_st = O.element_stats(want["MU"], want["SIGMA"], want["P"][:, 0, :], want["P_INDEL"][:, None], w["obs_snv"], w["obs_samples"],
+                              w["obs_indel"], w["cj"][None, :], w["cj_indel"][None, :])
+    for compact in (False, "auto"):
+        acc, st = engine.element_pipeline(*args, compact=compact)
+        torch.cuda.synchronize()
+        for k in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
+            assert np.array_equal(acc[k].cpu().numpy(), want[k]), (k, compact)
+        for k, tol in (("MU", 1e-12), ("SIGMA", 1e-12), ("P_INDEL", 1e-12), ("P", 1e-11)):
+            rel_close(acc[k].cpu().numpy(), want[k], tol)
+        for j, name in enumerate(engine.ES_PLANES):
+            rel_close(st[j].cpu().numpy(), want_st[name], RTOL)
+    assert (w["obs_snv"] > 0).any() and np.isfinite(want_st["PVAL_MUT_BURDEN"]).all()

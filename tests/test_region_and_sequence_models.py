@@ -34,6 +34,34 @@ def _golden_net():
     return net.eval(), d
 
 
+def _golden_net_735():
+    """The T = 735 / 5-head golden of tests/golden/make_golden.py::gen_cnn_735 (the reference module's own outputs)."""
+    d = np.load(os.path.join(GOLDEN, "cnn_forward_735_golden.npz"))
+    B, L, T, C = [int(v) for v in d["shape"]]
+    torch.manual_seed(3)
+    net = SimpleMultiTaskResNet((B, L, T), C)
+    g = torch.Generator().manual_seed(4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    return net.eval(), d
+
+
+def test_cnn_matches_reference_forward_at_735_tracks():
+    net, d = _golden_net_735()
+    assert net.conv11.weight.double().sum().item() == float(d["first_conv_w_sum"])   # same init stream as the reference
+    x = torch.tensor(d["x"].astype(np.float32))
+    with torch.no_grad():
+        outs, feats, _ = net(x)
+        o2, f2, _ = net.fold_batchnorm().forward_gemm(x)
+    for got_o, got_f in ((outs, feats), (o2, f2)):
+        np.testing.assert_allclose(torch.stack(got_o).numpy(), d["outputs"], rtol=1e-4, atol=1e-5 * np.abs(d["outputs"]).max())
+        np.testing.assert_allclose(torch.stack(got_f).numpy(), d["features"], rtol=1e-4, atol=1e-5 * np.abs(d["features"]).max())
+
+
 def test_cnn_matches_reference_forward():
     net, d = _golden_net()
     assert sum(p.numel() for p in net.parameters()) == int(d["n_params"])
