@@ -250,6 +250,111 @@ def cpu_baseline_all_cores(w, want_seconds=8.0):
                       "(one contiguous element slice each)" % (E, C, reps, cores)}
 
 
+
+# --------------------------------------------------------------------------------------
+# the other rows of SURVEY 8d (gather, CNN forward, per-base tiles, context counting): short legs run AFTER the timed
+# region, each timed per launch with HIP events on the stream it is launched on; reported as `aux_rooflines`
+# --------------------------------------------------------------------------------------
+def aux_rooflines(dev):
+    import torch
+    from digdriver_amd import _lib, engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.region_model.data_aux.dataset_generator import BinTrackStore
+    from digdriver_amd.region_model.nets.cnn_predictors import SimpleMultiTaskResNet, flops_per_bin
+
+    def timeit(fn, n=10, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e-3
+
+    def hbm(kernel, by, dt, what, **extra):
+        return dict({"kernel": kernel, "bound": "hbm", "achieved": by / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": by / dt / HBM_PEAK, "algorithmic_bytes_per_launch": by, "avg_launch_ms": dt * 1e3, "workload": what}, **extra)
+
+    out = []
+    g = torch.Generator(device=dev).manual_seed(2)
+    # a1: per-bin track gather from the HBM-resident int16 matrix (B bins x 100 positions x 735 tracks per launch)
+    N, L, T, B = 16384, 100, 735, 4096
+    x16 = torch.randint(0, 101, (N, L, T), dtype=torch.int16, device=dev, generator=g)
+    rows = torch.randint(0, N, (B,), dtype=torch.int64, device=dev, generator=g)
+    dt = timeit(lambda: engine.gather_bins(x16, rows, None, out_dtype="f32", transpose=False))
+    out.append(hbm("dig_gather_bins (all tracks, i16 -> f32, row-major: what the CNN's GEMM path consumes)", B * L * T * 6.0, dt,
+                   "%d bins x %d x %d per launch; L T 2 B read + L T 4 B written per bin" % (B, L, T), bins_per_s=B / dt))
+    sel = torch.sort(torch.randperm(T, device=dev, generator=g)[:512]).values.to(torch.int32)
+    dt = timeit(lambda: engine.gather_bins(x16, rows, sel, out_dtype="f32", transpose=False))
+    out.append(hbm("dig_gather_bins (512 of 735 tracks: gather_rows_subset_kernel)", B * L * (T * 2.0 + 512 * 4.0), dt,
+                   "%d bins per launch; whole source rows read, 512 tracks written" % B, bins_per_s=B / dt))
+    # a3: CNN forward, fp32, T = 735, 37 heads (PyTorch-ROCm GEMMs on the MFMA units; BatchNorm folded)
+    C_heads, Bc = 37, 2048
+    torch.manual_seed(0)
+    net = SimpleMultiTaskResNet((Bc, L, T), C_heads).eval().to(dev).fold_batchnorm()
+    store = BinTrackStore(x16)
+    crow = rows[:Bc].cpu().numpy()
+    with torch.no_grad():
+        dt = timeit(lambda: net.forward_gemm(store.batch(crow, channels_first=False)), n=5, warm=2)
+    fl = float(flops_per_bin(T, C_heads)) * Bc
+    out.append({"kernel": "gather + SimpleMultiTaskResNet forward (fp32, BN folded, tap-accumulated hipBLASLt GEMMs)", "bound": "mfma",
+                "achieved": fl / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": fl / dt / 157.3e12,
+                "algorithmic_flops_per_launch": fl, "avg_launch_ms": dt * 1e3, "workload": "%d bins, T = 735, 37 heads" % Bc,
+                "bins_per_s": Bc / dt})
+    del net, store, x16
+    torch.cuda.empty_cache()
+    # a18 back half: per-tile exact NB test, 37 cohorts x 8 000 bins x 200 tiles
+    Cc, nb, nt = 37, 8000, 200
+    rng = np.random.default_rng(5)
+    mu = torch.as_tensor(rng.gamma(9.0, 3.0, (Cc, nb)), device=dev)
+    sg = torch.as_tensor(rng.gamma(4.0, 1.0, (Cc, nb)), device=dev)
+    pt = torch.as_tensor(rng.dirichlet(np.ones(nt), size=nb), device=dev)
+    k = torch.poisson(mu[:, :, None] * pt[None, :, :]).to(torch.int32)
+    dt = timeit(lambda: engine.tiled_nb_test(pt, k, mu, sg), n=5, warm=1)
+    units = Cc * nb * nt
+    out.append(hbm("dig_tiled_nb_test", 28.0 * units + 16.0 * Cc * nb, dt, "37 cohorts x 8 000 bins x 200 tiles; 28 B per (tile, cohort)",
+                   tests_per_s=units / dt))
+    del pt, k, mu, sg
+    torch.cuda.empty_cache()
+    # f3 + a18 front half on a genome-sized packed sequence (2.88 G bases)
+    nwin, window = 288_000, 10_000
+    nbases = nwin * window
+    words = torch.randint(0, 2 ** 31 - 1, (nbases // 8 + 2,), dtype=torch.int32, device=dev, generator=g) & 0x33333333
+    words[0] = 0x44444444
+    words[-1] = 0x44444444
+    off = torch.zeros(1, dtype=torch.int64, device=dev)
+    ln = torch.full((1,), nbases, dtype=torch.int64, device=dev)
+    rc = torch.zeros(nwin, dtype=torch.int32, device=dev)
+    rs = torch.arange(nwin, dtype=torch.int64, device=dev) * window
+    re_ = rs + window
+    rm = torch.zeros(nwin, dtype=torch.uint8, device=dev)
+    res = torch.empty((nwin, 64), dtype=torch.int32, device=dev)
+    p = _lib.dev_ptr
+    dt = timeit(lambda: _lib.call("dig_count_contexts", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), p(rm), nwin,
+                                  p(res), _lib.stream_ptr()), n=5, warm=1)
+    out.append(hbm("dig_count_contexts", nbases * 0.5 + nwin * 256.0, dt, "all 288 000 10-kb windows of a 2.88 Gb packed genome; "
+                   "0.5 B per base + 256 B per window", bases_per_s=nbases / dt))
+    del res
+    S = torch.rand((37, 64), device=dev, generator=g, dtype=torch.float64) * 1e-2
+    chunk = 36_000
+    ptile = torch.empty((37, chunk, 200), dtype=torch.float64, device=dev)
+    first = torch.empty(chunk, dtype=torch.int64, device=dev)
+    nval = torch.empty(chunk, dtype=torch.int32, device=dev)
+    dt = timeit(lambda: _lib.call("dig_base_tile_probs", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S), 37,
+                                  50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=3, warm=1)
+    tiles = chunk * 200
+    fl = 2.0 * 64 * 37 * tiles
+    out.append({"kernel": "dig_base_tile_probs (base_tile_probs_mfma_kernel, v_mfma_f64_16x16x4)", "bound": "mfma", "achieved": fl / dt / 1e12,
+                "peak": 78.6, "unit": "TFLOP/s", "frac": fl / dt / 78.6e12, "algorithmic_flops_per_launch": fl,
+                "algorithmic_bytes_per_launch": chunk * window * 0.5 + tiles * 37 * 8.0,
+                "hbm_frac": (chunk * window * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK, "avg_launch_ms": dt * 1e3,
+                "workload": "36 000 bins x 200 tiles x 37 cohorts per launch (an eighth of BASELINE configs[4])",
+                "whole_genome_x37_ms": dt * 1e3 * nwin / chunk})
+    return out
+
 # --------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -268,6 +373,9 @@ def main():
     ap.add_argument("--form", choices=["auto", "general"], default="auto",
                     help="auto: the plan checks L once (plan time) for the three-fold context repetition of sequence_tools.py:560-564 "
                          "and runs the 64-context form of the accumulation when it holds; general: the 192-substitution form")
+    ap.add_argument("--aux", type=int, default=1,
+                    help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
+                         "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -681,6 +789,10 @@ def main():
             "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle, "two_stream_passes": args.settle_passes,
                                "what": "the sequential evaluation the loop is checked against, repeated before the warm-up steps"},
         }
+        if args.aux and world == 1:
+            del td, pipes, seq_plan
+            torch.cuda.empty_cache()
+            res["aux_rooflines"] = aux_rooflines(dev)
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
         else:

@@ -53,16 +53,21 @@ _SIGNATURES = {
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
+    "dig_element_pipeline_host": [_vp] * 25 + [_i64, _i64, _i64, _int],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_overlap_join_fill": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "dig_overlap_join_count_host": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int],
+    "dig_overlap_join_fill_host": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _int],
     "dig_ideal_overlaps_host": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp],
     "dig_gather_bins": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp],
     "dig_gather_bins_host": [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _int],
     "dig_tiled_nb_test": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
+    "dig_base_tile_probs_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _int],
+    "dig_tile_mut_counts_host": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
     "dig_rbf_cross": [_vp, _vp, _i64, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "dig_rbf_backward": [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp],

@@ -190,6 +190,15 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
 int dig_element_pipeline_prepare(const int32_t *L, int64_t E, int64_t C, void *workspace, int64_t workspace_bytes,
                                  int *compact_ok, void *stream);
+/* host twin: all pointers in host memory; stages the arrays, checks L (the compact form runs when it repeats), runs
+ * DIG_PIPE_ALL on the null stream and copies every output of accumulation and statistics back */
+int dig_element_pipeline_host(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
+                              const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
+                              const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,
+                              const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel, const double *cj,
+                              const double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
+                              int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
+                              int device);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
                          const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
                          const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,
@@ -235,6 +244,14 @@ int dig_base_tile_probs(const uint32_t *genome_words, int64_t n_words, const int
 int dig_tile_mut_counts(const int32_t *pair_mut, const int32_t *pair_reg, int64_t n_pairs, const int64_t *mut_start,
                         const int32_t *mut_cohort, const int64_t *first_pos, const int32_t *n_valid, int binsize,
                         int64_t n_tiles, int64_t R, int64_t C, int32_t *k, void *stream);
+/* host twins (n_mut: rows of mut_start / mut_cohort, so that the twin knows how much to stage) */
+int dig_base_tile_probs_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
+                             const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                             const int64_t *reg_end, int64_t R, const double *s_prob, int64_t C, int binsize, int64_t n_tiles,
+                             double *pt, int64_t *first_pos, int32_t *n_valid, int device);
+int dig_tile_mut_counts_host(const int32_t *pair_mut, const int32_t *pair_reg, int64_t n_pairs, const int64_t *mut_start,
+                             int64_t n_mut, const int32_t *mut_cohort, const int64_t *first_pos, const int32_t *n_valid,
+                             int binsize, int64_t n_tiles, int64_t R, int64_t C, int32_t *k, int device);
 
 /* ---- per-cohort sufficient statistics for the scale factors --------------------------- *
  * calc_scale_factor_efficient, genome mode (driver_model/transfer_tools.py:148-156):
@@ -305,6 +322,14 @@ int dig_overlap_join_count(const int64_t *blk_start_key, const int64_t *blk_runm
 int dig_overlap_join_fill(const int64_t *blk_start_key, const int64_t *blk_runmax_key, const int64_t *blk_end,
                           int64_t n_blk, const int64_t *mut_chrom, const int64_t *mut_start, const int64_t *mut_end,
                           int64_t n_mut, const int64_t *offsets, int32_t *pair_mut, int32_t *pair_blk, void *stream);
+/* host twins (n_pairs = offsets[n_mut - 1] + counts[n_mut - 1]: the size of pair_mut / pair_blk) */
+int dig_overlap_join_count_host(const int64_t *blk_start_key, const int64_t *blk_runmax_key, const int64_t *blk_end,
+                                int64_t n_blk, const int64_t *mut_chrom, const int64_t *mut_start, const int64_t *mut_end,
+                                int64_t n_mut, int32_t *counts, int device);
+int dig_overlap_join_fill_host(const int64_t *blk_start_key, const int64_t *blk_runmax_key, const int64_t *blk_end,
+                               int64_t n_blk, const int64_t *mut_chrom, const int64_t *mut_start, const int64_t *mut_end,
+                               int64_t n_mut, const int64_t *offsets, int64_t n_pairs, int32_t *pair_mut, int32_t *pair_blk,
+                               int device);
 
 /* ---- per-bin epigenomic-track gather (region_model/data_aux/mut_dataset.py:76-81) ---- *
  * out[b, l, t] = (float) x_data[bin_rows[b], l, tracks[t]]      (transpose_out == 0)

@@ -826,3 +826,76 @@ def test_configs0_chr21_every_element_against_the_oracle(torch_dev):
         for j, name in enumerate(engine.ES_PLANES):
             rel_close(st[j].cpu().numpy(), want_st[name], RTOL)
     assert (w["obs_snv"] > 0).any() and np.isfinite(want_st["PVAL_MUT_BURDEN"]).all()
+
+
+def test_host_twins_of_pipeline_tiles_and_join(torch_dev):
+    """The `_host` twins added in ABI 4 (dig_element_pipeline_host, dig_base_tile_probs_host, dig_tile_mut_counts_host,
+    dig_overlap_join_count_host / _fill_host): host pointers in, host arrays out, the same bits as the device entry points."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import _lib, engine
+    from digdriver_amd.data_tools import tabulate_gpu
+    from digdriver_amd.data_tools.genome import PackedGenome
+    hp = _lib.host_ptr
+    # ---- pipeline ----
+    w = make_workload(n_bins=700, n_elements=533, n_cohorts=5, seed=77)
+    E, C, N = 533, 5, 700
+    td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    acc_d, st_d = engine.element_pipeline(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"],
+                                          td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"],
+                                          td["cj"], td["cj_indel"], compact="auto")
+    o = dict(MU=np.empty((E, C)), SIGMA=np.empty((E, C)), R_OBS=np.empty((E, C), np.int32), FLAG=np.empty((E, C), np.int32),
+             P=np.empty((E, 1, C)), R_SIZE=np.empty(E, np.int32), ELT_SIZE=np.empty(E, np.int32), P_INDEL=np.empty(E))
+    st_h = np.empty((7, E, C))
+    c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    ins = [c(w["bin_mu"], np.float64), c(w["bin_std"], np.float64), c(w["bin_y"], np.int32), c(w["bin_flag"], np.uint8),
+           c(w["bin_ctx"], np.int32), c(w["ov_ptr"], np.int64), c(w["ov_idx"], np.int32), c(w["L"], np.int32),
+           c(w["strand_minus"], np.uint8), None, c(w["d_pr"], np.float64), c(w["obs_snv"], np.int32), c(w["obs_samples"], np.int32),
+           c(w["obs_indel"], np.int32), c(w["cj"], np.float64), c(w["cj_indel"], np.float64)]
+    _lib.call("dig_element_pipeline_host", *[hp(a) for a in ins], hp(o["MU"]), hp(o["SIGMA"]), hp(o["R_OBS"]), hp(o["FLAG"]), hp(o["P"]),
+              hp(o["R_SIZE"]), hp(o["ELT_SIZE"]), hp(o["P_INDEL"]), hp(st_h), N, E, C, 0)
+    for k in o:
+        assert np.array_equal(o[k], acc_d[k].cpu().numpy(), equal_nan=True), k
+    assert np.array_equal(st_h, st_d.cpu().numpy(), equal_nan=True)
+    # ---- tiles ----
+    rng = np.random.default_rng(3)
+    seqs = {"chr1": "".join(rng.choice(list("ACGTN"), 7013, p=[.24, .25, .25, .24, .02])), "chr2": "".join(rng.choice(list("ACGT"), 2500))}
+    genome = PackedGenome.from_sequences(seqs)
+    chroms = ["chr1"] * 7 + ["chr2"] * 3
+    starts = np.array([0, 1000, 2000, 3000, 4000, 5000, 6000, 0, 1000, 2000], np.int64)
+    ends = starts + 1000
+    S = rng.uniform(1e-3, 1e-2, (3, 64))
+    pt_d, first_d, nval_d = engine.base_tile_probs(genome, chroms, starts, ends, S, 50, device=0)
+    R, T = len(chroms), pt_d.shape[2]
+    pt_h, first_h, nval_h = np.empty((3, R, T)), np.empty(R, np.int64), np.empty(R, np.int32)
+    ci = genome.chrom_index(chroms)
+    _lib.call("dig_base_tile_probs_host", hp(genome.words), genome.words.size, hp(genome.offsets), hp(genome.lengths), len(genome.names),
+              hp(ci), hp(starts), hp(ends), R, hp(np.ascontiguousarray(S)), 3, 50, T, hp(pt_h), hp(first_h), hp(nval_h), 0)
+    assert np.array_equal(pt_h, pt_d.cpu().numpy(), equal_nan=True) and np.array_equal(first_h, first_d.cpu().numpy())
+    assert np.array_equal(nval_h, nval_d.cpu().numpy())
+    # ---- join + tile counts ----
+    M = 4000
+    mci = rng.integers(0, 2, M)
+    ms = np.array([rng.integers(0, len(seqs["chr%d" % (i + 1)])) for i in mci], np.int64)
+    me = ms + 1
+    co = rng.integers(-1, 4, M).astype(np.int32)                       # ids -1 and 3 are outside [0, C): skipped, not counted
+    blocks = tabulate_gpu.ElementBlocks(ci, starts, ends, np.arange(R), R, torch_dev)
+    mc_t = torch.as_tensor(mci, device=torch_dev).to(torch.int64)
+    pm_d, pb_d = tabulate_gpu.overlap_pairs(blocks, mc_t, torch.as_tensor(ms, device=torch_dev), torch.as_tensor(me, device=torch_dev))
+    keys = [blocks.start_key.cpu().numpy(), blocks.runmax_key.cpu().numpy(), blocks.end.cpu().numpy()]
+    counts = np.empty(M, np.int32)
+    mch = mci.astype(np.int64)
+    _lib.call("dig_overlap_join_count_host", hp(keys[0]), hp(keys[1]), hp(keys[2]), R, hp(mch), hp(ms), hp(me), M, hp(counts), 0)
+    offs = (np.cumsum(counts) - counts).astype(np.int64)
+    n_pairs = int(counts.sum())
+    pm_h, pb_h = np.empty(n_pairs, np.int32), np.empty(n_pairs, np.int32)
+    _lib.call("dig_overlap_join_fill_host", hp(keys[0]), hp(keys[1]), hp(keys[2]), R, hp(mch), hp(ms), hp(me), M, hp(offs), n_pairs,
+              hp(pm_h), hp(pb_h), 0)
+    assert n_pairs == pm_d.numel() and np.array_equal(pm_h, pm_d.cpu().numpy()) and np.array_equal(pb_h, pb_d.cpu().numpy())
+    k_d = engine.tile_mut_counts(genome, chroms, starts, ends, first_d, nval_d, ["chr%d" % (i + 1) for i in mci], ms, me, co, 3, 50, T)
+    pr_h = blocks.elt.cpu().numpy()[pb_h].astype(np.int32)
+    k_h = np.empty((3, R, T), np.int32)
+    _lib.call("dig_tile_mut_counts_host", hp(pm_h), hp(pr_h), n_pairs, hp(ms), M, hp(co), hp(first_h), hp(nval_h), 50, T, R, 3, hp(k_h), 0)
+    assert np.array_equal(k_h, k_d.cpu().numpy())
+    inside = (co >= 0) & (co < 3)
+    assert 0 < int(k_h.sum()) <= int(inside.sum())
