@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_h
 
 DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
 DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS, DIG_PIPE_WORKLIST_CLEAN, DIG_PIPE_COMPACT_L = 1, 2, 4, 8, 16
+GENE_CLASSES = ("SYN", "MIS", "NONS", "SPL", "TRUNC", "NONSYN")
+GS_PLANES = tuple("EXP_" + c for c in GENE_CLASSES) + tuple("PVAL_%s_BURDEN" % c for c in GENE_CLASSES) + \
+    tuple("PVAL_%s_BURDEN_SAMPLE" % c for c in GENE_CLASSES) + ("THETA_INDEL", "EXP_INDEL", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN")
 ES_PLANES = ("EXP_SNV", "PVAL_SNV_BURDEN", "PVAL_SAMPLE_BURDEN", "THETA_INDEL", "EXP_INDEL",
              "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN")
 
@@ -54,6 +57,9 @@ _SIGNATURES = {
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "dig_element_pipeline_host": [_vp] * 25 + [_i64, _i64, _i64, _int],
+    "dig_gene_stats": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp],
+    "dig_gene_stats_host": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _int],
+    "dig_gene_pipeline": [_vp] * 15 + [_int] + [_vp] * 9 + [_i64, _i64, _i64, _vp, _i64, _vp],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],

@@ -375,7 +375,43 @@ def element_statistics_block(df_model, cj, cj_indel, skip_pvals=False):
     return df_model
 
 
-def _gene_statistics(df_model, burden=True, indel=True, all_cosmic=None, announce=True):
+def gene_statistics_block(df_model, cj, indel=True, all_cosmic=None):
+    """The statistics of the gene route -- gene_expected_muts_nb, gene_pvalue_burden_nb, gene_pvalue_burden_nb_by_sample,
+    gene_pvalue_indel and the Fisher combination (transfer_tools.py:331-340,394-456,554-583,709-729,860-861) -- as ONE
+    launch (dig_gene_stats) instead of four.  `df_model` comes from transfer_gene_model(..., cj) and `cj` is that same
+    factor: the kernel forms theta = sigma^2 / mu * cj from MU / SIGMA with the IEEE operations that made the frame's
+    THETA column.  Same columns in the same order as the column-by-column route."""
+    with_indel = bool(indel and df_model.OBS_INDEL.sum() != 0)
+    t_indel = None
+    if with_indel:
+        null = df_model.loc[~df_model.index.isin(cosmic_null_set(all_cosmic))]
+        t_indel = null.OBS_INDEL.sum() / (null.Pi_INDEL * null.ALPHA_INDEL * null.THETA_INDEL).sum()      # :720-721
+    pi = np.stack([_f64(df_model, 'Pi_' + c) for c in GENE_CLASSES], axis=1)[:, :, None]
+    obs = np.stack([df_model[c].values for c in ('OBS_SYN', 'OBS_MIS', 'OBS_NONS', 'OBS_SPL', 'OBS_INDEL')], axis=1)[:, :, None]
+    n_samp = np.stack([df_model['N_SAMP_' + c].values for c in GENE_CLASSES], axis=1)[:, :, None]
+    planes = engine.gene_stats(_f64(df_model, 'MU'), _f64(df_model, 'SIGMA'), pi, _f64(df_model, 'Pi_INDEL'), obs.astype(np.int32),
+                               n_samp.astype(np.int32), np.array([float(cj)]),
+                               None if t_indel is None else np.array([float(t_indel)]),
+                               mu_indel=_f64(df_model, 'MU_INDEL'), sigma_indel=_f64(df_model, 'SIGMA_INDEL'))
+    for c in GENE_CLASSES:
+        df_model['EXP_' + c] = planes['EXP_' + c][:, 0]
+    for pattern in ('PVAL_%s_BURDEN', 'PVAL_%s_BURDEN_SAMPLE'):
+        for c in GENE_CLASSES:
+            df_model[pattern % c] = planes[pattern % c][:, 0]
+    if with_indel:
+        _say("\tCalculating indel burden p-values")
+        for name in ('THETA_INDEL', 'EXP_INDEL', 'PVAL_INDEL_BURDEN', 'PVAL_MUT_BURDEN'):
+            df_model[name] = planes[name][:, 0]
+    return df_model
+
+
+def _gene_statistics(df_model, burden=True, indel=True, all_cosmic=None, announce=True, fused_cj=None):
+    """fused_cj: the cohort factor the frame was transferred with -> the one-launch form (gene_statistics_block); None: the
+    reference's column-by-column sequence.  Same results (tests/test_gpu_host_mirror.py)."""
+    if fused_cj is not None and burden:
+        if announce:
+            _say("\tCalculating burden p-values")
+        return gene_statistics_block(df_model, fused_cj, indel=indel, all_cosmic=all_cosmic)
     df_model = gene_expected_muts_nb(df_model)
     if burden:
         if announce:

@@ -20,6 +20,7 @@ import numpy as np
 from . import _lib
 
 ES_PLANES = _lib.ES_PLANES
+GS_PLANES = _lib.GS_PLANES
 
 
 def _is_cuda(x):
@@ -110,6 +111,91 @@ def element_stats(mu, sigma, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel, 
               _lib.host_ptr(pi_sum), _lib.host_ptr(pi_indel), per_cohort, _lib.host_ptr(obs[0]), _lib.host_ptr(obs[1]),
               _lib.host_ptr(obs[2]), _lib.host_ptr(cj), _lib.host_ptr(cj_indel), _lib.host_ptr(res), E, C, device)
     return {name: res[i] for i, name in enumerate(ES_PLANES)}
+
+
+# ---------------------------------------------------------------------------
+def gene_stats(mu, sigma, pi, pi_indel, obs, n_samp, cj, t_indel=None, mu_indel=None, sigma_indel=None, device=0, out=None):
+    """The gene route's statistics block (transfer_tools.py:331-340,394-456,554-583,709-729,860-861) for G genes x C cohorts
+    in ONE launch (dig_gene_stats).  mu, sigma f64 [G, C]; pi f64 [G, 6 or 4, C]; pi_indel [G] or [G, C]; obs i32 [G, 5, C]
+    (SYN, MIS, NONS, SPL, INDEL); n_samp i32 [G, 6, C]; cj [C]; t_indel [C] or None (no indel block: those planes are NaN).
+    Returns dict plane name -> [G, C] (views of one [22, G, C] buffer); CUDA tensors in -> CUDA tensors out."""
+    with_indel = int(t_indel is not None)
+    if _is_cuda(mu):
+        import torch
+        dev = mu.device
+        f64, i32 = torch.float64, torch.int32
+        mu, sigma, pi = _t(mu, f64, dev), _t(sigma, f64, dev), _t(pi, f64, dev)
+        G, C = mu.shape
+        n_pi = pi.shape[1]
+        assert pi.shape == (G, n_pi, C) and n_pi in (4, 6)
+        pi_indel = _t(pi_indel, f64, dev)
+        per_cohort = int(pi_indel is not None and pi_indel.dim() == 2)
+        obs, n_samp = _t(obs, i32, dev), _t(n_samp, i32, dev)
+        assert obs.shape == (G, 5, C) and n_samp.shape == (G, 6, C)
+        cj, t_indel = _t(cj, f64, dev).reshape(-1), (None if t_indel is None else _t(t_indel, f64, dev).reshape(-1))
+        mu_indel, sigma_indel = _t(mu_indel, f64, dev), _t(sigma_indel, f64, dev)
+        if out is None:
+            out = torch.empty((len(GS_PLANES), G, C), dtype=f64, device=dev)
+        p = _lib.dev_ptr
+        with torch.cuda.device(dev):
+            _lib.call("dig_gene_stats", p(mu), p(sigma), p(mu_indel), p(sigma_indel), p(pi), n_pi, p(pi_indel), per_cohort, p(obs),
+                      p(n_samp), p(cj), p(t_indel), with_indel, p(out), G, C, _lib.stream_ptr())
+        return {name: out[i] for i, name in enumerate(GS_PLANES)}
+    mu = _lib.as_host(mu, np.float64)
+    if mu.ndim == 1:
+        mu = mu[:, None]
+    G, C = mu.shape
+    sigma = _lib.as_host(sigma, np.float64).reshape(G, C)
+    pi = _lib.as_host(pi, np.float64)
+    if pi.ndim == 2:
+        pi = pi[:, :, None]
+    pi = np.ascontiguousarray(pi)
+    n_pi = pi.shape[1]
+    assert pi.shape == (G, n_pi, C) and n_pi in (4, 6)
+    pi_indel = None if pi_indel is None else _lib.as_host(pi_indel, np.float64)
+    per_cohort = int(pi_indel is not None and pi_indel.ndim == 2)
+    obs = np.ascontiguousarray(_lib.as_host(obs, np.int32).reshape(G, 5, C))
+    n_samp = np.ascontiguousarray(_lib.as_host(n_samp, np.int32).reshape(G, 6, C))
+    cj = _lib.as_host(np.broadcast_to(np.asarray(cj, np.float64).reshape(-1), (C,)), np.float64)
+    ti = None if t_indel is None else _lib.as_host(np.broadcast_to(np.asarray(t_indel, np.float64).reshape(-1), (C,)), np.float64)
+    mi = None if mu_indel is None else _lib.as_host(mu_indel, np.float64).reshape(G, C)
+    si = None if sigma_indel is None else _lib.as_host(sigma_indel, np.float64).reshape(G, C)
+    res = np.empty((len(GS_PLANES), G, C), np.float64)
+    h = _lib.host_ptr
+    _lib.call("dig_gene_stats_host", h(mu), h(sigma), h(mi), h(si), h(pi), n_pi, h(pi_indel), per_cohort, h(obs), h(n_samp), h(cj),
+              h(ti), with_indel, h(res), G, C, device)
+    return {name: res[i] for i, name in enumerate(GS_PLANES)}
+
+
+def gene_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr, obs, n_samp, cj,
+                  t_indel=None):
+    """genic_model (genic_driver_tools.py:31-203) + the gene statistics block as one call on device tensors
+    (dig_gene_pipeline): L i32 [G, 4, 192] (silent, missense, nonsense, splice columns), gene_length i32 [G].
+    Returns (accumulate dict with P [G, 4, C], dict of the 22 statistics planes)."""
+    import torch
+    dev = bin_mu.device
+    f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
+    bin_mu, bin_std = _t(bin_mu, f64, dev), _t(bin_std, f64, dev)
+    N, C = bin_mu.shape
+    bin_y, bin_flag, bin_ctx = _t(bin_y, i32, dev), _t(bin_flag, u8, dev), _t(bin_ctx, i32, dev)
+    ov_ptr, ov_idx, L = _t(ov_ptr, i64, dev), _t(ov_idx, i32, dev), _t(L, i32, dev)
+    G = L.shape[0]
+    assert L.shape == (G, 4, 192) and ov_ptr.numel() == G + 1
+    strand_minus, gene_length, d_pr = _t(strand_minus, u8, dev), _t(gene_length, i32, dev), _t(d_pr, f64, dev)
+    obs, n_samp = _t(obs, i32, dev), _t(n_samp, i32, dev)
+    assert obs.shape == (G, 5, C) and n_samp.shape == (G, 6, C)
+    cj = _t(cj, f64, dev).reshape(-1)
+    ti = None if t_indel is None else _t(t_indel, f64, dev).reshape(-1)
+    o = alloc_accumulate_outputs(G, C, 4, dev)
+    out = torch.empty((len(GS_PLANES), G, C), dtype=f64, device=dev)
+    ws, wsb = _workspace("accumulate", G, C, dev)
+    p = _lib.dev_ptr
+    with torch.cuda.device(dev):
+        _lib.call("dig_gene_pipeline", p(bin_mu), p(bin_std), p(bin_y), p(bin_flag), p(bin_ctx), p(ov_ptr), p(ov_idx), p(L),
+                  p(strand_minus), p(gene_length), p(d_pr), p(obs), p(n_samp), p(cj), p(ti), int(ti is not None), p(o["MU"]),
+                  p(o["SIGMA"]), p(o["R_OBS"]), p(o["FLAG"]), p(o["P"]), p(o["R_SIZE"]), p(o["ELT_SIZE"]), p(o["P_INDEL"]), p(out),
+                  N, G, C, p(ws), wsb, _lib.stream_ptr())
+    return o, {name: out[i] for i, name in enumerate(GS_PLANES)}
 
 
 # ---------------------------------------------------------------------------

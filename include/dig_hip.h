@@ -207,6 +207,34 @@ int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int3
                          int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
                          int stages, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- the gene route's statistics block as one launch (ABI 4) -------------------------------- *
+ * gene_expected_muts_nb :331-340, gene_pvalue_burden_nb :394-456, gene_pvalue_burden_nb_by_sample :554-583,
+ * gene_pvalue_indel :709-729 and the Fisher combination :860-861 of driver_model/transfer_tools.py, for G genes x C cohorts;
+ * classes SYN, MIS, NONS, SPL, TRUNC = NONS + SPL, NONSYN = MIS + TRUNC.
+ *   mu, sigma f64 [G, C] (ALPHA, THETA = normal_params_to_gamma; THETA *= cj[c]); mu_indel, sigma_indel: the indel pair or NULL
+ *   pi f64 [G, n_pi, C]: n_pi = 6 (Pi_SYN .. Pi_NONSYN as load_pretrained_model hands them) or 4 (P_SILENT, P_MIS, P_NONS,
+ *       P_SPLICE straight from dig_accumulate_elements(n_class = 4): TRUNC and NONSYN are added here)
+ *   pi_indel f64 [G] or [G, C]; obs i32 [G, 5, C] = OBS_SYN, MIS, NONS, SPL, INDEL (TRUNC / NONSYN are added here);
+ *   n_samp i32 [G, 6, C] = N_SAMP_c (distinct samples per class); cj, t_indel f64 [C] (t_indel: the indel calibration of
+ *       :720-721, formed by the caller over its null gene set); with_indel = 0 leaves the four indel planes NaN.
+ *   out f64 [22, G, C]: EXP_c x 6, PVAL_c_BURDEN x 6, PVAL_c_BURDEN_SAMPLE x 6, THETA_INDEL, EXP_INDEL, PVAL_INDEL_BURDEN,
+ *       PVAL_MUT_BURDEN (Fisher of PVAL_TRUNC_BURDEN and PVAL_INDEL_BURDEN).
+ * dig_gene_pipeline == dig_accumulate_elements(n_class = 4, gene_length) followed by dig_gene_stats(MU, SIGMA, NULL, NULL, P, 4,
+ *   P_INDEL [G], ...): genic_model (genic_driver_tools.py:31-203) to p-values in one call; workspace as dig_accumulate_elements. */
+int dig_gene_stats(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel, const double *pi,
+                   int n_pi, const double *pi_indel, int pi_indel_per_cohort, const int32_t *obs, const int32_t *n_samp,
+                   const double *cj, const double *t_indel, int with_indel, double *out, int64_t G, int64_t C, void *stream);
+int dig_gene_stats_host(const double *mu, const double *sigma, const double *mu_indel, const double *sigma_indel,
+                        const double *pi, int n_pi, const double *pi_indel, int pi_indel_per_cohort, const int32_t *obs,
+                        const int32_t *n_samp, const double *cj, const double *t_indel, int with_indel, double *out, int64_t G,
+                        int64_t C, int device);
+int dig_gene_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
+                      const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
+                      const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr, const int32_t *obs,
+                      const int32_t *n_samp, const double *cj, const double *t_indel, int with_indel, double *MU, double *SIGMA,
+                      int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out,
+                      int64_t N, int64_t G, int64_t C, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- sufficient statistics in canonical chunks (bin-sharded runs) --------------------------- *
  * Same quantity as dig_scale_suffstats / dig_scale_factors, defined so that it does not depend on the sharding: the bins
  * are cut into K canonical chunks of the GLOBAL grid (boundaries floor(N j / K)); a rank computes the chunk sums of the
