@@ -428,8 +428,9 @@ def _gene_statistics(df_model, burden=True, indel=True, all_cosmic=None, announc
 # ---------------------------------------------------------------------------------------------
 def run_gene_model(f_mut, f_h5_genemodel, scale_by_sample=False, pval_burden_nb=True, pval_burden_dnds=True,
                    pval_sel=True, max_muts_per_sample=3e9, max_muts_per_gene_per_sample=3e9, scale_factor=None,
-                   scale_by_expectation=True, cgc_genes=False, all_cosmic=None):
-    """transfer_tools.py:789-874"""
+                   scale_by_expectation=True, cgc_genes=False, all_cosmic=None, fused=False):
+    """transfer_tools.py:789-874.  `fused=True` computes the whole statistics block with the single dig_gene_stats launch
+    (gene_statistics_block) instead of the reference's column-by-column sequence; same columns, same values."""
     run = CohortRun(f_mut, f_h5_genemodel)
     model, rows = run.gene_model(), run.coding_rows()
     if cgc_genes:
@@ -445,7 +446,8 @@ def run_gene_model(f_mut, f_h5_genemodel, scale_by_sample=False, pval_burden_nb=
     else:
         cj = run.ratio_scale(rows, 'sample' if scale_by_sample else 'exome')
     _say("\tScaling factor is: {}".format(cj))
-    return _gene_statistics(transfer_gene_model(rows, counts, model, cj), burden=pval_burden_nb, all_cosmic=all_cosmic)
+    return _gene_statistics(transfer_gene_model(rows, counts, model, cj), burden=pval_burden_nb, all_cosmic=all_cosmic,
+                            fused_cj=cj if fused else None)
 
 
 def run_target_model(f_mut, f_h5_genemodel, scale_by_sample=False, panel="MSK_341", max_muts_per_sample=3e9,

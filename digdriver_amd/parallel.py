@@ -354,9 +354,11 @@ class ShardedTiles:
             ln = np.where(ok, self.genome.lengths[np.maximum(mi, 0)], 0)
             keep = ok & (ms - sh >= 0) & (ms - sh < ln)
             self.mut = (mc[keep], (ms - sh)[keep], (me - sh)[keep], co[keep])
+            self.mut_chrom_index = mi[keep].astype(np.int64)
         else:
             self.mut = (mc[:0], ms[:0], me[:0], co[:0])
-        self.result = None
+            self.mut_chrom_index = np.zeros(0, np.int64)
+        self.result = self._mut_dev = None
 
     def run(self):
         """The rank's tiles: dict of device tensors pval, exp, pt [C, R_r, n_tiles], k i32, first_pos [R_r] (TRUE
@@ -369,13 +371,35 @@ class ShardedTiles:
             self.result = dict(pval=z(torch.float64), exp=z(torch.float64), pt=z(torch.float64), k=z(torch.int32),
                                first_pos=torch.empty(0, dtype=torch.int64, device=dev), n_valid=torch.empty(0, dtype=torch.int32, device=dev))
             return self.result
-        pt, first, nval = engine.base_tile_probs(self.genome, self.chroms, self.starts, self.ends, self.s_prob, self.binsize,
-                                                 n_tiles=self.n_tiles, device=dev)
-        mc, ms, me, co = self.mut
-        k = engine.tile_mut_counts(self.genome, self.chroms, self.starts, self.ends, first, nval, mc, ms, me, co, C, self.binsize,
-                                   self.n_tiles)
-        pval, ex = engine.tiled_nb_test(pt, k, torch.as_tensor(self.mu, device=dev), torch.as_tensor(self.sigma, device=dev))
-        self.result = dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first + torch.as_tensor(self.reg_shift, device=dev), n_valid=nval)
+        from . import _lib
+        from .data_tools import tabulate_gpu
+        if self._mut_dev is None:
+            # everything a step needs goes to the device ONCE: the slab, the region table (as join blocks too), the rank's
+            # mutations, the model; a step is then five C-ABI calls with device pointers
+            ci = self.genome.chrom_index(self.chroms)
+            words, off, ln = self.genome.on_device(dev)
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+            _, ms, me, co = self.mut
+            self._mut_dev = dict(words=words, off=off, ln=ln, rc=t(ci), rs=t(self.starts), re=t(self.ends), S=t(self.s_prob),
+                                 mu=t(self.mu), sg=t(self.sigma), mc=t(self.mut_chrom_index), ms=t(ms), me=t(me), co=t(co),
+                                 blocks=tabulate_gpu.ElementBlocks(ci, self.starts, self.ends, np.arange(Rr), Rr, dev),
+                                 shift=t(self.reg_shift))
+        d = self._mut_dev
+        p = _lib.dev_ptr
+        T = self.n_tiles
+        pt = torch.empty((C, Rr, T), dtype=torch.float64, device=dev)
+        first = torch.empty(Rr, dtype=torch.int64, device=dev)
+        nval = torch.empty(Rr, dtype=torch.int32, device=dev)
+        k = torch.empty((C, Rr, T), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("dig_base_tile_probs", p(d["words"]), d["words"].numel(), p(d["off"]), p(d["ln"]), len(self.genome.names),
+                      p(d["rc"]), p(d["rs"]), p(d["re"]), Rr, p(d["S"]), C, self.binsize, T, p(pt), p(first), p(nval), _lib.stream_ptr())
+            pm, pb = tabulate_gpu.overlap_pairs(d["blocks"], d["mc"], d["ms"], d["me"])
+            pr = d["blocks"].elt[pb.long()].to(torch.int32).contiguous()
+            _lib.call("dig_tile_mut_counts", p(pm), p(pr), pm.numel(), p(d["ms"]), p(d["co"]), p(first), p(nval), self.binsize, T, Rr, C,
+                      p(k), _lib.stream_ptr())
+        pval, ex = engine.tiled_nb_test(pt, k, d["mu"], d["sg"])
+        self.result = dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first + d["shift"], n_valid=nval)
         return self.result
 
     def valid_pvalues(self, cohort):

@@ -38,7 +38,8 @@ def cmd_gene(args):
     res = transfer_tools.run_gene_model(
         args.fmut, args.model, scale_by_sample=args.scale_by_samples, pval_burden_nb=args.pval_burden,
         max_muts_per_sample=args.max_muts_per_sample, max_muts_per_gene_per_sample=args.max_muts_per_gene_per_sample,
-        scale_factor=args.scale_factor_manual, scale_by_expectation=args.scale_by_expectation, cgc_genes=args.cgc_genes)
+        scale_factor=args.scale_factor_manual, scale_by_expectation=args.scale_by_expectation, cgc_genes=args.cgc_genes,
+        fused=True)
     write_results(res, args)
 
 

@@ -115,20 +115,26 @@ def test_run_gene_model_matches_reference(_gpu, tmp_path):
     frame.insert(0, "CHROM", g["frame_chrom"])
     path = str(tmp_path / "genes.map")
     mapfile.write_frame(path, "genic_model", frame)
-    df = tt.run_gene_model(os.path.join(GOLDEN, "gene_mutations.tsv"), path,
-                           max_muts_per_sample=int(g["max_muts_per_sample"]),
-                           max_muts_per_gene_per_sample=int(g["max_muts_per_gene_per_sample"]),
-                           all_cosmic=list(g["null_excluded"]))
-    assert list(df.index) == list(g["out_index"])
-    cols = list(g["out_cols"])
-    assert [c for c in df.columns if c != "CHROM"] == cols          # same columns, same order as the reference
-    vals = g["out_vals"]
-    for i, c in enumerate(cols):
-        got = df[c].values.astype(float)
-        if c.startswith(("OBS_", "N_SAMP_")) or c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
-            assert np.array_equal(got, vals[:, i]), c                # integer columns: bit-exact
-        else:
-            rel_close(got, vals[:, i], 1e-6)
+    frames = []
+    for fused in (False, True):               # the reference's column-by-column sequence; the one-launch form (dig_gene_stats)
+        df = tt.run_gene_model(os.path.join(GOLDEN, "gene_mutations.tsv"), path,
+                               max_muts_per_sample=int(g["max_muts_per_sample"]),
+                               max_muts_per_gene_per_sample=int(g["max_muts_per_gene_per_sample"]),
+                               all_cosmic=list(g["null_excluded"]), fused=fused)
+        assert list(df.index) == list(g["out_index"])
+        cols = list(g["out_cols"])
+        assert [c for c in df.columns if c != "CHROM"] == cols          # same columns, same order as the reference
+        vals = g["out_vals"]
+        for i, c in enumerate(cols):
+            got = df[c].values.astype(float)
+            if c.startswith(("OBS_", "N_SAMP_")) or c in ("GENE_LENGTH", "R_SIZE", "R_OBS", "R_INDEL", "FLAG"):
+                assert np.array_equal(got, vals[:, i]), c                # integer columns: bit-exact
+            else:
+                rel_close(got, vals[:, i], 1e-6)
+        frames.append(df)
+    for c in frames[0].columns:                # the two routes run the same device functions: same bits
+        a, b = frames[0][c].values, frames[1][c].values
+        assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else (a == b).all(), c
 
 
 def test_run_element_region_model_end_to_end(_gpu, tmp_path):

@@ -899,3 +899,59 @@ def test_host_twins_of_pipeline_tiles_and_join(torch_dev):
     assert np.array_equal(k_h, k_d.cpu().numpy())
     inside = (co >= 0) & (co < 3)
     assert 0 < int(k_h.sum()) <= int(inside.sum())
+
+
+def test_gene_pipeline_all_cohorts_against_oracle(torch_dev):
+    """dig_gene_pipeline: genic_model's accumulation (four class columns of L, P_INDEL = GENE_LENGTH / R_SIZE) + the gene
+    statistics block (six classes x count / sample tests, indel test, Fisher on TRUNC + INDEL) for G genes x C cohorts in one
+    call, against the oracle's gene_stats on the oracle's accumulation; integer planes exact, p-values within the contract;
+    and dig_gene_stats through its host twin gives the same bits."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    G, C, N = 417, 5, 900
+    w = make_workload(n_bins=N, n_elements=G, n_cohorts=C, seed=41, max_blocks=8)
+    rng = np.random.default_rng(42)
+    L64 = rng.poisson(6.0, (G, 4, 64))
+    L = np.repeat(L64, 3, axis=2).astype(np.int32)
+    L[:, :, ::7] += rng.integers(0, 3, (G, 4, 28))                   # class columns do not repeat per context (no compact form)
+    gene_length = rng.integers(300, 9000, G).astype(np.int32)
+    acc_w = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], w["ov_ptr"], w["ov_idx"], L,
+                                  w["strand_minus"].astype(bool), w["d_pr"], gene_length=gene_length)
+    alpha = acc_w["MU"] ** 2 / acc_w["SIGMA"] ** 2
+    theta = acc_w["SIGMA"] ** 2 / acc_w["MU"] * w["cj"][None, :]
+    P4 = acc_w["P"]                                                 # [G, 4, C]
+    pi = {"SYN": P4[:, 0], "MIS": P4[:, 1], "NONS": P4[:, 2], "SPL": P4[:, 3]}
+    pi["TRUNC"] = pi["NONS"] + pi["SPL"]
+    pi["NONSYN"] = pi["MIS"] + pi["TRUNC"]
+    obs5 = np.stack([rng.poisson(alpha * theta * pi[c] * 1.2) for c in ("SYN", "MIS", "NONS", "SPL")] +
+                    [rng.poisson(alpha * theta * acc_w["P_INDEL"][:, None] * 0.1)], axis=1).astype(np.int32)
+    obs5[::50, 1] += 400                                             # a few counts beyond the recurrence's table
+    obs = {"SYN": obs5[:, 0], "MIS": obs5[:, 1], "NONS": obs5[:, 2], "SPL": obs5[:, 3]}
+    obs["TRUNC"] = obs["NONS"] + obs["SPL"]
+    obs["NONSYN"] = obs["MIS"] + obs["TRUNC"]
+    ns = {c: rng.binomial(obs[c], 0.9) for c in O.GENE_CLASSES}
+    n_samp = np.stack([ns[c] for c in O.GENE_CLASSES], axis=1).astype(np.int32)
+    t_indel = rng.uniform(0.05, 0.3, C)
+    want = O.gene_stats(acc_w["MU"], acc_w["SIGMA"], pi, obs, ns, w["cj"][None, :], pi_indel=acc_w["P_INDEL"][:, None],
+                        obs_indel=obs5[:, 4], t_indel=t_indel[None, :])
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=torch_dev)
+    acc, st = engine.gene_pipeline(t(w["bin_mu"]), t(w["bin_std"]), t(w["bin_y"]), t(w["bin_flag"]), t(w["bin_ctx"]), t(w["ov_ptr"]),
+                                   t(w["ov_idx"]), t(L), t(w["strand_minus"]), t(gene_length), t(w["d_pr"]), t(obs5), t(n_samp),
+                                   t(w["cj"]), t(t_indel))
+    torch.cuda.synchronize()
+    rel_close(acc["P"].cpu().numpy(), acc_w["P"], 1e-11)
+    rel_close(acc["P_INDEL"].cpu().numpy(), acc_w["P_INDEL"], 1e-12)
+    assert np.array_equal(acc["R_SIZE"].cpu().numpy(), acc_w["R_SIZE"])
+    for name in engine.GS_PLANES:
+        rel_close(st[name].cpu().numpy(), want[name], 1e-12 if name.startswith(("EXP", "THETA")) else RTOL)
+    assert (want["PVAL_MIS_BURDEN"][::50] < 1e-20).any()
+    # the statistics alone, through the host twin, on the device's own accumulation: the same bits
+    host = engine.gene_stats(acc["MU"].cpu().numpy(), acc["SIGMA"].cpu().numpy(), acc["P"].cpu().numpy(), acc["P_INDEL"].cpu().numpy(),
+                             obs5, n_samp, w["cj"], t_indel)
+    for name in engine.GS_PLANES:
+        assert np.array_equal(host[name], st[name].cpu().numpy(), equal_nan=True), name
+    # without the indel block those four planes are NaN and nothing else moves
+    no_ind = engine.gene_stats(acc["MU"], acc["SIGMA"], acc["P"], acc["P_INDEL"], t(obs5), t(n_samp), t(w["cj"]))
+    assert torch.isnan(no_ind["PVAL_MUT_BURDEN"]).all() and torch.equal(no_ind["PVAL_TRUNC_BURDEN"], st["PVAL_TRUNC_BURDEN"])
