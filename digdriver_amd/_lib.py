@@ -72,6 +72,7 @@ _SIGNATURES = {
     "dig_tiled_nb_test": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
+    "dig_base_tile_probs_ctx": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_base_tile_probs_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _int],
     "dig_tile_mut_counts_host": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],

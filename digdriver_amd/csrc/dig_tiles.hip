@@ -430,6 +430,133 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
 #endif
 }
 
+// =======================================================================================
+// General-context form: n_up = n_down = U, U = 2 is the DEFAULT signature of the reference's per-base functions
+// (penta-nucleotide contexts: base_probabilities_by_region / apply_nb_to_region / nb_model, sequence_tools.py:292,
+// nb_model.py:126,188); U = 1 reproduces the trinucleotide kernels above (used to cross-check this one).
+//   region r: positions first .. stop - 1 with first = (start == 0 ? U : start), stop = min(end, chrom_len - U)
+//       (fetch_sequence :21-29: START == 0 becomes n_up, the fetch is widened by U bases on either side and cut at the
+//       chromosome end); a position whose (2 U + 1)-base window holds a non-ACGT base has probability 0.
+// 4^(2U+1) contexts (1 024 for U = 2) rule out the per-tile histograms and the 64-row matrix product of the trinucleotide
+// kernels; here the per-position table values are added up directly: persistent workgroups keep the table of a chunk of
+// 16 cohorts in LDS ([cohort][context], 128 KB for U = 2: the context index spreads the lanes' reads over the banks),
+// stage a region's packed bases, and every lane walks one tile with a rolling context index -- one LDS read per base and
+// 16 table reads + adds per position.  pt = (sum over the tile) / (sum over the region): the reference normalises every
+// position first and then sums (a few ulp apart, as for the trinucleotide kernels).  Regions of up to 12 280 - 2 U
+// positions (a 10-kb bin with room to spare).
+// =======================================================================================
+constexpr int kCtxChunk = 16;             // cohorts whose table is resident in LDS at a time
+
+template <int U>
+__global__ __launch_bounds__(kTileBlock) void base_tile_probs_ctx_kernel(
+    const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
+    const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
+    const int64_t* __restrict__ reg_end, int64_t R, const double* __restrict__ s_prob, int64_t C, int binsize, int64_t n_tiles,
+    double* __restrict__ pt, int64_t* __restrict__ first_pos, int32_t* __restrict__ n_valid)
+{
+    constexpr int W = 2 * U + 1;                      // window
+    constexpr int K = 1 << (2 * W);                   // contexts
+    constexpr unsigned kMask = (unsigned)K - 1u;
+    __shared__ double s_S[kCtxChunk][K];
+    __shared__ uint32_t s_words[kTileMaxWords + 2];
+    __shared__ double s_part[kTileBlock / 64][kCtxChunk];
+    __shared__ double s_T[kCtxChunk];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t c0 = 0; c0 < C; c0 += kCtxChunk) {
+        const int cc = (int)(C - c0 < kCtxChunk ? C - c0 : kCtxChunk);
+        __syncthreads();
+        for (int idx = tid; idx < kCtxChunk * K; idx += kTileBlock) {
+            const int c = idx / K, x = idx - c * K;
+            s_S[c][x] = c < cc ? s_prob[(c0 + c) * K + x] : 0.0;
+        }
+        __syncthreads();
+        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+            const int chrom = reg_chrom[r];
+            const int64_t len = chrom_len[chrom], start = reg_start[r], end = reg_end[r];
+            const int64_t first = start == 0 ? U : start;
+            const int64_t stop = end < len - U ? end : len - U;
+            const int64_t n_pos = stop > first ? stop - first : 0;
+            const int64_t g0 = chrom_off[chrom] + first;
+            const int64_t tiles_valid = (n_pos + binsize - 1) / binsize;
+            if (tid == 0 && c0 == 0) {
+                first_pos[r] = first;
+                n_valid[r] = (int32_t)(tiles_valid < n_tiles ? tiles_valid : n_tiles);
+            }
+            // stage the bases first - U .. stop + U - 1
+            const int64_t ga = g0 - U;
+            const int64_t w0 = (ga >> 3) + 1;                   // array word = genome word + 1 (leading pad word)
+            const int64_t nw = n_pos > 0 ? ((ga + n_pos + 2 * U - 1) >> 3) + 1 - w0 + 1 : 0;
+            __syncthreads();
+            for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+            __syncthreads();
+            const int64_t g_lds0 = (w0 - 1) << 3;
+            // one tile: the table values of its positions, summed per cohort of the chunk
+            auto tile_sums = [&](int64_t t, double (&acc)[kCtxChunk]) {
+#pragma unroll
+                for (int c = 0; c < kCtxChunk; ++c) acc[c] = 0.0;
+                const int64_t p0 = t * binsize;
+                int64_t cnt = binsize;
+                if (cnt > n_pos - p0) cnt = n_pos - p0;
+                unsigned ctx = 0;
+                int good = 0;                                    // consecutive ACGT bases ending at the newest one
+#pragma unroll
+                for (int j = 0; j < 2 * U; ++j) {                // the window of position p0, all but its last base
+                    const unsigned b = tile_base(s_words, g0 + p0 - U + j, g_lds0);
+                    good = b > 3u ? 0 : good + 1;
+                    ctx = ((ctx << 2) | (b & 3u)) & kMask;
+                }
+                for (int64_t j = 0; j < cnt; ++j) {
+                    const unsigned b = tile_base(s_words, g0 + p0 + j + U, g_lds0);
+                    good = b > 3u ? 0 : good + 1;
+                    ctx = ((ctx << 2) | (b & 3u)) & kMask;
+                    if (good >= W) {
+#pragma unroll
+                        for (int c = 0; c < kCtxChunk; ++c) acc[c] += s_S[c][ctx];
+                    }
+                }
+            };
+            const int64_t tiles = tiles_valid < n_tiles ? tiles_valid : n_tiles;       // tiles that are written with values
+            const bool one_pass = n_tiles <= kTileBlock;
+            double mine[kCtxChunk], tot[kCtxChunk];
+#pragma unroll
+            for (int c = 0; c < kCtxChunk; ++c) tot[c] = mine[c] = 0.0;
+            // region totals: over ALL tiles of the region (also those beyond n_tiles, if the caller asked for fewer)
+            for (int64_t t = tid; t < tiles_valid; t += kTileBlock) {
+                double acc[kCtxChunk];
+                tile_sums(t, acc);
+#pragma unroll
+                for (int c = 0; c < kCtxChunk; ++c) {
+                    tot[c] += acc[c];
+                    if (one_pass && t < kTileBlock) mine[c] = acc[c];        // (a region may have more tiles than the caller asked for)
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kCtxChunk; ++c) {
+                double v = tot[c];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) s_part[wave][c] = v;
+            }
+            __syncthreads();
+            if (tid < kCtxChunk) {
+                double v = 0.0;
+                for (int w = 0; w < kTileBlock / 64; ++w) v += s_part[w][tid];
+                s_T[tid] = v;
+            }
+            __syncthreads();
+            for (int64_t t = tid; t < n_tiles; t += kTileBlock) {
+                double acc[kCtxChunk];
+                const bool live = t < tiles;
+                if (live && !one_pass) tile_sums(t, acc);
+#pragma unroll
+                for (int c = 0; c < kCtxChunk; ++c)
+                    if (c < cc) pt[((c0 + c) * R + r) * n_tiles + t] = live ? (one_pass ? mine[c] : acc[c]) / s_T[c] : nan;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_mut_counts_kernel(const int32_t* __restrict__ pair_mut, const int32_t* __restrict__ pair_reg,
                                                               int64_t n_pairs, const int64_t* __restrict__ mut_start,
                                                               const int32_t* __restrict__ mut_cohort, const int64_t* __restrict__ first_pos,
@@ -506,6 +633,37 @@ int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int
                            chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
     else
         hipLaunchKernelGGL((base_tile_probs_kernel<false>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,
+                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+int dig_base_tile_probs_ctx(const uint32_t* genome_words, int64_t n_words, const int64_t* chrom_off, const int64_t* chrom_len,
+                            int n_chrom, const int32_t* reg_chrom, const int64_t* reg_start, const int64_t* reg_end, int64_t R,
+                            const double* s_prob, int64_t C, int n_up, int binsize, int64_t n_tiles, double* pt, int64_t* first_pos,
+                            int32_t* n_valid, void* stream)
+{
+    DIG_REQUIRE(n_up == 1 || n_up == 2, "n_up = n_down = 1 (trinucleotide) or 2 (penta-nucleotide)");
+    static const bool general = []() {
+        const char* e = getenv("DIG_TILES_FORM");        // developer switch: "general" sends n_up = 1 through this kernel too
+        return e && e[0] == 'g';
+    }();
+    if (n_up == 1 && !general)
+        return dig_base_tile_probs(genome_words, n_words, chrom_off, chrom_len, n_chrom, reg_chrom, reg_start, reg_end, R, s_prob, C,
+                                   binsize, n_tiles, pt, first_pos, n_valid, stream);
+    DIG_REQUIRE(R >= 0 && C >= 0 && n_words >= 2 && n_chrom >= 0 && n_tiles >= 0, "non-negative sizes, n_words >= 2 (pad words)");
+    DIG_REQUIRE(binsize >= 1, "binsize >= 1");
+    if (R == 0) return DIG_OK;
+    DIG_REQUIRE(genome_words && chrom_off && chrom_len && reg_chrom && reg_start && reg_end && first_pos && n_valid, "non-null pointers");
+    DIG_REQUIRE(C == 0 || n_tiles == 0 || (s_prob && pt), "s_prob and pt");
+    // (regions longer than the staging buffer -- 12 280 - 2 n_up positions -- are refused by the host wrapper, which knows
+    //  the coordinates; the kernel stages one region at a time)
+    const int grid = grid_for(R * kTileBlock, kTileBlock, 1);
+    if (n_up == 1)
+        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<1>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,
+                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
+    else
+        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<2>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,
                            chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;

@@ -619,7 +619,8 @@ def tiled_nb_test(pt, k, mu, sigma, device=0):
 # ---------------------------------------------------------------------------
 def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None, device=0):
     """Tile probabilities of regions of a PackedGenome for C cohorts at once (sequence_tools.py:292-317 + the tiling of
-    nb_model.py:126-186, trinucleotide contexts).  s_prob: f64 [C, 64] in context index order (16 b0 + 4 b1 + b2).
+    nb_model.py:126-186).  s_prob: f64 [C, 64] (trinucleotide contexts, index 16 b0 + 4 b1 + b2) or [C, 1024]
+    (penta-nucleotide: the reference's default n_up = n_down = 2; index in itertools.product('ACGT', repeat=5) order).
     Returns device tensors (pt [C, R, n_tiles], first_pos [R], n_valid [R]); n_tiles defaults to what the longest region
     needs."""
     import torch
@@ -633,8 +634,14 @@ def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None,
     if n_tiles is None:
         n_tiles = int(max(1, -(-int((en - st).max() if R else 1) // binsize)))
     s_prob = _t(s_prob, torch.float64, dev)
-    assert s_prob.dim() == 2 and s_prob.shape[1] == 64, "s_prob must be [C, 64] (trinucleotide contexts)"
+    assert s_prob.dim() == 2 and s_prob.shape[1] in (64, 1024), "s_prob must be [C, 64] (trinucleotide) or [C, 1024] (penta-nucleotide)"
     C = s_prob.shape[0]
+    n_up = 1 if s_prob.shape[1] == 64 else 2
+    if n_up == 2:
+        if R and int((en - st).max()) > 12280 - 4:
+            raise ValueError("penta-nucleotide regions may hold at most 12 276 positions")
+        if R and ((st > 0) & (st < n_up)).any():
+            raise ValueError("a region that starts at 1 would fetch from a negative position (the reference's pysam fetch fails too)")
     words, off, ln = genome.on_device(dev)
     t = lambda a: torch.as_tensor(a, device=dev)
     rc, rs, re_ = t(ci), t(st), t(en)
@@ -642,8 +649,8 @@ def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None,
     first = torch.empty(R, dtype=torch.int64, device=dev)
     nval = torch.empty(R, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("dig_base_tile_probs", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln),
-                  len(genome.names), _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), R, _lib.dev_ptr(s_prob), C,
+        _lib.call("dig_base_tile_probs_ctx", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln),
+                  len(genome.names), _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), R, _lib.dev_ptr(s_prob), C, n_up,
                   binsize, n_tiles, _lib.dev_ptr(pt), _lib.dev_ptr(first), _lib.dev_ptr(nval), _lib.stream_ptr())
     return pt, first, nval
 

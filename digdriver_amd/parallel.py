@@ -392,8 +392,10 @@ class ShardedTiles:
         nval = torch.empty(Rr, dtype=torch.int32, device=dev)
         k = torch.empty((C, Rr, T), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("dig_base_tile_probs", p(d["words"]), d["words"].numel(), p(d["off"]), p(d["ln"]), len(self.genome.names),
-                      p(d["rc"]), p(d["rs"]), p(d["re"]), Rr, p(d["S"]), C, self.binsize, T, p(pt), p(first), p(nval), _lib.stream_ptr())
+            n_up = 1 if d["S"].shape[1] == 64 else 2          # [C, 64] trinucleotide or [C, 1024] penta-nucleotide tables
+            _lib.call("dig_base_tile_probs_ctx", p(d["words"]), d["words"].numel(), p(d["off"]), p(d["ln"]), len(self.genome.names),
+                      p(d["rc"]), p(d["rs"]), p(d["re"]), Rr, p(d["S"]), C, n_up, self.binsize, T, p(pt), p(first), p(nval),
+                      _lib.stream_ptr())
             pm, pb = tabulate_gpu.overlap_pairs(d["blocks"], d["mc"], d["ms"], d["me"])
             pr = d["blocks"].elt[pb.long()].to(torch.int32).contiguous()
             _lib.call("dig_tile_mut_counts", p(pm), p(pr), pm.numel(), p(d["ms"]), p(d["co"]), p(first), p(nval), self.binsize, T, Rr, C,

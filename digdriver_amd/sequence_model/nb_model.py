@@ -128,15 +128,15 @@ def fisher_combine(p1, p2, device=0):
 # ---------------------------------------------------------------------------------------------
 # per-base / tiled route (nb_model.py:126-234, 340-342)
 # ---------------------------------------------------------------------------------------------
-def _s_prob64(d_pr):
-    """S_prob (dict / Series keyed by trinucleotide) -> 64 values in context index order; other key lengths are the
-    reference's penta-nucleotide mode (n_up = n_down = 2), which no part of the live pipeline trains a model for."""
+def _s_prob_table(d_pr, n_up=1):
+    """S_prob (dict / Series keyed by the (2 n_up + 1)-mer) -> 4^(2 n_up + 1) values in context index order: 64 for the
+    trinucleotide models of the live pipeline, 1 024 for the penta-nucleotide default of the reference's signatures."""
     import itertools
-    keys = ["".join(t) for t in itertools.product("ACGT", repeat=3)]
+    keys = ["".join(t) for t in itertools.product("ACGT", repeat=2 * n_up + 1)]
     try:
         return np.array([float(d_pr[k]) for k in keys])
     except KeyError as exc:
-        raise NotImplementedError("the tile kernels take trinucleotide models (n_up = n_down = 1); key %s is missing" % exc) from exc
+        raise KeyError("S_prob has no entry for context %s (n_up = n_down = %d needs all %d-mers)" % (exc, n_up, 2 * n_up + 1)) from exc
 
 
 def _mutation_rows(f_mut):
@@ -149,17 +149,18 @@ def _mutation_rows(f_mut):
     return df
 
 
-def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=1, n_down=1, binsize=50, collapse=False, device=0):
+def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=2, n_down=2, binsize=50, collapse=False, device=0):
     """nb_model.py:188-234: the tiled NB test over the bins `idx` [(chrom, start, end)] of one cohort; returns the
     reference's frame (CHROM, POS, OBS, EXP, PVAL, Pi, MU, SIGMA, REGION; numeric columns as float, as its np.hstack makes
     them).  `f_tabix`: the cohort's bed-like mutation file (the reference reads it through tabix; here it is joined on the
     GPU in one pass); `f_fasta`: the genome (data_tools.genome.PackedGenome or a FASTA path).  All bins in three launches
-    (engine.tiled_nb_model); the reference's default penta-nucleotide mode (n_up = n_down = 2) is not built."""
+    (engine.tiled_nb_model).  n_up = n_down = 2 (penta-nucleotide contexts, the reference's default) or 1 (the trinucleotide
+    models every live part of the pipeline trains); collapse=True (pyrimidine-collapsed contexts) is not built."""
     import pandas as pd
     from .. import engine
     from ..data_tools import genome as genome_mod
-    if (n_up, n_down) != (1, 1) or collapse:
-        raise NotImplementedError("the tile kernels take trinucleotide contexts: n_up = n_down = 1, collapse=False")
+    if n_up != n_down or n_up not in (1, 2) or collapse:
+        raise NotImplementedError("the tile kernels take n_up = n_down = 1 or 2 and collapse=False")
     g = f_fasta if isinstance(f_fasta, genome_mod.PackedGenome) else genome_mod.PackedGenome.from_fasta(f_fasta)
     idx = np.asarray(idx)
     chroms = [str(c) for c in idx[:, 0]]
@@ -167,12 +168,12 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=1, n_down=1, b
     muts = f_tabix if isinstance(f_tabix, pd.DataFrame) else _mutation_rows(f_tabix)
     known = set(n.replace("chr", "") for n in g.names)
     muts = muts[muts.CHROM.astype(str).str.replace("chr", "", regex=False).isin(known)]
-    res = engine.tiled_nb_model(g, chroms, starts, ends, _s_prob64(d_pr)[None, :], np.asarray(mu_lst, float)[None, :],
+    res = engine.tiled_nb_model(g, chroms, starts, ends, _s_prob_table(d_pr, n_up)[None, :], np.asarray(mu_lst, float)[None, :],
                                 np.asarray(sigma_lst, float)[None, :], muts.CHROM.astype(str).values, muts.START.values,
                                 muts.END.values, np.zeros(len(muts), np.int32), binsize=binsize, device=device)
     host = {k: v.cpu().numpy() for k, v in res.items()}
     first, nval = host["first_pos"], host["n_valid"].astype(np.int64)
-    n_pos = np.minimum(ends, np.array([g.lengths[i] for i in g.chrom_index(chroms)]) - 1) - first
+    n_pos = np.minimum(ends, np.array([g.lengths[i] for i in g.chrom_index(chroms)]) - n_up) - first
     cols = ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi", "MU", "SIGMA", "REGION"]
     if len(idx) == 0 or nval.sum() == 0:
         return pd.DataFrame(columns=cols)

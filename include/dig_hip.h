@@ -272,6 +272,15 @@ int dig_base_tile_probs(const uint32_t *genome_words, int64_t n_words, const int
 int dig_tile_mut_counts(const int32_t *pair_mut, const int32_t *pair_reg, int64_t n_pairs, const int64_t *mut_start,
                         const int32_t *mut_cohort, const int64_t *first_pos, const int32_t *n_valid, int binsize,
                         int64_t n_tiles, int64_t R, int64_t C, int32_t *k, void *stream);
+/* General-context form (ABI 4): n_up = n_down = 1 (forwards to dig_base_tile_probs) or 2 -- penta-nucleotide contexts, the
+ * DEFAULT signature of the reference's per-base functions (sequence_tools.py:292, nb_model.py:126,188).  s_prob f64
+ * [C, 4^(2 n_up + 1)] by context index (itertools.product('ACGT', repeat = 2 n_up + 1) order); positions
+ * (start == 0 ? n_up : start) .. min(end, chrom_len - n_up) - 1 (fetch_sequence :21-29); a region may hold at most
+ * 12 280 - 2 n_up positions.  Everything else as dig_base_tile_probs. */
+int dig_base_tile_probs_ctx(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off, const int64_t *chrom_len,
+                            int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start, const int64_t *reg_end, int64_t R,
+                            const double *s_prob, int64_t C, int n_up, int binsize, int64_t n_tiles, double *pt,
+                            int64_t *first_pos, int32_t *n_valid, void *stream);
 /* host twins (n_mut: rows of mut_start / mut_cohort, so that the twin knows how much to stage) */
 int dig_base_tile_probs_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
                              const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,

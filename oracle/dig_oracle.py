@@ -406,21 +406,26 @@ def expand_contexts_192(counts64):
 # --------------------------------------------------------------------------
 # per-base route, front half (sequence_tools.py:292-317, nb_model.py:126-186; trinucleotide contexts, n_up = n_down = 1)
 # --------------------------------------------------------------------------
-def base_probabilities_by_region(chrom_seq, s_prob64, start, end):
-    """sequence_tools.py:292-317 with n_up = n_down = 1, normed=True.  chrom_seq: the chromosome string; s_prob64: 64
-    probabilities in context64() order.  fetch_sequence (:21-29): START == 0 becomes 1, the fetch is widened by one base
-    on either side and truncated at the chromosome end; a position whose triplet holds a non-ACGT letter gets 0.
-    Returns (probs, positions): probs normalised over the region (np.sum, as the reference)."""
+def base_probabilities_by_region(chrom_seq, s_prob, start, end, n_up=1):
+    """sequence_tools.py:292-317 with n_up = n_down (1: trinucleotide contexts, the live pipeline; 2: the functions' default,
+    penta-nucleotide), normed=True.  chrom_seq: the chromosome string; s_prob: 4^(2 n_up + 1) probabilities in
+    itertools.product('ACGT', repeat=2 n_up + 1) order.  fetch_sequence (:21-29): START == 0 becomes n_up, the fetch is
+    widened by n_up bases on either side and truncated at the chromosome end; a position whose window holds a non-ACGT
+    letter gets 0.  Returns (probs, positions): probs normalised over the region (np.sum, as the reference)."""
     if start == 0:
-        start = 1
-    seq = chrom_seq[start - 1:end + 1].upper()
+        start = n_up
+    assert start - n_up >= 0, "pysam refuses a negative fetch start"
+    seq = chrom_seq[start - n_up:end + n_up].upper()
     code = {"A": 0, "C": 1, "G": 2, "T": 3}
     probs, poss = [], []
-    for i in range(1, len(seq) - 1):
-        poss.append(start - 1 + i)
-        tri = seq[i - 1:i + 2]
-        if all(ch in code for ch in tri):
-            probs.append(s_prob64[16 * code[tri[0]] + 4 * code[tri[1]] + code[tri[2]]])
+    for i in range(n_up, len(seq) - n_up):
+        poss.append(start - n_up + i)
+        win = seq[i - n_up:i + n_up + 1]
+        if all(ch in code for ch in win):
+            k = 0
+            for ch in win:
+                k = 4 * k + code[ch]
+            probs.append(s_prob[k])
         else:
             probs.append(0)
     probs = np.array(probs, dtype=float)
@@ -429,12 +434,12 @@ def base_probabilities_by_region(chrom_seq, s_prob64, start, end):
     return probs, np.array(poss)
 
 
-def apply_nb_to_region(chrom_seq, s_prob64, start, end, mu, sigma, mut_starts, binsize):
+def apply_nb_to_region(chrom_seq, s_prob64, start, end, mu, sigma, mut_starts, binsize, n_up=1):
     """nb_model.py:126-186: tiles of `binsize` consecutive positions (the last one may be shorter); pt = np.sum of the
     tile's normalised probabilities, k = number of mutation rows whose START is one of the tile's positions
     (value_counts of START, :135-136,160-163), p = 1 / (pt theta + 1), nb_pvalue_exact, exp = pt mu, pos = mean position.
     mut_starts: START of every mutation row of this chromosome.  Returns (pvals, pos, obs, exps, pts)."""
-    probs, pos_lst = base_probabilities_by_region(chrom_seq, s_prob64, start, end)
+    probs, pos_lst = base_probabilities_by_region(chrom_seq, s_prob64, start, end, n_up=n_up)
     mut_starts = np.asarray(mut_starts, np.int64)
     alpha, theta = normal_params_to_gamma(mu, sigma)
     pv, ps, ob, ex, pts = [], [], [], [], []

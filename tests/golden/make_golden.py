@@ -973,6 +973,56 @@ def gen_tiled():
     print("wrote tiled_golden.json.gz", {b: len(out["cohorts"][0]["runs"][b]["PVAL"]) for b in ("1", "50")})
 
 
+def gen_tiled_penta():
+    """The per-base route in the reference's DEFAULT mode -- penta-nucleotide contexts, n_up = n_down = 2, the default
+    arguments of nb_model / apply_nb_to_region / base_probabilities_by_region (nb_model.py:126,188; sequence_tools.py:292):
+    the reference's own nb_model, called without n_up / n_down, on a small genome (N runs, a soft-masked stretch, a bin at
+    position 0, one cut off by the chromosome end), tiles of 50 (the default) and of 1 position, two cohorts."""
+    import gzip
+    import itertools
+    rng = np.random.default_rng(188)
+    genome = {}
+    for chrom, n in (("chr1", 2100), ("chr2", 1237)):
+        seq = rng.choice(list("ACGT"), n)
+        for _ in range(3):
+            a = int(rng.integers(0, n - 60))
+            seq[a:a + int(rng.integers(1, 40))] = "N"
+        a = int(rng.integers(0, n - 200))
+        seq[a:a + 120] = np.char.lower(seq[a:a + 120])
+        genome[chrom] = "".join(seq)
+    _FakeFasta.genomes["mem://penta"] = genome
+    sys.modules["pysam"].FastaFile = _FakeFasta
+    sys.modules["pysam"].TabixFile = _FakeTabix
+    window = 500
+    idx = [(1, s, s + window) for s in range(0, 2100, window)] + [(2, s, s + window) for s in range(0, 1237, window)]
+    ctx = ["".join(t) for t in itertools.product("ACGT", repeat=5)]
+    out = dict(genome=genome, idx=[list(map(int, r)) for r in idx], window=window, cohorts=[])
+    for c in range(2):
+        d_pr = dict(zip(ctx, (rng.dirichlet(np.ones(1024)) * 1e-2).tolist()))
+        rows = []
+        for chrom, n in (("1", 2100), ("2", 1237)):
+            for _ in range(80 + 30 * c):
+                p_ = int(rng.integers(0, n))
+                rows.append((chrom, p_, p_ + 1, "A", "T", "S%d" % rng.integers(0, 6)))
+            for _ in range(5):
+                p_ = int(rng.integers(0, n - 5))
+                rows += [(chrom, p_, p_ + 1, "C", "G", "S1"), (chrom, p_, p_ + 1, "C", "G", "S2")]
+        rows.sort()
+        _FakeTabix.tables["mem://pmuts%d" % c] = rows
+        mu = rng.gamma(9.0, 3.0, len(idx))
+        sigma = rng.gamma(4.0, 1.0, len(idx))
+        coh = dict(d_pr=[d_pr[k] for k in ctx], rows=[list(r) for r in rows], mu=mu.tolist(), sigma=sigma.tolist(), runs={})
+        df = ref_nb.nb_model(d_pr, idx, mu, sigma, "mem://pmuts%d" % c, "mem://penta")          # every default: penta, binsize 50
+        df1 = ref_nb.nb_model(d_pr, idx, mu, sigma, "mem://pmuts%d" % c, "mem://penta", binsize=1)
+        for tag, frame in (("50", df), ("1", df1)):
+            coh["runs"][tag] = {k: frame[k].astype(float).tolist() for k in ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi"]}
+            coh["runs"][tag]["REGION_first_last"] = [frame["REGION"].iloc[0], frame["REGION"].iloc[-1]]
+        out["cohorts"].append(coh)
+    with gzip.GzipFile(os.path.join(HERE, "tiled_penta_golden.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
+    print("wrote tiled_penta_golden.json.gz", {b: len(out["cohorts"][0]["runs"][b]["PVAL"]) for b in ("1", "50")})
+
+
 def gen_sites():
     """The sites route (mutation_tools.py:232-283, sequence_tools.py:643-700): the reference's own preprocess_sites and
     tabulate_sites_in_element on a small synthetic sites file."""
@@ -1036,6 +1086,9 @@ def main():
     if "--only-sites" in sys.argv:
         gen_sites()
         return
+    if "--only-tiled-penta" in sys.argv:
+        gen_tiled_penta()
+        return
     if "--only-tiled" in sys.argv:
         gen_tiled()
         return
@@ -1066,6 +1119,7 @@ def main():
     gen_contexts()
     gen_sites()
     gen_tiled()
+    gen_tiled_penta()
     gen_run_element_expectation()
     gen_run_target()
     import torch

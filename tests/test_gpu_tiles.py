@@ -231,3 +231,77 @@ def test_sharded_tiles_equal_unsharded_bit_for_bit():
                 got.append(q[r.valid_pvalues(c)[1]])
                 off += p.numel()
             assert torch.equal(torch.cat(got), want), (world, c)
+
+
+@pytest.mark.parametrize("binsize", [50, 1])
+def test_nb_model_penta_default_mode_matches_reference(binsize):
+    """The per-base route in the reference's DEFAULT mode (n_up = n_down = 2: penta-nucleotide contexts, 1 024-entry S_prob;
+    nb_model.py:126,188, sequence_tools.py:292): nb_model called WITHOUT n_up / n_down against the reference's own frames
+    (tests/golden/tiled_penta_golden.json.gz: default call and binsize = 1)."""
+    import itertools
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.sequence_model import nb_model
+    g = json.loads(gzip.open(os.path.join(GOLDEN, "tiled_penta_golden.json.gz")).read())
+    genome = PackedGenome.from_sequences(g["genome"])
+    ctx = ["".join(t) for t in itertools.product("ACGT", repeat=5)]
+    for coh in g["cohorts"]:
+        muts = pd.DataFrame(coh["rows"], columns=["CHROM", "START", "END", "REF", "ALT", "ID"])
+        muts["CHROM"] = muts.CHROM.astype(str)
+        d_pr = dict(zip(ctx, coh["d_pr"]))
+        kw = {} if binsize == 50 else {"binsize": 1}
+        df = nb_model.nb_model(d_pr, np.array(g["idx"]), coh["mu"], coh["sigma"], muts, genome, **kw)       # the defaults
+        run = coh["runs"][str(binsize)]
+        assert len(df) == len(run["PVAL"])
+        assert np.array_equal(df.OBS.values, np.array(run["OBS"])) and np.array_equal(df.POS.values, np.array(run["POS"]))
+        assert [df.REGION.iloc[0], df.REGION.iloc[-1]] == run["REGION_first_last"]
+        np.testing.assert_allclose(df.Pi.values, run["Pi"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(df.EXP.values, run["EXP"], rtol=1e-12, atol=0)
+        rel_close(df.PVAL.values, np.array(run["PVAL"]), rtol=1e-6)
+        assert int(df.OBS.sum()) > 0
+
+
+def test_general_context_kernel_many_cohorts_against_oracle_and_trinucleotide_kernels():
+    """base_tile_probs_ctx_kernel: 37 cohorts (three LDS chunks of the table), ragged last tiles, N runs, a region at a
+    chromosome's start and one over its end, fewer tiles asked for than a region has -- penta-nucleotide tables against the
+    oracle; and the same kernel at n_up = 1 (DIG_TILES_FORM=general, own process) against the trinucleotide kernels."""
+    import subprocess
+    import sys
+    import torch
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(17)
+    seqs = {"chr1": "".join(rng.choice(list("ACGTN"), 4211, p=[.24, .25, .25, .24, .02])), "chr2": "".join(rng.choice(list("ACGT"), 1803))}
+    genome = PackedGenome.from_sequences(seqs)
+    chroms = ["chr1"] * 5 + ["chr2"] * 2
+    starts = np.array([0, 1000, 2000, 3000, 4000, 0, 1000], np.int64)
+    ends = np.array([1000, 2000, 3000, 4000, 5000, 1000, 2000], np.int64)          # two regions poke over the chromosome end
+    C = 37
+    S5 = rng.uniform(1e-4, 1e-2, (C, 1024))
+    for binsize, n_tiles in ((50, None), (7, None), (50, 11)):
+        pt, first, nval = engine.base_tile_probs(genome, chroms, starts, ends, S5, binsize, n_tiles=n_tiles, device=0)
+        pt, first, nval = pt.cpu().numpy(), first.cpu().numpy(), nval.cpu().numpy()
+        for r in range(len(chroms)):
+            for c in (0, 15, 16, 36):
+                probs, poss = O.base_probabilities_by_region(seqs[chroms[r]], S5[c], int(starts[r]), int(ends[r]), n_up=2)
+                assert first[r] == poss[0]
+                want = np.array([probs[i:i + binsize].sum() for i in range(0, len(probs), binsize)])
+                assert nval[r] == min(len(want), pt.shape[2])
+                np.testing.assert_allclose(pt[c, r, :nval[r]], want[:nval[r]], rtol=1e-12)
+                assert np.isnan(pt[c, r, nval[r]:]).all()
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from digdriver_amd import engine; "
+            "from digdriver_amd.data_tools.genome import PackedGenome; d = np.load(sys.argv[1], allow_pickle=True); "
+            "g = PackedGenome.from_sequences(d['seqs'].item()); "
+            "pt, f, n = engine.base_tile_probs(g, list(d['chroms']), d['starts'], d['ends'], d['S'], 50, device=0); "
+            "np.savez(sys.argv[2], pt=pt.cpu().numpy(), f=f.cpu().numpy(), n=n.cpu().numpy())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        S3 = rng.uniform(1e-4, 1e-2, (5, 64))
+        np.savez(os.path.join(tmp, "in.npz"), seqs=np.array(seqs, dtype=object), chroms=np.array(chroms), starts=starts, ends=ends, S=S3)
+        out = {}
+        for form in ("mfma", "general"):
+            env = dict(os.environ, DIG_TILES_FORM=form)
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, form + ".npz")], env=env)
+            out[form] = np.load(os.path.join(tmp, form + ".npz"))
+        assert np.array_equal(out["mfma"]["f"], out["general"]["f"]) and np.array_equal(out["mfma"]["n"], out["general"]["n"])
+        np.testing.assert_allclose(out["general"]["pt"], out["mfma"]["pt"], rtol=1e-12, equal_nan=True)
