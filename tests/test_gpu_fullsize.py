@@ -73,3 +73,39 @@ def test_configs1_whole_genome_cnn_forward_and_burden_test():
                                td["obs_samples"], td["obs_indel"], td["cj"], td["cj_indel"])
     for j, name in enumerate(engine.ES_PLANES):
         assert torch.equal(torch.nan_to_num(st[j], nan=-7.0), torch.nan_to_num(st2[name], nan=-7.0)), name
+
+
+@pytest.mark.timeout(600)
+def test_configs2_compact_form_at_full_size_against_general_form():
+    """BASELINE configs[2] at full size (288 000 bins, 37 cohorts, 120 091 elements): the compact form of the accumulation
+    (what bench.py's plans run) against the general 192-substitution form -- rate sums, sizes and P_INDEL bit-identical, P
+    within 1e-13, every statistics plane within the contract; and a sample of elements against the oracle."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    from conftest import rel_close
+    dev = torch.device("cuda:0")
+    w = make_workload(288_000, 120_091, 37, seed=3)
+    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+    args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+            td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+    acc_g, st_g = engine.element_pipeline(*args, td["cj"], td["cj_indel"])
+    plan = engine.PipelinePlan(*args)
+    assert plan.compact
+    acc_c, st_c = plan.run(td["cj"], td["cj_indel"])
+    torch.cuda.synchronize()
+    for k in ("MU", "SIGMA", "R_OBS", "FLAG", "R_SIZE", "ELT_SIZE", "P_INDEL"):
+        assert torch.equal(acc_g[k], acc_c[k]), k
+    rel = ((acc_c["P"] - acc_g["P"]).abs() / acc_g["P"].abs()).max().item()
+    assert rel <= 1e-13, rel
+    sg, sc = st_g.cpu().numpy(), st_c.cpu().numpy()
+    for j, name in enumerate(engine.ES_PLANES):
+        rel_close(sc[j], sg[j], 2e-7 if name.startswith("PVAL") else 1e-12)
+    pick = np.sort(np.random.default_rng(5).choice(120_091, 1500, replace=False))
+    ptr = np.concatenate([[0], np.cumsum(np.diff(w["ov_ptr"])[pick])])
+    idx = np.concatenate([w["ov_idx"][w["ov_ptr"][e]:w["ov_ptr"][e + 1]] for e in pick])
+    want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], ptr, idx, w["L"][pick],
+                                 w["strand_minus"][pick].astype(bool), w["d_pr"])
+    rel_close(acc_c["P"].cpu().numpy()[pick], want["P"], 1e-11)
+    assert np.array_equal(acc_c["R_SIZE"].cpu().numpy()[pick], want["R_SIZE"])

@@ -34,6 +34,11 @@ def main(tag, known_suffstats_bytes):
     base = "gpurun_out/" + tag
     stats = glob.glob(base + "a/**/*kernel_stats.csv", recursive=True)[0]
     shutil.copy(stats, "profiles/%s_kernel_stats.csv" % tag)
+    # the kernels of bench.py's aux_rooflines legs (gather, CNN forward GEMMs, per-base tiles, context counting), same trace
+    with open(stats) as f, open("profiles/%s_aux_kernel_stats.csv" % tag, "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or any(k in line for k in ("gather_", "Cijk_", "base_tile_probs", "tiled_nb", "context_count", "tile_mut")):
+                g.write(line)
     fetch = {k: v.get("FETCH_SIZE", 0.0) for k, v in counters(base + "f").items()}
     write = {k: v.get("WRITE_SIZE", 0.0) for k, v in counters(base + "w").items()}
     cal = [k for k in fetch if "suffstats_chunk_stage1" in k or "suffstats_stage1" in k][0]
