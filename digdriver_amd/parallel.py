@@ -362,7 +362,7 @@ class ShardedTiles:
 
     def run(self):
         """The rank's tiles: dict of device tensors pval, exp, pt [C, R_r, n_tiles], k i32, first_pos [R_r] (TRUE
-        coordinates), n_valid [R_r]."""
+        coordinates), n_valid [R_r].  The tensors belong to the object and are rewritten by the next run()."""
         import torch
         from . import engine
         dev, C, Rr = self.device, self.C, self.hi - self.lo
@@ -387,10 +387,14 @@ class ShardedTiles:
         d = self._mut_dev
         p = _lib.dev_ptr
         T = self.n_tiles
-        pt = torch.empty((C, Rr, T), dtype=torch.float64, device=dev)
-        first = torch.empty(Rr, dtype=torch.int64, device=dev)
-        nval = torch.empty(Rr, dtype=torch.int32, device=dev)
-        k = torch.empty((C, Rr, T), dtype=torch.int32, device=dev)
+        if "pt" not in d:                            # the outputs live as long as the object: a step allocates nothing
+            d["pt"] = torch.empty((C, Rr, T), dtype=torch.float64, device=dev)
+            d["first"] = torch.empty(Rr, dtype=torch.int64, device=dev)
+            d["nval"] = torch.empty(Rr, dtype=torch.int32, device=dev)
+            d["k"] = torch.empty((C, Rr, T), dtype=torch.int32, device=dev)
+            d["pval"] = torch.empty((C, Rr, T), dtype=torch.float64, device=dev)
+            d["exp"] = torch.empty((C, Rr, T), dtype=torch.float64, device=dev)
+        pt, first, nval, k, pval, ex = d["pt"], d["first"], d["nval"], d["k"], d["pval"], d["exp"]
         with torch.cuda.device(dev):
             n_up = 1 if d["S"].shape[1] == 64 else 2          # [C, 64] trinucleotide or [C, 1024] penta-nucleotide tables
             _lib.call("dig_base_tile_probs_ctx", p(d["words"]), d["words"].numel(), p(d["off"]), p(d["ln"]), len(self.genome.names),
@@ -400,7 +404,7 @@ class ShardedTiles:
             pr = d["blocks"].elt[pb.long()].to(torch.int32).contiguous()
             _lib.call("dig_tile_mut_counts", p(pm), p(pr), pm.numel(), p(d["ms"]), p(d["co"]), p(first), p(nval), self.binsize, T, Rr, C,
                       p(k), _lib.stream_ptr())
-        pval, ex = engine.tiled_nb_test(pt, k, d["mu"], d["sg"])
+            _lib.call("dig_tiled_nb_test", p(pt), 1, p(k), p(d["mu"]), p(d["sg"]), p(pval), p(ex), C, Rr, T, _lib.stream_ptr())
         self.result = dict(pval=pval, exp=ex, pt=pt, k=k, first_pos=first + d["shift"], n_valid=nval)
         return self.result
 
