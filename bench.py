@@ -448,7 +448,8 @@ def main():
     # the statistics stage.  (With two alternating sets the side stream had to be released by an event recorded on the
     # main stream; that record is a barrier packet and cost a 7 us bubble per step in front of the dot kernel, and the
     # reduction, squeezed beside the dot kernel, finished 5 us after it: rocprofv3 kernel trace, 0.301 -> 0.290 ms.)
-    RING = args.steps + args.warmup + 2      # one set of scale-factor buffers per step: the side stream never waits
+    SIDE_LEAD_STEPS = 3                      # the side stream is enqueued this many steps ahead of the main stream (slack for the all-gather at N > 1)
+    RING = args.steps + args.warmup + SIDE_LEAD_STEPS + 2      # one set of scale-factor buffers per step: the side stream never waits
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
                for _ in range(RING)]
     main_stream = torch.cuda.current_stream(dev)
@@ -498,6 +499,10 @@ def main():
                 staged("contexts", which, lambda: pipes[t % PLAN_RING].run(cj_out[0], cj_out[1], stages=1, stream=side_stream),
                        side_stream)
             side_done[b].record(side_stream)
+            if sampling[0] and t % SLACK_EVERY == SLACK_SLOT and slack_events:
+                ev = slack_events.pop()                      # when this step's scale factors were ready (side stream's clock)
+                ev.record(side_stream)
+                slack_side[t] = ev
 
     queued = [-1]      # last step whose scale factors have been enqueued
     # Per-stage durations are sampled INSIDE the timed loop: on every 8th step one stage (contexts, dot or statistics) is
@@ -512,9 +517,15 @@ def main():
 
     # every event of the run exists before the loop starts (HIP creates the object behind a torch event at its first
     # record, and a growing pool of them costs a one-off stall of tens of milliseconds at some point of the loop)
+    # how far ahead of its consumer the side stream runs: on every 8th step (one that carries no stage bracket) the moment the
+    # step's scale factors are ready is recorded on the side stream and the moment the main stream starts waiting for them on
+    # the main stream; slack = the second minus the first (negative: the main stream had to wait)
+    SLACK_EVERY, SLACK_SLOT = 8, 7
+    slack_events = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ((args.steps + args.warmup) // SLACK_EVERY + 4))]
+    slack_side, slack_main = {}, {}
     n_sample_events = 2 * (4 * ((args.steps + args.warmup) // SAMPLE_EVERY + 2))
     sample_events = [torch.cuda.Event(enable_timing=True) for _ in range(n_sample_events)]
-    for e in side_done + main_done + sample_events:
+    for e in side_done + main_done + sample_events + slack_events:
         e.record(main_stream)
     torch.cuda.synchronize()
 
@@ -565,10 +576,15 @@ def main():
             throttle_events[k % len(throttle_events)].record(main_stream)
             if k >= 3:
                 throttle_events[(k - 3) % len(throttle_events)].synchronize()
-        while queued[0] < t + 1:                 # this step's (first call only) and the next step's scale factors
+        # this step's (first call only) and the coming steps' scale factors; nothing beyond the last step of the run
+        while queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps - 1):
             queued[0] += 1
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
+        if t in slack_side and slack_events:
+            ev = slack_events.pop()
+            ev.record(main_stream)
+            slack_main[t] = ev
         main_stream.wait_event(side_done[b])
         which = sample_which(t)
         plan = pipes[t % PLAN_RING]
@@ -675,6 +691,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
+    slack_us = sorted(slack_side[t].elapsed_time(slack_main[t]) * 1e3 for t in slack_main)
     stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
     if trace is not None and rank == 0:
         print("BENCH_TRACE statistics-stage samples (us):", [round(a.elapsed_time(b_) * 1e3, 1) for a, b_ in samples["statistics"]][:40],
@@ -786,6 +803,10 @@ def main():
                              "averages of the same command: profiles/" % (args.contexts_on, SAMPLE_EVERY, args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
+            "side_stream_slack_us": ({"min": slack_us[0], "median": slack_us[len(slack_us) // 2], "samples": len(slack_us),
+                                      "what": "main stream's arrival at the wait for a step's scale factors minus the moment the side "
+                                              "stream had them ready (events on both streams, every 8th timed step); negative = the "
+                                              "main stream waited"} if slack_us else None),
             "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle, "two_stream_passes": args.settle_passes,
                                "what": "the sequential evaluation the loop is checked against, repeated before the warm-up steps"},
         }
