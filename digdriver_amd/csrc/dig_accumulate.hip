@@ -723,17 +723,31 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
     Idx x_c = load_idx(b_c);
 
     // stage the B operand: per-context sums of d_pr in the per-lane order of the matrix instructions
-    for (int idx = threadIdx.x; idx < kCtxSteps * SL * 64; idx += kCtxWaves * 64) {
-        const int lane_ = idx & 63, slot = (idx >> 6) % SL, step = idx / (SL * 64);
-        const bool tail = NQ > 0 && slot == NT;
-        const int kappa = 16 * (step >> 2) + 4 * (tail ? (lane_ >> 2) & 3 : lane_ >> 4) + (step & 3);
-        const int c = c0 + slot * 16 + (tail ? 4 * (lane_ >> 4) + (lane_ & 3) : lane_ & 15);
-        double v = 0.0;
-        if (c < C && (!tail || (lane_ >> 4) < NQ)) {
-            const double* d = d_pr + (int64_t)c * 192 + 3 * kappa;
-            v = (d[0] + d[1]) + d[2];
+    {   // (all loads of a thread are issued before its first LDS write: a plain loop waits for every entry's loads in turn,
+        //  four L2 round trips at the start of every workgroup)
+        constexpr int kTotal = kCtxSteps * SL * 64;
+        constexpr int kPer = (kTotal + kCtxWaves * 64 - 1) / (kCtxWaves * 64);
+        double d0[kPer], d1[kPer], d2[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = threadIdx.x + j * kCtxWaves * 64;
+            const int lane_ = idx & 63, slot = (idx >> 6) % SL, step = idx / (SL * 64);
+            const bool tail = NQ > 0 && slot == NT;
+            const int kappa = 16 * (step >> 2) + 4 * (tail ? (lane_ >> 2) & 3 : lane_ >> 4) + (step & 3);
+            const int c = c0 + slot * 16 + (tail ? 4 * (lane_ >> 4) + (lane_ & 3) : lane_ & 15);
+            d0[j] = d1[j] = d2[j] = 0.0;
+            if (idx < kTotal && c < C && (!tail || (lane_ >> 4) < NQ)) {
+                const double* d = d_pr + (int64_t)c * 192 + 3 * kappa;
+                d0[j] = d[0];
+                d1[j] = d[1];
+                d2[j] = d[2];
+            }
         }
-        tab[idx] = v;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = threadIdx.x + j * kCtxWaves * 64;
+            if (idx < kTotal) tab[idx] = (d0[j] + d1[j]) + d2[j];
+        }
     }
     Rows r_c = load_rows(b_c, x_c);
     __syncthreads();

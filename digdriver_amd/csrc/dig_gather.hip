@@ -110,6 +110,67 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_subset_kernel(const 
     }
 }
 
+// Wide form of the subset gather (round 3).  The kernel above reads a source row value by value (2-byte accesses for the
+// int16 matrix: 128 bytes per load instruction).  Rows of a bin are contiguous, and G = 8 / sizeof(S) consecutive rows
+// (4 of int16, 2 of float, 1 of double) are one block of 8 T bytes that starts 8-byte aligned whenever a bin does
+// (L T sizeof(S) % 8 == 0) -- whatever T is.  A wave therefore takes GROUPS of G positions: T 8-byte loads (512 bytes per
+// instruction) put the block into LDS in the source type; then, row by row, every lane assembles four consecutive outputs
+// from LDS with the track list it keeps in registers and writes them with one vector store.  Needs L % G == 0 and
+// T <= kWideMaxT; anything else takes the kernel above.
+constexpr int kWideMaxT = 1024;
+
+template <typename S, typename D>
+__global__ __launch_bounds__(kGatherBlock) void gather_rows_subset_wide_kernel(const S* __restrict__ x, int64_t L, int64_t T,
+                                                                               const int64_t* __restrict__ rows, int64_t B,
+                                                                               const int32_t* __restrict__ tracks, int64_t T_sel,
+                                                                               D* __restrict__ out)
+{
+    constexpr int G = 8 / (int)sizeof(S);
+    __shared__ uint2 s_blk[kGatherBlock / 64][kWideMaxT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kGatherBlock >> 6;
+    uint2* blk = s_blk[wave];
+    const S* vals = reinterpret_cast<const S*>(blk);             // [G][T]
+    const int n_vec = (int)(T_sel >> 2);
+    int4 sel[kSubsetMaxVec];
+#pragma unroll
+    for (int v = 0; v < kSubsetMaxVec; ++v) {
+        const int q = lane + 64 * v;
+        sel[v] = q < n_vec ? *reinterpret_cast<const int4*>(tracks + 4 * q) : make_int4(0, 0, 0, 0);
+    }
+    const int64_t groups_per_bin = L / G, n_groups = B * groups_per_bin;
+    for (int64_t grp = (int64_t)blockIdx.x * nw + wave; grp < n_groups; grp += (int64_t)gridDim.x * nw) {
+        const int64_t b = grp / groups_per_bin, g = grp - b * groups_per_bin;
+        const uint2* src = reinterpret_cast<const uint2*>(x + (rows[b] * L + g * G) * T);
+        {   // all loads of the block are issued before the first LDS write (a plain loop waits for every load in turn)
+            uint2 tmp[kWideMaxT / 64];
+#pragma unroll
+            for (int j = 0; j < kWideMaxT / 64; ++j) {
+                const int t = lane + 64 * j;
+                if (t < (int)T) tmp[j] = src[t];
+            }
+#pragma unroll
+            for (int j = 0; j < kWideMaxT / 64; ++j) {
+                const int t = lane + 64 * j;
+                if (t < (int)T) blk[t] = tmp[j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the block is in LDS (one wave: no s_barrier needed)
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            const S* row = vals + (int64_t)r * T;
+            D* od = out + ((b * L + g * G + r) * T_sel);
+#pragma unroll
+            for (int v = 0; v < kSubsetMaxVec; ++v) {
+                const int q = lane + 64 * v;
+                if (q < n_vec)
+                    store_vec4(od + 4 * q, (float)row[sel[v].x], (float)row[sel[v].y], (float)row[sel[v].z], (float)row[sel[v].w]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // All tracks selected (tracks == NULL), row-major output: a bin is ONE contiguous block of L * T values on both sides, so
 // the gather is a batched block copy with conversion.  Four values per lane and access (8-byte loads of i16, 16-byte
 // of f32; 8-byte stores of bf16, 16-byte of f32), kBlockUnroll independent accesses per lane in flight.
@@ -187,8 +248,19 @@ __global__ __launch_bounds__(kGatherBlock) void gather_transpose_kernel(const S*
     for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
         const int64_t src0 = rows[b] * L * T;
         const int tr = (lane < nt) ? (tracks ? tracks[t0 + lane] : (int)(t0 + lane)) : 0;
-        for (int64_t l = wave; l < L; l += nw)
-            if (lane < nt) tile[l * 65 + lane] = load_as_float<S>(x, src0 + l * T + tr);
+        for (int64_t l0 = wave; l0 < L; l0 += 8 * nw) {           // eight rows of the tile in flight per wave (a plain loop waits
+            float v[8];                                             //  for every load in turn)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t l = l0 + u * nw;
+                v[u] = (lane < nt && l < L) ? load_as_float<S>(x, src0 + l * T + tr) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t l = l0 + u * nw;
+                if (lane < nt && l < L) tile[l * 65 + lane] = v[u];
+            }
+        }
         __syncthreads();
         for (int tt = wave; tt < nt; tt += nw) {
             D* od = out + (b * T_sel + t0 + tt) * L;
@@ -281,6 +353,13 @@ static int launch_gather(const void* x, int64_t n_total, int64_t L, int64_t T, c
         const int gy = (int)std::min<int64_t>(B, 65535);
         hipLaunchKernelGGL((gather_block_kernel<S, D>), dim3(chunks, gy), dim3(kGatherBlock), 0, stream, (const S*)x, L * T,
                            rows, B, (D*)out);
+    } else if (!transpose_out && tracks && T <= kWideMaxT && (T_sel & 3) == 0 && T_sel > 0 && T_sel <= 256 * kSubsetMaxVec &&
+               ((uintptr_t)out & 15) == 0 && ((uintptr_t)tracks & 15) == 0 && ((uintptr_t)x & 7) == 0 &&
+               (L * T * (int64_t)sizeof(S)) % 8 == 0 && L % (8 / (int64_t)sizeof(S)) == 0 && (T_sel * (int64_t)sizeof(D)) % 16 == 0) {
+        const int64_t n_groups = B * (L / (8 / (int64_t)sizeof(S)));
+        int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + 3) / 4, (int64_t)cu_count() * 4));
+        hipLaunchKernelGGL((gather_rows_subset_wide_kernel<S, D>), dim3(grid), dim3(kGatherBlock), 0, stream, (const S*)x, L, T, rows,
+                           B, tracks, T_sel, (D*)out);
     } else if (!transpose_out && tracks && T <= kSubsetMaxT && (T_sel & 3) == 0 && T_sel > 0 && T_sel <= 256 * kSubsetMaxVec &&
                ((uintptr_t)out & 15) == 0 && ((uintptr_t)tracks & 15) == 0) {
         int grid = (int)std::min<int64_t>(B, (int64_t)cu_count() * 8);

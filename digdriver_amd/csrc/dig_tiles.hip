@@ -51,6 +51,27 @@ __device__ __forceinline__ TileRegion tile_region(const int64_t* chrom_off, cons
     return t;
 }
 
+// Stage nw <= kTileMaxWords + 2 packed words (from array word w0 on, clamped to the trailing pad word) into LDS: all loads of a
+// thread are issued before its first LDS write -- the plain loop `s_words[i] = words[...]` waits for every load in turn (one
+// memory round trip per 256 words instead of one per region).
+template <int BLOCK>
+__device__ __forceinline__ void stage_words(uint32_t* s_words, const uint32_t* __restrict__ words, int64_t n_words, int64_t w0,
+                                            int64_t nw, int tid)
+{
+    constexpr int kPer = (1538 + BLOCK - 1) / BLOCK;       // kTileMaxWords + 2
+    uint32_t tmp[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int64_t i = tid + (int64_t)j * BLOCK;
+        tmp[j] = i < nw ? words[(w0 + i < n_words ? w0 + i : n_words - 1)] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int64_t i = tid + (int64_t)j * BLOCK;
+        if (i < nw) s_words[i] = tmp[j];
+    }
+}
+
 // 4-bit code of global base g (word 0 of the array is the leading pad word)
 __device__ __forceinline__ unsigned tile_base(const uint32_t* s_words, int64_t g, int64_t g_lds0)
 {
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
             const int64_t ga = reg.g0 + p0 - 1;                 // leftmost base needed (left neighbour of the first position)
             const int64_t w0 = (ga >> 3) + 1;                   // array word holding it (array word = genome word + 1)
             const int64_t nw = ((ga + np + 1) >> 3) + 1 - w0 + 1;
-            for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+            stage_words<256>(s_words, words, n_words, w0, nw, tid);
             __syncthreads();
             const int64_t g_lds0 = (w0 - 1) << 3;
             for (int64_t j = tid; j < np; j += kTileBlock) {
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_kernel(
                 const int64_t w0 = (ga >> 3) + 1;
                 const int64_t nw = ((ga + nq + 1) >> 3) + 1 - w0 + 1;
                 __syncthreads();
-                for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+                stage_words<256>(s_words, words, n_words, w0, nw, tid);
                 __syncthreads();
                 const int64_t g_lds0 = (w0 - 1) << 3;
                 const int64_t tp = (int64_t)tid * binsize - q0;          // first position of this lane's tile inside the pass
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
         const int64_t g_lds0 = (w0 - 1) << 3;
         {
             const int nw = (int)(((ga + n_cov + 1) >> 3) + 1 - w0 + 1);
-            for (int i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+            stage_words<256>(s_words, words, n_words, w0, nw, tid);
         }
         TM_MARK(0);
         __syncthreads();
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
                 const int64_t wb0 = (gb >> 3) + 1;
                 const int64_t nw = ((gb + np + 1) >> 3) + 1 - wb0 + 1;
                 __syncthreads();
-                for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(wb0 + i < n_words ? wb0 + i : n_words - 1)];
+                stage_words<256>(s_words, words, n_words, wb0, nw, tid);
                 __syncthreads();
                 const int64_t gl = (wb0 - 1) << 3;
                 for (int64_t j = tid; j < np; j += kTileBlock) {
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_ctx_kernel(
             const int64_t w0 = (ga >> 3) + 1;                   // array word = genome word + 1 (leading pad word)
             const int64_t nw = n_pos > 0 ? ((ga + n_pos + 2 * U - 1) >> 3) + 1 - w0 + 1 : 0;
             __syncthreads();
-            for (int64_t i = tid; i < nw; i += kTileBlock) s_words[i] = words[(w0 + i < n_words ? w0 + i : n_words - 1)];
+            stage_words<256>(s_words, words, n_words, w0, nw, tid);
             __syncthreads();
             const int64_t g_lds0 = (w0 - 1) << 3;
             // one tile: the table values of its positions, summed per cohort of the chunk

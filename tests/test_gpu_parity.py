@@ -374,6 +374,31 @@ def test_gather_bins(torch_dev, src):
     assert np.array_equal(engine.gather_bins(xd, big, None).cpu().numpy(), x[big].astype(np.float32))
 
 
+@pytest.mark.parametrize("src", ["i16", "f32", "f64"])
+def test_gather_track_subset_wide_and_row_forms(torch_dev, src):
+    """A track-selection file (dataset_generator.py:57-80) with a multiple of four tracks: the wide subset kernel (groups of
+    rows as 8-byte aligned blocks through LDS) for every source type, odd and even track counts, f32 and bf16 outputs; shapes
+    it does not take (L not a multiple of the group, T beyond its LDS block) go through the row kernel -- all against the
+    oracle's x_data[rows][:, :, tracks]."""
+    import torch
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(9)
+    dt = {"f32": np.float32, "f64": np.float64, "i16": np.int16}[src]
+    for (N, L, T, n_sel) in ((37, 100, 77, 44), (20, 100, 735, 512), (11, 100, 64, 64), (9, 99, 77, 40), (5, 100, 1100, 16), (3, 4, 8, 8)):
+        x = (np.round(rng.uniform(0, 1, (N, L, T)), 2) * 100).astype(dt)
+        rows = rng.integers(0, N, 19)
+        tracks = np.sort(rng.permutation(T)[:n_sel]).astype(np.int32)
+        tracks[:2] = tracks[:2][::-1]                       # not sorted everywhere: the order of the list is the order of the output
+        want = O.gather_bins(x, rows, tracks)
+        xd = torch.as_tensor(x, device=torch_dev)
+        got = engine.gather_bins(xd, rows, tracks)
+        assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy(), want), (N, L, T, n_sel)
+        if n_sel % 8 == 0:
+            b = engine.gather_bins(xd, rows, tracks, out_dtype="bf16")
+            assert torch.equal(b, torch.as_tensor(want, device=torch_dev).to(torch.bfloat16)), (N, L, T, n_sel)
+
+
 def test_tiled_nb_test_vs_oracle(torch_dev):
     from digdriver_amd import engine
     from oracle import dig_oracle as O
