@@ -60,6 +60,7 @@ _SIGNATURES = {
     "dig_gene_stats": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp],
     "dig_gene_stats_host": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _int],
     "dig_gene_pipeline": [_vp] * 15 + [_int] + [_vp] * 9 + [_i64, _i64, _i64, _vp, _i64, _vp],
+    "dig_gene_pipeline_host": [_vp] * 15 + [_int] + [_vp] * 9 + [_i64, _i64, _i64, _int],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "dig_base_tile_probs": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_tile_mut_counts": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp],
     "dig_base_tile_probs_ctx": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _int, _i64, _vp, _vp, _vp, _vp],
+    "dig_base_tile_probs_ctx_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _int, _i64, _vp, _vp, _vp, _int],
     "dig_base_tile_probs_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _int],
     "dig_tile_mut_counts_host": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],

@@ -234,6 +234,12 @@ int dig_gene_pipeline(const double *bin_mu, const double *bin_std, const int32_t
                       const int32_t *n_samp, const double *cj, const double *t_indel, int with_indel, double *MU, double *SIGMA,
                       int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out,
                       int64_t N, int64_t G, int64_t C, void *workspace, int64_t workspace_bytes, void *stream);
+int dig_gene_pipeline_host(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
+                           const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
+                           const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr, const int32_t *obs,
+                           const int32_t *n_samp, const double *cj, const double *t_indel, int with_indel, double *MU,
+                           double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P, int32_t *R_SIZE, int32_t *ELT_SIZE,
+                           double *P_INDEL, double *out, int64_t N, int64_t G, int64_t C, int device);
 
 /* ---- sufficient statistics in canonical chunks (bin-sharded runs) --------------------------- *
  * Same quantity as dig_scale_suffstats / dig_scale_factors, defined so that it does not depend on the sharding: the bins
@@ -281,6 +287,10 @@ int dig_base_tile_probs_ctx(const uint32_t *genome_words, int64_t n_words, const
                             int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start, const int64_t *reg_end, int64_t R,
                             const double *s_prob, int64_t C, int n_up, int binsize, int64_t n_tiles, double *pt,
                             int64_t *first_pos, int32_t *n_valid, void *stream);
+int dig_base_tile_probs_ctx_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
+                                 const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                                 const int64_t *reg_end, int64_t R, const double *s_prob, int64_t C, int n_up, int binsize,
+                                 int64_t n_tiles, double *pt, int64_t *first_pos, int32_t *n_valid, int device);
 /* host twins (n_mut: rows of mut_start / mut_cohort, so that the twin knows how much to stage) */
 int dig_base_tile_probs_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
                              const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,

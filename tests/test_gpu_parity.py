@@ -924,6 +924,38 @@ def test_host_twins_of_pipeline_tiles_and_join(torch_dev):
     assert np.array_equal(k_h, k_d.cpu().numpy())
     inside = (co >= 0) & (co < 3)
     assert 0 < int(k_h.sum()) <= int(inside.sum())
+    # ---- general-context tile probabilities (penta-nucleotide tables) ----
+    S5 = rng.uniform(1e-4, 1e-2, (3, 1024))
+    pt5_d, f5_d, n5_d = engine.base_tile_probs(genome, chroms, starts, ends, S5, 50, device=0)
+    pt5_h, f5_h, n5_h = np.empty((3, R, T)), np.empty(R, np.int64), np.empty(R, np.int32)
+    _lib.call("dig_base_tile_probs_ctx_host", hp(genome.words), genome.words.size, hp(genome.offsets), hp(genome.lengths),
+              len(genome.names), hp(ci), hp(starts), hp(ends), R, hp(np.ascontiguousarray(S5)), 3, 2, 50, T, hp(pt5_h), hp(f5_h), hp(n5_h), 0)
+    assert np.array_equal(pt5_h, pt5_d.cpu().numpy(), equal_nan=True) and np.array_equal(f5_h, f5_d.cpu().numpy())
+    assert np.array_equal(n5_h, n5_d.cpu().numpy()) and f5_h[0] == 2
+    # ---- gene pipeline ----
+    G = 61
+    wg = make_workload(n_bins=300, n_elements=G, n_cohorts=4, seed=78)
+    Lg = np.repeat(rng.poisson(5.0, (G, 4, 64)), 3, axis=2).astype(np.int32)
+    glen = rng.integers(300, 9000, G).astype(np.int32)
+    obs5 = rng.poisson(3.0, (G, 5, 4)).astype(np.int32)
+    ns6 = rng.poisson(2.0, (G, 6, 4)).astype(np.int32)
+    ti = rng.uniform(0.05, 0.3, 4)
+    tg = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=torch_dev)
+    acc_g, st_g = engine.gene_pipeline(tg(wg["bin_mu"]), tg(wg["bin_std"]), tg(wg["bin_y"]), tg(wg["bin_flag"]), tg(wg["bin_ctx"]),
+                                       tg(wg["ov_ptr"]), tg(wg["ov_idx"]), tg(Lg), tg(wg["strand_minus"]), tg(glen), tg(wg["d_pr"]), tg(obs5),
+                                       tg(ns6), tg(wg["cj"]), tg(ti))
+    og = dict(MU=np.empty((G, 4)), SIGMA=np.empty((G, 4)), R_OBS=np.empty((G, 4), np.int32), FLAG=np.empty((G, 4), np.int32),
+              P=np.empty((G, 4, 4)), R_SIZE=np.empty(G, np.int32), ELT_SIZE=np.empty(G, np.int32), P_INDEL=np.empty(G))
+    out_h = np.empty((22, G, 4))
+    ins = [c(wg["bin_mu"], np.float64), c(wg["bin_std"], np.float64), c(wg["bin_y"], np.int32), c(wg["bin_flag"], np.uint8),
+           c(wg["bin_ctx"], np.int32), c(wg["ov_ptr"], np.int64), c(wg["ov_idx"], np.int32), Lg, c(wg["strand_minus"], np.uint8), glen,
+           c(wg["d_pr"], np.float64), obs5, ns6, c(wg["cj"], np.float64), c(ti, np.float64)]
+    _lib.call("dig_gene_pipeline_host", *[hp(a) for a in ins], 1, hp(og["MU"]), hp(og["SIGMA"]), hp(og["R_OBS"]), hp(og["FLAG"]),
+              hp(og["P"]), hp(og["R_SIZE"]), hp(og["ELT_SIZE"]), hp(og["P_INDEL"]), hp(out_h), 300, G, 4, 0)
+    for k in og:
+        assert np.array_equal(og[k], acc_g[k].cpu().numpy(), equal_nan=True), k
+    for j, name in enumerate(engine.GS_PLANES):
+        assert np.array_equal(out_h[j], st_g[name].cpu().numpy(), equal_nan=True), name
 
 
 def test_gene_pipeline_all_cohorts_against_oracle(torch_dev):
