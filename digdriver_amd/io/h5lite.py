@@ -125,6 +125,11 @@ class Dataset:
     def data(self, value):
         self._data = value
 
+    def peek(self):
+        """The payload WITHOUT keeping it: a lazily opened dataset is loaded for this call only (the writer passes unchanged
+        datasets through one at a time instead of materialising the whole tree)."""
+        return self._data.load() if isinstance(self._data, _Lazy) else self._data
+
     def read_rows(self, lo, hi):
         """data[lo:hi] without materialising the whole dataset when it was opened lazily."""
         if isinstance(self._data, _Lazy):
@@ -782,7 +787,7 @@ class _Writer:
 
     # ---- datasets ----
     def write_dataset(self, ds):
-        data = ds.data
+        data = ds.peek()
         if getattr(ds, "bitfield", False) and isinstance(data, np.ndarray) and data.dtype.kind == "b":
             data = B8(data)
         if isinstance(data, VLenObject):
@@ -888,8 +893,10 @@ def write_tree(path, root):
 
 
 def update(path, fn):
-    """Read `path` (or start from an empty tree), apply fn(root), write it back."""
+    """Read `path` (or start from an empty tree), apply fn(root), write it back.  The tree is opened lazily: datasets fn does
+    not touch are read one at a time while the new file is assembled (they used to be materialised all at once, next to the
+    output image); callers that write several keys should still batch them (mapfile.batch): every update rewrites the file."""
     import os
-    root = read_tree(path) if os.path.exists(path) else Group()
+    root = read_tree(path, lazy=True) if os.path.exists(path) else Group()
     fn(root)
     write_tree(path, root)
