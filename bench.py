@@ -289,7 +289,7 @@ def aux_rooflines(dev):
                    "%d bins x %d x %d per launch; L T 2 B read + L T 4 B written per bin" % (B, L, T), bins_per_s=B / dt))
     sel = torch.sort(torch.randperm(T, device=dev, generator=g)[:512]).values.to(torch.int32)
     dt = timeit(lambda: engine.gather_bins(x16, rows, sel, out_dtype="f32", transpose=False))
-    out.append(hbm("dig_gather_bins (512 of 735 tracks: gather_rows_subset_kernel)", B * L * (T * 2.0 + 512 * 4.0), dt,
+    out.append(hbm("dig_gather_bins (512 of 735 tracks: gather_rows_subset_wide_kernel)", B * L * (T * 2.0 + 512 * 4.0), dt,
                    "%d bins per launch; whole source rows read, 512 tracks written" % B, bins_per_s=B / dt))
     # a3: CNN forward, fp32, T = 735, 37 heads (PyTorch-ROCm GEMMs on the MFMA units; BatchNorm folded)
     C_heads, Bc = 37, 2048
