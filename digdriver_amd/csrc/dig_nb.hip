@@ -408,6 +408,9 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
 #endif
+#ifndef DIG_ES_ABL
+#define DIG_ES_ABL 0     // developer ablation builds (tools/build_variant.sh): 1 no stores, 2 counts forced to 0, 8 no arithmetic, 16 no bin gathers
+#endif
 // GIVEN = 0: dig_element_pipeline (the rate sums of a pair are formed here from the bin tables and written out);
 // GIVEN = 1 / 2: dig_element_stats (mu / sigma handed in per pair; 2: separate indel parameters) -- the same pipeline,
 // tickets and in-kernel second pass without the CSR and bin stages.
@@ -514,6 +517,10 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     auto fetch_bin = [&](const StageIn& r) {
         StageBin b;
         if (GIVEN != 0) return b;
+#if DIG_ES_ABL & 16
+        for (int j = 0; j < kPre; ++j) { b.mu[j] = 1.0 + r.c; b.sd[j] = 0.5; b.y[j] = 1; b.fl[j] = 0; }
+        return b;
+#endif
 #pragma unroll
         for (int j = 0; j < kPre; ++j) {
             const int64_t o = a.small_index ? (int64_t)(__umul24((uint32_t)r.idx[j], C32) + r.c)
@@ -594,7 +601,17 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         }
         w.pi_s = cur.pi_s; w.pi_i = cur.pi_i; w.cj = cur.cj; w.cji = cur.cji;
         w.k_snv = cur.k_snv; w.k_smp = cur.k_smp; w.k_ind = cur.k_ind;
+#if DIG_ES_ABL & 2
+        w.k_snv = w.k_smp = w.k_ind = 0;
+#endif
         w.q0 = w.q1 = 0; w.c = cur.c;
+#if DIG_ES_ABL & 8
+        PairInputs q;
+        q.alpha = q.alpha_i = w.mu; q.p = q.p_i = 0.5; q.exp_snv = w.sigma; q.theta_i = w.pi_s; q.exp_ind = w.pi_i + w.cj + w.cji;
+        q.k_snv = q.k_smp = q.k_ind = 0.0;
+        double pv_snv = (double)w.k_snv, pv_smp = (double)w.k_smp, pv_ind = (double)w.k_ind, pv_mut = 0.25;
+        const bool slow = false;
+#else
         const PairInputs q = prepare_pair(w, GIVEN == 2);
         // (a test the recurrence cannot finish keeps a NEGATIVE value for pass 2: -pmf(k) when the direct form
         //  cancelled, -2 when it was not eligible at all; no p-value is negative)
@@ -604,6 +621,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         const bool slow = ((d1 != 3u) || (d2 != 1u)) && live;
         double pv_mut = 0.0;
         if (!slow) pv_mut = fisher_combine_fast(pv_snv, pv_ind);
+#endif
         bin_c = fetch_bin(in_c);         // tile t+1: bin rates (requested BEFORE this tile's stores)
         unsigned long long m = __ballot(slow);
 #if DIG_ES_INWAVE
@@ -626,6 +644,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #endif
         if (slow && ((m >> lane) & 1ull)) park[parked + __popcll(m & lanes_below)] = (unsigned)i;
         parked += (unsigned)__popcll(m);
+#if DIG_ES_ABL & 1
+        if (pv_snv + pv_smp + pv_ind + pv_mut + q.exp_snv + q.exp_ind + q.theta_i + w.mu + w.sigma + robs + flag != 12345.678) continue;
+#endif
         if (GIVEN == 0) {
             DIG_STREAM_STORE(&a.mu_w[i], w.mu);
             DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);

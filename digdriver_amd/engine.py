@@ -403,7 +403,7 @@ class PipelinePlan:
     host time instead of ~60), which keeps the host ahead of a 0.3 ms GPU step.  The tensors are held by the plan."""
 
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
-                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto"):
+                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None):
         """compact: "auto" (default) checks ONCE, here, on the device whether L repeats every context count three times
         (sequence_tools.py:560-564: true for every elementModel / tiledModel / quickDriver set) and, if so, runs the
         64-context form of the accumulation (contexts + dot in one kernel, half the matrix work); False forces the
@@ -426,7 +426,11 @@ class PipelinePlan:
         self.dev = dev
         self.acc = out_acc if out_acc is not None else alloc_accumulate_outputs(self.E, self.C, 1, dev)
         self.stats = out_stats if out_stats is not None else torch.empty((len(ES_PLANES), self.E, self.C), dtype=f64, device=dev)
-        self.ws, self.wsb = _workspace("pipeline", self.E, self.C, dev, private=True)
+        if workspace is not None:          # a caller-owned scratch buffer (uint8, at least dig_element_pipeline_workspace bytes)
+            self.ws, self.wsb = workspace, _lib.workspace_bytes("pipeline", self.E, self.C)
+            assert workspace.numel() >= self.wsb and workspace.data_ptr() % 256 == 0
+        else:
+            self.ws, self.wsb = _workspace("pipeline", self.E, self.C, dev, private=True)
         if self.ws is None:
             raise _lib.DigHipError("dig_element_pipeline: problem too large for the fused path (E * C >= 2^32 - 1)")
         p = _lib.dev_ptr

@@ -6,11 +6,12 @@
 // and reads 5 doubles per item from 5 arrays in both cases.  Prints the achieved GB/s (read + written).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 constexpr int kOut = 13, kIn = 5;
 
-template <bool RECORDS>
+template <bool RECORDS, bool NT = true>
 __global__ __launch_bounds__(1024) void writer(const double* __restrict__ in, double* __restrict__ out, long n)
 {
     __shared__ unsigned s_ticket;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(1024) void writer(const double* __restrict__ in, do
         for (int j = 0; j < kIn; ++j) v += in[(long)j * n + i];
         if (!RECORDS) {
 #pragma unroll
-            for (int j = 0; j < kOut; ++j) __builtin_nontemporal_store(v + j, &out[(long)j * n + i]);
+            for (int j = 0; j < kOut; ++j) { if (NT) __builtin_nontemporal_store(v + j, &out[(long)j * n + i]); else out[(long)j * n + i] = v + j; }
         } else {
             double* tr = s_tr[wave];
 #pragma unroll
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(1024) void writer(const double* __restrict__ in, do
     }
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    const long n = 120091L * 37 / 64 * 64;
+    const long n = argc > 1 ? atol(argv[1]) : 120091L * 37 / 64 * 64;      // (a second run with 4443367 = E*C itself: planes not 64-byte aligned)
     double *in, *out;
     hipMalloc(&in, sizeof(double) * kIn * n);
     hipMalloc(&out, sizeof(double) * kOut * n);
@@ -62,20 +63,22 @@ int main()
     hipEventCreate(&b);
     const double bytes = 8.0 * (kIn + kOut) * n;
     for (int rep = 0; rep < 3; ++rep)
-        for (int form = 0; form < 2; ++form) {
+        for (int form = 0; form < 3; ++form) {
             for (int w = 0; w < 20; ++w)
-                if (form) hipLaunchKernelGGL(writer<true>, dim3(grid), dim3(1024), 0, 0, in, out, n);
+                if (form == 2) hipLaunchKernelGGL((writer<false, false>), dim3(grid), dim3(1024), 0, 0, in, out, n);
+                else if (form) hipLaunchKernelGGL(writer<true>, dim3(grid), dim3(1024), 0, 0, in, out, n);
                 else hipLaunchKernelGGL(writer<false>, dim3(grid), dim3(1024), 0, 0, in, out, n);
             hipEventRecord(a, 0);
             const int K = 100;
             for (int w = 0; w < K; ++w)
-                if (form) hipLaunchKernelGGL(writer<true>, dim3(grid), dim3(1024), 0, 0, in, out, n);
+                if (form == 2) hipLaunchKernelGGL((writer<false, false>), dim3(grid), dim3(1024), 0, 0, in, out, n);
+                else if (form) hipLaunchKernelGGL(writer<true>, dim3(grid), dim3(1024), 0, 0, in, out, n);
                 else hipLaunchKernelGGL(writer<false>, dim3(grid), dim3(1024), 0, 0, in, out, n);
             hipEventRecord(b, 0);
             hipEventSynchronize(b);
             float ms = 0;
             hipEventElapsedTime(&ms, a, b);
-            printf("%s: %.1f us per launch, %.0f GB/s (%.0f MB moved)\n", form ? "one record array (LDS transpose)" : "13 separate arrays            ",
+            printf("%s: %.1f us per launch, %.0f GB/s (%.0f MB moved)\n", form == 2 ? "13 separate arrays, plain stores" : form ? "one record array (LDS transpose)" : "13 separate arrays            ",
                    ms / K * 1e3, bytes / (ms / K * 1e-3) / 1e9, bytes / 1e6);
         }
     return 0;
