@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--form", choices=["auto", "general"], default="auto",
                     help="auto: the plan checks L once (plan time) for the three-fold context repetition of sequence_tools.py:560-564 "
                          "and runs the 64-context form of the accumulation when it holds; general: the 192-substitution form")
+    ap.add_argument("--pack-bins", type=int, default=1,
+                    help="1 (default): the plans gather from the packed bin records built at plan time (dig_bin_records_pack); "
+                         "0: from the four bin tables as handed in (A/B)")
     ap.add_argument("--aux", type=int, default=1,
                     help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
                          "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
@@ -471,8 +474,11 @@ def main():
         acc_k = out_acc if k == 0 else dict(out_acc, R_SIZE=torch.empty_like(out_acc["R_SIZE"]))
         return engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
-                                   td["obs_indel"], out_acc=acc_k, out_stats=out_stats, compact=args.form == "auto")
-    pipes = [make_plan(k) for k in range(PLAN_RING)]
+                                   td["obs_indel"], out_acc=acc_k, out_stats=out_stats, compact=args.form == "auto",
+                                   pack_bins=(pipes[0] if pipes else True) if args.pack_bins else False)      # (plan time; shared)
+    pipes = []
+    for k in range(PLAN_RING):
+        pipes.append(make_plan(k))
     pipe = pipes[0]
     # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
     # exchanges nothing (its plan has world = 1)
@@ -631,7 +637,7 @@ def main():
     #  stream order on the main stream, nothing overlapped)
     seq_plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
-                                   td["obs_indel"], compact=args.form == "auto")
+                                   td["obs_indel"], compact=args.form == "auto", pack_bins=pipe if args.pack_bins else False)
     assert seq_plan.compact == pipe.compact
     ref_acc, ref_stats = seq_plan.acc, seq_plan.stats
     n_settle = 0
@@ -785,6 +791,9 @@ def main():
                 "accumulation_form": ("compact: L repeats every context count three times (sequence_tools.py:560-564), verified on the "
                                       "device and compacted to [E, 64] at plan time; contexts + dot = acc_dot_ctx_kernel (K = 128)"
                                       if pipe.compact else "general: 192 substitution columns, acc_region_kernel + acc_dot_mfma_kernel (K = 256)"),
+                "bin_tables": ("packed at plan time (dig_bin_records_pack): {Y_PRED, STD^2} + Y_TRUE | FLAG << 31 per (bin, cohort), "
+                               "two gathers per overlapped bin in the statistics stage" if pipe.records is not None else
+                               "the four tables as handed in: four gathers per overlapped bin"),
                 "main stream": ("one dig_element_pipeline call per step: acc_dot_ctx_kernel (contexts + dot), "
                                 "element_stats_stream_fused_kernel" if pipe.compact else
                                 "one dig_element_pipeline call per step (stages DOT | STATISTICS): acc_dot_mfma_kernel, "

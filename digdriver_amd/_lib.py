@@ -54,7 +54,8 @@ _SIGNATURES = {
     "dig_scale_suffstats_chunked": [_vp, _vp, _i64, _vp, _int, _vp, _vp, _i64, _vp],
     "dig_scale_factors_chunked": [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _int, _vp, _i64, _vp],
+    "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _vp, _int, _vp, _i64, _vp],
+    "dig_bin_records_pack": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "dig_element_pipeline_host": [_vp] * 25 + [_i64, _i64, _i64, _int],
     "dig_gene_stats": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp],
@@ -90,9 +91,10 @@ _SIZE_QUERIES = {
     "dig_element_pipeline_workspace": [_i64, _i64],
     "dig_scale_suffstats_chunked_workspace": [_vp, _int, _i64],
     "dig_rbf_backward_partials": [_i64, _i64],
+    "dig_bin_records_bytes": [_i64, _i64],
 }
 
-ABI_VERSION = 4          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 5          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

@@ -100,7 +100,7 @@ int dig_element_pipeline_host(const double* bin_mu, const double* bin_std, const
                                  gene_length ? d_gl.as<int32_t>() : nullptr, d_dpr.as<double>(), d_o1.as<int32_t>(),
                                  d_o2.as<int32_t>(), d_o3.as<int32_t>(), d_cj.as<double>(), d_cji.as<double>(), o_mu.as<double>(),
                                  o_sg.as<double>(), o_ro.as<int32_t>(), o_fg.as<int32_t>(), o_p.as<double>(), o_rs.as<int32_t>(),
-                                 o_es.as<int32_t>(), o_pi.as<double>(), o_out.as<double>(), N, E, C,
+                                 o_es.as<int32_t>(), o_pi.as<double>(), o_out.as<double>(), N, E, C, nullptr,
                                  DIG_PIPE_ALL | (compact ? DIG_PIPE_COMPACT_L : 0), d_ws.p, wsb, nullptr));
     return st.down();
 }

@@ -87,6 +87,8 @@ struct ElementStatsArgs {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
+    const double2* bin_pack;   // dig_bin_records_pack: {Y_PRED, STD^2} per (bin, cohort), or NULL
+    const int32_t* bin_yf;     //                       Y_TRUE | (FLAG != 0) << 31
 #ifdef DIG_DEV_ABLATE
     int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
 #endif
@@ -219,7 +221,11 @@ __device__ __forceinline__ unsigned park_flush(unsigned* worklist, const unsigne
 // The streaming pass writes 80 bytes per pair that nothing reads back soon (the compacted pass revisits 1 % of the pairs):
 // non-temporal stores keep them from displacing the bin tables and the next tiles' inputs in L2 (same-box A/B:
 // 166 -> 157 us for dig_element_stats, 263 -> 256 us for dig_element_pipeline).
+#ifdef DIG_ES_PLAIN_STORES                     // developer A/B: write-back stores instead of streaming ones
+#define DIG_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#else
 #define DIG_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
 template <bool HAS_INDEL_PARAMS, bool FUSED_RATES = false>
 __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementStatsArgs a)
 {
@@ -411,7 +417,8 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 #ifndef DIG_ES_ABL
 #define DIG_ES_ABL 0     // developer ablation builds (tools/build_variant.sh): 1 no stores, 2 counts forced to 0, 8 no arithmetic, 16 no bin gathers
 #endif
-// GIVEN = 0: dig_element_pipeline (the rate sums of a pair are formed here from the bin tables and written out);
+// GIVEN = 0: dig_element_pipeline (the rate sums of a pair are formed here from the bin tables and written out); 3: the same
+// from the packed bin records of dig_bin_records_pack (two gathers per bin instead of four);
 // GIVEN = 1 / 2: dig_element_stats (mu / sigma handed in per pair; 2: separate indel parameters) -- the same pipeline,
 // tickets and in-kernel second pass without the CSR and bin stages.
 template <int TB, bool TICKETS, int GIVEN = 0>
@@ -420,6 +427,8 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #ifdef DIG_ES_TIMING
     if (threadIdx.x == 0) g_es_t0[blockIdx.x & 1023] = wall_clock64();
 #endif
+    constexpr bool FUSED = GIVEN == 0 || GIVEN == 3;      // rate sums formed here (3: from the packed bin records)
+    constexpr bool PACKED = GIVEN == 3;
     __shared__ unsigned park_all[TB / 64][kParkCap];
     __shared__ unsigned s_ticket;
     if (TICKETS && threadIdx.x == 0) s_ticket = 0;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         s.i = (uint32_t)(past ? n - 1 : iu);
         s.e = (uint32_t)(past ? a.E - 1 : eu);
         s.c = past ? C32 - 1 : cu;
-        if (GIVEN == 0) {
+        if (FUSED) {
             s.q0 = a.ov_ptr[s.e];
             s.q1 = a.ov_ptr[s.e + 1];
         } else
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         return s;
     };
     // every element's CSR range lies inside [0, nnz); with an empty CSR the index loads replay ov_ptr[0] (= 0: row 0)
-    const int64_t nnz = GIVEN == 0 ? a.ov_ptr[a.E] : 0;
+    const int64_t nnz = FUSED ? a.ov_ptr[a.E] : 0;
     const int32_t* oi_base = nnz > 0 ? a.ov_idx : reinterpret_cast<const int32_t*>(a.ov_ptr);
     const int64_t oi_last = nnz > 0 ? nnz - 1 : 0;
     auto fetch_in = [&](const StagePtr& s) {
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         r.nb = (uint32_t)(s.q1 - s.q0);
         r.i = s.i;
         r.c = s.c;
-        if (GIVEN == 0) {
+        if (FUSED) {
 #pragma unroll
             for (int j = 0; j < kPre; ++j)      // unconditional (the memory counter stays exact): bins past the pair's last replay a valid entry
                 r.idx[j] = oi_base[min(s.q0 + j, oi_last)];
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     };
     auto fetch_bin = [&](const StageIn& r) {
         StageBin b;
-        if (GIVEN != 0) return b;
+        if (!FUSED) return b;
 #if DIG_ES_ABL & 16
         for (int j = 0; j < kPre; ++j) { b.mu[j] = 1.0 + r.c; b.sd[j] = 0.5; b.y[j] = 1; b.fl[j] = 0; }
         return b;
@@ -525,10 +534,19 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         for (int j = 0; j < kPre; ++j) {
             const int64_t o = a.small_index ? (int64_t)(__umul24((uint32_t)r.idx[j], C32) + r.c)
                                             : (int64_t)r.idx[j] * a.C + r.c;      // bin row * C + cohort
+            if (PACKED) {
+            const double2 mv = a.bin_pack[o];
+            const int32_t yf = a.bin_yf[o];
+            b.mu[j] = mv.x;
+            b.sd[j] = mv.y;                       // (the square already)
+            b.y[j] = yf & 0x7fffffff;
+            b.fl[j] = (uint8_t)((uint32_t)yf >> 31);
+            } else {
             b.mu[j] = a.bin_mu[o];
             b.sd[j] = a.bin_std[o];
             b.y[j] = a.bin_y[o];
             b.fl[j] = a.bin_flag[o];
+            }
         }
         return b;
     };
@@ -565,12 +583,12 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         // rate sums (genic_driver_tools.py:262-271)
         double mu = 0.0, var = 0.0;
         int robs = 0, flag = 0;
-        if (GIVEN == 0) {
+        if (FUSED) {
 #pragma unroll
         for (int j = 0; j < kPre; ++j) {      // (bins past the pair's last were fetched from a replayed row: skipped here)
             if ((uint32_t)j < cur.nb) {
                 mu += bin.mu[j];
-                var += mul_rn(bin.sd[j], bin.sd[j]);
+                var += PACKED ? bin.sd[j] : mul_rn(bin.sd[j], bin.sd[j]);
                 robs += bin.y[j];
                 flag |= (bin.fl[j] != 0);
             }
@@ -579,16 +597,25 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             const int32_t* oi = a.ov_idx + cur.q0;
             for (uint32_t j = kPre; j < cur.nb; ++j) {
                 const int64_t o = (int64_t)oi[j] * a.C + cur.c;
-                const double sd = a.bin_std[o];
-                mu += a.bin_mu[o];
-                var += mul_rn(sd, sd);
-                robs += a.bin_y[o];
-                flag |= (a.bin_flag[o] != 0);
+                if (PACKED) {
+                    const double2 mv = a.bin_pack[o];
+                    const int32_t yf = a.bin_yf[o];
+                    mu += mv.x;
+                    var += mv.y;
+                    robs += yf & 0x7fffffff;
+                    flag |= (int)((uint32_t)yf >> 31);
+                } else {
+                    const double sd = a.bin_std[o];
+                    mu += a.bin_mu[o];
+                    var += mul_rn(sd, sd);
+                    robs += a.bin_y[o];
+                    flag |= (a.bin_flag[o] != 0);
+                }
             }
         }
         }
         PairRaw w;
-        if (GIVEN == 0) {
+        if (FUSED) {
             w.mu = w.mu_i = mu;
             w.sigma = w.sigma_i = sqrt(var);
         } else {
@@ -647,7 +674,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #if DIG_ES_ABL & 1
         if (pv_snv + pv_smp + pv_ind + pv_mut + q.exp_snv + q.exp_ind + q.theta_i + w.mu + w.sigma + robs + flag != 12345.678) continue;
 #endif
-        if (GIVEN == 0) {
+        if (FUSED) {
             DIG_STREAM_STORE(&a.mu_w[i], w.mu);
             DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
             DIG_STREAM_STORE(&a.r_obs[i], robs);
@@ -1089,6 +1116,8 @@ struct FusedRates {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
+    const double2* bin_pack;
+    const int32_t* bin_yf;
 };
 
 // DIG_ES_FORM / DIG_ES_BLOCKS_PER_CU are developer knobs for A/B runs (tools/variant_bench.py).
@@ -1121,7 +1150,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr
 #ifdef DIG_DEV_ABLATE
                        , 0
 #endif
@@ -1131,6 +1160,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.ov_ptr = fused->ov_ptr; a.ov_idx = fused->ov_idx;
         a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
         a.small_index = fused->small_index;
+        a.bin_pack = fused->bin_pack; a.bin_yf = fused->bin_yf;
     }
 #ifdef DIG_DEV_ABLATE
     a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;
@@ -1162,7 +1192,10 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         if (which == 2 && form == 1 && tickets == 1024) {
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
             DIG_REQUIRE(!DIG_ES_INWAVE || cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
-            hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            if (a.bin_pack)
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 3>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            else
+                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
             finished_in_wave = DIG_ES_INWAVE != 0;
         } else if (which == 2 && form == 1 && tickets == 256) {
             const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, true>, 256), stream_blocks_per_cu(8)));

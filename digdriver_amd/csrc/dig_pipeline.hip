@@ -22,6 +22,8 @@ struct FusedRates {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
+    const double2* bin_pack;
+    const int32_t* bin_yf;
 };
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
@@ -58,6 +60,35 @@ static PipeLayout pipe_layout(int64_t E, int64_t C, int64_t acc, int64_t stats)
     return p;
 }
 
+// Plan-time packing of the four bin tables into the records the statistics kernel gathers from (dig_bin_records_pack).
+__global__ __launch_bounds__(256) void pack_bins_kernel(const double* __restrict__ mu, const double* __restrict__ sd,
+                                                        const int32_t* __restrict__ y, const uint8_t* __restrict__ fl, int64_t n,
+                                                        double2* __restrict__ pack, int32_t* __restrict__ yf, int* __restrict__ bad)
+{
+#pragma clang fp contract(off)
+    int neg = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double s = sd[i];
+        const int32_t yi = y[i];
+        pack[i] = make_double2(mu[i], s * s);            // get_region_params_direct squares STD before summing (:266)
+        yf[i] = (yi & 0x7fffffff) | (fl[i] ? (int32_t)0x80000000 : 0);
+        neg |= yi < 0;
+    }
+    if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+struct BinRecords {
+    int64_t yf_off, flag_off, bytes;
+};
+static BinRecords bin_records_layout(int64_t N, int64_t C)
+{
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    BinRecords r{};
+    r.yf_off = up(N * C * (int64_t)sizeof(double2));
+    r.flag_off = r.yf_off + up(N * C * (int64_t)sizeof(int32_t));
+    r.bytes = r.flag_off + 256;
+    return r;
+}
 }  // namespace dig
 
 using namespace dig;
@@ -97,13 +128,40 @@ int dig_element_pipeline_prepare(const int32_t* L, int64_t E, int64_t C, void* w
     return DIG_OK;
 }
 
+int64_t dig_bin_records_bytes(int64_t N, int64_t C)
+{
+    if (N <= 0 || C <= 0) return 0;
+    return bin_records_layout(N, C).bytes;
+}
+
+int dig_bin_records_pack(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag, int64_t N,
+                         int64_t C, void* records, int64_t records_bytes, void* stream)
+{
+    DIG_REQUIRE(N >= 0 && C >= 0, "N, C >= 0");
+    if (N == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(bin_mu && bin_std && bin_y && bin_flag && records, "non-null pointers");
+    const BinRecords lay = bin_records_layout(N, C);
+    DIG_REQUIRE(records_bytes >= lay.bytes, "records of at least dig_bin_records_bytes(N, C) bytes");
+    DIG_REQUIRE(((uintptr_t)records & 255u) == 0, "records 256-byte aligned");
+    int* bad = (int*)((char*)records + lay.flag_off);
+    DIG_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(pack_bins_kernel, dim3(grid_for(N * C, 256)), dim3(256), 0, (hipStream_t)stream, bin_mu, bin_std, bin_y,
+                       bin_flag, N * C, (double2*)records, (int32_t*)((char*)records + lay.yf_off), bad);
+    DIG_HIP_TRY(hipGetLastError());
+    int neg = 0;
+    DIG_HIP_TRY(hipMemcpyAsync(&neg, bad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DIG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    DIG_REQUIRE(!neg, "bin_y holds a negative count: the packed records keep Y_TRUE in 31 bits");
+    return DIG_OK;
+}
+
 int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                          const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
                          const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
                          const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
                          const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
-                         int stages, void* workspace, int64_t workspace_bytes, void* stream)
+                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
     const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
     const int compact = (stages & DIG_PIPE_COMPACT_L) != 0 && N >= 1;
@@ -138,7 +196,12 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     }
     if (!(stages & 4)) return DIG_OK;
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
-    const FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index};
+    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr};
+    if (bin_records) {
+        const BinRecords lay_r = bin_records_layout(N, C);
+        f.bin_pack = (const double2*)bin_records;
+        f.bin_yf = (const int32_t*)((const char*)bin_records + lay_r.yf_off);
+    }
     return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel,
                                 out, E, C, (char*)workspace + acc_bytes, lay.stats_bytes, stream, &f,
                                 /* worklist header cleared by the context kernel of THIS call; a statistics-only call

@@ -393,7 +393,7 @@ def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, 
         _lib.call("dig_element_pipeline", p(bin_mu), p(bin_std), p(bin_y), p(bin_flag), p(bin_ctx), p(ov_ptr), p(ov_idx),
                   p(L), p(strand_minus), p(gene_length), p(d_pr), p(obs[0]), p(obs[1]), p(obs[2]), p(cj), p(cj_indel),
                   p(o["MU"]), p(o["SIGMA"]), p(o["R_OBS"]), p(o["FLAG"]), p(o["P"]), p(o["R_SIZE"]), p(o["ELT_SIZE"]),
-                  p(o["P_INDEL"]), p(st), N, E, C, int(stages), p(ws), wsb, _lib.stream_ptr())
+                  p(o["P_INDEL"]), p(st), N, E, C, None, int(stages), p(ws), wsb, _lib.stream_ptr())
     return o, st
 
 
@@ -403,11 +403,16 @@ class PipelinePlan:
     host time instead of ~60), which keeps the host ahead of a 0.3 ms GPU step.  The tensors are held by the plan."""
 
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
-                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None):
+                 obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None,
+                 pack_bins=True):
         """compact: "auto" (default) checks ONCE, here, on the device whether L repeats every context count three times
         (sequence_tools.py:560-564: true for every elementModel / tiledModel / quickDriver set) and, if so, runs the
         64-context form of the accumulation (contexts + dot in one kernel, half the matrix work); False forces the
-        general 192-substitution form.  `self.compact` tells which one runs."""
+        general 192-substitution form.  `self.compact` tells which one runs.
+        pack_bins: rewrite the four bin tables ONCE, here, as the packed records the statistics stage gathers from
+        (dig_bin_records_pack: 20 bytes per (bin, cohort) of plan-owned memory, two gathers per bin instead of four, same
+        bits).  The plan then reads the records, not the tables: call `repack_bins()` after changing a table in place.
+        Another PipelinePlan over the same tables may be given instead of True: its records are shared."""
         import ctypes
         import torch
         dev = bin_mu.device
@@ -436,8 +441,16 @@ class PipelinePlan:
         p = _lib.dev_ptr
         o = self.acc
         self._head = [p(x) for x in self.keep]
+        self.records = None
+        if isinstance(pack_bins, PipelinePlan):              # several plans over the SAME bin tables share one set of records
+            assert pack_bins.keep[0].data_ptr() == self.keep[0].data_ptr() and (pack_bins.N, pack_bins.C) == (self.N, self.C)
+            self.records = pack_bins.records
+        elif pack_bins and self.N >= 1:
+            nb = int(_lib.load().dig_bin_records_bytes(self.N, self.C))
+            self.records = torch.empty(nb, dtype=torch.uint8, device=dev)
+            self.repack_bins()
         self._tail = [p(o["MU"]), p(o["SIGMA"]), p(o["R_OBS"]), p(o["FLAG"]), p(o["P"]), p(o["R_SIZE"]), p(o["ELT_SIZE"]),
-                      p(o["P_INDEL"]), p(self.stats), self.N, self.E, self.C]
+                      p(o["P_INDEL"]), p(self.stats), self.N, self.E, self.C, p(self.records)]
         self._ws = p(self.ws)
         self._fn = getattr(_lib.load(), "dig_element_pipeline")
         self.compact = False
@@ -448,6 +461,16 @@ class PipelinePlan:
                           _lib.stream_ptr())
             self.compact = bool(ok.value)
         self._flags = _lib.DIG_PIPE_COMPACT_L if self.compact else 0
+
+    def repack_bins(self):
+        """(Re)build the packed bin records from the plan's bin tables on torch's current stream (waits for it)."""
+        import torch
+        if self.records is None:
+            return
+        k = self.keep
+        with torch.cuda.device(self.dev):
+            _lib.call("dig_bin_records_pack", _lib.dev_ptr(k[0]), _lib.dev_ptr(k[1]), _lib.dev_ptr(k[2]), _lib.dev_ptr(k[3]),
+                      self.N, self.C, _lib.dev_ptr(self.records), self.records.numel(), _lib.stream_ptr())
 
     def run(self, cj, cj_indel, stages=7, stream=None):
         """Enqueue the pipeline (or one of its stages) on `stream` (default: torch's current stream)."""

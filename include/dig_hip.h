@@ -34,8 +34,9 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 4   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
-                             * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L */
+#define DIG_ABI_VERSION 5   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+                             * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
+                             * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -199,13 +200,22 @@ int dig_element_pipeline_host(const double *bin_mu, const double *bin_std, const
                               const double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
                               int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
                               int device);
+/* Packed bin records (ABI 5), PLAN TIME, once per set of bin tables: the statistics stage gathers Y_PRED, STD, Y_TRUE and
+ * FLAG of every bin an element overlaps (get_region_params_direct, genic_driver_tools.py:258-272) -- four arrays, four
+ * random row segments per bin.  dig_bin_records_pack rewrites them as {Y_PRED, STD^2} pairs (16 bytes) and
+ * Y_TRUE | (FLAG != 0) << 31 (4 bytes) per (bin, cohort): two gathers per bin, the square of :266 taken once.  Pass the
+ * records as `bin_records` of dig_element_pipeline (NULL: the four tables are read as before; they stay required either
+ * way).  Same bits as without.  The call waits for `stream`; Y_TRUE must be >= 0.  Repack when a table changes. */
+int64_t dig_bin_records_bytes(int64_t N, int64_t C);
+int dig_bin_records_pack(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag, int64_t N,
+                         int64_t C, void *records, int64_t records_bytes, void *stream);
 int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
                          const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
                          const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,
                          const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel, const double *cj,
                          const double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
                          int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
-                         int stages, void *workspace, int64_t workspace_bytes, void *stream);
+                         const void *bin_records, int stages, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- the gene route's statistics block as one launch (ABI 4) -------------------------------- *
  * gene_expected_muts_nb :331-340, gene_pvalue_burden_nb :394-456, gene_pvalue_burden_nb_by_sample :554-583,

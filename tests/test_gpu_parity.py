@@ -699,6 +699,51 @@ def test_compact_pipeline_against_general_form_and_oracle(torch_dev):
     assert torch.equal(acc_p["P"], acc_g["P"]) and torch.equal(torch.nan_to_num(st_p, nan=-7.0), torch.nan_to_num(st_g, nan=-7.0))
 
 
+def test_packed_bin_records_give_the_same_bits(torch_dev):
+    """dig_bin_records_pack (plan time: {Y_PRED, STD^2} pairs + Y_TRUE | FLAG << 31 per (bin, cohort)) feeds the statistics
+    stage two gathers per bin instead of four.  Every output of a plan WITH the records equals the plan WITHOUT them bit
+    for bit -- general and compact accumulation, elements over 0 ... 12 bins (the first three travel in registers, the rest
+    in a loop), C on both sides of 37 -- a table changed in place needs repack_bins(), plans over the same tables share
+    one set of records, and a negative count is refused (the record keeps Y_TRUE in 31 bits)."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import _lib, engine
+    for (nb, E, C, seed, mb) in ((900, 700, 37, 2, 3), (400, 333, 1, 3, 9), (700, 1601, 40, 9, 12), (300, 260, 104, 6, 3), (64, 1, 37, 8, 1)):
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed, max_blocks=mb)
+        w["bin_flag"][::7] = 1
+        w["bin_y"][3, 0] = 2 ** 31 - 1                       # the largest count a record holds
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+        for compact in ("auto", False):
+            plain = engine.PipelinePlan(*args, compact=compact, pack_bins=False)
+            packed = engine.PipelinePlan(*args, compact=compact)
+            shared = engine.PipelinePlan(*args, compact=compact, pack_bins=packed)
+            assert plain.records is None and packed.records is not None and shared.records is packed.records
+            a0, s0 = plain.run(td["cj"], td["cj_indel"])
+            for plan in (packed, shared):
+                a1, s1 = plan.run(td["cj"], td["cj_indel"])
+                torch.cuda.synchronize()
+                for k in a0:
+                    assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, C, compact)
+                assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (C, compact)
+        # a table changed in place: the plan reads its records until they are rebuilt
+        td["bin_mu"][: nb // 2] *= 1.5
+        td["bin_flag"][1::3] ^= 1
+        stale = packed.run(td["cj"], td["cj_indel"])[0]["MU"].clone()
+        packed.repack_bins()
+        a1, s1 = packed.run(td["cj"], td["cj_indel"])
+        a0, s0 = plain.run(td["cj"], td["cj_indel"])
+        torch.cuda.synchronize()
+        assert not torch.equal(stale, a0["MU"]) or nb < 4
+        for k in a0:
+            assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), k
+        assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0))
+    td["bin_y"][5, 0] = -1
+    with pytest.raises(_lib.DigHipError, match="negative count"):
+        engine.PipelinePlan(*args)
+
+
 def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
     """The fused stream pass finishes its unfinished pairs itself: through the workgroup's LDS queue (1024 records) and, beyond
     that, through the workgroup's own segment of the worklist.  With every SNV count raised past the recurrence's range
