@@ -354,7 +354,13 @@ __global__ __launch_bounds__(kBlock) void element_stats_stream_kernel(ElementSta
 // The first kPre bins of a pair travel through the pipeline in registers; a tile in which some pair overlaps more bins
 // finishes those sums with the plain loop (wave-uniform branch; gene-sized elements).  Same operations in the same
 // order per pair as acc_region_kernel (genic_driver_tools.py:262-271: mu += Y_PRED, var += STD**2 in CSR order).
-constexpr int kPre = 3;
+// (kPre = 2 since round 3: elements of the element / tile routes overlap one or two 10-kb bins -- 1.3 % of the bench
+//  workload's elements three -- and a third register slot cost more in replayed gathers than the loop costs the few:
+//  142.4 -> 139.9 us, same bits; -DDIG_ES_KPRE=3 restores it)
+#ifndef DIG_ES_KPRE
+#define DIG_ES_KPRE 2
+#endif
+constexpr int kPre = DIG_ES_KPRE;
 
 struct StagePtr {            // tile t+2
     int64_t q0, q1;
@@ -415,7 +421,8 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 #define DIG_ES_XCD 1
 #endif
 #ifndef DIG_ES_ABL
-#define DIG_ES_ABL 0     // developer ablation builds (tools/build_variant.sh): 1 no stores, 2 counts forced to 0, 8 no arithmetic, 16 no bin gathers
+#define DIG_ES_ABL 0     // developer ablation builds (tools/build_variant.sh): 1 no stores, 2 counts forced to 0, 8 no arithmetic, 16 no bin gathers,
+                         // 32 no CSR / index loads, 64 no stores of the four rate outputs, 128 no stores of the seven planes
 #endif
 // GIVEN = 0: dig_element_pipeline (the rate sums of a pair are formed here from the bin tables and written out); 3: the same
 // from the packed bin records of dig_bin_records_pack (two gathers per bin instead of four);
@@ -476,11 +483,15 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         s.i = (uint32_t)(past ? n - 1 : iu);
         s.e = (uint32_t)(past ? a.E - 1 : eu);
         s.c = past ? C32 - 1 : cu;
+#if DIG_ES_ABL & 32
+        s.q0 = s.q1 = 0;
+#else
         if (FUSED) {
             s.q0 = a.ov_ptr[s.e];
             s.q1 = a.ov_ptr[s.e + 1];
         } else
             s.q0 = s.q1 = 0;
+#endif
         if (!TICKETS) {
             iu += step_pairs;
             eu += step_e;
@@ -505,7 +516,11 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         if (FUSED) {
 #pragma unroll
             for (int j = 0; j < kPre; ++j)      // unconditional (the memory counter stays exact): bins past the pair's last replay a valid entry
+#if DIG_ES_ABL & 32
+                r.idx[j] = (int)(s.e & 1023u);
+#else
                 r.idx[j] = oi_base[min(s.q0 + j, oi_last)];
+#endif
         } else {
             r.mu = a.mu[s.i];
             r.sg = a.sigma[s.i];
@@ -674,12 +689,19 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #if DIG_ES_ABL & 1
         if (pv_snv + pv_smp + pv_ind + pv_mut + q.exp_snv + q.exp_ind + q.theta_i + w.mu + w.sigma + robs + flag != 12345.678) continue;
 #endif
+#if !(DIG_ES_ABL & 64)
         if (FUSED) {
             DIG_STREAM_STORE(&a.mu_w[i], w.mu);
             DIG_STREAM_STORE(&a.sigma_w[i], w.sigma);
             DIG_STREAM_STORE(&a.r_obs[i], robs);
             DIG_STREAM_STORE(&a.flag[i], flag);
         }
+#else
+        if (w.mu + w.sigma + robs + flag == 12345.678) DIG_STREAM_STORE(&a.mu_w[i], w.mu);
+#endif
+#if DIG_ES_ABL & 128
+        if (pv_snv + pv_smp + pv_ind + pv_mut + q.exp_snv + q.exp_ind + q.theta_i != 12345.678) continue;
+#endif
         DIG_STREAM_STORE(&a.out[0 * n + i], q.exp_snv);
         DIG_STREAM_STORE(&a.out[1 * n + i], pv_snv);
         DIG_STREAM_STORE(&a.out[2 * n + i], pv_smp);
