@@ -366,7 +366,8 @@ def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, 
     import torch
     if compact:
         plan = PipelinePlan(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv, obs_samples,
-                            obs_indel, out_acc=out_acc, out_stats=out_stats, gene_length=gene_length, compact=compact)
+                            obs_indel, out_acc=out_acc, out_stats=out_stats, gene_length=gene_length, compact=compact,
+                            pack_bins=False)               # (one call: packing the tables would cost more than it saves)
         return plan.run(_t(cj, torch.float64, plan.dev), _t(cj_indel, torch.float64, plan.dev), stages=stages)
     dev = bin_mu.device
     f64, i32, i64, u8 = torch.float64, torch.int32, torch.int64, torch.uint8
