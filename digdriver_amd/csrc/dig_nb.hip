@@ -1138,8 +1138,8 @@ struct FusedRates {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
-    const double2* bin_pack;
-    const int32_t* bin_yf;
+    const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
+    const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
 };
 
 // DIG_ES_FORM / DIG_ES_BLOCKS_PER_CU are developer knobs for A/B runs (tools/variant_bench.py).

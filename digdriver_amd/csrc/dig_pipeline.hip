@@ -7,8 +7,11 @@
 // HBM-bound pass fewer).  All outputs of both operations are still written; results are bit-identical to the two
 // separate calls (tests/test_gpu_parity.py).  `stages` lets a caller enqueue the three stages (context kernel, dot
 // kernel, statistics) as separate calls in that order on the same workspace, e.g. to form the scale factors -- which
-// only the statistics stage needs -- on another stream beside the MFMA-bound dot kernel.  Kernel sequence: acc_region_kernel (contexts + parameter table) ->
-// acc_dot_mfma_kernel -> element_stats_stream_kernel<false, true> -> element_stats_slow_kernel.
+// only the statistics stage needs -- on another stream beside the MFMA-bound dot kernel.
+// Kernel sequence per call: acc_dot_ctx_kernel (contexts + dot, the compact form: DIG_PIPE_COMPACT_L after
+// dig_element_pipeline_prepare) or acc_region_kernel -> acc_dot_mfma_kernel (general form), then
+// element_stats_stream_fused_kernel (which finishes its own slow pairs).  Plan-time helpers live here too:
+// dig_element_pipeline_prepare (compact L) and dig_bin_records_pack (the bin tables as 20-byte records).
 #include "dig_common.hpp"
 
 namespace dig {
@@ -22,8 +25,8 @@ struct FusedRates {
     double *mu_w, *sigma_w;
     int32_t *r_obs, *flag;
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
-    const double2* bin_pack;
-    const int32_t* bin_yf;
+    const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
+    const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
 };
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,

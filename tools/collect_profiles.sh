@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 B="python3 bench.py --cpu-sample 0"
+rocm-smi --showserial --showmemvendor 2>/dev/null | grep -i "Serial N\|vendor" > $OUT/${TAG}_gpu.txt      # which GPU of the pool
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}a -- $B --steps 300 --warmup 20 > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}a.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_steps20.json 2> $OUT/${TAG}_b20.err
 python3 bench.py --cpu-sample 0 --aux 0 --steps 1000 --warmup 50 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_b1000.err
