@@ -148,25 +148,31 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_chunk_stage1(const double*
     const int64_t r_end = (r_begin + rows_per_block < tab.row[j + 1]) ? r_begin + rows_per_block : tab.row[j + 1];
     const int rpp = kSsBlock / (int)C;              // rows per pass (C <= kSsBlock)
     const int col = tid % (int)C, rg = tid / (int)C;
+    // A BACKGROUND kernel: in the burden-test loop it runs on a side stream beside the statistics kernel, whose one
+    // 1024-thread workgroup per CU leaves 32 of the 512 vector registers of a SIMD lane, one wave slot and a few KB of LDS
+    // free.  With <= 32 VGPRs (four loads in flight per thread, 32-bit element offsets from the block's base) a workgroup of
+    // this kernel fits into exactly that, so its 96 MB stream no longer waits for -- or holds up -- the big kernels
+    // (round 3: 20 us of the step, tools/loop_probe.py).  Same additions in the same order per thread as before.
     double acc = 0.0;
     if (rg < rpp) {
-        int64_t r = r_begin + rg;
-        for (; r + 7 * rpp < r_end; r += 8 * rpp) {
-            double v[8];
-            uint8_t f[8];
+        const double* mu0 = bin_mu + r_begin * C;
+        const uint8_t* fl0 = bin_flag + r_begin * C;
+        const int n_rows = (int)(r_end - r_begin);
+        const int stride = rpp * (int)C;
+        int r = rg;
+        unsigned o = (unsigned)(rg * (int)C + col);
+        for (; r + 3 * rpp < n_rows; r += 4 * rpp, o += 4u * (unsigned)stride) {
+            double v[4];
+            uint8_t f[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int64_t o = (r + (int64_t)q * rpp) * C + col;
-                v[q] = bin_mu[o];
-                f[q] = bin_flag[o];
+            for (int q = 0; q < 4; ++q) {
+                v[q] = mu0[o + (unsigned)(q * stride)];
+                f[q] = fl0[o + (unsigned)(q * stride)];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += f[q] ? 0.0 : v[q];
+            for (int q = 0; q < 4; ++q) acc += f[q] ? 0.0 : v[q];
         }
-        for (; r < r_end; r += rpp) {
-            const int64_t o = r * C + col;
-            acc += bin_flag[o] ? 0.0 : bin_mu[o];
-        }
+        for (; r < n_rows; r += rpp, o += (unsigned)stride) acc += fl0[o] ? 0.0 : mu0[o];
     }
     part[tid] = acc;
     __syncthreads();

@@ -25,3 +25,19 @@ def buckets(x, k=10):
 t0 = int(rows[0]["Start_Timestamp"])
 print("settle phase medians over time:", buckets(d[:-n]), " (%.0f ms long)" % ((int(rows[-n - 1]["End_Timestamp"]) - t0) / 1e6))
 print("loop medians over time        :", buckets(d[-n:]), " (%.0f ms long)" % ((int(rows[-1]["End_Timestamp"]) - int(rows[-n]["Start_Timestamp"])) / 1e6))
+# the loop's timeline on the main stream: gap in front of every accumulation kernel (= between two steps) and step period
+acc = [r for r in allr if "acc_dot" in r["Kernel_Name"]][-n:]
+ends = {}
+per, gap2 = [], []
+prev_start = None
+for r in allr:
+    q = r.get("Queue_Id") or r.get("Stream_Id")
+    if "acc_dot" in r["Kernel_Name"]:
+        if q in ends: gap2.append((int(r["Start_Timestamp"]) - ends[q]) / 1e3)
+        if prev_start is not None: per.append((int(r["Start_Timestamp"]) - prev_start) / 1e3)
+        prev_start = int(r["Start_Timestamp"])
+    ends[q] = int(r["End_Timestamp"])
+print("gap before the accumulation kernel, last %d:" % n, st(gap2[-n:]))
+print("step period (start to start of the accumulation kernel), last %d:" % n, st(per[-n:]))
+dd = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in acc]
+print("accumulation kernel, last %d:" % n, st(dd))
