@@ -646,6 +646,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #if DIG_ES_ABL & 2
         w.k_snv = w.k_smp = w.k_ind = 0;
 #endif
+#if DIG_ES_ABL & 256                                   // counts capped at 28: what a sorted wave's trip count would cost (timing only)
+        w.k_snv = min(w.k_snv, 28); w.k_smp = min(w.k_smp, 28);
+#endif
         w.q0 = w.q1 = 0; w.c = cur.c;
 #if DIG_ES_ABL & 8
         PairInputs q;

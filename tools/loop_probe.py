@@ -16,8 +16,11 @@ w["cj"], w["cj_indel"] = wg["cj"], wg["cj_indel"]
 td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray) and k not in ("chunk_rows", "elements")}
 plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"],
                            td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
-scale = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"], parallel.N_CHUNKS, world=1)
-main, side = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+div = int(os.environ.get("LP_DIV", "1"))          # 1 / div of the bins in the side stream's sums (developer: what does the side work cost per byte?)
+scale = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], np.asarray(w["chunk_rows"]) // div, parallel.N_CHUNKS, world=1)
+pr = os.environ.get("LP_PRIO") == "1"
+main, side = torch.cuda.Stream(dev, priority=-1 if pr else 0), torch.cuda.Stream(dev, priority=0)
+print("stream priorities (main, side):", main.priority, side.priority, torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "")
 RING = 64
 cjs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev)) for _ in range(RING)]
 done = [torch.cuda.Event() for _ in range(RING)]
