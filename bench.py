@@ -520,6 +520,7 @@ def main():
     sample_slot = {1: "contexts", 3: "dot", 5: "statistics"}
     samples = {"contexts": [], "dot": [], "statistics": []}
     sampling = [False]
+    warming = [False]
 
     # every event of the run exists before the loop starts (HIP creates the object behind a torch event at its first
     # record, and a growing pool of them costs a one-off stall of tens of milliseconds at some point of the loop)
@@ -554,9 +555,14 @@ def main():
     def sample_which(t):
         """The stage bracketed on step t (None: no bracket)."""
         if not sampling[0]:
+            # short runs bracket the two SMALLER stages on their (untimed) warm-up steps instead of inside the K timed ones: a
+            # bracket splits the step's one call into three and adds two event packets, ~10 us of a 200-us step
+            if SAMPLE_EVERY == 4 and warming[0]:
+                which = ("dot", "contexts")[t % 2]
+                return "dot" if which == "contexts" and pipe.compact else which
             return None
-        if SAMPLE_EVERY == 4:       # short runs: statistics on steps 1 mod 4, dot / contexts in turn on 3 mod 4
-            which = "statistics" if t % 4 == 1 else (("dot", "contexts")[(t // 4) % 2] if t % 4 == 3 else None)
+        if SAMPLE_EVERY == 4:       # short runs: statistics (the `roofline` kernel) on the timed steps 1 mod 4
+            which = "statistics" if t % 4 == 1 else None
         else:
             which = sample_slot.get(t % SAMPLE_EVERY)
         if which == "contexts" and pipe.compact:       # the compact form has no context kernel: contexts + dot are one launch
@@ -664,8 +670,10 @@ def main():
         pipe.run(seq_cj, seq_cji, stages=7, stream=main_stream)
     torch.cuda.synchronize()
     settle_ms = (time.perf_counter() - t_settle) * 1e3
+    warming[0] = True
     for _ in range(args.warmup):
         step()
+    warming[0] = False
     barrier()
     # The step's kernels run on two streams and overlap, so the roofline is taken for the step as a whole: two HIP events
     # on the main stream bracket the K timed steps (the main stream waits for the side stream's scale factors inside
@@ -807,9 +815,12 @@ def main():
                                 "workspaces, at most 32 steps ahead of the main stream)" if ctx_side else ""),
                 "algorithmic_bytes": {"accumulate": b_acc, "element_stats": b_stat, "scale_suffstats": b_suff}},
             "kernel_timing": "HIP events on the stream a stage is launched on (statistics and dot: main; contexts: %s): "
-                             "`roofline` and `roofline_other_stages` bracket one stage on every %d-th timed step, `roofline_step` "
-                             "brackets all %d timed steps on the main stream (side-stream work overlapped); rocprofv3 per-kernel "
-                             "averages of the same command: profiles/" % (args.contexts_on, SAMPLE_EVERY, args.steps),
+                             "`roofline` brackets the statistics stage on every %d-th timed step, `roofline_other_stages` %s, "
+                             "`roofline_step` brackets all %d timed steps on the main stream (side-stream work overlapped); rocprofv3 "
+                             "per-kernel averages of the same command: profiles/"
+                             % (args.contexts_on, SAMPLE_EVERY, "one of the smaller stages on every %d-th timed step" % SAMPLE_EVERY
+                                if SAMPLE_EVERY != 4 else "the smaller stages on the warm-up steps (a run this short keeps them out of "
+                                                          "its timed steps)", args.steps),
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "side_stream_slack_us": ({"min": slack_us[0], "median": slack_us[len(slack_us) // 2], "samples": len(slack_us),
