@@ -707,6 +707,18 @@ def main():
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
     slack_us = sorted(slack_side[t].elapsed_time(slack_main[t]) * 1e3 for t in slack_main)
     stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
+    # what a bracket itself costs: the same two events around a one-element fill (a ~1.5 us kernel), after the timed region
+    cal = []
+    one = torch.empty(1, dtype=torch.float64, device=dev)
+    with torch.cuda.stream(main_stream):
+        for _ in range(24):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(main_stream)
+            one.zero_()
+            eb.record(main_stream)
+            cal.append((ea, eb))
+    torch.cuda.synchronize()
+    bracket_us = sorted(x.elapsed_time(y) for x, y in cal[4:])[len(cal[4:]) // 2] * 1e3
     if trace is not None and rank == 0:
         print("BENCH_TRACE statistics-stage samples (us):", [round(a.elapsed_time(b_) * 1e3, 1) for a, b_ in samples["statistics"]][:40],
               file=sys.stderr)
@@ -776,6 +788,12 @@ def main():
             # streaming pass (what actually bounds it)
             vf, src = committed_valu_frac("element_stats_stream")
             dominant_roof["valu_frac"], dominant_roof["valu_frac_source"] = vf, src
+        if dominant_roof is stage_roofs["statistics"]:
+            dominant_roof["bracket_of_a_one_element_fill_us"] = bracket_us
+            dominant_roof["bracket_note"] = ("avg_launch_ms is the raw event-to-event time of a bracket; a bracket around a one-element "
+                                             "fill kernel takes the figure above, so ~4-6 us of avg_launch_ms are the two event packets "
+                                             "and the dispatch, not the kernel (profiles/r03_kernel_stats_loop_only.csv: 124.1 us by the "
+                                             "kernel's own timestamps where the brackets of that run say 129.8)")
         res = {
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
