@@ -45,6 +45,14 @@ for case in range(n_cases):
     ok = all(torch.equal(torch.nan_to_num(st[name], nan=-7.0), torch.nan_to_num(st2[j], nan=-7.0))
              for j, name in enumerate(engine.ES_PLANES))
     ok = ok and all(torch.equal(torch.nan_to_num(acc[k].double(), nan=-7.0), torch.nan_to_num(acc2[k].double(), nan=-7.0)) for k in acc)
+    # a plan with the packed bin records (and, L being context-repeated, the compact accumulation): rate outputs and the
+    # statistics that do not depend on P bit for bit, the others through P within its tolerance
+    plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                               td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"], compact=False)
+    acc3, st3 = plan.run(td["cj"], td["cj_indel"])
+    torch.cuda.synchronize()
+    ok = ok and torch.equal(torch.nan_to_num(st3, nan=-7.0), torch.nan_to_num(st2, nan=-7.0))
+    ok = ok and all(torch.equal(torch.nan_to_num(acc[k].double(), nan=-7.0), torch.nan_to_num(acc3[k].double(), nan=-7.0)) for k in acc)
     neg = int((torch.nan_to_num(st2[1], nan=0.0) < 0).sum() + (torch.nan_to_num(st2[5], nan=0.0) < 0).sum())
     if not ok or neg:
         bad += 1
