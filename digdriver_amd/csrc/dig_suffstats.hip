@@ -161,18 +161,31 @@ __global__ __launch_bounds__(kSsBlock) void suffstats_chunk_stage1(const double*
         const int stride = rpp * (int)C;
         int r = rg;
         unsigned o = (unsigned)(rg * (int)C + col);
-        for (; r + 3 * rpp < n_rows; r += 4 * rpp, o += 4u * (unsigned)stride) {
-            double v[4];
-            uint8_t f[4];
+        if (bin_flag) {
+            for (; r + 3 * rpp < n_rows; r += 4 * rpp, o += 4u * (unsigned)stride) {
+                double v[4];
+                uint8_t f[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[q] = mu0[o + (unsigned)(q * stride)];
-                f[q] = fl0[o + (unsigned)(q * stride)];
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = mu0[o + (unsigned)(q * stride)];
+                    f[q] = fl0[o + (unsigned)(q * stride)];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += f[q] ? 0.0 : v[q];
             }
+            for (; r < n_rows; r += rpp, o += (unsigned)stride) acc += fl0[o] ? 0.0 : mu0[o];
+        } else {
+            // bin_flag == NULL: the caller's table holds +0.0 where a bin is flagged (a plan-time copy: 8 instead of 9 bytes per
+            // (bin, cohort) and step) -- the same additions, the same bits
+            for (; r + 3 * rpp < n_rows; r += 4 * rpp, o += 4u * (unsigned)stride) {
+                double v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc += f[q] ? 0.0 : v[q];
+                for (int q = 0; q < 4; ++q) v[q] = mu0[o + (unsigned)(q * stride)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += v[q];
+            }
+            for (; r < n_rows; r += rpp, o += (unsigned)stride) acc += mu0[o];
         }
-        for (; r < n_rows; r += rpp, o += (unsigned)stride) acc += fl0[o] ? 0.0 : mu0[o];
     }
     part[tid] = acc;
     __syncthreads();
@@ -334,7 +347,7 @@ int dig_scale_suffstats_chunked(const double* bin_mu, const uint8_t* bin_flag, i
     DIG_REQUIRE(workspace_bytes >= (int64_t)std::max(blocks, 1) * C * (int64_t)sizeof(double), "workspace smaller than dig_scale_suffstats_chunked_workspace");
     hipStream_t s = (hipStream_t)stream;
     if (blocks > 0) {
-        DIG_REQUIRE(bin_mu && bin_flag, "non-null inputs");
+        DIG_REQUIRE(bin_mu, "non-null bin_mu (bin_flag may be NULL: flagged entries of bin_mu are +0.0 then)");
         hipLaunchKernelGGL(suffstats_chunk_stage1, dim3(blocks), dim3(kSsBlock), 0, s, bin_mu, bin_flag, C, ss_chunk_rows_per_block(C), tab,
                            (double*)workspace);
         DIG_HIP_TRY(hipGetLastError());

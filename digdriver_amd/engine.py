@@ -734,11 +734,17 @@ class ChunkedScaleFactorPlan:
         -> every rank adds the K chunk sums first to last and divides (dig_scale_factors_chunked).
     Without a process group the all-gather is skipped: same kernels, same bits."""
 
-    def __init__(self, bin_mu, bin_flag, n_snv_obs, n_ind_obs, chunk_rows, n_chunks_total, group=None, world=None):
+    def __init__(self, bin_mu, bin_flag, n_snv_obs, n_ind_obs, chunk_rows, n_chunks_total, group=None, world=None, premask=True):
+        """premask: keep a plan-time copy of bin_mu with +0.0 in the flagged entries and sum THAT every step (8 instead of 9
+        bytes per (bin, cohort) and step, the same additions and bits); call `remask()` after changing a table in place."""
         import torch
         import torch.distributed as dist
         dev = bin_mu.device
         self.mu, self.flag = _t(bin_mu, torch.float64, dev), _t(bin_flag, torch.uint8, dev)
+        self.masked = None
+        if premask:
+            self.masked = torch.empty_like(self.mu)
+            self.remask()
         self.C = int(self.mu.shape[1])
         self.chunk_rows = np.ascontiguousarray(chunk_rows, np.int64)
         self.n_own, self.n_total, self.group = len(self.chunk_rows) - 1, int(n_chunks_total), group
@@ -759,10 +765,17 @@ class ChunkedScaleFactorPlan:
         self.obs = torch.empty((self.world, 2, self.C), dtype=torch.float64, device=dev)
         self._lib = lib
 
+    def remask(self):
+        """(Re)build the masked copy of the rate table on torch's current stream."""
+        import torch
+        if self.masked is not None:
+            torch.where(self.flag != 0, torch.zeros((), dtype=torch.float64, device=self.mu.device), self.mu, out=self.masked)
+
     def enqueue_part(self, stream=None):
         """This rank's contribution [n_own + 2, C]: chunk sums of its own chunks, then its observed counts."""
         p = _lib.dev_ptr
-        rc = self._lib.dig_scale_suffstats_chunked(p(self.mu), p(self.flag), self.C, _lib.host_ptr(self.chunk_rows), self.n_own,
+        mu, flag = (self.masked, None) if self.masked is not None else (self.mu, self.flag)
+        rc = self._lib.dig_scale_suffstats_chunked(p(mu), p(flag), self.C, _lib.host_ptr(self.chunk_rows), self.n_own,
                                                    p(self.part), p(self.ws), self.wsb, _lib.stream_ptr(stream))
         if rc != 0:
             raise _lib.DigHipError("dig_scale_suffstats_chunked failed (%d): %s" % (rc, _lib.last_error()))

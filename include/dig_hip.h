@@ -258,7 +258,9 @@ int dig_gene_pipeline_host(const double *bin_mu, const double *bin_std, const in
  * all ranks are all-gathered in chunk order and added first to last; obs f64 [world, 2, C] hold every rank's observed
  * SNV / indel counts (integers).  Bit-identical scale factors for any number of ranks.
  *   chunk_rows int64 [n_chunks + 1], HOST memory: first row of every chunk in this rank's table (+ end); n_chunks <= 256;
- *   C <= 256.  workspace: dig_scale_suffstats_chunked_workspace(chunk_rows, n_chunks, C) bytes. */
+ *   C <= 256.  workspace: dig_scale_suffstats_chunked_workspace(chunk_rows, n_chunks, C) bytes.
+ *   bin_flag may be NULL (ABI 5): bin_mu then holds +0.0 in the flagged entries already (a plan-time copy saves the flag
+ *   bytes of every step); the same additions, the same bits. */
 int64_t dig_scale_suffstats_chunked_workspace(const int64_t *chunk_rows, int n_chunks, int64_t C);
 int dig_scale_suffstats_chunked(const double *bin_mu, const uint8_t *bin_flag, int64_t C, const int64_t *chunk_rows,
                                 int n_chunks, double *out_chunks, void *workspace, int64_t workspace_bytes, void *stream);

@@ -67,6 +67,39 @@ def engine_scale_local(w, dev):
     return engine.scale_factors_local(t(w["bin_mu"]), t(w["bin_flag"]), t(w["n_snv_obs"]), t(w["n_ind_obs"]))
 
 
+def test_premasked_rate_table_gives_the_same_scale_factors():
+    """ChunkedScaleFactorPlan sums a plan-time copy of Y_PRED that holds +0.0 in the flagged entries (bin_flag = NULL in
+    dig_scale_suffstats_chunked: 8 instead of 9 bytes per (bin, cohort) and step).  Same chunk sums, same scale factors, bit
+    for bit, as the plan that reads the flags every step; a table changed in place needs remask()."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine, parallel
+    dev = torch.device("cuda:0")
+    for (nb, C, seed) in ((40_000, 37, 3), (777, 1, 4), (5000, 100, 5)):
+        w = make_workload(n_bins=nb, n_elements=500, n_cohorts=C, seed=seed)
+        w["bin_mu"][::11] *= -1.0                          # (negative and zero rates: -0.0 + 0.0 must come out the same way too)
+        w["bin_mu"][5] = 0.0
+        t = lambda a: torch.as_tensor(a, device=dev)
+        rows = parallel.canonical_chunks(nb)
+        out = []
+        for premask in (False, True):
+            plan = engine.ChunkedScaleFactorPlan(t(w["bin_mu"]), t(w["bin_flag"]), t(w["n_snv_obs"]), t(w["n_ind_obs"]), rows,
+                                                 parallel.N_CHUNKS, world=1, premask=premask)
+            cj, cji = torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev)
+            plan.run(cj, cji)
+            out.append((plan.enqueue_part().clone(), cj.clone(), cji.clone(), plan))
+        torch.cuda.synchronize()
+        for a, b in zip(out[0][:3], out[1][:3]):
+            assert torch.equal(a, b), (nb, C)
+        plan = out[1][3]
+        plan.mu[: nb // 3] *= 2.0
+        plan.flag[1::5] ^= 1
+        plan.remask()
+        ref = engine.ChunkedScaleFactorPlan(plan.mu, plan.flag, t(w["n_snv_obs"]), t(w["n_ind_obs"]), rows, parallel.N_CHUNKS, world=1,
+                                            premask=False)
+        assert torch.equal(plan.enqueue_part(), ref.enqueue_part())
+
+
 def test_ragged_shards_and_single_cohort():
     """Bin counts that no rank count divides, one cohort (C = 1 takes the no-fastdiv path), elements spanning shard
     boundaries (long elements: up to 12 bins -> the halo is used and the stream kernel's long-element loop runs)."""
