@@ -84,4 +84,4 @@ def main(tag, known_suffstats_bytes):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 288000 * 37 * 9.0)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 288000 * 37 * 8.0)      # (round 3: the chunk sums read the pre-masked table, 8 B per entry; 9 before)
