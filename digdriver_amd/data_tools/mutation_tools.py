@@ -120,9 +120,8 @@ def bed12_boundaries(f_bed):
 # interval join (replaces `bedtools intersect -wa -wb` on mutations x bed6 blocks)
 # ---------------------------------------------------------------------------------------------
 def _chrom_key(chrom):
-    """Chromosome labels compare as strings in bedtools; normalise 'chr' prefixes like pybedtools callers do."""
-    s = np.asarray(chrom).astype(str)
-    return np.char.lstrip(s, 'chr') if len(s) and s.dtype.kind in 'US' else s
+    """Chromosome labels compare as text in bedtools: '1' and 'chr1' are different chromosomes."""
+    return np.asarray(chrom).astype(str)
 
 
 def _overlap_pairs(m_chrom, m_start, m_end, b_chrom, b_start, b_end):
@@ -198,14 +197,11 @@ def tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=False, drop_dup
     if drop_duplicates:
         ident = muts.iloc[mi, :5].reset_index(drop=True)
         hits = hits.loc[~pd.concat([ident, hits[['SAMPLE', 'ELT']]], axis=1).duplicated().values]
-    # counts per (element, sample); the reference merges its SNV table with its INDEL table (outer): SNV pairs first,
-    # each part in (ELT, SAMPLE) order
-    wide = hits.groupby(['ELT', 'SAMPLE', 'KIND']).size().unstack('KIND')
-    for kind in ('OBS_SNV', 'OBS_INDEL'):
-        if kind not in wide.columns:
-            wide[kind] = np.nan
-    with_snv = wide.OBS_SNV.notna()
-    wide = pd.concat([wide.loc[with_snv], wide.loc[~with_snv]]).fillna(0.0).reset_index()
+    # counts per (element, sample): the SNV table outer-joined with the INDEL table on (ELT, SAMPLE) (:219-222) -- the
+    # row order of the result is pandas' (key-sorted since pandas 2.2, SNV pairs first before)
+    snv = hits.loc[hits.KIND == 'OBS_SNV'].groupby(['ELT', 'SAMPLE']).size().reset_index(name='OBS_SNV')
+    ind = hits.loc[hits.KIND == 'OBS_INDEL'].groupby(['ELT', 'SAMPLE']).size().reset_index(name='OBS_INDEL')
+    wide = snv.merge(ind, how='outer').fillna({'OBS_SNV': 0.0, 'OBS_INDEL': 0.0})
     wide['OBS_MUT'] = wide.OBS_SNV + wide.OBS_INDEL
     return wide[out_cols].rename_axis(columns=None)
 

@@ -37,18 +37,21 @@ class ElementBlocks:
     @classmethod
     def from_bed12(cls, f_bed, device, names=None):
         """bed12 file -> blocks; element ids follow `names` (default: first appearance in the file).
-        Chromosome labels are normalised to integers (autosomes 1..22; others are dropped like bedtools would
-        never match them against integer-labelled autosomal mutations)."""
+        Chromosome labels are compared as TEXT, as bedtools does (mutation_tools.py:193-200): every label of the bed
+        file gets an id (`blocks.chrom_ids`, pass it to encode_mutations); '1' and 'chr1' are different chromosomes and
+        sex chromosomes are joined like any other."""
         import pandas as pd
         df = pd.read_csv(f_bed, sep="\t", header=None, low_memory=False, dtype={0: str})
         blocks = mutation_tools._bed12_to_bed6(df)
-        ch = blocks.CHROM.astype(str).str.replace("chr", "", regex=False)
-        keep = ch.isin([str(i) for i in range(1, 23)])
-        blocks, ch = blocks[keep], ch[keep].astype(int)
+        labels = blocks.CHROM.astype(str)
+        chrom_ids = {lab: i + 1 for i, lab in enumerate(dict.fromkeys(labels.tolist()))}
         if names is None:
             names = list(dict.fromkeys(df[3].tolist()))
         pos = {n: i for i, n in enumerate(names)}
-        return cls(ch.values, blocks.START.values, blocks.END.values, blocks.ELT.map(pos).values, len(names), device), names
+        obj = cls(labels.map(chrom_ids).values, blocks.START.values, blocks.END.values, blocks.ELT.map(pos).values,
+                  len(names), device)
+        obj.chrom_ids = chrom_ids
+        return obj, names
 
 
 def overlap_pairs(blocks, m_chrom, m_start, m_end):
@@ -72,14 +75,23 @@ def overlap_pairs(blocks, m_chrom, m_start, m_end):
     return pm[:total], pb[:total]
 
 
-def encode_mutations(df_mut, device, cohort_id=0):
+def encode_mutations(df_mut, device, cohort_id=0, chrom_ids=None):
     """Mutation frame (reference column names) -> device tensors.  Strings become dense integer ids on the host:
-    `uid` identifies (CHROM, START, END, REF, ALT) and `sample` the sample label, both exactly (no hashing)."""
+    `uid` identifies (CHROM, START, END, REF, ALT) and `sample` the sample label, both exactly (no hashing).
+    `chrom_ids`: label -> id of the block set the mutations will be joined with (ElementBlocks.from_bed12: labels
+    compared as text, rows on other chromosomes cannot hit anything and are dropped here).  Without it the blocks
+    carry the integer autosome numbers of a pretrained model (bed12_boundaries, mutation_tools.py:383-414) and the
+    mutation labels '1' ... '22' (optionally 'chr'-prefixed) are mapped onto them."""
     import pandas as pd
     import torch
-    ch = df_mut.CHROM.astype(str).str.replace("chr", "", regex=False)
-    keep = ch.isin([str(i) for i in range(1, 23)])
-    df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
+    if chrom_ids is not None:
+        ch = df_mut.CHROM.astype(str).map(chrom_ids)
+        keep = ch.notna()
+        df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
+    else:
+        ch = df_mut.CHROM.astype(str).str.replace("chr", "", regex=False)
+        keep = ch.isin([str(i) for i in range(1, 23)])
+        df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
     # exact ids of the distinct (CHROM, START, END, REF, ALT): the two string columns are factorized on their own (few
     # distinct alleles), then the five integer columns are grouped as rows (a MultiIndex factorize of the same columns
     # took 0.5 s per 200 000 mutations, 85 % of the many-cohort driver's wall time)

@@ -541,9 +541,10 @@ class ScaleFactorPlan:
         rc = lib.dig_scale_suffstats(self._args[0], self._args[1], self.N, self.C, _lib.dev_ptr(part[0]), self._ws, self.wsb, sp)
         if rc != 0:
             raise _lib.DigHipError("dig_scale_suffstats failed (%d): %s" % (rc, _lib.last_error()))
+        from . import parallel
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         parts = part
-        if world > 1:
+        if parallel.collectives_on(group):
             if getattr(self, "_parts", None) is None or self._parts.shape[0] != world:
                 self._parts = torch.empty((world, 3, self.C), dtype=torch.float64, device=part.device)
             dist.all_gather_into_tensor(self._parts, part, group=group)
@@ -645,6 +646,20 @@ def tiled_nb_test(pt, k, mu, sigma, device=0):
 # ---------------------------------------------------------------------------
 # per-base / tiled route: front half (dig_base_tile_probs + dig_tile_mut_counts) and the whole chain
 # ---------------------------------------------------------------------------
+TILE_CTX_MAX_POSITIONS = 12276      # what base_tile_probs_ctx_kernel<2> stages per region (dig_tiles.hip)
+
+
+def check_tile_regions(starts, ends, n_up):
+    """What every caller of dig_base_tile_probs_ctx with host-side coordinates must check (the device entry point sees
+    device pointers only): a region that starts inside (0, n_up) would fetch from a negative position -- the reference's
+    pysam fetch fails there too (sequence_tools.py:21-29)."""
+    st, en = np.asarray(starts, np.int64), np.asarray(ends, np.int64)
+    if st.size and n_up > 1 and int((en - st).max()) > TILE_CTX_MAX_POSITIONS:
+        raise ValueError("penta-nucleotide regions may hold at most %d positions" % TILE_CTX_MAX_POSITIONS)
+    if st.size and n_up > 1 and ((st > 0) & (st < n_up)).any():
+        raise ValueError("a region that starts at 1 would fetch from a negative position (the reference's pysam fetch fails too)")
+
+
 def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None, device=0):
     """Tile probabilities of regions of a PackedGenome for C cohorts at once (sequence_tools.py:292-317 + the tiling of
     nb_model.py:126-186).  s_prob: f64 [C, 64] (trinucleotide contexts, index 16 b0 + 4 b1 + b2) or [C, 1024]
@@ -665,11 +680,7 @@ def base_tile_probs(genome, chroms, starts, ends, s_prob, binsize, n_tiles=None,
     assert s_prob.dim() == 2 and s_prob.shape[1] in (64, 1024), "s_prob must be [C, 64] (trinucleotide) or [C, 1024] (penta-nucleotide)"
     C = s_prob.shape[0]
     n_up = 1 if s_prob.shape[1] == 64 else 2
-    if n_up == 2:
-        if R and int((en - st).max()) > 12280 - 4:
-            raise ValueError("penta-nucleotide regions may hold at most 12 276 positions")
-        if R and ((st > 0) & (st < n_up)).any():
-            raise ValueError("a region that starts at 1 would fetch from a negative position (the reference's pysam fetch fails too)")
+    check_tile_regions(st, en, n_up)
     words, off, ln = genome.on_device(dev)
     t = lambda a: torch.as_tensor(a, device=dev)
     rc, rs, re_ = t(ci), t(st), t(en)
@@ -760,7 +771,11 @@ class ChunkedScaleFactorPlan:
         self.part = torch.zeros((self.n_own + 2, self.C), dtype=torch.float64, device=dev)
         self.part[self.n_own] = _t(n_snv_obs, torch.float64, dev)
         self.part[self.n_own + 1] = _t(n_ind_obs, torch.float64, dev)
-        self.all = torch.empty((self.world, self.n_own + 2, self.C), dtype=torch.float64, device=dev) if self.world > 1 else None
+        # the exchange step: with more than one rank, or when parallel.FORCE_COLLECTIVES sends a world of one through RCCL too
+        from . import parallel
+        self.exchange = self.world == self.dist_world and parallel.collectives_on(group)
+        self.all = torch.empty((self.world, self.n_own + 2, self.C), dtype=torch.float64, device=dev) \
+            if (self.world > 1 or self.exchange) else None
         self.sums = torch.empty((self.n_total, self.C), dtype=torch.float64, device=dev)
         self.obs = torch.empty((self.world, 2, self.C), dtype=torch.float64, device=dev)
         self._lib = lib
@@ -810,7 +825,7 @@ class ChunkedScaleFactorPlan:
         import torch.distributed as dist
         assert self.world in (1, self.dist_world), "run() needs the process group the plan was built for"
         part = self.enqueue_part(stream)
-        if self.world > 1:
+        if self.exchange:
             with self._on(stream):
                 dist.all_gather_into_tensor(self.all, part, group=self.group)
             self.finish(self.all, cj, cj_indel, out_sum, stream)

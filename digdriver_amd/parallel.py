@@ -13,7 +13,33 @@ kfold_mutations_main.py:143).  The burden-test path shards naturally
 
 `torch.distributed` is used with backend "nccl" (= RCCL over xGMI) on GPUs and "gloo" in the CPU tests.
 """
+import os
+
 import numpy as np
+
+# DIG_FORCE_COLLECTIVES=1 (or parallel.FORCE_COLLECTIVES = True): every exchange step below goes through the process
+# group's backend even when the group has ONE rank -- a world of 1 normally skips them.  With backend "nccl" on one GPU
+# this is the check that the RCCL calls of the multi-GPU paths (arguments, device placement, stream ordering) work
+# (tests/test_gpu_rccl_world1.py); results must have the bits of the no-group path.
+FORCE_COLLECTIVES = os.environ.get("DIG_FORCE_COLLECTIVES") == "1"
+
+
+def collectives_on(group=None):
+    """Do the exchange steps run?  A process group exists and has more than one rank, or FORCE_COLLECTIVES."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
+def comm_device(device, group=None):
+    """Where tensors handed to a collective must live: `device` (a GPU) under the "nccl" (= RCCL) backend, the host
+    under "gloo"."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        return torch.device(device)
+    return torch.device("cpu")
 
 
 def bin_ranges(n_bins, world):
@@ -124,7 +150,7 @@ def rank_ordered_sum(t, group=None):
     """All-gather `t` from every rank and add the pieces in rank order: identical bits everywhere."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return t
     pieces = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(pieces, t.contiguous(), group=group)
@@ -148,7 +174,7 @@ def scale_factors_from_part(part, group=None, out=None):
     rank order and divides (dig_scale_factors); host tensors (the gloo tests) use the same arithmetic in torch."""
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         world = dist.get_world_size(group)
         parts = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
         if part.is_cuda:
@@ -170,7 +196,7 @@ def gather_to_rank0(t, group=None):
     """Variable-length row gather (result frames) to rank 0; returns the concatenation on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return t
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
@@ -192,7 +218,7 @@ def average_gradients(params, group=None):
     message instead of ~60 small ones) and divided by the world size.  No-op without a process group."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -221,7 +247,7 @@ def gather_visiting_order(t, n_rows, bs, group=None):
     them to the reference (kfold_mutations_main.py:143,177), not a 1/world sample."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return t
     world = dist.get_world_size(group)
     pos = [strided_positions(n_rows, bs, r, world) for r in range(world)]
@@ -241,7 +267,7 @@ def broadcast_module_buffers(module, src=0, group=None):
     running statistics of replica 0 only (the other replicas' updates are discarded), so this is the reference's
     semantics -- and it keeps eval-mode outputs, and therefore every epoch-selection decision, identical on all ranks."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return
     for b in module.buffers():
         dist.broadcast(b, src=src, group=group)
@@ -251,7 +277,7 @@ def broadcast_flag(value, device, src=0, group=None):
     """A yes/no decision taken on rank `src`, made known to every rank."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return bool(value)
     f = torch.tensor([1 if value else 0], dtype=torch.int32, device=device)
     dist.broadcast(f, src=src, group=group)
@@ -265,7 +291,7 @@ def chunked_scale_factors_reference(part, n_own, group=None):
     dig_scale_factors_chunked."""
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         world = dist.get_world_size(group)
         parts = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(parts, part.contiguous(), group=group)
@@ -294,7 +320,7 @@ def all_gather_rows(t, group=None):
     """Variable-length row all-gather: the concatenation, in rank order, of every rank's `t` (dim 0), on EVERY rank."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return t
     world = dist.get_world_size(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
@@ -341,6 +367,9 @@ class ShardedTiles:
             self.starts, self.ends = starts[sl], ends[sl]
         self.s_prob = np.asarray(s_prob, np.float64)
         self.C = self.s_prob.shape[0]
+        assert self.s_prob.ndim == 2 and self.s_prob.shape[1] in (64, 1024), "s_prob must be [C, 64] or [C, 1024]"
+        from . import engine
+        engine.check_tile_regions(starts[sl], ends[sl], 1 if self.s_prob.shape[1] == 64 else 2)   # TRUE coordinates
         self.mu = np.ascontiguousarray(np.asarray(mu, np.float64).reshape(self.C, R)[:, sl])
         self.sigma = np.ascontiguousarray(np.asarray(sigma, np.float64).reshape(self.C, R)[:, sl])
         # mutations that start inside the slab (a row counts in the tile that holds its START, nb_model.py:160-163)
@@ -416,42 +445,44 @@ class ShardedTiles:
         mask = t < r["n_valid"][:, None]
         return r["pval"][cohort][mask], mask
 
-    def q_values(self, cohort, gathered=None):
+    def q_values(self, cohort, gathered=None, offset=None):
         """Benjamini-Hochberg q-values (nb_model.get_q_vals) of the rank's tiles of one cohort among the tiles of ALL ranks:
-        [R_r, n_tiles], NaN where a bin has no such tile.  `gathered`: the concatenation of valid_pvalues() of all ranks in
-        rank order when the caller did the exchange (one-device walks); default: all_gather_rows over the process group."""
+        [R_r, n_tiles], NaN where a bin has no such tile.  Default: the exchange is all_gather_rows over the process group.
+        `gathered` + `offset`: the caller did the exchange (one-device rank walks) -- the concatenation of
+        valid_pvalues() of all ranks in rank order, and the position of THIS rank's first p-value in it."""
         import torch
         from .sequence_model import nb_model
         mine, mask = self.valid_pvalues(cohort)
-        counts = all_gather_rows(torch.tensor([mine.numel()], dtype=torch.int64, device=mine.device), self.group) \
-            if gathered is None else None
-        everything = all_gather_rows(mine.contiguous(), self.group) if gathered is None else gathered
         if gathered is None:
+            counts = all_gather_rows(torch.tensor([mine.numel()], dtype=torch.int64, device=mine.device), self.group)
+            everything = all_gather_rows(mine.contiguous(), self.group)
             before = int(counts[: self.rank].sum().item()) if counts.numel() > 1 else 0
         else:
-            before = int(self._offset_in(gathered))
+            if offset is None:
+                raise ValueError("q_values(gathered=...) needs offset= (where this rank's p-values start in `gathered`)")
+            everything, before = gathered, int(offset)
         q_all = nb_model.get_q_vals(everything) if everything.is_cuda else torch.as_tensor(nb_model.get_q_vals(everything.numpy()))
         out = torch.full(mask.shape, float("nan"), dtype=torch.float64, device=mine.device)
         out[mask] = q_all[before:before + mine.numel()]
         return out
 
-    def _offset_in(self, gathered):
-        return getattr(self, "offset", 0)
 
-
-def standardisation_stats(X, y, group=None):
+def standardisation_stats(X, y, group=None, comm=None):
     """Feature means / population standard deviations and label mean / std over the rows of ALL ranks -- what sklearn's
     StandardScaler and y.mean() / y.std() give the reference on the whole training set (gp_trainer.py:107-120) -- from
     this rank's rows X [n_r, d], y [n_r]: two passes (sums, then squared deviations from the global means), each ONE
     rank-ordered sum of d + 2 numbers (all-gather + first-to-last add: the same bits on every rank).  Zero-variance
-    columns keep scale 1.  Returns (mean [d], std [d], y_mean, y_std, n)."""
+    columns keep scale 1.  `comm`: device the two small vectors are exchanged on (comm_device(): the GPU under RCCL); the
+    arithmetic itself stays on the host in float64.  Returns (mean [d], std [d], y_mean, y_std, n)."""
     import torch
     X = torch.as_tensor(np.ascontiguousarray(X), dtype=torch.float64)
     y = torch.as_tensor(np.ascontiguousarray(y), dtype=torch.float64).reshape(-1)
-    s1 = rank_ordered_sum(torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64), X.sum(0), y.sum().reshape(1)]), group)
+    comm = torch.device("cpu") if comm is None else comm
+    total = lambda v: rank_ordered_sum(v.to(comm), group).cpu()
+    s1 = total(torch.cat([torch.tensor([float(X.shape[0])], dtype=torch.float64), X.sum(0), y.sum().reshape(1)]))
     n = float(s1[0])
     mean, y_mean = s1[1:-1] / n, s1[-1] / n
-    s2 = rank_ordered_sum(torch.cat([((X - mean) ** 2).sum(0), ((y - y_mean) ** 2).sum().reshape(1)]), group)
+    s2 = total(torch.cat([((X - mean) ** 2).sum(0), ((y - y_mean) ** 2).sum().reshape(1)]))
     std = torch.sqrt(s2[:-1] / n)
     std = torch.where(std == 0, torch.ones_like(std), std)
     return mean.numpy(), std.numpy(), float(y_mean), float(torch.sqrt(s2[-1] / n)), int(n)
@@ -462,7 +493,7 @@ def broadcast_state(state, idx_feat, device, comm_device, src=0, group=None, dty
     rank: shapes first (the receivers do not know m or d), then the payload as one flat buffer."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return state, idx_feat
     keys = ("Z", "L", "LB", "c", "scalars")
     rank = dist.get_rank(group)

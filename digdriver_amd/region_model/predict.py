@@ -77,8 +77,8 @@ def predict_sharded(model, store, bin_rows, labels=None, batch_size=2048, group=
     pos = [np.flatnonzero(owner == r) for r in range(world)]
     p, f, _ = predict(model, store, bin_rows[pos[rank]], labels=None, batch_size=batch_size, **kw)
     C = p.shape[0]
-    if world > 1:
-        dev = next(model.parameters()).device if (on and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    if world > 1 or parallel.collectives_on(group):
+        dev = parallel.comm_device(next(model.parameters()).device, group)
         flat = torch.cat([torch.as_tensor(p.T, dtype=torch.float32), torch.as_tensor(f.transpose(1, 0, 2).reshape(len(pos[rank]), C * 16),
                                                                                   dtype=torch.float32)], dim=1).to(dev)
         everything = parallel.all_gather_rows(flat.contiguous(), group).cpu().numpy()       # rows in rank order

@@ -368,11 +368,11 @@ def run_gp_sharded(device, train_tup, val_tup, heldout_tup, group=None, src=0, n
     Returns (results, means, stds) as run_gp does, for the rank's own held-out rows."""
     import torch.distributed as dist
     from ... import parallel
-    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    on = parallel.collectives_on(group)
     rank = dist.get_rank(group) if on else 0
     tx, ty = np.asarray(train_tup[0], float), np.asarray(train_tup[1], float)
-    mean, std, y_mean, y_std, _ = parallel.standardisation_stats(tx, ty, group)
-    comm = device if (on and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    comm = parallel.comm_device(device, group) if on else torch.device("cpu")
+    mean, std, y_mean, y_std, _ = parallel.standardisation_stats(tx, ty, group, comm=comm)
     gather = lambda a: parallel.all_gather_rows(torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=comm), group).cpu().numpy()
     all_tx, all_ty = gather(tx), gather(ty)
     vy_all, hy_all = gather(np.asarray(val_tup[1], float)), gather(np.asarray(heldout_tup[1], float))

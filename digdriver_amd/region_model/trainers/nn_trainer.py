@@ -76,7 +76,7 @@ class NNTrainer:
         # visiting order (the GP is fitted on the activations of ALL training rows, kfold_mutations_main.py:177), take
         # rank 0's BatchNorm running statistics (what nn.DataParallel keeps) and average the per-batch scores.
         n_rows = len(order)
-        if self.world > 1:
+        if self.world > 1 or parallel.collectives_on(self.group):
             whole = lambda v, width: parallel.gather_visiting_order(
                 torch.cat(v) if v else torch.zeros((0,) + width, dtype=torch.float32, device=self.device), n_rows, self.bs, self.group)
             feats = [[whole(f, (16,))] for f in feats]

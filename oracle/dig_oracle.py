@@ -455,3 +455,101 @@ def apply_nb_to_region(chrom_seq, s_prob64, start, end, mu, sigma, mut_starts, b
         ex.append(pt * mu)
         pts.append(pt)
     return np.array(pv), np.array(ps), np.array(ob), np.array(ex), np.array(pts)
+
+
+# --------------------------------------------------------------------------
+# mutation x element-block interval join and integer tabulation
+# (mutation_tools.py:155-230; the join itself is `bedtools intersect -wa -wb`, a third-party binary:
+#  bedtools 2.30.0 / pybedtools 0.8.1 in conda-recipe/meta.yaml:47,65, absent from this image)
+# --------------------------------------------------------------------------
+def bed12_blocks(bed_rows):
+    """`bedtools bed12tobed6` (mutation_tools.py:196-197): one (chrom, start, end, name, strand) row per block of every
+    bed12 row, in file order; blockSizes / blockStarts are comma lists with an optional trailing comma."""
+    out = []
+    for row in bed_rows:
+        chrom, start, name, strand = row[0], int(row[1]), row[3], row[5]
+        sizes = [int(x) for x in str(row[10]).split(",") if x != ""]
+        rel = [int(x) for x in str(row[11]).split(",") if x != ""]
+        for s, z in zip(rel, sizes):
+            out.append((chrom, start + s, start + s + z, name, strand))
+    return out
+
+
+def _chrom_label(c):
+    """bedtools compares chromosome labels as text: '1' and 'chr1' are different chromosomes (the reference hands both
+    files to bedtools as they are, mutation_tools.py:193-200)."""
+    return str(c)
+
+
+def interval_join_pairs(m_chrom, m_start, m_end, b_chrom, b_start, b_end):
+    """`bedtools intersect -wa -wb` of mutations (A) with element blocks (B), restated from bedtools' published
+    definition of an overlap: same chromosome and at least one shared base of the half-open intervals,
+        a.start < b.end  and  b.start < a.end.
+    One output pair per (mutation, overlapped block), mutation-major in the order of the mutation file
+    (mutation_tools.py:200); blocks may overlap or nest each other and every hit is reported.
+    A zero-length feature (start == end) is given the one base [start, start + 1): the reference's annotated mutation
+    files hold 1-bp SNV rows and longer indel rows only, and bedtools' own treatment of zero-length records cannot be
+    run here -- parity unpinned for that corner, stated in tests/golden/make_golden.py::gen_tabulate as well.
+    Plain loop over mutations; returns two int64 arrays (mutation row, block row), blocks ascending per mutation."""
+    b_lab = np.array([_chrom_label(c) for c in b_chrom], dtype=object)
+    b_start = np.asarray(b_start, np.int64)
+    b_end = np.asarray(b_end, np.int64)
+    b_end = np.where(b_end == b_start, b_start + 1, b_end)
+    by_chrom = {}
+    for j, c in enumerate(b_lab):
+        by_chrom.setdefault(c, []).append(j)
+    by_chrom = {c: np.array(v, np.int64) for c, v in by_chrom.items()}
+    mi, bi = [], []
+    for i in range(len(m_chrom)):
+        rows = by_chrom.get(_chrom_label(m_chrom[i]))
+        if rows is None:
+            continue
+        s, e = int(m_start[i]), int(m_end[i])
+        if e == s:
+            e = s + 1
+        hit = rows[(s < b_end[rows]) & (b_start[rows] < e)]
+        mi.extend([i] * len(hit))
+        bi.extend(hit.tolist())
+    return np.array(mi, np.int64), np.array(bi, np.int64)
+
+
+def tabulate_elements(mut_rows, block_rows, drop_duplicates=False, max_muts_per_sample=1e9,
+                      max_muts_per_elt_per_sample=3e9):
+    """tabulate_muts_per_sample_per_element + tabulate_mutations_in_element (mutation_tools.py:191-230, 155-189) on
+    in-memory rows, with dictionaries and loops only.
+      mut_rows:   mutation-file rows, columns 0..9 = CHROM, START, END, REF, ALT, SAMPLE, GENE, ANNOT, MUT_TYPE, CONTEXT
+      block_rows: (chrom, start, end, name, ...) bed6 rows (bed12_blocks for a bed12 file)
+    Steps: join (:200); duplicates of (chrom, start, end, ref, alt, sample, element) dropped, first kept (:207-208);
+    ANNOT != 'INDEL' counts as SNV (:211-213); counts per (element, sample) (:219-227); samples whose counts summed over
+    all elements exceed max_muts_per_sample are removed (:163-166); the per-(element, sample) counts are capped
+    (:169-170); per element OBS_SAMPLES = number of remaining (element, sample) rows, OBS_SNV / OBS_INDEL = sums
+    (:172-174).  Returns (per_pair, per_element, blacklist):
+      per_pair    {(element, sample): [OBS_SNV, OBS_INDEL]}   before blacklist and cap  (= the frame of :191-230)
+      per_element {element: (OBS_SAMPLES, OBS_SNV, OBS_INDEL)}  only elements with a remaining row
+      blacklist   sorted sample labels."""
+    mi, bi = interval_join_pairs([r[0] for r in mut_rows], [r[1] for r in mut_rows], [r[2] for r in mut_rows],
+                                 [b[0] for b in block_rows], [b[1] for b in block_rows], [b[2] for b in block_rows])
+    seen = set()
+    per_pair = {}
+    for i, j in zip(mi.tolist(), bi.tolist()):
+        m, elt = mut_rows[i], block_rows[j][3]
+        if drop_duplicates:
+            key = (_chrom_label(m[0]), int(m[1]), int(m[2]), str(m[3]), str(m[4]), str(m[5]), elt)
+            if key in seen:
+                continue
+            seen.add(key)
+        cell = per_pair.setdefault((elt, str(m[5])), [0, 0])
+        cell[1 if m[7] == "INDEL" else 0] += 1
+    load = {}
+    for (elt, sample), (snv, ind) in per_pair.items():
+        load[sample] = load.get(sample, 0) + snv + ind
+    blacklist = sorted(s for s, n in load.items() if n > max_muts_per_sample)
+    per_element = {}
+    for (elt, sample), (snv, ind) in per_pair.items():
+        if sample in blacklist:
+            continue
+        acc = per_element.setdefault(elt, [0, 0, 0])
+        acc[0] += 1
+        acc[1] += min(snv, max_muts_per_elt_per_sample)
+        acc[2] += min(ind, max_muts_per_elt_per_sample)
+    return per_pair, {k: tuple(int(x) for x in v) for k, v in per_element.items()}, blacklist

@@ -1079,7 +1079,146 @@ def gen_sites():
     print("wrote sites_golden.json", len(out["elements"]), len(tab))
 
 
+# ----------------------------------------------------------------------------
+# (xx) mutation x element tabulation (mutation_tools.py:155-230)
+# ----------------------------------------------------------------------------
+class _StandInBedTool:
+    """Stand-in for pybedtools.BedTool -- pybedtools and the bedtools binary are absent from this image.  It holds the
+    rows of a tab-separated file and offers exactly what tabulate_muts_per_sample_per_element calls.  THE ONLY PART OF
+    THE ROUTE THAT IS NOT THE REFERENCE'S OWN CODE IS `intersect`: a brute-force restatement of `bedtools intersect
+    -wa -wb` (same chromosome label as text, half-open overlap a.start < b.end and b.start < a.end, one output row =
+    the A fields followed by the B fields, A in file order).  Everything after the join -- the duplicate drop, the
+    SNV / INDEL split, the (element, sample) counts, the blacklist, the caps, the per-element summary -- is executed by
+    the reference's functions unmodified.  Inputs hold no zero-length records (bedtools' handling of those cannot be
+    checked here)."""
+
+    def __init__(self, src):
+        if isinstance(src, str):
+            with open(src) as f:
+                self.rows = [ln.rstrip("\n").split("\t") for ln in f if ln.strip()]
+        else:
+            self.rows = [list(r) for r in src]
+
+    def bed12tobed6(self):
+        out = []
+        for r in self.rows:
+            start = int(r[1])
+            sizes = [int(x) for x in r[10].split(",") if x != ""]
+            rel = [int(x) for x in r[11].split(",") if x != ""]
+            for s, z in zip(rel, sizes):
+                out.append([r[0], str(start + s), str(start + s + z), r[3], r[4], r[5]])
+        return _StandInBedTool(out)
+
+    def intersect(self, other, wa=False, wb=False, **kw):
+        assert wa and wb and not kw
+        out = []
+        for a in self.rows:
+            a_s, a_e = int(a[1]), int(a[2])
+            assert a_e > a_s
+            for b in other.rows:
+                b_s, b_e = int(b[1]), int(b[2])
+                assert b_e > b_s
+                if a[0] == b[0] and a_s < b_e and b_s < a_e:
+                    out.append(a + b)
+        return _StandInBedTool(out)
+
+    def __len__(self):
+        return len(self.rows)
+
+    def field_count(self):
+        return len(self.rows[0])
+
+    def to_dataframe(self, **kw):
+        # pybedtools: pandas.read_csv(self.fn, sep="\t", **kw)
+        text = "".join("\t".join(r) + "\n" for r in self.rows)
+        return pd.read_csv(io.StringIO(text), sep="\t", **kw)
+
+
+def gen_tabulate():
+    """tabulate_muts_per_sample_per_element and tabulate_mutations_in_element run by the reference itself on a seeded
+    mutation file and a bed12 file (blocks of different elements overlap and nest; indels span two blocks of one
+    element; mutations annotated twice; an X chromosome), with `pybedtools.BedTool` = _StandInBedTool above."""
+    import gzip
+    import tempfile
+    import warnings
+    warnings.simplefilter("ignore")
+    rng = np.random.default_rng(191)
+    sys.modules["pybedtools"].BedTool = _StandInBedTool
+    ref_mt.pybedtools = sys.modules["pybedtools"]
+    chroms = ["1", "2", "3", "4", "X"]
+    bed, spans = [], []
+    for i in range(160):
+        c = chroms[int(rng.integers(0, len(chroms)))] if i % 10 else "X"
+        nb = int(rng.integers(1, 5))
+        if i % 7 == 3 and spans:                                   # nested inside / overlapping an earlier element
+            c, s0, e0 = spans[int(rng.integers(0, len(spans)))]
+            start = int(rng.integers(s0, max(s0 + 1, e0 - 50)))
+        else:
+            start = int(rng.integers(1000, 60000))
+        sizes = rng.integers(20, 400, nb)
+        gaps = rng.integers(1, 120, nb)
+        rel = np.concatenate([[0], np.cumsum(sizes + gaps)[:-1]])
+        end = start + int(rel[-1] + sizes[-1])
+        spans.append((c, start, end))
+        trail = "," if i % 3 == 0 else ""
+        bed.append([c, start, end, "E%03d" % i, 0, "+-"[i % 2], start, start, ".", nb,
+                    ",".join(map(str, sizes)) + trail, ",".join(map(str, rel)) + trail])
+    blocks = [(r[0], r[1] + int(x), r[1] + int(x) + int(z)) for r in bed
+              for x, z in zip(str(r[11]).rstrip(",").split(","), str(r[10]).rstrip(",").split(","))]
+    rows = []
+    for _ in range(3500):
+        c, s, e = blocks[int(rng.integers(0, len(blocks)))]
+        p = int(rng.integers(max(s - 40, 0), e + 40))
+        smp = "S%02d" % int(min(rng.geometric(0.12), 30))            # a few heavy samples: the blacklist has work to do
+        u = rng.uniform()
+        if u < 0.12:                                                 # indels, some long enough to span a gap between blocks
+            ln = int(rng.integers(2, 140))
+            rows.append([c, p, p + ln, "A" * min(ln, 5), "A", smp, "G%d" % rng.integers(0, 9), "INDEL", "DEL", "."])
+        else:
+            rows.append([c, p, p + 1, "ACGT"[int(rng.integers(0, 4))], "ACGT"[int(rng.integers(0, 4))], smp,
+                         "G%d" % rng.integers(0, 9), ["Noncoding", "Missense", "Synonymous"][int(rng.integers(0, 3))], "A>T", "CAG"])
+    for i in rng.integers(0, len(rows), 250):                        # same mutation under a second gene annotation
+        r = list(rows[int(i)]); r[6] = "H" + r[6]; rows.append(r)
+    for i in rng.integers(0, len(rows), 60):                         # exact duplicate rows
+        rows.append(list(rows[int(i)]))
+    rows.append(["7", 5, 6, "A", "T", "S01", ".", "Noncoding", "A>T", "CAG"])      # chromosome without elements
+    tmp = tempfile.mkdtemp()
+    f_mut, f_bed = os.path.join(tmp, "m.tsv"), os.path.join(tmp, "e.bed")
+    pd.DataFrame(rows).to_csv(f_mut, sep="\t", header=False, index=False)
+    pd.DataFrame(bed).to_csv(f_bed, sep="\t", header=False, index=False)
+    out = {"note": "outputs of the reference's tabulate_* functions; only pybedtools' intersect was replaced by a "
+                   "brute-force half-open overlap join (see _StandInBedTool in make_golden.py)",
+           "mut_rows": [list(map(str, r)) for r in rows], "bed_rows": [list(map(str, r)) for r in bed], "cases": []}
+    for dd in (False, True):
+        cnt = ref_mt.tabulate_muts_per_sample_per_element(f_mut, f_bed, bed12=True, drop_duplicates=dd)
+        out["per_pair_dedup" if dd else "per_pair"] = dict(
+            ELT=cnt.ELT.tolist(), SAMPLE=cnt.SAMPLE.tolist(), OBS_SNV=cnt.OBS_SNV.astype(int).tolist(),
+            OBS_INDEL=cnt.OBS_INDEL.astype(int).tolist(), OBS_MUT=cnt.OBS_MUT.astype(int).tolist())
+        for caps in ((1e9, 3e9), (60, 2), (25, 1)):
+            for all_elements in (False, True):
+                tab, black = ref_mt.tabulate_mutations_in_element(
+                    f_mut, f_bed, bed12=True, drop_duplicates=dd, all_elements=all_elements,
+                    max_muts_per_sample=caps[0], max_muts_per_elt_per_sample=caps[1], return_blacklist=True)
+                out["cases"].append(dict(
+                    drop_duplicates=dd, max_muts_per_sample=caps[0], max_muts_per_elt_per_sample=caps[1],
+                    all_elements=all_elements, index=[str(i) for i in tab.index], columns=list(tab.columns),
+                    OBS_SAMPLES=tab.OBS_SAMPLES.astype(int).tolist(), OBS_SNV=tab.OBS_SNV.astype(int).tolist(),
+                    OBS_INDEL=tab.OBS_INDEL.astype(int).tolist(), blacklist=sorted(str(b) for b in black)))
+    # the empty intersection (mutation_tools.py:201-202)
+    f_none = os.path.join(tmp, "none.tsv")
+    pd.DataFrame(rows[-1:]).to_csv(f_none, sep="\t", header=False, index=False)
+    empty = ref_mt.tabulate_mutations_in_element(f_none, f_bed, bed12=True)
+    out["empty_columns"], out["empty_len"] = list(empty.columns), int(len(empty))
+    with gzip.GzipFile(os.path.join(HERE, "tabulate_golden.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
+    print("wrote tabulate_golden.json.gz", len(rows), "mutations", len(bed), "elements",
+          len(out["per_pair"]["ELT"]), "pairs", [len(c["blacklist"]) for c in out["cases"]])
+
+
 def main():
+    if "--only-tabulate" in sys.argv:
+        gen_tabulate()
+        return
     if "--only-contexts" in sys.argv:
         gen_contexts()
         return
@@ -1122,6 +1261,7 @@ def main():
     gen_tiled_penta()
     gen_run_element_expectation()
     gen_run_target()
+    gen_tabulate()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

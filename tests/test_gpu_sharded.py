@@ -114,3 +114,97 @@ def test_ragged_shards_and_single_cohort():
         assert torch.equal(got["cj"], base["cj"])
         assert torch.equal(torch.nan_to_num(stats, nan=-7.0), torch.nan_to_num(stats1, nan=-7.0))
         assert torch.equal(acc["MU"], acc1["MU"]) and torch.equal(acc["P"], acc1["P"]) and halo > 0
+
+
+def _walk_against_unsharded_and_oracle(w, world, dev, n_per_shard, min_halo_elts):
+    """The `world` ranks of a plan walked on one device: bits of the unsharded run; then every halo element (one that reads
+    a neighbour's bins; at most 200 per shard) and `n_per_shard` others per shard against the ORACLE on the global tables."""
+    import torch
+    from conftest import rel_close
+    from digdriver_amd import engine, parallel
+    from oracle import dig_oracle as O
+    N, C = w["bin_mu"].shape
+    base, stats1, acc1, _ = _run_world(w, 1, dev)
+    got, stats, acc, halo = _run_world(w, world, dev)
+    assert torch.equal(got["cj"], base["cj"]) and torch.equal(got["cj_indel"], base["cj_indel"])
+    assert torch.equal(torch.nan_to_num(stats, nan=-7.0), torch.nan_to_num(stats1, nan=-7.0))
+    for k in acc1:
+        assert torch.equal(acc[k], acc1[k]), k
+    plans = parallel.plan_shards(w["ov_ptr"], w["ov_idx"], N, world)
+    ranges = parallel.bin_ranges(N, world)
+    rng = np.random.default_rng(8)
+    pick, n_halo_elts = [], 0
+    for p, (lo, hi) in zip(plans, ranges):
+        elts = p["elements"]
+        assert len(elts) > 0.8 * len(w["L"]) / world                  # every shard holds about its share of the elements
+        rows = p["bin_rows"][p["ov_idx"]]                             # global bin rows of the shard's CSR
+        foreign = (rows < lo) | (rows >= hi)
+        owner_of_entry = np.repeat(np.arange(len(elts)), np.diff(p["ov_ptr"]))
+        halo_elts = elts[np.unique(owner_of_entry[foreign])]          # elements that need a neighbour's bins
+        n_halo_elts += len(halo_elts)
+        rest = np.setdiff1d(elts, halo_elts)
+        pick.append(np.concatenate([halo_elts[:200], rng.choice(rest, n_per_shard, replace=False)]))
+    assert n_halo_elts >= min_halo_elts and halo >= 1
+    pick = np.sort(np.concatenate(pick))
+    ptr = np.concatenate([[0], np.cumsum(np.diff(w["ov_ptr"])[pick])])
+    idx = np.concatenate([w["ov_idx"][w["ov_ptr"][e]:w["ov_ptr"][e + 1]] for e in pick])
+    want = O.accumulate_elements(w["bin_mu"], w["bin_std"], w["bin_y"], w["bin_flag"], w["bin_ctx"], ptr, idx, w["L"][pick],
+                                 w["strand_minus"][pick].astype(bool), w["d_pr"])
+    pk = torch.as_tensor(pick, device=dev)
+    np.testing.assert_allclose(acc["MU"][pk].cpu().numpy(), want["MU"], rtol=1e-12)
+    np.testing.assert_allclose(acc["SIGMA"][pk].cpu().numpy(), want["SIGMA"], rtol=1e-12)
+    rel_close(acc["P"][pk].cpu().numpy(), want["P"], 1e-11)
+    for k in ("R_OBS", "FLAG", "R_SIZE", "ELT_SIZE"):
+        assert np.array_equal(acc[k][pk].cpu().numpy(), want[k]), k
+    cj_o, cji_o = zip(*[O.scale_factor_genome(w["bin_mu"][:, c], w["bin_flag"][:, c], w["n_snv_obs"][c], w["n_ind_obs"][c])
+                        for c in range(C)])
+    np.testing.assert_allclose(got["cj"].cpu().numpy(), np.array(cj_o), rtol=1e-12)
+    np.testing.assert_allclose(got["cj_indel"].cpu().numpy(), np.array(cji_o), rtol=1e-12)
+    ref_st = O.element_stats(want["MU"], want["SIGMA"], want["P"][:, 0, :], want["P_INDEL"][:, None], w["obs_snv"][pick],
+                             w["obs_samples"][pick], w["obs_indel"][pick], np.array(cj_o)[None, :], np.array(cji_o)[None, :])
+    st_h = stats[:, pk].cpu().numpy()
+    for j, name in enumerate(engine.ES_PLANES):
+        rel_close(st_h[j], ref_st[name], rtol=1e-6)
+    return len(pick), n_halo_elts
+
+
+def _plant_boundary_elements(w, world, per_boundary, seed=5):
+    """Re-point the overlapped-bin lists of `per_boundary` multi-bin elements per inner shard boundary to consecutive bins
+    that straddle it (the first bin stays on the left: the element belongs to the left rank and reads the right rank's
+    bins through the halo).  Only the CSR entries change; every other input keeps its value."""
+    rng = np.random.default_rng(seed)
+    N = w["bin_mu"].shape[0]
+    nov = np.diff(w["ov_ptr"])
+    cand = rng.permutation(np.flatnonzero(nov >= 2))
+    n = 0
+    for r, (lo, hi) in enumerate(parallel_bin_ranges(N, world)[:-1]):
+        for e in cand[n:n + per_boundary]:
+            k = int(nov[e])
+            j0 = int(rng.integers(1, k))                       # bins on the left of the boundary: 1 .. k - 1
+            w["ov_idx"][w["ov_ptr"][e]:w["ov_ptr"][e + 1]] = hi - j0 + np.arange(k)
+        n += per_boundary
+    return n
+
+
+def parallel_bin_ranges(n_bins, world):
+    from digdriver_amd import parallel
+    return parallel.bin_ranges(n_bins, world)
+
+
+@pytest.mark.timeout(1500)
+def test_configs3_full_size_eight_way_walk_with_oracle_sample():
+    """BASELINE configs[3] at FULL size -- 288 000 bins x 37 cohorts x 120 091 elements, bin-sharded 8 ways (strong mode:
+    one genome, one element set) -- the eight ranks walked on one device: every output, scale factors included, has the
+    bits of the unsharded run, and > 1 000 elements spread over all eight shards agree with the ORACLE evaluated on the
+    unsharded global tables.  The bench workload's short elements cross a shard boundary once or twice per genome, so a
+    second whole-genome walk uses long elements (up to 12 blocks) of which 40 per inner boundary are moved across it:
+    280 halo elements, all checked."""
+    import torch
+    from bench import make_workload
+    dev = torch.device("cuda:0")
+    n, n_halo = _walk_against_unsharded_and_oracle(make_workload(288_000, 120_091, 37, seed=3), 8, dev, 130, 1)
+    assert n >= 1040
+    w = make_workload(288_000, 40_009, 37, seed=4, max_blocks=12)
+    planted = _plant_boundary_elements(w, 8, 40)
+    n, n_halo = _walk_against_unsharded_and_oracle(w, 8, dev, 40, planted)
+    assert n_halo >= 7 * 40

@@ -149,3 +149,30 @@ def test_get_q_vals_equals_statsmodels():
     g = json.load(open(os.path.join(GOLDEN, "qvals_golden.json")))
     assert np.array_equal(nb_model.get_q_vals(np.array(g["p"])), np.array(g["q"]))
     assert nb_model.get_q_vals([]).size == 0
+
+
+def test_tabulation_matches_the_reference_functions(tmp_path):
+    """mutation_tools.tabulate_* of this package against the frames the reference's functions returned on the same
+    files (tests/golden/tabulate_golden.json.gz: only pybedtools' intersect was stood in for): row order, column order,
+    index, counts and blacklist."""
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "tabulate_golden.json.gz"), "rt") as f:
+        g = json.load(f)
+    f_mut, f_bed = tmp_path / "m.tsv", tmp_path / "e.bed"
+    f_mut.write_text("".join("\t".join(r) + "\n" for r in g["mut_rows"]))
+    f_bed.write_text("".join("\t".join(r) + "\n" for r in g["bed_rows"]))
+    for dd in (False, True):
+        cnt = mt.tabulate_muts_per_sample_per_element(str(f_mut), str(f_bed), bed12=True, drop_duplicates=dd)
+        want = g["per_pair_dedup" if dd else "per_pair"]
+        assert list(cnt.columns) == ['ELT', 'SAMPLE', 'OBS_SNV', 'OBS_INDEL', 'OBS_MUT']
+        for col in cnt.columns:
+            assert cnt[col].tolist() == want[col], (dd, col)
+    for case in g["cases"]:
+        tab, black = mt.tabulate_mutations_in_element(
+            str(f_mut), str(f_bed), bed12=True, drop_duplicates=case["drop_duplicates"], all_elements=case["all_elements"],
+            max_muts_per_sample=case["max_muts_per_sample"], max_muts_per_elt_per_sample=case["max_muts_per_elt_per_sample"],
+            return_blacklist=True)
+        assert sorted(str(b) for b in black) == case["blacklist"]
+        assert [str(i) for i in tab.index] == case["index"] and list(tab.columns) == case["columns"]
+        for col in ("OBS_SAMPLES", "OBS_SNV", "OBS_INDEL"):
+            assert tab[col].astype(int).tolist() == case[col], (case, col)

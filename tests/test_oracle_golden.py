@@ -317,3 +317,49 @@ def test_per_base_front_half_oracle_vs_reference_nb_model():
             np.testing.assert_allclose(pt, run["Pi"], rtol=1e-14, atol=0)
             np.testing.assert_allclose(ex, run["EXP"], rtol=1e-14, atol=0)
             rel_close(pv, np.array(run["PVAL"]), rtol=1e-12)
+
+
+def _tabulate_golden():
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "tabulate_golden.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def test_oracle_tabulation_is_the_reference_tabulation():
+    """oracle.interval_join_pairs + tabulate_elements against the reference's own tabulate_muts_per_sample_per_element /
+    tabulate_mutations_in_element (mutation_tools.py:155-230; only pybedtools' intersect was stood in for when the
+    golden was made): the (element, sample) count frame and every per-element summary, bit-exact."""
+    g = _tabulate_golden()
+    muts = [[r[0], int(r[1]), int(r[2])] + r[3:] for r in g["mut_rows"]]
+    blocks = O.bed12_blocks(g["bed_rows"])
+    bed_names = [r[3] for r in g["bed_rows"]]
+    for dd in (False, True):
+        per_pair, _, _ = O.tabulate_elements(muts, blocks, drop_duplicates=dd)
+        want = g["per_pair_dedup" if dd else "per_pair"]
+        want_map = {(e, s): (a, b) for e, s, a, b in zip(want["ELT"], want["SAMPLE"], want["OBS_SNV"], want["OBS_INDEL"])}
+        assert len(want_map) == len(want["ELT"])
+        assert {k: tuple(v) for k, v in per_pair.items()} == want_map
+        assert [a + b for a, b in want_map.values()] == want["OBS_MUT"]
+    assert sum(c["drop_duplicates"] for c in g["cases"]) == 6
+    for case in g["cases"]:
+        _, per_elt, black = O.tabulate_elements(muts, blocks, drop_duplicates=case["drop_duplicates"],
+                                                max_muts_per_sample=case["max_muts_per_sample"],
+                                                max_muts_per_elt_per_sample=case["max_muts_per_elt_per_sample"])
+        assert black == case["blacklist"]
+        got = {e: per_elt.get(e, (0, 0, 0)) for e in bed_names} if case["all_elements"] else per_elt
+        want = dict(zip(case["index"], zip(case["OBS_SAMPLES"], case["OBS_SNV"], case["OBS_INDEL"])))
+        assert got == want
+    # the cases are not trivial: duplicates change counts, the caps bite, samples are blacklisted
+    a, b = g["per_pair"], g["per_pair_dedup"]
+    assert sum(a["OBS_MUT"]) > sum(b["OBS_MUT"]) and max(b["OBS_SNV"]) > 2 and max(b["OBS_INDEL"]) >= 1
+    assert any(c["blacklist"] for c in g["cases"])
+
+
+def test_oracle_interval_join_edges():
+    """Half-open on both sides, text chromosome labels, nested blocks, the 1-bp convention for zero-length records."""
+    mi, bi = O.interval_join_pairs(["1"] * 4, [99, 100, 199, 200], [100, 101, 200, 201], ["1"], [100], [200])
+    assert mi.tolist() == [1, 2] and bi.tolist() == [0, 0]
+    mi, bi = O.interval_join_pairs(["1", "chr1", "2"], [10, 10, 10], [11, 11, 11], ["1", "1", "chr1"], [0, 5, 0], [50, 20, 50])
+    assert list(zip(mi.tolist(), bi.tolist())) == [(0, 0), (0, 1), (1, 2)]
+    mi, bi = O.interval_join_pairs(["1", "1"], [7, 20], [7, 20], ["1", "1"], [7, 3], [7, 20])
+    assert list(zip(mi.tolist(), bi.tolist())) == [(0, 0), (0, 1)]
