@@ -217,7 +217,10 @@ class SparseGP(torch.nn.Module):
         with torch.no_grad():
             L, A, LB, r, c = self._factor()
             scal = torch.stack([self.lengthscale, self.outputscale, self.noise, self.mean_const]).detach()
-            return dict(Z=self.inducing_points.detach().clone(), L=L.detach(), LB=LB.detach(), c=c.detach(), scalars=scal)
+            # row-major copies: the factorisation routines hand back column-major factors, and a predictor that went through
+            # broadcast_state (a flat buffer) is row-major -- with one layout both predict with the same kernels and bits
+            return dict(Z=self.inducing_points.detach().clone().contiguous(), L=L.detach().contiguous(),
+                        LB=LB.detach().contiguous(), c=c.detach().contiguous(), scalars=scal.contiguous())
 
     @staticmethod
     @torch.no_grad()

@@ -158,6 +158,7 @@ def main(port, out_path):
     same = lambda a, b: bool(np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[0][0]["r2"] == b[0][0]["r2"]
                              and a[0][1]["val"]["r2"] == b[0][1]["val"]["r2"])
     report["gp_fit_is_deterministic"] = same(runs[False], runs["again"])
+    report["gp_forced_vs_plain_max_abs"] = [float(np.max(np.abs(runs[True][1] - runs[False][1]))), float(np.max(np.abs(runs[True][2] - runs[False][2])))]
     if report["gp_fit_is_deterministic"]:
         ok["run_gp_sharded"] = same(runs[True], runs[False])
     else:                                              # atomics in the fit: the two no-group runs differ too; compare to that spread
