@@ -49,9 +49,12 @@ HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md chip table
 # --------------------------------------------------------------------------------------
 # synthetic workload: seeded, no reference code or data needed
 # --------------------------------------------------------------------------------------
-def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, window=10_000, max_blocks=3):
-    """Returns a dict of host arrays in the HBM layouts of include/dig_hip.h."""
-    from digdriver_amd import engine
+ELEMENT_BLOCK = 8192     # the per-element arrays are drawn block by block, every block from its own seeded stream
+
+
+def _workload_tables(n_bins, n_elements, n_cohorts, seed, window, max_blocks):
+    """The parts of the synthetic problem every rank needs whole and that are cheap to draw (about a second for the whole
+    genome x 37 cohorts): the bin tables [N, C], the 1-D element / block arrays, the cohort parameters."""
     rng = np.random.default_rng(seed)
     N, E, C = n_bins, n_elements, n_cohorts
     # bins: 22 "chromosomes" of equal size, genome ordered
@@ -70,12 +73,10 @@ def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, wind
     blk_ptr = np.concatenate([[0], np.cumsum(nblk)]).astype(np.int64)
     nb_tot = int(blk_ptr[-1])
     owner = np.repeat(np.arange(E), nblk)
-    rank_in_elt = np.arange(nb_tot) - blk_ptr[owner]
     blen = rng.integers(200, 3000, nb_tot)
     gap = rng.integers(0, 4000, nb_tot)
     step = blen + gap
-    # running offset inside each element
-    cs = np.cumsum(step) - step
+    cs = np.cumsum(step) - step                         # running offset inside each element
     off = cs - cs[blk_ptr[owner]]
     base = bin_start[first_bin][owner] + rng.integers(0, window, E)[owner]
     blk_start = base + off
@@ -87,37 +88,120 @@ def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, wind
     np.maximum.at(shift, owner, over)
     blk_start = np.maximum(blk_start - shift[owner], 0)
     blk_end = blk_start + blen
-    elt_chrom = bin_chrom[first_bin]
-    ov_ptr, ov_idx = engine.ideal_overlaps(elt_chrom, blk_ptr, blk_start, blk_end, window, bin_chrom, bin_start)
     elt_len = np.zeros(E, np.int64)
     np.add.at(elt_len, owner, blen)
-    # per-context element counts: Poisson around len * composition (integer counts, sum ~ len)
-    L64 = rng.poisson(np.outer(elt_len, ctx_p)).astype(np.int32)
-    L = np.repeat(L64, 3, axis=1)[:, None, :].astype(np.int32)
     strand_minus = (rng.uniform(size=E) < 0.5).astype(np.uint8)
     d_pr = rng.dirichlet(np.ones(192), size=C) * 1e-6 * 192
     cj = rng.uniform(0.2, 3.0, C)
     cj_indel = rng.uniform(0.02, 0.3, C)
-    # observed counts: OBS ~ NB(alpha, p) under the model itself (Gamma-Poisson with the element's
-    # accumulated alpha = MU^2/SIGMA^2 and theta = SIGMA^2/MU * cj), 1 % planted 5x drivers
-    seg_mu = np.add.reduceat(bin_mu[ov_idx], ov_ptr[:-1], axis=0)
-    seg_var = np.add.reduceat(bin_std[ov_idx] ** 2, ov_ptr[:-1], axis=0)
-    nbin = np.diff(ov_ptr)[:, None]
-    frac = (elt_len[:, None] / (nbin * float(window)))          # ~ P_SUM
-    alpha = seg_mu ** 2 / seg_var
-    theta = seg_var / seg_mu
-    driver = np.where(rng.uniform(size=(E, 1)) < 0.01, 5.0, 1.0)
-    obs_snv = rng.poisson(rng.gamma(alpha, theta * cj[None, :] * frac) * driver).astype(np.int32)
-    obs_samples = rng.binomial(obs_snv, 0.93).astype(np.int32)
-    obs_indel = rng.poisson(rng.gamma(alpha, theta * cj_indel[None, :] * frac) * driver).astype(np.int32)
     # per-cohort totals used by the genome-mode scale factor (transfer_tools.py:148-156)
     exp_unflagged = (bin_mu * (bin_flag == 0)).sum(axis=0)
-    n_snv_obs = np.rint(exp_unflagged * cj)          # so that N_SNV_OBS / sum(Y_PRED[~FLAG]) ~= cj
-    n_ind_obs = np.rint(exp_unflagged * cj_indel)
-    return dict(bin_mu=bin_mu, bin_std=bin_std, bin_y=bin_y, bin_flag=bin_flag, bin_ctx=bin_ctx,
-                ov_ptr=ov_ptr, ov_idx=ov_idx, L=L, strand_minus=strand_minus, d_pr=d_pr, cj=cj, cj_indel=cj_indel,
-                obs_snv=obs_snv, obs_samples=obs_samples, obs_indel=obs_indel, n_snv_obs=n_snv_obs,
-                n_ind_obs=n_ind_obs, window=window)
+    return dict(bin_mu=bin_mu, bin_std=bin_std, bin_y=bin_y, bin_flag=bin_flag, bin_ctx=bin_ctx, bin_chrom=bin_chrom,
+                bin_start=bin_start, ctx_p=ctx_p, first_bin=first_bin, blk_ptr=blk_ptr, blk_start=blk_start, blk_end=blk_end,
+                elt_chrom=bin_chrom[first_bin], elt_len=elt_len, strand_minus=strand_minus, d_pr=d_pr, cj=cj, cj_indel=cj_indel,
+                n_snv_obs=np.rint(exp_unflagged * cj),      # so that N_SNV_OBS / sum(Y_PRED[~FLAG]) ~= cj
+                n_ind_obs=np.rint(exp_unflagged * cj_indel), window=window, seed=seed)
+
+
+def _element_blocks(t, blocks):
+    """Everything per element for the elements of the blocks `blocks` (ascending; block b = elements b * ELEMENT_BLOCK ...):
+    the CSR of overlapped GLOBAL bin rows, the element context counts L and the observed counts.  A block is always drawn
+    whole and from its own stream (seeded by (seed, block)), with parameters that depend on the global tables only: an
+    element has the same values whoever draws its block -- the whole problem on one rank, or a shard on one of eight.
+    Observed counts: OBS ~ NB(alpha, p) under the model itself (Gamma-Poisson with the element's accumulated
+    alpha = MU^2 / SIGMA^2 and theta = SIGMA^2 / MU * cj), 1 % planted 5x drivers.
+    Returns (element ids, ov_ptr, ov_idx, L [n, 1, 192], obs_snv, obs_samples, obs_indel [n, C])."""
+    from digdriver_amd import engine
+    E, C = len(t["first_bin"]), t["bin_mu"].shape[1]
+    blocks = np.asarray(blocks, np.int64)
+    elts = np.concatenate([np.arange(b * ELEMENT_BLOCK, min((b + 1) * ELEMENT_BLOCK, E)) for b in blocks]) if len(blocks) \
+        else np.zeros(0, np.int64)
+    bp = t["blk_ptr"]
+    cnt = bp[elts + 1] - bp[elts]
+    ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    take = np.repeat(bp[elts] - ptr[:-1], cnt) + np.arange(int(ptr[-1]))
+    ov_ptr, ov_idx = engine.ideal_overlaps(t["elt_chrom"][elts], ptr, t["blk_start"][take], t["blk_end"][take], t["window"],
+                                           t["bin_chrom"], t["bin_start"])
+    n = len(elts)
+    L64 = np.empty((n, 64), np.int32)
+    obs = [np.empty((n, C), np.int32) for _ in range(3)]
+    row0 = 0
+    for b in blocks:
+        lo, hi = int(b) * ELEMENT_BLOCK, min((int(b) + 1) * ELEMENT_BLOCK, E)
+        m = hi - lo
+        rng = np.random.default_rng([int(t["seed"]), 7919, int(b)])
+        p0, p1 = int(ov_ptr[row0]), int(ov_ptr[row0 + m])
+        idx, starts = ov_idx[p0:p1], (ov_ptr[row0:row0 + m] - p0)
+        seg_mu = np.add.reduceat(t["bin_mu"][idx], starts, axis=0)
+        seg_var = np.add.reduceat(t["bin_std"][idx] ** 2, starts, axis=0)
+        nbin = np.diff(ov_ptr[row0:row0 + m + 1])[:, None]
+        frac = (t["elt_len"][lo:hi][:, None] / (nbin * float(t["window"])))          # ~ P_SUM
+        alpha = seg_mu ** 2 / seg_var
+        theta = seg_var / seg_mu
+        out = slice(row0, row0 + m)
+        L64[out] = rng.poisson(np.outer(t["elt_len"][lo:hi], t["ctx_p"]))
+        driver = np.where(rng.uniform(size=(m, 1)) < 0.01, 5.0, 1.0)
+        obs[0][out] = rng.poisson(rng.gamma(alpha, theta * t["cj"][None, :] * frac) * driver)
+        obs[1][out] = rng.binomial(obs[0][out], 0.93)
+        obs[2][out] = rng.poisson(rng.gamma(alpha, theta * t["cj_indel"][None, :] * frac) * driver)
+        row0 += m
+    L = np.repeat(L64, 3, axis=1)[:, None, :].astype(np.int32)
+    return elts, ov_ptr, ov_idx, L, obs[0], obs[1], obs[2]
+
+
+_SHARED_KEYS = ("bin_mu", "bin_std", "bin_y", "bin_flag", "bin_ctx", "d_pr", "cj", "cj_indel", "n_snv_obs", "n_ind_obs", "window")
+
+
+def make_workload(n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, window=10_000, max_blocks=3):
+    """The whole synthetic problem: a dict of host arrays in the HBM layouts of include/dig_hip.h."""
+    t = _workload_tables(n_bins, n_elements, n_cohorts, seed, window, max_blocks)
+    n_blocks = (n_elements + ELEMENT_BLOCK - 1) // ELEMENT_BLOCK
+    _, ov_ptr, ov_idx, L, obs_snv, obs_samples, obs_indel = _element_blocks(t, np.arange(n_blocks))
+    w = {k: t[k] for k in _SHARED_KEYS}
+    w.update(ov_ptr=ov_ptr, ov_idx=ov_idx, L=L, strand_minus=t["strand_minus"], obs_snv=obs_snv, obs_samples=obs_samples,
+             obs_indel=obs_indel)
+    return w
+
+
+def make_shard_workload(rank, world, n_bins=288_000, n_elements=120_091, n_cohorts=37, seed=3, window=10_000, max_blocks=3):
+    """Rank `rank`'s shard of make_workload(n_bins, n_elements, ...) without building the whole problem: exactly what
+    parallel.shard_inputs(make_workload(...), parallel.plan_shards(...)[rank], world) returns (tests/test_distributed_gloo.py),
+    from the cheap global tables plus the element blocks that hold the rank's elements.  An element belongs to the rank
+    that owns its first overlapped bin; that bin lies at most a few bins in front of the element's anchor bin, so the
+    rank's elements are among those anchored in its own bin range or just behind it."""
+    from digdriver_amd import parallel
+    t = _workload_tables(n_bins, n_elements, n_cohorts, seed, window, max_blocks)
+    lo, hi = parallel.bin_ranges(n_bins, world)[rank]
+    fb = t["first_bin"]
+    margin = 64                                           # bins; an element's blocks are moved left by less than its own span
+    a, b = int(np.searchsorted(fb, lo, side="left")), int(np.searchsorted(fb, hi + margin, side="left"))
+    blocks = np.arange(a // ELEMENT_BLOCK, (max(b, a + 1) - 1) // ELEMENT_BLOCK + 1) if b > a else np.zeros(0, np.int64)
+    elts, ov_ptr, ov_idx, L, obs_snv, obs_samples, obs_indel = _element_blocks(t, blocks)
+    nov = np.diff(ov_ptr)
+    assert (nov > 0).all(), "an element without bins belongs to rank 0 wherever it lies: build the whole problem instead"
+    first = ov_idx[ov_ptr[:-1]]
+    mine = np.flatnonzero((first >= lo) & (first < hi))
+    plan = parallel.plan_one_shard(rank, elts[mine], nov[mine], parallel.csr_take(ov_ptr, ov_idx, mine), lo, hi)
+    w = {k: t[k] for k in _SHARED_KEYS}
+    w.update(L=L, strand_minus=t["strand_minus"], obs_snv=obs_snv, obs_samples=obs_samples, obs_indel=obs_indel)
+    # shard_inputs indexes the per-element arrays with GLOBAL element ids: hand it views that accept them
+    local = {k: _Rebased(w[k], elts) for k in ("L", "obs_snv", "obs_samples", "obs_indel")}
+    w.update(local)
+    out = parallel.shard_inputs(w, plan, world)
+    out["cj"], out["cj_indel"] = t["cj"], t["cj_indel"]
+    return out, plan
+
+
+class _Rebased:
+    """array[global element ids] for an array that holds the rows of the ascending id list `ids` only."""
+
+    def __init__(self, rows, ids):
+        self.rows, self.ids = rows, ids
+
+    def __getitem__(self, want):
+        pos = np.searchsorted(self.ids, want)
+        assert np.array_equal(self.ids[pos], want)
+        return self.rows[pos]
 
 
 def committed_traffic(kernel_prefixes):
@@ -411,13 +495,16 @@ def main():
     # The global problem and this rank's shard of it (at N = 1 the shard is the whole problem)
     sharded = args.mode != "replicas" and world > 1
     n_elements_global = args.elements * (world if args.mode == "sharded" else 1)
-    w_global = make_workload(args.bins, n_elements_global if sharded else args.elements, args.cohorts,
-                             seed=args.seed + (0 if sharded else rank))
-    plan = parallel.plan_shards(w_global["ov_ptr"], w_global["ov_idx"], args.bins, world if sharded else 1)[rank if sharded else 0]
-    w = parallel.shard_inputs(w_global, plan, world if sharded else 1)
-    w["cj"], w["cj_indel"] = w_global["cj"], w_global["cj_indel"]
+    if sharded:
+        # only this rank's shard is built: the cheap global tables + the element blocks that hold its elements
+        w, plan = make_shard_workload(rank, world, args.bins, n_elements_global, args.cohorts, seed=args.seed)
+    else:
+        w_global = make_workload(args.bins, args.elements, args.cohorts, seed=args.seed + rank)
+        plan = parallel.plan_shards(w_global["ov_ptr"], w_global["ov_idx"], args.bins, 1, only_rank=0)[0]
+        w = parallel.shard_inputs(w_global, plan, 1)
+        w["cj"], w["cj_indel"] = w_global["cj"], w_global["cj_indel"]
+        del w_global
     E_total = n_elements_global if sharded else args.elements * world
-    del w_global
     # CPU baselines first: the all-core one forks workers, which must happen before this process touches the GPU
     cpu_res = (None, None)
     if world == 1 and args.cpu_sample > 0:
@@ -436,6 +523,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("BENCH_FORCE_DIST") == "1":
+            parallel.FORCE_COLLECTIVES = True       # a world of one sends its all-gather through RCCL too
 
     E, C = w["L"].shape[0], w["d_pr"].shape[0]
     N = w["bin_mu"].shape[0]                          # rows this rank holds (own range + halo)

@@ -113,10 +113,31 @@ class ShardedPipeline:
         return self.out_acc, self.out_stats
 
 
-def plan_shards(ov_ptr, ov_idx, n_bins, world):
+def csr_take(ov_ptr, ov_idx, rows):
+    """The concatenated CSR entries of the rows `rows` (one vectorised gather, no per-row Python loop)."""
+    ov_ptr = np.asarray(ov_ptr, np.int64)
+    rows = np.asarray(rows, np.int64)
+    cnt = ov_ptr[rows + 1] - ov_ptr[rows]
+    out_ptr = np.concatenate([[0], np.cumsum(cnt)])
+    take = np.repeat(ov_ptr[rows] - out_ptr[:-1], cnt) + np.arange(int(out_ptr[-1]))
+    return np.asarray(ov_idx)[take]
+
+
+def plan_one_shard(rank, elts, cnt, touched, lo, hi):
+    """One rank's plan from its elements (global ids, ascending), their bin counts and the concatenation of their
+    overlapped GLOBAL bin rows: own bin range [lo, hi) plus the halo, CSR re-indexed into those rows."""
+    touched = np.asarray(touched, np.int64)
+    halo = np.unique(touched[(touched < lo) | (touched >= hi)])
+    rows = np.concatenate([halo[halo < lo], np.arange(lo, hi), halo[halo >= hi]])
+    local = np.searchsorted(rows, touched)
+    return dict(rank=rank, elements=np.asarray(elts, np.int64), bin_rows=rows, n_halo=int(len(halo)),
+                ov_ptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ov_idx=local.astype(np.int32))
+
+
+def plan_shards(ov_ptr, ov_idx, n_bins, world, only_rank=None):
     """Partition elements by the owner of their first overlapped bin and build each rank's local CSR.
 
-    Returns a list (one entry per rank) of dicts:
+    Returns a list (one entry per rank; with `only_rank` = r a list holding rank r's plan alone) of dicts:
         elements   global element ids owned by the rank (ascending)
         bin_rows   global bin rows the rank must hold: its own range plus the halo (ascending)
         n_halo     how many of those lie outside the rank's own range
@@ -124,7 +145,6 @@ def plan_shards(ov_ptr, ov_idx, n_bins, world):
     Elements without any overlapped bin go to rank 0."""
     ov_ptr = np.asarray(ov_ptr, np.int64)
     ov_idx = np.asarray(ov_idx, np.int64)
-    E = len(ov_ptr) - 1
     ranges = bin_ranges(n_bins, world)
     his = np.array([hi for _, hi in ranges])
     nov = np.diff(ov_ptr)
@@ -133,16 +153,10 @@ def plan_shards(ov_ptr, ov_idx, n_bins, world):
     owner = np.where(nov > 0, owner, 0)
     plans = []
     for r, (lo, hi) in enumerate(ranges):
+        if only_rank is not None and r != only_rank:
+            continue
         elts = np.flatnonzero(owner == r)
-        cnt = nov[elts]
-        take = (np.concatenate([np.arange(ov_ptr[e], ov_ptr[e + 1]) for e in elts]) if len(elts) and cnt.sum()
-                else np.zeros(0, np.int64))
-        touched = ov_idx[take]
-        halo = np.unique(touched[(touched < lo) | (touched >= hi)])
-        rows = np.concatenate([halo[halo < lo], np.arange(lo, hi), halo[halo >= hi]])
-        local = np.searchsorted(rows, touched)
-        plans.append(dict(rank=r, elements=elts, bin_rows=rows, n_halo=int(len(halo)),
-                          ov_ptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ov_idx=local.astype(np.int32)))
+        plans.append(plan_one_shard(r, elts, nov[elts], csr_take(ov_ptr, ov_idx, elts), lo, hi))
     return plans
 
 

@@ -40,6 +40,28 @@ def test_plan_shards_covers_problem_without_remote_bins():
             assert sum(p["n_halo"] for p in plans) < 0.05 * 2000               # halo is a few boundary bins
 
 
+def test_shard_generator_equals_sliced_global_problem():
+    """bench.make_shard_workload(rank, world) -- what a rank of the N > 1 bench builds, from the global bin tables and the
+    element blocks that hold its elements only -- is exactly parallel.shard_inputs of the whole problem, for every rank of
+    2- and 8-rank plans (the element blocks are drawn whole from their own seeded streams); plan_shards(only_rank=r) is
+    entry r of the full list."""
+    import bench
+    n_bins, E, C = 6400, 20_011, 2                          # three element blocks, shard boundaries inside blocks
+    w = make_workload(n_bins, E, C, seed=5)
+    for world in (1, 2, 8):
+        plans = parallel.plan_shards(w["ov_ptr"], w["ov_idx"], n_bins, world)
+        for r in range(world):
+            one = parallel.plan_shards(w["ov_ptr"], w["ov_idx"], n_bins, world, only_rank=r)
+            assert len(one) == 1 and all(np.array_equal(np.asarray(one[0][k]), np.asarray(plans[r][k])) for k in plans[r])
+            want = parallel.shard_inputs(w, plans[r], world)
+            got, plan = bench.make_shard_workload(r, world, n_bins, E, C, seed=5)
+            assert set(want) <= set(got)
+            for k in want:
+                assert np.array_equal(np.asarray(want[k]), np.asarray(got[k])), (world, r, k)
+            for k in plans[r]:
+                assert np.array_equal(np.asarray(plans[r][k]), np.asarray(plan[k])), (world, r, k)
+
+
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

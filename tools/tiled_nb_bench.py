@@ -40,7 +40,7 @@ if __name__ == "__main__":
         child(sys.argv[2], sys.argv[3] == "1"); sys.exit(0)
     ref = "/tmp/tn_ref.npy"
     for i, spec in enumerate(sys.argv[1:]):
-        path = spec if os.path.isabs(spec) else os.path.join(ROOT, "digdriver_amd/lib/variants", spec)
+        path = spec if os.path.isabs(spec) else os.path.join(ROOT, "tools/variants", spec)
         env = dict(os.environ, DIG_HIP_LIB=path)
         r = subprocess.run([sys.executable, __file__, "--child", ref, "1" if i == 0 else "0"], env=env, capture_output=True, text=True)
         print("%-28s %s" % (spec, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]), flush=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B kernel builds on the bench workload (developer tool, not the judged bench).
 
-    python tools/variant_bench.py base.so new.so ...      (paths under digdriver_amd/lib/variants/, or absolute)
+    python tools/variant_bench.py base.so new.so ...      (paths under tools/variants/, or absolute)
 
 Each library runs in its own process (DIG_HIP_LIB).  Per library: HIP-event times of the statistics stage alone
 (`stages=4`), the accumulate stages (`stages=3`) and the whole dig_element_pipeline, interleaved over several rounds;
@@ -80,7 +80,7 @@ def main():
     ref = "/tmp/variant_ref.npy"
     for i, spec in enumerate(sys.argv[1:]):          # lib.so[:ENV=VAL,ENV=VAL]
         lib, _, envs = spec.partition(":")
-        path = lib if os.path.isabs(lib) else os.path.join(ROOT, "digdriver_amd", "lib", "variants", lib)
+        path = lib if os.path.isabs(lib) else os.path.join(ROOT, "tools", "variants", lib)
         env = dict(os.environ, DIG_HIP_LIB=path)
         env.update(dict(kv.split("=") for kv in envs.split(",") if kv))
         p = subprocess.run([sys.executable, __file__, "--child", ref, "1" if i == 0 else "0"], env=env, capture_output=True, text=True)
