@@ -419,9 +419,23 @@ def aux_rooflines(dev):
     p = _lib.dev_ptr
     dt = timeit(lambda: _lib.call("dig_count_contexts", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), p(rm), nwin,
                                   p(res), _lib.stream_ptr()), n=5, warm=1)
-    out.append(hbm("dig_count_contexts", nbases * 0.5 + nwin * 256.0, dt, "all 288 000 10-kb windows of a 2.88 Gb packed genome; "
-                   "0.5 B per base + 256 B per window", bases_per_s=nbases / dt))
-    del res
+    out.append(hbm("dig_count_contexts (4-bit genome: the round-3 form)", nbases * 0.5 + nwin * 256.0, dt,
+                   "all 288 000 10-kb windows of a 2.88 Gb packed genome; 0.5 B per base + 256 B per window", bases_per_s=nbases / dt))
+    # ... and the form everything uses since round 4: 2 bits per base + the list of non-ACGT runs (here: 300 runs, as in hg19)
+    words2 = torch.randint(-2 ** 31, 2 ** 31 - 1, (4 + nbases // 16 + 24,), dtype=torch.int32, device=dev, generator=g)
+    n_int = 300
+    ns_h = np.sort(np.random.default_rng(6).choice(nbases - 200_000, n_int, replace=False)).astype(np.int64) + 64
+    ne_h = ns_h + np.random.default_rng(7).integers(1, 50_000, n_int)
+    keep = np.concatenate([[True], ns_h[1:] > ne_h[:-1]])
+    ns_h, ne_h = ns_h[keep], ne_h[keep]
+    bk_h = np.searchsorted(ne_h, np.arange(((nbases + 64) >> 12) + 2, dtype=np.int64) << 12, side="right").astype(np.int32)
+    ns_d, ne_d, bk_d = (torch.as_tensor(a, device=dev) for a in (ns_h, ne_h, bk_h))
+    dt = timeit(lambda: _lib.call("dig_count_contexts2", p(words2), words2.numel(), p(ns_d), p(ne_d), len(ns_h), p(bk_d), len(bk_h), p(off),
+                                  p(ln), 1, p(rc), p(rs), p(re_), p(rm), nwin, p(res), _lib.stream_ptr()), n=5, warm=1)
+    out.append(hbm("dig_count_contexts2 (2-bit genome, 4-mers at even bases)", nbases * 0.25 + nwin * 256.0, dt,
+                   "all 288 000 10-kb windows of a 2.88 Gb genome at 2 bits per base; 0.25 B per base + 256 B per window",
+                   bases_per_s=nbases / dt))
+    del res, words2
     S = torch.rand((37, 64), device=dev, generator=g, dtype=torch.float64) * 1e-2
     chunk = 36_000
     ptile = torch.empty((37, chunk, 200), dtype=torch.float64, device=dev)

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "dig_gene_pipeline_host": [_vp] * 15 + [_int] + [_vp] * 9 + [_i64, _i64, _i64, _int],
     "dig_count_contexts": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
+    "dig_count_contexts2": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "dig_count_contexts2_host": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_overlap_join_fill": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dig_overlap_join_count_host": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int],
@@ -94,7 +96,7 @@ _SIZE_QUERIES = {
     "dig_bin_records_bytes": [_i64, _i64],
 }
 
-ABI_VERSION = 5          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 6          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

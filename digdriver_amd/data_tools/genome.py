@@ -120,6 +120,58 @@ class PackedGenome:
         pieces.append(np.full(1, 0x44444444, np.uint32))
         return PackedGenome(self.names, offsets, new_len, np.concatenate(pieces)), shift
 
+    # ---- the 2-bit form (dig_count_contexts2, include/dig_hip.h) ------------------------------------------
+    PAD2_BASES = 64            # bases in front of the chromosome data of the 2-bit array
+    BUCKET_SHIFT = 12
+
+    def two_bit(self):
+        """(words2, nint_start, nint_end, nint_bucket): the genome at 2 bits per base (every letter other than ACGT stored as
+        A), the maximal runs of such letters as sorted intervals of ARRAY bases (array base = 64 + offset + position; the
+        alignment padding between chromosomes counts as such letters) and the bucket index of the interval list.
+        Derived from the 4-bit words once, 32 M bases at a time."""
+        if getattr(self, "_two_bit", None) is not None:
+            return self._two_bit
+        body = self.words[1:-1]                                   # without the two pad words
+        total = int(body.size) * 8
+        words2 = np.zeros(4 + (total + 15) // 16 + 24, np.uint32)
+        shifts4 = (4 * np.arange(8, dtype=np.uint32))[None, :]
+        shifts2 = (2 * np.arange(16, dtype=np.uint32))[None, :]
+        starts, ends = [], []
+        chunk = 1 << 22                                           # 4-bit words per pass (an even number: whole 2-bit words)
+        for w0 in range(0, body.size, chunk):
+            nib = ((body[w0:w0 + chunk, None] >> shifts4) & np.uint32(15)).astype(np.uint8).reshape(-1)
+            base0 = w0 * 8                                        # offset + position of nib[0]
+            isn = nib > 3
+            code = np.where(isn, 0, nib & 3).astype(np.uint32)
+            if len(code) % 16:
+                code = np.concatenate([code, np.zeros(16 - len(code) % 16, np.uint32)])
+            packed = (code.reshape(-1, 16) << shifts2).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+            words2[4 + base0 // 16: 4 + base0 // 16 + len(packed)] = packed
+            edge = np.diff(np.concatenate([[0], isn.astype(np.int8), [0]]))       # runs cut at the chunk's ends are joined below
+            starts.append(base0 + np.flatnonzero(edge == 1).astype(np.int64))
+            ends.append(base0 + np.flatnonzero(edge == -1).astype(np.int64))
+        ns = np.concatenate(starts) if starts else np.zeros(0, np.int64)
+        ne = np.concatenate(ends) if ends else np.zeros(0, np.int64)
+        if len(ns) > 1:                                           # a run that crosses a chunk boundary: end == next start
+            glue = ne[:-1] == ns[1:]
+            ns, ne = ns[np.concatenate([[True], ~glue])], ne[np.concatenate([~glue, [True]])]
+        ns, ne = ns + self.PAD2_BASES, ne + self.PAD2_BASES
+        n_buckets = ((total + self.PAD2_BASES) >> self.BUCKET_SHIFT) + 2
+        bucket = np.searchsorted(ne, np.arange(n_buckets, dtype=np.int64) << self.BUCKET_SHIFT, side="right").astype(np.int32)
+        self._two_bit = (words2, ns, ne, bucket)
+        return self._two_bit
+
+    def on_device2(self, device):
+        """Device tensors of the 2-bit form: (words2, nint_start, nint_end, nint_bucket, offsets, lengths)."""
+        import torch
+        dev = torch.device(device)
+        key = ("2bit", dev.type, dev.index)
+        if key not in self._dev:
+            w2, ns, ne, bk = self.two_bit()
+            self._dev[key] = (torch.as_tensor(w2.view(np.int32), device=dev), torch.as_tensor(ns, device=dev), torch.as_tensor(ne, device=dev),
+                              torch.as_tensor(bk, device=dev), torch.as_tensor(self.offsets, device=dev), torch.as_tensor(self.lengths, device=dev))
+        return self._dev[key]
+
     def on_device(self, device):
         import torch
         dev = torch.device(device)

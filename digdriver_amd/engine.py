@@ -587,33 +587,48 @@ def gather_bins(x_data, bin_rows, tracks=None, out_dtype="f32", transpose=False,
     return out
 
 
-def count_contexts(genome, chroms, starts, ends, minus=None, device=0, on_device=True):
+def count_contexts(genome, chroms, starts, ends, minus=None, device=0, on_device=True, form="2bit"):
     """Trinucleotide context counts [R, 64] of regions of a PackedGenome (sequence_tools.py:65-99,527-566).
     on_device=True keeps the genome resident in HBM (uploaded on first use) and returns a device tensor; False goes
-    through the host twin (uploads the genome for this call; small genomes / tests)."""
+    through the host twin (uploads the genome for this call; small genomes / tests).
+    form: "2bit" (dig_count_contexts2: the genome at 2 bits per base + the list of non-ACGT runs; what everything uses) or
+    "4bit" (dig_count_contexts, the first form; kept as a cross-check) -- the same counts."""
     ci = genome.chrom_index(chroms)
     R = len(ci)
     st, en = _lib.as_host(starts, np.int64).ravel(), _lib.as_host(ends, np.int64).ravel()
     mi = np.zeros(R, np.uint8) if minus is None else _lib.as_host(np.asarray(minus).astype(np.uint8), np.uint8).ravel()
-    assert len(st) == len(en) == len(mi) == R
+    assert len(st) == len(en) == len(mi) == R and form in ("2bit", "4bit")
     if (st < 0).any() or (en < 0).any():
         raise ValueError("negative region coordinates")
     if on_device:
         import torch
         dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
-        words, off, ln = genome.on_device(dev)
         t = lambda a: torch.as_tensor(a, device=dev)
         out = torch.empty((R, 64), dtype=torch.int32, device=dev)
         rc, rs, re_, rm = t(ci), t(st), t(en), t(mi)
+        p = _lib.dev_ptr
         with torch.cuda.device(dev):
-            _lib.call("dig_count_contexts", _lib.dev_ptr(words), words.numel(), _lib.dev_ptr(off), _lib.dev_ptr(ln),
-                      len(genome.names), _lib.dev_ptr(rc), _lib.dev_ptr(rs), _lib.dev_ptr(re_), _lib.dev_ptr(rm), R,
-                      _lib.dev_ptr(out), _lib.stream_ptr())
+            if form == "2bit":
+                w2, ns, ne, bk, off, ln = genome.on_device2(dev)
+                _lib.call("dig_count_contexts2", p(w2), w2.numel(), p(ns) if ns.numel() else None, p(ne) if ns.numel() else None,
+                          ns.numel(), p(bk) if ns.numel() else None, bk.numel(), p(off), p(ln), len(genome.names), p(rc), p(rs),
+                          p(re_), p(rm), R, p(out), _lib.stream_ptr())
+            else:
+                words, off, ln = genome.on_device(dev)
+                _lib.call("dig_count_contexts", p(words), words.numel(), p(off), p(ln), len(genome.names), p(rc), p(rs), p(re_),
+                          p(rm), R, p(out), _lib.stream_ptr())
         return out
     out = np.empty((R, 64), np.int32)
-    _lib.call("dig_count_contexts_host", _lib.host_ptr(genome.words), genome.words.size, _lib.host_ptr(genome.offsets),
-              _lib.host_ptr(genome.lengths), len(genome.names), _lib.host_ptr(ci), _lib.host_ptr(st), _lib.host_ptr(en),
-              _lib.host_ptr(mi), R, _lib.host_ptr(out), device if isinstance(device, int) else 0)
+    h = _lib.host_ptr
+    dv = device if isinstance(device, int) else 0
+    if form == "2bit":
+        w2, ns, ne, bk = genome.two_bit()
+        _lib.call("dig_count_contexts2_host", h(w2), w2.size, h(ns) if ns.size else None, h(ne) if ns.size else None, ns.size,
+                  h(bk) if ns.size else None, bk.size, h(genome.offsets), h(genome.lengths), len(genome.names), h(ci), h(st), h(en),
+                  h(mi), R, h(out), dv)
+    else:
+        _lib.call("dig_count_contexts_host", h(genome.words), genome.words.size, h(genome.offsets), h(genome.lengths),
+                  len(genome.names), h(ci), h(st), h(en), h(mi), R, h(out), dv)
     return out
 
 

@@ -34,9 +34,9 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 5   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 6   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
-                             * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline */
+                             * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome) */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -354,6 +354,23 @@ int dig_count_contexts(const uint32_t *genome_words, int64_t n_words, const int6
 int dig_count_contexts_host(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off,
                             const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
                             const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, int device);
+
+/* The same counts from the 2-BIT genome (ABI 6) -- half the bytes, no per-base test for unknown letters in the scan:
+ *   words2 u32 [n_words2], 16-byte aligned: 2 bits per base (A=0 C=1 G=2 T=3; EVERY OTHER LETTER STORED AS A), 16 bases
+ *       per word, base 0 in the low bits; array base g of chromosome position p is 64 + chrom_off[c] + p (64 pad bases
+ *       = one 4-word group in front; chrom_off as above; at least 24 pad words behind the last chromosome).
+ *   nint_start / nint_end i64 [n_int]: the maximal runs [start, end) of letters other than ACGT, in ARRAY bases, sorted,
+ *       disjoint and not touching; nint_bucket i32 [n_buckets]: index of the first run that ends behind array base
+ *       b << 12 (b = 0 .. n_buckets - 1, n_buckets > (last array base) >> 12).  n_int == 0: the three may be NULL.
+ *   regions, strand flag and out exactly as dig_count_contexts; the same bits. */
+int dig_count_contexts2(const uint32_t *words2, int64_t n_words2, const int64_t *nint_start, const int64_t *nint_end,
+                        int64_t n_int, const int32_t *nint_bucket, int64_t n_buckets, const int64_t *chrom_off,
+                        const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                        const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, void *stream);
+int dig_count_contexts2_host(const uint32_t *words2, int64_t n_words2, const int64_t *nint_start, const int64_t *nint_end,
+                             int64_t n_int, const int32_t *nint_bucket, int64_t n_buckets, const int64_t *chrom_off,
+                             const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
+                             const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, int device);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins

@@ -587,6 +587,43 @@ def test_context_counting_matches_reference_golden_and_oracle():
     want = O.count_contexts_regions(seqs, chroms, starts, ends, minus)
     assert np.array_equal(got, want)
     assert got.sum() > 0
+    # the first (4-bit) form and the 2-bit form's host twin: the same counts
+    assert np.array_equal(engine.count_contexts(genome, chroms, starts, ends, minus, device=0, form="4bit").cpu().numpy(), want)
+    assert np.array_equal(engine.count_contexts(genome, chroms[:50], starts[:50], ends[:50], minus[:50], on_device=False), want[:50])
+
+
+def test_context_counting_2bit_form_on_letter_runs_and_every_alignment():
+    """dig_count_contexts2 (2 bits per base + the list of non-ACGT runs; 4-mers at even bases, counters that are never
+    cleared, take-backs at the group ends, single centres, interval corrections) against the oracle: genomes from N-free to
+    90 % N, runs that start / end at every offset of a region and of a 64-base group, adjacent runs one base apart, regions
+    of 0 ... 3 000 centres at every alignment, chromosome starts and ends, both strands; many more regions than waves, so
+    that every wave's running totals carry over many regions."""
+    import torch
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(41)
+    for p_n in (0.0, 0.01, 0.2, 0.9):
+        seqs = {"chr1": "".join(rng.choice(list("ACGTN"), 30_011, p=[(1 - p_n) / 4] * 4 + [p_n])),
+                "chr2": "".join(rng.choice(list("ACGT"), 5_003)),
+                "chr3": "N" * 10 + "".join(rng.choice(list("ACGT"), 300)) + "N" * 700 + "ACGNAC" + "".join(rng.choice(list("ACGT"), 4000))}
+        genome = PackedGenome.from_sequences(seqs)
+        names = list(seqs)
+        regs = []
+        for _ in range(6000):
+            c = names[int(rng.integers(0, 3))]
+            n = len(seqs[c])
+            a = int(rng.integers(0, n))
+            e = a + int(rng.integers(0, (5, 70, 300, 3000)[int(rng.integers(0, 4))]))
+            u = rng.uniform()
+            regs.append((c, 0 if u < 0.03 else a, n + 5 if u > 0.95 else e))
+        regs += [("chr3", 300 + k, 1020 + k) for k in range(70)] + [("chr3", k, k + 1) for k in range(40)]
+        chroms, starts, ends = zip(*regs)
+        minus = rng.uniform(size=len(regs)) < 0.5
+        got = engine.count_contexts(genome, chroms, starts, ends, minus, device=0).cpu().numpy()
+        want = O.count_contexts_regions(seqs, chroms, starts, ends, minus)
+        bad = np.flatnonzero((got != want).any(axis=1))
+        assert len(bad) == 0, (p_n, len(bad), regs[bad[0]], bool(minus[bad[0]]), (got - want)[bad[0]].tolist())
 
 
 def test_element_pipeline_equals_separate_calls(torch_dev):
