@@ -219,7 +219,8 @@ int dig_base_tile_probs_ctx_host(const uint32_t* genome_words, int64_t n_words, 
     DIG_REQUIRE(C == 0 || n_tiles == 0 || (s_prob && pt), "s_prob and pt");
     for (int64_t r = 0; r < R; ++r) {
         DIG_REQUIRE(reg_chrom[r] >= 0 && reg_chrom[r] < n_chrom && reg_start[r] >= 0 && reg_end[r] >= 0, "regions inside the genome table");
-        DIG_REQUIRE(n_up == 1 || reg_end[r] - reg_start[r] <= 12280 - 2 * n_up, "a region of the general-context form holds at most 12 276 positions");
+        DIG_REQUIRE(n_up == 1 || reg_end[r] - reg_start[r] <= 16384, "a region of the general-context form holds at most 16 384 positions");
+        DIG_REQUIRE(n_up == 1 || reg_start[r] == 0 || reg_start[r] >= n_up, "a region that starts inside (0, n_up) would fetch from a negative position");
     }
     DIG_HIP_TRY(hipSetDevice(device));
     const int64_t K = n_up == 1 ? 64 : 1024;

@@ -459,17 +459,59 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
 //       (fetch_sequence :21-29: START == 0 becomes n_up, the fetch is widened by U bases on either side and cut at the
 //       chromosome end); a position whose (2 U + 1)-base window holds a non-ACGT base has probability 0.
 // 4^(2U+1) contexts (1 024 for U = 2) rule out the per-tile histograms and the 64-row matrix product of the trinucleotide
-// kernels; here the per-position table values are added up directly: persistent workgroups keep the table of a chunk of
-// 16 cohorts in LDS ([cohort][context], 128 KB for U = 2: the context index spreads the lanes' reads over the banks),
-// stage a region's packed bases, and every lane walks one tile with a rolling context index -- one LDS read per base and
-// 16 table reads + adds per position.  pt = (sum over the tile) / (sum over the region): the reference normalises every
-// position first and then sums (a few ulp apart, as for the trinucleotide kernels).  Regions of up to 12 280 - 2 U
-// positions (a 10-kb bin with room to spare).
+// kernels: pt[c][tile] = sum over the tile's positions of S[c][context(position)] is a gather-sum, 13.3 G table reads per
+// 36 000 bins x 37 cohorts.  Round 3's kernel (a lane = a tile, table [cohort][context] of 16 cohorts = 128 KB, one
+// workgroup of four waves per CU, 64 lanes reading 64 random 8-byte entries: 5-6 lanes deep on a bank pair, every lane
+// walking its own bases and contexts) took 13.9 ms per 36 000 bins.  Round 4:
+//   * the table of a pass is [context][8 cohorts]: a row is 64 contiguous bytes, EIGHT LANES (the 8 cohorts) walk a tile
+//     together -- one ds_read_b64 per wave and 8 positions, each group reading one row; 64 KB per pass, five passes for 37
+//     cohorts, so that a workgroup of EIGHT waves (two per SIMD) fits a CU with its buffers;
+//   * the contexts of a region are formed ONCE per pass by all 512 threads (one position per thread and step, two words
+//     of the packed genome each) and staged in LDS as 16-bit codes -- left base in the low bits, the table is staged in
+//     that order -- with code 4^(2U+1) = an all-zero row for a window that holds a non-ACGT base: the walk has no test;
+//   * tile sums wait in LDS ([cohort][tile], stride 513: the eight writers of a tile hit eight banks) until the region
+//     total is known, then leave as pt = sum / total with a lane = a tile (coalesced 8-byte stores per cohort plane);
+//     a region with more than 512 tiles (binsize 1) is walked twice: totals first, then 512 tiles at a time.
+//   pt = (sum over the tile) / (sum over the region): the reference normalises every position first and then sums (a few
+//   ulp apart, as for the trinucleotide kernels).  Regions of up to 16 384 positions; a longer one is NOT evaluated: its
+//   n_valid is -1 and its pt NaN (the host-side callers refuse such regions before the launch: engine.check_tile_regions).
 // =======================================================================================
-constexpr int kCtxChunk = 16;             // cohorts whose table is resident in LDS at a time
+constexpr int kCtxBlock = 512;            // threads per workgroup: 64 walkers of 8 lanes
+constexpr int kCtxCoh = 8;                // cohorts per pass = lanes per walker
+constexpr int kCtxMaxPos = 16384;         // positions of a region whose codes are staged
+constexpr int kCtxSumTiles = 512;         // tile sums kept per walk
+constexpr int kCtxSumStride = kCtxSumTiles + 1;
+
+struct CtxRaw {                           // a region as handed in
+    int chrom;
+    int64_t start, end;
+};
+struct CtxRegion {                        // wave-uniform description of a region
+    int64_t first, n_pos, g0, tiles_valid, w0, nw;
+    bool too_long;
+};
 
 template <int U>
-__global__ __launch_bounds__(kTileBlock) void base_tile_probs_ctx_kernel(
+__device__ __forceinline__ CtxRegion ctx_region(const CtxRaw& a, int64_t len, int64_t off, int binsize)
+{
+    CtxRegion q;
+    q.first = a.start == 0 ? U : a.start;
+    const int64_t stop = a.end < len - U ? a.end : len - U;
+    q.n_pos = stop > q.first ? stop - q.first : 0;
+    q.g0 = off + q.first;
+    q.tiles_valid = (q.n_pos + binsize - 1) / binsize;
+    q.too_long = q.n_pos > kCtxMaxPos;
+    const int64_t ga0 = q.g0 - U;                     // leftmost base of the first window
+    q.w0 = (ga0 >> 3) + 1;                            // array word = genome word + 1 (leading pad word)
+    q.nw = (q.n_pos > 0 && !q.too_long) ? ((ga0 + q.n_pos + 2 * U - 1) >> 3) + 1 - q.w0 + 3 : 0;
+    return q;
+}
+
+constexpr int kCtxWordsPer = (kCtxMaxPos / 8 + 8 + kCtxBlock - 1) / kCtxBlock;       // packed words a thread stages per region
+constexpr int kCtxSplitSlots = 64;        // extra unit sums: the pieces of the last tiles of a region (below)
+
+template <int U>
+__global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
     const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
     const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
     const int64_t* __restrict__ reg_end, int64_t R, const double* __restrict__ s_prob, int64_t C, int binsize, int64_t n_tiles,
@@ -477,105 +519,244 @@ __global__ __launch_bounds__(kTileBlock) void base_tile_probs_ctx_kernel(
 {
     constexpr int W = 2 * U + 1;                      // window
     constexpr int K = 1 << (2 * W);                   // contexts
-    constexpr unsigned kMask = (unsigned)K - 1u;
-    __shared__ double s_S[kCtxChunk][K];
-    __shared__ uint32_t s_words[kTileMaxWords + 2];
-    __shared__ double s_part[kTileBlock / 64][kCtxChunk];
-    __shared__ double s_T[kCtxChunk];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double s_S[K + 1][kCtxCoh];            // row K: zeros (a window with a non-ACGT base)
+    __shared__ alignas(16) unsigned short s_code[kCtxMaxPos + 8];
+    __shared__ uint32_t s_words[kCtxMaxPos / 8 + 8];
+    __shared__ double s_sum[kCtxCoh][kCtxSumStride + kCtxSplitSlots];      // tile sums, then the pieces of split tiles
+    __shared__ double s_part[kCtxBlock / 8][kCtxCoh];
+    __shared__ double s_T[kCtxCoh];
+    const int tid = threadIdx.x, c = tid & 7, walker = tid >> 3;
+#ifdef DIG_TM_TIMING
+    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_last = __builtin_readcyclecounter();
+#endif
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int64_t c0 = 0; c0 < C; c0 += kCtxChunk) {
-        const int cc = (int)(C - c0 < kCtxChunk ? C - c0 : kCtxChunk);
-        __syncthreads();
-        for (int idx = tid; idx < kCtxChunk * K; idx += kTileBlock) {
-            const int c = idx / K, x = idx - c * K;
-            s_S[c][x] = c < cc ? s_prob[(c0 + c) * K + x] : 0.0;
+    // Every load of a thread is issued before its first LDS write, and a region's words are requested while the region
+    // before it is walked; its description (three loads, then two that depend on the chromosome) is read a region earlier
+    // still.  (A load per position inside the code loop was a memory round trip per iteration: 20 us per region and pass, the
+    // whole of the first build's 14.7 ms; words fetched when the region is reached: 2 us of every 11.)
+    auto request = [&](const CtxRegion& q, uint32_t (&tmp)[kCtxWordsPer]) {
+#pragma unroll
+        for (int j = 0; j < kCtxWordsPer; ++j) {
+            const int64_t i = tid + (int64_t)j * kCtxBlock;
+            tmp[j] = i < q.nw ? words[(q.w0 + i < n_words ? q.w0 + i : n_words - 1)] : 0u;
         }
+    };
+    auto raw_of = [&](int64_t r) {
+        CtxRaw a{0, 0, 0};
+        if (r < R) {
+            a.chrom = reg_chrom[r];
+            a.start = reg_start[r];
+            a.end = reg_end[r];
+        }
+        return a;
+    };
+    const int64_t G = gridDim.x;
+    for (int64_t c0 = 0; c0 < C; c0 += kCtxCoh) {
+        const int cc = (int)(C - c0 < kCtxCoh ? C - c0 : kCtxCoh);
         __syncthreads();
-        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-            const int chrom = reg_chrom[r];
-            const int64_t len = chrom_len[chrom], start = reg_start[r], end = reg_end[r];
-            const int64_t first = start == 0 ? U : start;
-            const int64_t stop = end < len - U ? end : len - U;
-            const int64_t n_pos = stop > first ? stop - first : 0;
-            const int64_t g0 = chrom_off[chrom] + first;
-            const int64_t tiles_valid = (n_pos + binsize - 1) / binsize;
+        for (int idx = tid; idx < (K + 1) * kCtxCoh; idx += kCtxBlock) {
+            const int code = idx >> 3, co = idx & 7;
+            // code: base d of the window (d = 0 leftmost) at bits 2 d; the reference's index counts the leftmost base highest
+            int ref = 0;
+#pragma unroll
+            for (int d = 0; d < W; ++d) ref = ref * 4 + ((code >> (2 * d)) & 3);
+            s_S[code][co] = (code < K && co < cc) ? s_prob[(c0 + co) * K + ref] : 0.0;
+        }
+        CtxRegion nxt{};
+        uint32_t staged[kCtxWordsPer];
+        CtxRaw raw1 = raw_of(blockIdx.x);
+        if ((int64_t)blockIdx.x < R) {
+            nxt = ctx_region<U>(raw1, chrom_len[raw1.chrom], chrom_off[raw1.chrom], binsize);
+            request(nxt, staged);
+        }
+        raw1 = raw_of(blockIdx.x + G);                // the region after this workgroup's first
+        for (int64_t r = blockIdx.x; r < R; r += G) {
+            const CtxRegion q = nxt;
+            const int64_t tiles = q.too_long ? 0 : (q.tiles_valid < n_tiles ? q.tiles_valid : n_tiles);     // tiles written with values
             if (tid == 0 && c0 == 0) {
-                first_pos[r] = first;
-                n_valid[r] = (int32_t)(tiles_valid < n_tiles ? tiles_valid : n_tiles);
+                first_pos[r] = q.first;
+                n_valid[r] = q.too_long ? -1 : (int32_t)tiles;
             }
-            // stage the bases first - U .. stop + U - 1
-            const int64_t ga = g0 - U;
-            const int64_t w0 = (ga >> 3) + 1;                   // array word = genome word + 1 (leading pad word)
-            const int64_t nw = n_pos > 0 ? ((ga + n_pos + 2 * U - 1) >> 3) + 1 - w0 + 1 : 0;
+            // (requested now, used after the codes: the description of the region after the next, the chromosome of the next)
+            const CtxRaw raw2 = raw_of(r + 2 * G);
+            int64_t len1 = 0, off1 = 0;
+            if (r + G < R) {
+                len1 = chrom_len[raw1.chrom];
+                off1 = chrom_off[raw1.chrom];
+            }
+            TM_MARK(0);
+            __syncthreads();                          // the previous region's walkers are done with s_code / s_sum (and the table is staged)
+            TM_MARK(1);
+#pragma unroll
+            for (int j = 0; j < kCtxWordsPer; ++j) {
+                const int64_t i = tid + (int64_t)j * kCtxBlock;
+                if (i < q.nw) s_words[i] = staged[j];
+            }
             __syncthreads();
-            stage_words<256>(s_words, words, n_words, w0, nw, tid);
-            __syncthreads();
-            const int64_t g_lds0 = (w0 - 1) << 3;
-            // one tile: the table values of its positions, summed per cohort of the chunk
-            auto tile_sums = [&](int64_t t, double (&acc)[kCtxChunk]) {
+            TM_MARK(2);
+            // ---- context codes: a thread forms the codes of EIGHT consecutive positions from three words and stores them
+            // as one 16-byte piece.  The sixteen nibbles from the first window's leftmost base on are squeezed to sixteen
+            // 2-bit fields (five mask-and-fold steps), every (2 W)-bit substring of which IS a code; a window that holds a
+            // nibble > 3 gets the zero row (looked at only when the sixteen nibbles hold one). ----
+            if (!q.too_long) {
+                const int sh = 4 * (int)((q.g0 - U) & 7);        // bit of the first window's leftmost base in s_words[0]
+                for (int64_t j = tid; 8 * j < q.n_pos; j += kCtxBlock) {
+                    const uint32_t wa = s_words[j], wb = s_words[j + 1], wc = s_words[j + 2];
+                    const uint32_t lo = (uint32_t)((((uint64_t)wb << 32) | wa) >> sh), hi = (uint32_t)((((uint64_t)wc << 32) | wb) >> sh);
+                    const uint64_t n64 = ((uint64_t)hi << 32) | lo;          // nibbles of the bases 8 j + sh / 4 .. + 15
+                    uint64_t y = n64 & 0x3333333333333333ull;
+                    y = (y | (y >> 2)) & 0x0f0f0f0f0f0f0f0full;
+                    y = (y | (y >> 4)) & 0x00ff00ff00ff00ffull;
+                    y = (y | (y >> 8)) & 0x0000ffff0000ffffull;
+                    const uint32_t z = (uint32_t)(y | (y >> 16));            // base i at bits 2 i
+                    uint32_t code[8];
 #pragma unroll
-                for (int c = 0; c < kCtxChunk; ++c) acc[c] = 0.0;
-                const int64_t p0 = t * binsize;
-                int64_t cnt = binsize;
-                if (cnt > n_pos - p0) cnt = n_pos - p0;
-                unsigned ctx = 0;
-                int good = 0;                                    // consecutive ACGT bases ending at the newest one
+                    for (int k = 0; k < 8; ++k) code[k] = (z >> (2 * k)) & (uint32_t)(K - 1);
+                    const uint64_t hb = n64 & 0xccccccccccccccccull;
+                    if (hb) {
 #pragma unroll
-                for (int j = 0; j < 2 * U; ++j) {                // the window of position p0, all but its last base
-                    const unsigned b = tile_base(s_words, g0 + p0 - U + j, g_lds0);
-                    good = b > 3u ? 0 : good + 1;
-                    ctx = ((ctx << 2) | (b & 3u)) & kMask;
-                }
-                for (int64_t j = 0; j < cnt; ++j) {
-                    const unsigned b = tile_base(s_words, g0 + p0 + j + U, g_lds0);
-                    good = b > 3u ? 0 : good + 1;
-                    ctx = ((ctx << 2) | (b & 3u)) & kMask;
-                    if (good >= W) {
-#pragma unroll
-                        for (int c = 0; c < kCtxChunk; ++c) acc[c] += s_S[c][ctx];
+                        for (int k = 0; k < 8; ++k)
+                            if ((hb >> (4 * k)) & ((1ull << (4 * W)) - 1)) code[k] = (uint32_t)K;
                     }
+                    *reinterpret_cast<uint4*>(s_code + 8 * j) = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16),
+                                                                           code[4] | (code[5] << 16), code[6] | (code[7] << 16));
                 }
+            }
+            __syncthreads();
+            TM_MARK(3);
+            if (r + G < R) {                          // the next region's words travel during this region's walk
+                nxt = ctx_region<U>(raw1, len1, off1, binsize);
+                request(nxt, staged);
+            }
+            raw1 = raw2;
+            // the sum of the table values of positions [p0, p1) for cohort lane c
+            auto span_sum = [&](int64_t p0, int64_t p1) {
+                double acc = 0.0;
+                int64_t p = p0;
+                // sixteen positions per trip: their codes, then their table rows, are all in flight together (two dependent LDS
+                // round trips per trip instead of per position: with two waves per SIMD nothing else hides them); the rest of a
+                // span in one trip too: positions past its end read the zero row
+                while (p1 - p >= 4) {
+                    unsigned k[16];
+                    double v[16];
+                    if (!(p & 1)) {                   // codes in pairs
+                        const uint32_t* c32 = reinterpret_cast<const uint32_t*>(s_code + p);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t two = c32[i];
+                            k[2 * i] = two & 0xffffu;
+                            k[2 * i + 1] = two >> 16;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) k[i] = s_code[p + i];
+                    }
+                    if (p1 - p < 16) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) k[i] = p + i < p1 ? k[i] : (unsigned)K;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = s_S[k[i]][c];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc += v[i];        // (+ 0.0 leaves the sum as it is)
+                    p = p + 16 < p1 ? p + 16 : p1;
+                }
+                for (; p < p1; ++p) acc += s_S[s_code[p]][c];
+                return acc;
             };
-            const int64_t tiles = tiles_valid < n_tiles ? tiles_valid : n_tiles;       // tiles that are written with values
-            const bool one_pass = n_tiles <= kTileBlock;
-            double mine[kCtxChunk], tot[kCtxChunk];
-#pragma unroll
-            for (int c = 0; c < kCtxChunk; ++c) tot[c] = mine[c] = 0.0;
-            // region totals: over ALL tiles of the region (also those beyond n_tiles, if the caller asked for fewer)
-            for (int64_t t = tid; t < tiles_valid; t += kTileBlock) {
-                double acc[kCtxChunk];
-                tile_sums(t, acc);
-#pragma unroll
-                for (int c = 0; c < kCtxChunk; ++c) {
-                    tot[c] += acc[c];
-                    if (one_pass && t < kTileBlock) mine[c] = acc[c];        // (a region may have more tiles than the caller asked for)
+            // 64 walkers take the tiles in rounds of 64.  The tiles of a last, short round (200 tiles: 8) are cut into pieces so
+            // that every walker of that round has one -- a piece of seven positions is one trip where a tile of fifty is four: the
+            // busiest walker then makes 13 trips instead of 16.  A split tile's value is the sum of its pieces in order.
+            const int64_t whole = q.tiles_valid & ~(int64_t)63, rest = q.tiles_valid - whole;
+            int pieces = 1;
+            if (rest > 0 && rest <= 32 && binsize >= 8 && q.tiles_valid <= kCtxSumTiles) {
+                pieces = 2;
+                while (pieces < 8 && pieces * 2 * rest <= 64 && pieces * 2 * 4 <= binsize) pieces *= 2;
+            }
+            const int64_t piece_len = (binsize + pieces - 1) / pieces;
+            const bool stash = q.tiles_valid <= kCtxSumTiles;
+            // ---- region totals over ALL tiles (also those beyond n_tiles, if the caller asked for fewer) ----
+            double mine = 0.0;
+            if (!q.too_long) {
+                const int64_t full_tiles = pieces > 1 ? whole : q.tiles_valid;
+                for (int64_t t = walker; t < full_tiles; t += kCtxBlock / 8) {
+                    const int64_t p0 = t * binsize, p1 = p0 + binsize < q.n_pos ? p0 + binsize : q.n_pos;
+                    const double a = span_sum(p0, p1);
+                    mine += a;
+                    if (stash) s_sum[c][t] = a;
+                }
+                if (pieces > 1 && walker < rest * pieces) {
+                    const int64_t t = whole + walker / pieces, j = walker % pieces;
+                    const int64_t t1 = (t + 1) * binsize < q.n_pos ? (t + 1) * binsize : q.n_pos;
+                    int64_t p0 = t * binsize + j * piece_len, p1 = p0 + piece_len;
+                    if (p1 > t1) p1 = t1;
+                    const double a = p0 < p1 ? span_sum(p0, p1) : 0.0;
+                    mine += a;
+                    s_sum[c][kCtxSumStride + walker] = a;
                 }
             }
-#pragma unroll
-            for (int c = 0; c < kCtxChunk; ++c) {
-                double v = tot[c];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (lane == 0) s_part[wave][c] = v;
-            }
+            s_part[walker][c] = mine;
+            TM_MARK(4);
             __syncthreads();
-            if (tid < kCtxChunk) {
+            TM_MARK(5);
+            if (tid < 64) {                           // lane (g, c): walkers 8 g .. 8 g + 7, then the eight g's
+                const int g = tid >> 3;
                 double v = 0.0;
-                for (int w = 0; w < kTileBlock / 64; ++w) v += s_part[w][tid];
-                s_T[tid] = v;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += s_part[8 * g + w][c];
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (tid < kCtxCoh) s_T[tid] = v;
             }
             __syncthreads();
-            for (int64_t t = tid; t < n_tiles; t += kTileBlock) {
-                double acc[kCtxChunk];
-                const bool live = t < tiles;
-                if (live && !one_pass) tile_sums(t, acc);
+            TM_MARK(6);
+            // ---- pt = sum / total, a lane = a tile ----
+            if (stash || q.too_long) {
+                for (int64_t t = tid; t < n_tiles; t += kCtxBlock)
 #pragma unroll
-                for (int c = 0; c < kCtxChunk; ++c)
-                    if (c < cc) pt[((c0 + c) * R + r) * n_tiles + t] = live ? (one_pass ? mine[c] : acc[c]) / s_T[c] : nan;
+                    for (int co = 0; co < kCtxCoh; ++co)
+                        if (co < cc) {
+                            double v = nan;
+                            if (t < tiles) {
+                                if (pieces > 1 && t >= whole) {
+                                    // (all reads first: one after the other they were 64 LDS round trips for the threads of the
+                                    //  split tiles, and the whole workgroup waited for them at the next barrier)
+                                    double pc[8];
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) pc[j] = j < pieces ? s_sum[co][kCtxSumStride + (t - whole) * pieces + j] : 0.0;
+                                    v = pc[0];
+#pragma unroll
+                                    for (int j = 1; j < 8; ++j) v += pc[j];          // (+ 0.0 leaves the sum as it is)
+                                } else {
+                                    v = s_sum[co][t];
+                                }
+                                v = v / s_T[co];
+                            }
+                            pt[((c0 + co) * R + r) * n_tiles + t] = v;
+                        }
+            } else {
+                for (int64_t tb = 0; tb < n_tiles; tb += kCtxSumTiles) {
+                    __syncthreads();
+                    const int64_t te = tb + kCtxSumTiles < tiles ? tb + kCtxSumTiles : tiles;
+                    for (int64_t t = tb + walker; t < te; t += kCtxBlock / 8) {
+                        const int64_t p0 = t * binsize, p1 = p0 + binsize < q.n_pos ? p0 + binsize : q.n_pos;
+                        s_sum[c][t - tb] = span_sum(p0, p1);
+                    }
+                    __syncthreads();
+                    const int64_t tn = tb + kCtxSumTiles < n_tiles ? tb + kCtxSumTiles : n_tiles;
+                    for (int64_t t = tb + tid; t < tn; t += kCtxBlock)
+#pragma unroll
+                        for (int co = 0; co < kCtxCoh; ++co)
+                            if (co < cc) pt[((c0 + co) * R + r) * n_tiles + t] = t < tiles ? s_sum[co][t - tb] / s_T[co] : nan;
+                }
             }
         }
     }
+#ifdef DIG_TM_TIMING
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_tm_prof[k], tm_acc[k]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void tile_mut_counts_kernel(const int32_t* __restrict__ pair_mut, const int32_t* __restrict__ pair_reg,
@@ -677,14 +858,14 @@ int dig_base_tile_probs_ctx(const uint32_t* genome_words, int64_t n_words, const
     if (R == 0) return DIG_OK;
     DIG_REQUIRE(genome_words && chrom_off && chrom_len && reg_chrom && reg_start && reg_end && first_pos && n_valid, "non-null pointers");
     DIG_REQUIRE(C == 0 || n_tiles == 0 || (s_prob && pt), "s_prob and pt");
-    // (regions longer than the staging buffer -- 12 280 - 2 n_up positions -- are refused by the host wrapper, which knows
-    //  the coordinates; the kernel stages one region at a time)
-    const int grid = grid_for(R * kTileBlock, kTileBlock, 1);
+    // (a region of more than kCtxMaxPos positions is not evaluated -- n_valid -1, pt NaN; the host wrappers, which know the
+    //  coordinates, refuse such regions before the launch)
+    const int grid = grid_for(R * kCtxBlock, kCtxBlock, 1);
     if (n_up == 1)
-        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<1>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,
+        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<1>), dim3(grid), dim3(kCtxBlock), 0, (hipStream_t)stream, genome_words, n_words,
                            chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
     else
-        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<2>), dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words,
+        hipLaunchKernelGGL((base_tile_probs_ctx_kernel<2>), dim3(grid), dim3(kCtxBlock), 0, (hipStream_t)stream, genome_words, n_words,
                            chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;

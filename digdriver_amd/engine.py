@@ -661,7 +661,7 @@ def tiled_nb_test(pt, k, mu, sigma, device=0):
 # ---------------------------------------------------------------------------
 # per-base / tiled route: front half (dig_base_tile_probs + dig_tile_mut_counts) and the whole chain
 # ---------------------------------------------------------------------------
-TILE_CTX_MAX_POSITIONS = 12276      # what base_tile_probs_ctx_kernel<2> stages per region (dig_tiles.hip)
+TILE_CTX_MAX_POSITIONS = 16384      # positions of a region base_tile_probs_ctx_kernel evaluates (kCtxMaxPos, dig_tiles.hip)
 
 
 def check_tile_regions(starts, ends, n_up):

@@ -293,8 +293,10 @@ int dig_tile_mut_counts(const int32_t *pair_mut, const int32_t *pair_reg, int64_
 /* General-context form (ABI 4): n_up = n_down = 1 (forwards to dig_base_tile_probs) or 2 -- penta-nucleotide contexts, the
  * DEFAULT signature of the reference's per-base functions (sequence_tools.py:292, nb_model.py:126,188).  s_prob f64
  * [C, 4^(2 n_up + 1)] by context index (itertools.product('ACGT', repeat = 2 n_up + 1) order); positions
- * (start == 0 ? n_up : start) .. min(end, chrom_len - n_up) - 1 (fetch_sequence :21-29); a region may hold at most
- * 12 280 - 2 n_up positions.  Everything else as dig_base_tile_probs. */
+ * (start == 0 ? n_up : start) .. min(end, chrom_len - n_up) - 1 (fetch_sequence :21-29).  A region of more than 16 384
+ * positions is NOT evaluated by the device entry point (n_valid[r] = -1, its pt NaN; ABI 6 -- before, such a region
+ * overran a staging buffer); a caller that holds the coordinates on the host refuses such regions, and regions that
+ * start inside (0, n_up), before the launch (the _host twin does).  Everything else as dig_base_tile_probs. */
 int dig_base_tile_probs_ctx(const uint32_t *genome_words, int64_t n_words, const int64_t *chrom_off, const int64_t *chrom_len,
                             int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start, const int64_t *reg_end, int64_t R,
                             const double *s_prob, int64_t C, int n_up, int binsize, int64_t n_tiles, double *pt,

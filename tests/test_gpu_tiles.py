@@ -226,11 +226,12 @@ def test_sharded_tiles_equal_unsharded_bit_for_bit():
             assert bool(torch.isfinite(want).all())
             off, got = 0, []
             for r, p in zip(ranks, parts):
-                r.offset = off
-                q = r.q_values(c, gathered=allp)
+                q = r.q_values(c, gathered=allp, offset=off)
                 got.append(q[r.valid_pvalues(c)[1]])
                 off += p.numel()
             assert torch.equal(torch.cat(got), want), (world, c)
+        with pytest.raises(ValueError):
+            ranks[0].q_values(0, gathered=allp)                                    # the caller's exchange needs the rank's offset
 
 
 @pytest.mark.parametrize("binsize", [50, 1])
