@@ -477,6 +477,11 @@ def main():
     ap.add_argument("--aux", type=int, default=1,
                     help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
                          "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
+    ap.add_argument("--e2e", type=int, default=1,
+                    help="1: after the timed region (N = 1 only) write configs[2] as FILES (37 HDF5 maps, element data, 37 mutation "
+                         "files) and time the drop-in from files to 37 results.txt, stage by stage (tools/e2e_bench.py; ~40 s, 1.7 GB "
+                         "under --e2e-dir); reported as e2e; 0: skip")
+    ap.add_argument("--e2e-dir", default=None, help="scratch directory of the e2e leg (default: a fresh directory under the system's temp)")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -955,6 +960,23 @@ def main():
             del td, pipes, seq_plan
             torch.cuda.empty_cache()
             res["aux_rooflines"] = aux_rooflines(dev)
+        if args.e2e and world == 1 and (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37):
+            # the number a user of the drop-in sees: files in, results.txt out; never mixed into `value`
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import e2e_bench
+            torch.cuda.empty_cache()
+            work = args.e2e_dir or tempfile.mkdtemp(prefix="dig_e2e_")
+            saved = os.dup(1)
+            os.dup2(2, 1)                                 # the pipeline's progress lines go to stderr: stdout carries the JSON line only
+            try:
+                res["e2e"] = e2e_bench.run_e2e(workdir=work)
+            except Exception as exc:                      # (a full disk must not cost the bench line)
+                res["e2e"] = {"error": repr(exc)}
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
         else:

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "dig_count_contexts_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "dig_count_contexts2": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_count_contexts2_host": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _int],
+    "dig_write_tsv_host": [ctypes.c_char_p, ctypes.c_char_p, _vp, _vp, _i64, _int, _vp, _vp, _int],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_overlap_join_fill": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dig_overlap_join_count_host": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int],

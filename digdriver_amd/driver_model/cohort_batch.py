@@ -67,47 +67,84 @@ def genome_scale_factors(tables, cohorts, device):
     return n_snv / exp_sum, n_ind / exp_sum
 
 
+class _Stages:
+    """Wall-clock per stage of run_element_cohorts (tools/e2e_bench.py): the device is drained at every boundary."""
+
+    def __init__(self, sink, dev):
+        import time
+        self.sink, self.dev, self.clock, self.t = sink, dev, time.perf_counter, time.perf_counter()
+
+    def mark(self, name):
+        if self.sink is None:
+            return
+        import torch
+        torch.cuda.synchronize(self.dev)
+        now = self.clock()
+        self.sink[name] = self.sink.get(name, 0.0) + (now - self.t)
+        self.t = now
+
+
 def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_factors=None, max_muts_per_sample=3e9,
-                        max_muts_per_elt_per_sample=3e9, device=0):
+                        max_muts_per_elt_per_sample=3e9, device=0, timings=None, read_workers=None):
     """One result frame per cohort (index ELT, the columns of run_element_region_model) for the mutation files
     `f_muts[c]` against the pretrained maps `f_pretrained[c]` (one bin grid) and the element set `save_key` of
-    `f_element_data`.  scale_factors: (cj [C], cj_indel [C]) or None for the genome mode."""
+    `f_element_data`.  scale_factors: (cj [C], cj_indel [C]) or None for the genome mode.
+    timings: dict that receives seconds per stage; read_workers: threads that parse the C mutation files and read the C
+    maps side by side (default: min(C, cores) from 8 cohorts on, else 1 = in this process)."""
+    import os
     import torch
     dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
     assert len(f_muts) == len(f_pretrained) and len(f_muts) > 0
     C = len(f_muts)
-    files, tables, d_pr = genic_driver_tools._load_cohorts(list(f_pretrained))
+    if read_workers is None:
+        read_workers = min(C, os.cpu_count() or 1) if C >= 8 else 1
+    st_ = _Stages(timings, dev)
+    files, tables, d_pr = genic_driver_tools._load_cohorts(list(f_pretrained), workers=read_workers)
+    st_.mark("read_maps")
     w = tables.window
     elts = genic_driver_tools._element_set(f_element_data, w, save_key)
     E = len(elts['names'])
     ctx = tables.aligned_context(mapfile.read_array(f_element_data, 'window_{}/full_window_si_index'.format(w)),
                                  mapfile.read_array(f_element_data, 'window_{}/full_window_si_values'.format(w)))
+    st_.mark("read_element_data")
     ov_ptr, ov_idx = engine.ideal_overlaps(elts['chrom'], elts['blk_ptr'], elts['blk_start'], elts['blk_end'], w,
                                            tables.chrom, tables.start)
+    st_.mark("bin_overlaps")
     print('Tabulating mutations')
     owner = np.repeat(np.arange(E), np.diff(elts['blk_ptr']))
     blocks = tabulate_gpu.ElementBlocks(elts['chrom'][owner], elts['blk_start'], elts['blk_end'], owner, E, dev)
-    cohorts = [tabulate_gpu.encode_mutations(_read_raw_mutations(f), dev, cohort_id=c) for c, f in enumerate(f_muts)]
+    enc = _encode_all_mutations(f_muts, read_workers)
+    st_.mark("parse_mutation_files")
+    cohorts = [tabulate_gpu.to_device(e, dev) for e in enc]
+    del enc
+    st_.mark("mutations_h2d")
     obs_snv, obs_smp, obs_ind, _ = tabulate_gpu.tabulate_cohorts(blocks, cohorts, drop_duplicates=True,
                                                                  max_muts_per_sample=max_muts_per_sample,
                                                                  max_muts_per_elt_per_sample=max_muts_per_elt_per_sample)
+    st_.mark("join_tabulate")
     if scale_factors is None:
         print('Calculating scale factor')
         cj, cji = genome_scale_factors(tables, cohorts, dev)
     else:
         cj = torch.as_tensor(np.asarray(scale_factors[0], float), device=dev).reshape(C)
         cji = torch.as_tensor(np.asarray(scale_factors[1], float), device=dev).reshape(C)
+    st_.mark("scale_factors")
     print('Calculating statistics')
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
-    acc, st = engine.element_pipeline(t(tables.mu), t(tables.std), t(tables.y), t(tables.flag), t(ctx), t(ov_ptr), t(ov_idx),
-                                      t(elts['L']), t(elts['strand_minus']), t(d_pr), obs_snv, obs_smp, obs_ind, cj, cji)
+    args = (t(tables.mu), t(tables.std), t(tables.y), t(tables.flag), t(ctx), t(ov_ptr), t(ov_idx), t(elts['L']),
+            t(elts['strand_minus']), t(d_pr))
+    st_.mark("h2d")
+    acc, st = engine.element_pipeline(*args, obs_snv, obs_smp, obs_ind, cj, cji)
     alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
+    st_.mark("kernels")
     host = lambda x: x.cpu().numpy()
     A = {k: host(v) for k, v in acc.items()}
     S, al, th = host(st), host(alpha), host(theta)
     cj_h, cji_h = host(cj), host(cji)
     o_snv, o_smp, o_ind = host(obs_snv), host(obs_smp), host(obs_ind)
+    st_.mark("d2h")
     frames = []
+    index = pd.Index(elts['names'], name='ELT')              # one object for all cohorts
     for c in range(C):
         have_indel = o_ind[:, c].sum() != 0
         d = {'ELT_SIZE': A['ELT_SIZE'], 'FLAG': A['FLAG'][:, c].astype(bool), 'R_SIZE': A['R_SIZE'], 'R_OBS': A['R_OBS'][:, c],
@@ -118,5 +155,50 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
              'EXP_SNV': S[0][:, c], 'PVAL_SNV_BURDEN': S[1][:, c], 'PVAL_SAMPLE_BURDEN': S[2][:, c]}
         if have_indel:                                       # transfer_tools.py:1079-1087
             d.update({'EXP_INDEL': S[4][:, c], 'PVAL_INDEL_BURDEN': S[5][:, c], 'PVAL_MUT_BURDEN': S[6][:, c]})
-        frames.append(pd.DataFrame(d, index=pd.Index(elts['names'], name='ELT')))
+        frames.append(pd.DataFrame(d, index=index))
+    st_.mark("frames")
     return frames
+
+
+def _encode_all_mutations(f_muts, workers=None):
+    """The C mutation files as the host arrays of tabulate_gpu.encode_mutation_file, parsed and encoded side by side: a
+    cohort's file is 10^5 - 10^6 rows (pandas: 0.45 s per 300 000; C of them one after the other were the largest stage of a
+    many-cohort run).  Threads, not processes: pyarrow's reader and numpy's sorts release the interpreter lock, and worker
+    processes would have to be spawned -- this process may hold the GPU -- which re-imports the caller's main module."""
+    import os
+    n = len(f_muts)
+    workers = min(n, os.cpu_count() or 1) if workers is None else int(workers)
+    job = lambda cf: tabulate_gpu.encode_mutation_file(cf[1], cohort_id=cf[0])
+    if workers <= 1 or n == 1:
+        return [job(cf) for cf in enumerate(f_muts)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return list(pool.map(job, list(enumerate(f_muts))))
+
+
+def write_results(frames, outdir, prefixes, workers=None):
+    """<outdir>/<prefix>.results.txt per cohort, as DigDriver.py writes it (DigDriver.py:108-118: the OBS_* columns as
+    integers, tab-separated, the index column first) -- through the native writer (mapfile.write_results_tsv: the bytes
+    of DataFrame.to_csv), several files at a time (the native call does not hold the interpreter lock)."""
+    import os
+    os.makedirs(outdir, exist_ok=True)
+    paths = [os.path.join(outdir, pfx + '.results.txt') for pfx in prefixes]
+
+    def one(job):
+        df, path = job
+        ints = {col: df[col].astype(int) for col in ('OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL') if col in df.columns}
+        mapfile.write_results_tsv(df.assign(**ints), path)      # (same index object for every cohort: its text is encoded once)
+        return path
+
+    jobs = list(zip(frames, paths))
+    workers = min(len(jobs), 8, os.cpu_count() or 1) if workers is None else int(workers)
+    if jobs:
+        one(jobs[0])                                         # (fills the label cache)
+    if workers <= 1:
+        for job in jobs[1:]:
+            one(job)
+    elif len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(one, jobs[1:]))
+    return paths

@@ -144,8 +144,9 @@ def _decode_index(node, encoding="utf-8"):
     return pd.Index(vals, name=name)
 
 
-def decode_frame(g):
-    """h5lite.Group in pandas' fixed format -> DataFrame."""
+def decode_frame(g, with_index=True):
+    """h5lite.Group in pandas' fixed format -> DataFrame.  with_index=False: a RangeIndex instead of the stored row labels
+    (a whole-genome region_params frame stores 288 000 label strings nobody reads: two thirds of the time to load it)."""
     if not isinstance(g, H.Group):
         raise FrameFormatError("not a frame group (it is a dataset)")
     ptype = _attr_text(g.attrs.get("pandas_type"))
@@ -155,7 +156,7 @@ def decode_frame(g):
         raise FrameFormatError("not a pandas fixed-format frame (pandas_type=%r)" % (ptype,))
     enc = _attr_text(g.attrs.get("encoding")) or "utf-8"
     columns = _decode_index(g.children["axis0"], enc)
-    index = _decode_index(g.children["axis1"], enc)
+    index = _decode_index(g.children["axis1"], enc) if with_index else pd.RangeIndex(int(np.shape(g.children["axis1"].data)[0]))
     nblocks = int(g.attrs.get("nblocks", sum(1 for k in g.children if k.endswith("_items"))))
     data = {}
     for b in range(nblocks):

@@ -91,10 +91,27 @@ def sorted_d_pr(df_seq):
     return np.asarray(df_seq.FREQ.values, np.float64)[order]
 
 
-def _load_cohorts(f_pretrained, key='region_params'):
+def _read_cohort_frames(args):
+    f, key = args
+    df = mapfile.read_frame(f, key, index=False)
+    # only what RegionTables takes: a process that read the map for another hands back six columns, not the whole frame
+    return df[['CHROM', 'START', 'END', 'Y_PRED', 'STD', 'Y_TRUE', 'FLAG']], mapfile.read_frame(f, 'sequence_model_192')
+
+
+def _load_cohorts(f_pretrained, key='region_params', workers=1):
+    """The maps' region_params as RegionTables + the [C, 192] sequence models.  workers > 1: the C maps are read side by
+    side by spawned processes (37 whole-genome maps: 37 x 288 000 rows of HDF5)."""
     files = [f_pretrained] if isinstance(f_pretrained, (str, bytes)) or hasattr(f_pretrained, "__fspath__") else list(f_pretrained)
-    tables = RegionTables([mapfile.read_frame(f, key) for f in files])
-    d_pr = np.stack([sorted_d_pr(mapfile.read_frame(f, 'sequence_model_192')) for f in files])
+    import os
+    workers = min(len(files), os.cpu_count() or 1) if workers is None else int(workers)
+    if workers > 1 and len(files) > 1:
+        from concurrent.futures import ThreadPoolExecutor          # (zlib and numpy release the interpreter lock)
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            got = list(pool.map(_read_cohort_frames, [(f, key) for f in files]))
+    else:
+        got = [_read_cohort_frames((f, key)) for f in files]
+    tables = RegionTables([g[0] for g in got])
+    d_pr = np.stack([sorted_d_pr(g[1]) for g in got])
     return files, tables, d_pr
 
 

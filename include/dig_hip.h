@@ -374,6 +374,16 @@ int dig_count_contexts2_host(const uint32_t *words2, int64_t n_words2, const int
                              const int64_t *chrom_len, int n_chrom, const int32_t *reg_chrom, const int64_t *reg_start,
                              const int64_t *reg_end, const uint8_t *reg_minus, int64_t R, int32_t *out, int device);
 
+/* ---- result files (ABI 6; host code only) ------------------------------------------------- *
+ * The text DataFrame.to_csv(path, header=True, index=True, sep="\t") writes for a frame (DigDriver.py:115-118): `header`
+ * (a complete first line, no newline), then n_rows rows  label TAB col_0 TAB ... col_{n_cols-1}.
+ *   labels: the row labels as one UTF-8 blob, label r = bytes label_off[r] .. label_off[r + 1] - 1;
+ *   col_kind[j]: 0 = float64, written as Python's repr (shortest round-trip digits; positional for 1e-4 <= |x| < 1e16, else
+ *       d.ddde-XX; NaN = empty field, inf / -inf), 1 = int64, 2 = bool as uint8 (True / False);
+ *   n_threads: rows are formatted by up to 16 threads and written in order. */
+int dig_write_tsv_host(const char *path, const char *header, const char *labels, const int64_t *label_off, int64_t n_rows,
+                       int n_cols, const void *const *col_ptr, const int *col_kind, int n_threads);
+
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins
  * floor(start/w)*w ... ceil(end/w)*w; duplicates removed; rows are looked up in the sorted bin

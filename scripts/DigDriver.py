@@ -14,6 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from digdriver_amd.driver_model import transfer_tools  # noqa: E402
+from digdriver_amd.io import mapfile  # noqa: E402
 
 PANELS = ['MSK_230', 'MSK_341', 'MSK_410', 'MSK_468', 'metabric_173', 'ucla_1202']
 CGC_SETS = ['CGC_ALL', 'CGC_ONC', 'CGC_TSG']
@@ -29,7 +30,7 @@ def write_results(frame, args):
     os.makedirs(args.outdir, exist_ok=True)
     target = os.path.join(args.outdir, args.outpfx + '.results.txt')
     print('\tSaving results to {}'.format(target))
-    frame.to_csv(target, header=True, index=True, sep="\t")
+    mapfile.write_results_tsv(frame, target)               # the bytes of frame.to_csv(target, header=True, index=True, sep="\t")
 
 
 def cmd_gene(args):

@@ -98,3 +98,40 @@ def test_bad_arguments_are_reported_through_dig_last_error():
                                           None, None, None, None, None, None, None, 1, 1, 1, 0)
     assert rc == -1
     assert "n_class" in _lib.last_error()
+
+
+def test_native_result_writer_writes_the_bytes_pandas_writes(tmp_path):
+    """mapfile.write_results_tsv (dig_write_tsv_host: std::to_chars digits + the layout rules of Python's float repr) against
+    DataFrame.to_csv(sep="\\t") -- what DigDriver.py writes (DigDriver.py:115-118) -- byte for byte: p-values down to the
+    subnormals, whole numbers, 1e-4 / 1e16 switch-overs, NaN, infinities, signed zeros, integers, bools; and the fall-back to
+    pandas for frames the writer does not cover."""
+    import numpy as np
+    import pandas as pd
+    from digdriver_amd.io import mapfile
+    rng = np.random.default_rng(0)
+    n = 20_011
+    edge = np.array([0.0, -0.0, 5e-324, 2.2250738585072014e-308, 1e-5, 9.999999999999999e-05, 1e-4, 0.00012345, 0.1, 1 / 3, 1.0, 12.0, 123456.0,
+                     1e15, 9999999999999998.0, 1e16, 1.2345e16, 1e22, 1.7976931348623157e308, np.inf, -np.inf, np.nan, -1.5e-7, -2.5, 100.0, 1e-300])
+    cols = {
+        'ELT_SIZE': rng.integers(200, 9000, n), 'FLAG': rng.uniform(size=n) < 0.1, 'MU': rng.gamma(9, 3, n),
+        'PVAL': 10.0 ** rng.uniform(-320, 0, n), 'Z': np.where(rng.uniform(size=n) < 0.01, np.nan, rng.normal(size=n)),
+        'WHOLE': rng.integers(0, 50, n).astype(float), 'BIG': rng.uniform(1e15, 1e18, n), 'SMALL': rng.uniform(1e-6, 1e-3, n),
+        'BITS': rng.integers(0, 2 ** 63 - 1, n, dtype=np.int64).view(np.float64), 'OBS': rng.integers(-5, 50, n).astype(np.int32),
+        'EDGE': np.resize(edge, n)}
+    df = pd.DataFrame(cols, index=pd.Index(['ELT%06d' % i for i in range(n)], name='ELT'))
+    a, b = tmp_path / "native.txt", tmp_path / "pandas.txt"
+    mapfile.write_results_tsv(df, str(a))
+    df.to_csv(str(b), header=True, index=True, sep="\t")
+    assert a.read_bytes() == b.read_bytes()
+    back = pd.read_csv(str(a), sep="\t", index_col=0, float_precision="round_trip")
+    assert np.array_equal(back.PVAL.values, df.PVAL.values) and np.array_equal(back.BITS.values, df.BITS.values, equal_nan=True)
+    # an unnamed integer index, no rows, no columns
+    for frame in (df.reset_index(drop=True).iloc[:7], df.iloc[:0], df.iloc[:5, :0]):
+        mapfile.write_results_tsv(frame, str(a))
+        frame.to_csv(str(b), header=True, index=True, sep="\t")
+        assert a.read_bytes() == b.read_bytes()
+    # not covered: a string column, a label with a tab -> pandas writes them
+    for frame in (df.iloc[:5].assign(NAME=list("abcde")), df.iloc[:3].rename(index={'ELT000001': 'a\tb'})):
+        mapfile.write_results_tsv(frame, str(a))
+        frame.to_csv(str(b), header=True, index=True, sep="\t")
+        assert a.read_bytes() == b.read_bytes()
