@@ -466,6 +466,19 @@ def aux_rooflines(dev):
                 "hbm_frac": (chunk * window * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK, "avg_launch_ms": dt * 1e3,
                 "workload": "36 000 bins x 200 tiles x 37 cohorts per launch (an eighth of BASELINE configs[4])",
                 "whole_genome_x37_ms": dt * 1e3 * nwin / chunk})
+    dt3 = dt
+    # the reference's DEFAULT contexts (n_up = n_down = 2, 1 024-entry tables): a gather-sum through the LDS
+    S5 = torch.rand((37, 1024), device=dev, generator=g, dtype=torch.float64) * 1e-2
+    dt = timeit(lambda: _lib.call("dig_base_tile_probs_ctx", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S5), 37,
+                                  2, 50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=2, warm=1)
+    reads = float(chunk) * window * 37
+    out.append({"kernel": "dig_base_tile_probs_ctx, n_up = 2 (penta-nucleotide contexts, the reference's default: base_tile_probs_ctx_kernel<2>)",
+                "bound": "lds", "achieved": reads * 8.0 / dt / 1e12, "peak": 150.0, "unit": "TB/s of LDS reads (8 B per position and cohort)",
+                "frac": reads * 8.0 / dt / 150e12, "algorithmic_bytes_per_launch": chunk * window * 0.5 + tiles * 37 * 8.0,
+                "hbm_frac": (chunk * window * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK, "avg_launch_ms": dt * 1e3,
+                "times_the_trinucleotide_kernel": dt / dt3, "table_reads_per_s": reads / dt,
+                "workload": "36 000 bins x 200 tiles x 37 cohorts per launch; 13.3 G table reads",
+                "whole_genome_x37_ms": dt * 1e3 * nwin / chunk})
     return out
 
 # --------------------------------------------------------------------------------------
