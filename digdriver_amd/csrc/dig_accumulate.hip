@@ -443,6 +443,9 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 // (inf * 0) and inf otherwise; numerator / 0 alone would say inf in both cases.  `lzero`: this lane's slices of the row's L
 // hold a zero.  The numerators of such rows are replaced so that the quotient that follows gives the reference's value.
 // Rare: one wave-uniform test per tile in front of it.
+// (Known deviation, ADVICE r3: a cohort whose SIGNATURE d_pr holds an exact zero makes the reference's t_pi hold 0 / 0 = NaN
+//  at that substitution whatever L is, so the reference says NaN for such a cohort even when every L[j] > 0; this kernel says
+//  inf there.  It takes a zero denominator AND an exact zero in a fitted 192-frequency table AND no zero in L: not reproduced.)
 template <int NT, int NQ>
 __device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT > 0 ? NT : 1], const double (&denq)[NQ > 0 ? NQ : 1],
                                                       double4_t (&num)[NT > 0 ? NT : 1], double (&numq)[NQ > 0 ? NQ : 1],

@@ -403,6 +403,8 @@ class PipelinePlan:
     the same tensors many times (the driver's cohort loop, bench.py): a call is then one ctypes invocation (~10 us of
     host time instead of ~60), which keeps the host ahead of a 0.3 ms GPU step.  The tensors are held by the plan."""
 
+    _ws_owner = {}         # data_ptr of a caller-owned workspace -> weak reference to the plan that owns it
+
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
                  obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None,
                  pack_bins=True):
@@ -432,9 +434,19 @@ class PipelinePlan:
         self.dev = dev
         self.acc = out_acc if out_acc is not None else alloc_accumulate_outputs(self.E, self.C, 1, dev)
         self.stats = out_stats if out_stats is not None else torch.empty((len(ES_PLANES), self.E, self.C), dtype=f64, device=dev)
-        if workspace is not None:          # a caller-owned scratch buffer (uint8, at least dig_element_pipeline_workspace bytes)
+        if workspace is not None:
+            # A caller-owned buffer (uint8, at least dig_element_pipeline_workspace bytes).  NOT plain scratch: a compact plan
+            # keeps its [E, 64] copy of L and the repetition flag in it from construction on (dig_element_pipeline_prepare), so
+            # the buffer belongs to THIS plan (or to plans over the very same L tensor) for the plan's lifetime -- two live plans
+            # over different element sets on one buffer would compute P from each other's L: refused below.
             self.ws, self.wsb = workspace, _lib.workspace_bytes("pipeline", self.E, self.C)
             assert workspace.numel() >= self.wsb and workspace.data_ptr() % 256 == 0
+            import weakref
+            owner = PipelinePlan._ws_owner.get(workspace.data_ptr())
+            if owner is not None and owner[0]() is not None and owner[0]() is not self and owner[1] != (L.data_ptr(), tuple(L.shape)):
+                raise ValueError("this workspace buffer already belongs to a live PipelinePlan over ANOTHER element set (a compact "
+                                 "plan keeps its copy of L in it): give every plan its own workspace")
+            PipelinePlan._ws_owner[workspace.data_ptr()] = (weakref.ref(self), (L.data_ptr(), tuple(L.shape)))
         else:
             self.ws, self.wsb = _workspace("pipeline", self.E, self.C, dev, private=True)
         if self.ws is None:
