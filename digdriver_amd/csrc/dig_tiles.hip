@@ -711,30 +711,33 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
             }
             __syncthreads();
             TM_MARK(6);
-            // ---- pt = sum / total, a lane = a tile ----
+            // ---- pt = sum / total: wave w writes cohort w's plane, a lane = a tile (with a thread = a tile for all eight cohorts
+            // 200 of the 512 threads wrote and the rest waited at the next barrier) ----
             if (stash || q.too_long) {
-                for (int64_t t = tid; t < n_tiles; t += kCtxBlock)
+                const int co = tid >> 6;
+                if (co < cc) {
+                    const double total = s_T[co];
+                    double* plane = pt + ((c0 + co) * R + r) * n_tiles;
+                    for (int64_t t = tid & 63; t < n_tiles; t += 64) {
+                        double v = nan;
+                        if (t < tiles) {
+                            if (pieces > 1 && t >= whole) {
+                                // (all reads first: one after the other they were 64 LDS round trips for the threads of the
+                                //  split tiles, and the whole workgroup waited for them at the next barrier)
+                                double pc[8];
 #pragma unroll
-                    for (int co = 0; co < kCtxCoh; ++co)
-                        if (co < cc) {
-                            double v = nan;
-                            if (t < tiles) {
-                                if (pieces > 1 && t >= whole) {
-                                    // (all reads first: one after the other they were 64 LDS round trips for the threads of the
-                                    //  split tiles, and the whole workgroup waited for them at the next barrier)
-                                    double pc[8];
+                                for (int j = 0; j < 8; ++j) pc[j] = j < pieces ? s_sum[co][kCtxSumStride + (t - whole) * pieces + j] : 0.0;
+                                v = pc[0];
 #pragma unroll
-                                    for (int j = 0; j < 8; ++j) pc[j] = j < pieces ? s_sum[co][kCtxSumStride + (t - whole) * pieces + j] : 0.0;
-                                    v = pc[0];
-#pragma unroll
-                                    for (int j = 1; j < 8; ++j) v += pc[j];          // (+ 0.0 leaves the sum as it is)
-                                } else {
-                                    v = s_sum[co][t];
-                                }
-                                v = v / s_T[co];
+                                for (int j = 1; j < 8; ++j) v += pc[j];          // (+ 0.0 leaves the sum as it is)
+                            } else {
+                                v = s_sum[co][t];
                             }
-                            pt[((c0 + co) * R + r) * n_tiles + t] = v;
+                            v = v / total;
                         }
+                        plane[t] = v;
+                    }
+                }
             } else {
                 for (int64_t tb = 0; tb < n_tiles; tb += kCtxSumTiles) {
                     __syncthreads();
