@@ -128,15 +128,22 @@ def fisher_combine(p1, p2, device=0):
 # ---------------------------------------------------------------------------------------------
 # per-base / tiled route (nb_model.py:126-234, 340-342)
 # ---------------------------------------------------------------------------------------------
-def _s_prob_table(d_pr, n_up=1):
+def _s_prob_table(d_pr, n_up=1, collapse=False):
     """S_prob (dict / Series keyed by the (2 n_up + 1)-mer) -> 4^(2 n_up + 1) values in context index order: 64 for the
-    trinucleotide models of the live pipeline, 1 024 for the penta-nucleotide default of the reference's signatures."""
+    trinucleotide models of the live pipeline, 1 024 for the penta-nucleotide default of the reference's signatures.
+    collapse=True (pyrimidine-collapsed contexts: K = 96 substitution types, 32 / 512 contexts): the table holds the C- and
+    T-centred windows only; a window centred on A or G is looked up as its reverse complement (seq_to_context,
+    sequence_tools.py:42-55) -- expanded here into the full table, so that the kernels look every window up directly."""
     import itertools
+    from . import sequence_tools
     keys = ["".join(t) for t in itertools.product("ACGT", repeat=2 * n_up + 1)]
+    if collapse:
+        keys = [k if k[n_up] in "CT" else sequence_tools.reverse_complement(k) for k in keys]
     try:
         return np.array([float(d_pr[k]) for k in keys])
     except KeyError as exc:
-        raise KeyError("S_prob has no entry for context %s (n_up = n_down = %d needs all %d-mers)" % (exc, n_up, 2 * n_up + 1)) from exc
+        raise KeyError("S_prob has no entry for context %s (n_up = n_down = %d%s needs all %s%d-mers)" % (
+            exc, n_up, ", collapse=True" if collapse else "", "C- and T-centred " if collapse else "", 2 * n_up + 1)) from exc
 
 
 def _mutation_rows(f_mut):
@@ -155,12 +162,13 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=2, n_down=2, b
     them).  `f_tabix`: the cohort's bed-like mutation file (the reference reads it through tabix; here it is joined on the
     GPU in one pass); `f_fasta`: the genome (data_tools.genome.PackedGenome or a FASTA path).  All bins in three launches
     (engine.tiled_nb_model).  n_up = n_down = 2 (penta-nucleotide contexts, the reference's default) or 1 (the trinucleotide
-    models every live part of the pipeline trains); collapse=True (pyrimidine-collapsed contexts) is not built."""
+    models every live part of the pipeline trains); collapse=True: S_prob keyed by the pyrimidine-centred contexts (the
+    96-substitution model), windows centred on a purine looked up as their reverse complement."""
     import pandas as pd
     from .. import engine
     from ..data_tools import genome as genome_mod
-    if n_up != n_down or n_up not in (1, 2) or collapse:
-        raise NotImplementedError("the tile kernels take n_up = n_down = 1 or 2 and collapse=False")
+    if n_up != n_down or n_up not in (1, 2):
+        raise NotImplementedError("the tile kernels take n_up = n_down = 1 or 2")
     g = f_fasta if isinstance(f_fasta, genome_mod.PackedGenome) else genome_mod.PackedGenome.from_fasta(f_fasta)
     idx = np.asarray(idx)
     chroms = [str(c) for c in idx[:, 0]]
@@ -168,7 +176,7 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=2, n_down=2, b
     muts = f_tabix if isinstance(f_tabix, pd.DataFrame) else _mutation_rows(f_tabix)
     known = set(n.replace("chr", "") for n in g.names)
     muts = muts[muts.CHROM.astype(str).str.replace("chr", "", regex=False).isin(known)]
-    res = engine.tiled_nb_model(g, chroms, starts, ends, _s_prob_table(d_pr, n_up)[None, :], np.asarray(mu_lst, float)[None, :],
+    res = engine.tiled_nb_model(g, chroms, starts, ends, _s_prob_table(d_pr, n_up, collapse)[None, :], np.asarray(mu_lst, float)[None, :],
                                 np.asarray(sigma_lst, float)[None, :], muts.CHROM.astype(str).values, muts.START.values,
                                 muts.END.values, np.zeros(len(muts), np.int32), binsize=binsize, device=device)
     host = {k: v.cpu().numpy() for k, v in res.items()}

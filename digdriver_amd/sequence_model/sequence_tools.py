@@ -136,20 +136,30 @@ def load_genome(f_fasta):
 
 
 def _require_trinuc(n_up, n_down, collapse):
-    if (n_up, n_down, bool(collapse)) != (1, 1, False):
-        raise NotImplementedError("the GPU context counter handles trinucleotides (n_up = n_down = 1, collapse=False), the "
-                                  "only configuration the driver path uses (onthefly_tools.py:70-71,120)")
+    if (n_up, n_down) != (1, 1):
+        raise NotImplementedError("the GPU context counter handles trinucleotides (n_up = n_down = 1), the only configuration "
+                                  "the driver path uses (onthefly_tools.py:70-71,120)")
 
 
 def count_contexts_by_regions(f_fasta, chrom_lst, start_lst, end_lst, n_up=2, n_down=2, collapse=False):
     """sequence_tools.py:82-99: frame [regions x 64 contexts] (columns in mk_context_sequences order, index
-    "{CHROM}:{START}-{END}") -- one dig_count_contexts launch for all regions.  `f_fasta`: path or PackedGenome."""
+    "{CHROM}:{START}-{END}") -- one dig_count_contexts2 launch for all regions; collapse=True: the 32 pyrimidine-centred
+    contexts.  `f_fasta`: path or PackedGenome."""
     from .. import engine
     _require_trinuc(n_up, n_down, collapse)
     genome = f_fasta if hasattr(f_fasta, "words") else load_genome(f_fasta)
     cnt = engine.count_contexts(genome, list(chrom_lst), np.asarray(start_lst, np.int64), np.asarray(end_lst, np.int64))
     idx = ["{}:{}-{}".format(c, s, e) for c, s, e in zip(chrom_lst, start_lst, end_lst)]
-    return pd.DataFrame(cnt.cpu().numpy().astype(np.int64), index=idx, columns=list(mk_context_sequences(1, 1).keys()))
+    cnt = cnt.cpu().numpy().astype(np.int64)
+    ctx64 = list(mk_context_sequences(1, 1).keys())
+    if not collapse:
+        return pd.DataFrame(cnt, index=idx, columns=ctx64)
+    # collapse=True (the K = 96 model): a window centred on A or G counts as its reverse complement (seq_to_context,
+    # sequence_tools.py:42-55): the 32 pyrimidine-centred columns, each the sum of a context and its reverse complement
+    pos = {c: i for i, c in enumerate(ctx64)}
+    ctx32 = list(mk_context_sequences(1, 1, collapse=True).keys())
+    cols = np.array([pos[c] for c in ctx32]), np.array([pos[reverse_complement(c)] for c in ctx32])
+    return pd.DataFrame(cnt[:, cols[0]] + cnt[:, cols[1]], index=idx, columns=ctx32)
 
 
 def nonc_elt_context_count(regions, trans_idx, f_fasta, n_up=1, n_down=1):

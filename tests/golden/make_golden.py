@@ -1215,7 +1215,64 @@ def gen_tabulate():
           len(out["per_pair"]["ELT"]), "pairs", [len(c["blacklist"]) for c in out["cases"]])
 
 
+# ----------------------------------------------------------------------------
+# (xxi) pyrimidine-collapsed contexts (collapse=True: K = 96 substitution types)
+# ----------------------------------------------------------------------------
+def gen_collapse():
+    """The collapse=True branch of the per-base route and of the context counter (sequence_tools.py:31-55,65-99,232-262,
+    292-317; nb_model.py:126-234): no live caller of the reference passes it, the north star names it ("96-trinucleotide-
+    context").  The reference's own count_contexts_by_regions(collapse=True), mk_mutation_context / mk_trans_idx
+    (collapse=True) and nb_model(..., n_up=1, n_down=1, collapse=True) and (penta, collapse=True) on a small genome."""
+    import gzip
+    import itertools
+    rng = np.random.default_rng(96)
+    genome = {}
+    for chrom, n in (("chr1", 1500), ("chr2", 777)):
+        seq = rng.choice(list("ACGT"), n)
+        a = int(rng.integers(0, n - 60))
+        seq[a:a + 25] = "N"
+        genome[chrom] = "".join(seq)
+    _FakeFasta.genomes["mem://collapse"] = genome
+    sys.modules["pysam"].FastaFile = _FakeFasta
+    sys.modules["pysam"].TabixFile = _FakeTabix
+    window = 500
+    idx = [(1, s, s + window) for s in range(0, 1500, window)] + [(2, s, s + window) for s in range(0, 777, window)]
+    out = dict(genome=genome, idx=[list(map(int, r)) for r in idx])
+    out["mutation_context_96"] = [list(k) for k in ref_seq.mk_mutation_context(n_up=1, n_down=1, collapse=True).keys()]
+    out["trans_idx_96"] = ref_seq.mk_trans_idx(n_up=1, n_down=1, collapse=True)
+    regs = [("chr1", 0, 700), ("chr1", 650, 1500), ("chr2", 3, 5), ("chr2", 100, 900)]
+    cc = ref_seq.count_contexts_by_regions("mem://collapse", [r[0] for r in regs], [r[1] for r in regs], [r[2] for r in regs],
+                                           n_up=1, n_down=1, collapse=True)
+    out["count_regions"] = [list(r) for r in regs]
+    out["count_columns"] = list(cc.columns)
+    out["count_index"] = list(cc.index)
+    out["count_values"] = cc.values.astype(int).tolist()
+    rows = []
+    for chrom, n in (("1", 1500), ("2", 777)):
+        for _ in range(90):
+            p_ = int(rng.integers(0, n))
+            rows.append((chrom, p_, p_ + 1, "A", "T", "S%d" % rng.integers(0, 6)))
+    rows.sort()
+    _FakeTabix.tables["mem://cmuts"] = rows
+    out["rows"] = [list(r) for r in rows]
+    mu = rng.gamma(9.0, 3.0, len(idx))
+    sigma = rng.gamma(4.0, 1.0, len(idx))
+    out["mu"], out["sigma"], out["runs"] = mu.tolist(), sigma.tolist(), {}
+    for n_up in (1, 2):
+        keys = list(ref_seq.mk_context_sequences(n_up=n_up, n_down=n_up, collapse=True).keys())
+        d_pr = dict(zip(keys, (rng.dirichlet(np.ones(len(keys))) * 1e-2).tolist()))
+        df = ref_nb.nb_model(d_pr, idx, mu, sigma, "mem://cmuts", "mem://collapse", n_up=n_up, n_down=n_up, binsize=25, collapse=True)
+        out["runs"][str(n_up)] = dict(keys=keys, d_pr=[d_pr[k] for k in keys],
+                                      **{k: df[k].astype(float).tolist() for k in ["CHROM", "POS", "OBS", "EXP", "PVAL", "Pi"]})
+    with gzip.GzipFile(os.path.join(HERE, "collapse_golden.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
+    print("wrote collapse_golden.json.gz", len(out["trans_idx_96"]), {k: len(v["PVAL"]) for k, v in out["runs"].items()})
+
+
 def main():
+    if "--only-collapse" in sys.argv:
+        gen_collapse()
+        return
     if "--only-tabulate" in sys.argv:
         gen_tabulate()
         return
@@ -1262,6 +1319,7 @@ def main():
     gen_run_element_expectation()
     gen_run_target()
     gen_tabulate()
+    gen_collapse()
     import torch
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", reference=REF,

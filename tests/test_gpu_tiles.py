@@ -306,3 +306,29 @@ def test_general_context_kernel_many_cohorts_against_oracle_and_trinucleotide_ke
             out[form] = np.load(os.path.join(tmp, form + ".npz"))
         assert np.array_equal(out["mfma"]["f"], out["general"]["f"]) and np.array_equal(out["mfma"]["n"], out["general"]["n"])
         np.testing.assert_allclose(out["general"]["pt"], out["mfma"]["pt"], rtol=1e-12, equal_nan=True)
+
+
+def test_collapsed_contexts_k96_per_base_route_and_counts_match_reference():
+    """collapse=True (the north star's "96-trinucleotide-context" wording; no live caller of the reference passes it): the
+    per-base route nb_model(..., collapse=True) for trinucleotide (32-context S_prob) and penta-nucleotide (512) tables and
+    count_contexts_by_regions(collapse=True) against the reference's own outputs (tests/golden/collapse_golden.json.gz)."""
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from digdriver_amd.sequence_model import nb_model, sequence_tools
+    g = json.loads(gzip.open(os.path.join(GOLDEN, "collapse_golden.json.gz")).read())
+    genome = PackedGenome.from_sequences(g["genome"])
+    regs = g["count_regions"]
+    cc = sequence_tools.count_contexts_by_regions(genome, [r[0] for r in regs], [r[1] for r in regs], [r[2] for r in regs],
+                                                  n_up=1, n_down=1, collapse=True)
+    assert list(cc.columns) == g["count_columns"] and list(cc.index) == g["count_index"]
+    assert np.array_equal(cc.values, np.array(g["count_values"]))
+    muts = pd.DataFrame(g["rows"], columns=["CHROM", "START", "END", "REF", "ALT", "ID"])
+    muts["CHROM"] = muts.CHROM.astype(str)
+    for n_up in (1, 2):
+        run = g["runs"][str(n_up)]
+        df = nb_model.nb_model(dict(zip(run["keys"], run["d_pr"])), np.array(g["idx"]), g["mu"], g["sigma"], muts, genome, n_up=n_up,
+                               n_down=n_up, binsize=25, collapse=True)
+        assert len(df) == len(run["PVAL"])
+        assert np.array_equal(df.OBS.values, np.array(run["OBS"])) and np.array_equal(df.POS.values, np.array(run["POS"]))
+        np.testing.assert_allclose(df.Pi.values, run["Pi"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(df.EXP.values, run["EXP"], rtol=1e-12, atol=0)
+        rel_close(df.PVAL.values, np.array(run["PVAL"]), rtol=1e-6)

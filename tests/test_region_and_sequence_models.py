@@ -297,3 +297,27 @@ def test_nn_trainer_epoch_matches_reference_trainer():
     np.testing.assert_allclose(vl, d["val_losses"], rtol=5e-3)
     np.testing.assert_allclose(np.stack(vpreds), d["val_preds"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(np.stack(vfeats), d["val_features"], rtol=5e-3, atol=5e-3)
+
+
+def test_collapsed_contexts_k96_tables_match_reference():
+    """The K = 96 vocabulary (collapse=True: sequence_tools.py:31-55,232-289): mk_mutation_context / mk_trans_idx /
+    mk_context_sequences of this package against the reference's own (tests/golden/collapse_golden.json.gz), and the table
+    expansion nb_model uses for collapsed S_prob (a purine-centred window reads its reverse complement's entry)."""
+    import gzip
+    import itertools
+    import json
+    from digdriver_amd.sequence_model import nb_model, sequence_tools as st
+    g = json.loads(gzip.open(os.path.join(GOLDEN, "collapse_golden.json.gz")).read())
+    assert [list(k) for k in st.mk_mutation_context(1, 1, collapse=True).keys()] == g["mutation_context_96"]
+    assert st.mk_trans_idx(1, 1, collapse=True) == g["trans_idx_96"] and len(g["trans_idx_96"]) == 96
+    assert list(st.mk_context_sequences(1, 1, collapse=True).keys()) == g["count_columns"]
+    for n_up in (1, 2):
+        run = g["runs"][str(n_up)]
+        assert list(st.mk_context_sequences(n_up, n_up, collapse=True).keys()) == run["keys"]
+        d_pr = dict(zip(run["keys"], run["d_pr"]))
+        tab = nb_model._s_prob_table(d_pr, n_up, collapse=True)
+        keys = ["".join(t) for t in itertools.product("ACGT", repeat=2 * n_up + 1)]
+        for k, v in zip(keys, tab):
+            assert v == d_pr[st.seq_to_context(k, baseix=n_up, collapse=True)]
+    with pytest.raises(KeyError):
+        nb_model._s_prob_table({"ACA": 1.0}, 1, collapse=True)
