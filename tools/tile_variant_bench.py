@@ -99,7 +99,7 @@ def main():
     ref = "/tmp/tile_variant_ref.npz"
     for i, spec in enumerate(sys.argv[1:]):
         lib, _, envs = spec.partition(":")
-        path = lib if os.path.isabs(lib) else os.path.join(ROOT, "digdriver_amd", "lib", "variants", lib)
+        path = lib if os.path.isabs(lib) else os.path.join(ROOT, "tools", "variants", lib)
         env = dict(os.environ, DIG_HIP_LIB=path)
         env.update(dict(kv.split("=") for kv in envs.split(",") if kv))
         p = subprocess.run([sys.executable, __file__, "--child", ref, "1" if i == 0 else "0"], env=env, capture_output=True, text=True)
