@@ -415,7 +415,7 @@ __device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsi
 
 #ifdef DIG_ES_TIMING
 // developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
-__device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_b1[1024];
+__device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_b1[1024], g_es_q[1024];
 #endif
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
@@ -748,6 +748,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             if (open & 4u) g_tests[tb + c0 + c1 + (unsigned)__popcll(b2 & lanes_below)] = (unsigned)rec * 4u + 2u;
             __syncthreads();
             const unsigned n_tests = g_n_tests;
+#ifdef DIG_ES_TIMING
+            if (threadIdx.x == 0) g_es_q[blockIdx.x & 1023] = (unsigned long long)total | ((unsigned long long)n_tests << 32);
+#endif
             const int quad = lane >> 2, sub = lane & 3;
             for (;;) {
                 unsigned t0 = 0;
@@ -1018,6 +1021,11 @@ int dig_debug_es_timing(unsigned long long* out2048)
     static unsigned long long big[1024];
     for (auto& v : big) v = ~0ull;
     DIG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dig::g_es_b0), big, sizeof(big)));
+    return DIG_OK;
+}
+int dig_debug_es_queue(unsigned long long* out1024)      // records | open tests << 32 of every workgroup's queue, last launch
+{
+    DIG_HIP_TRY(hipMemcpyFromSymbol(out1024, HIP_SYMBOL(dig::g_es_q), 1024 * sizeof(unsigned long long)));
     return DIG_OK;
 }
 #endif

@@ -26,6 +26,9 @@ lib = _lib.load()
 fn = lib.dig_debug_es_timing
 fn.argtypes = [ctypes.c_void_p]
 buf = np.zeros(4096, np.uint64)
+fq = lib.dig_debug_es_queue
+fq.argtypes = [ctypes.c_void_p]
+qbuf = np.zeros(1024, np.uint64)
 for _ in range(50):
     plan.run(td["cj"], td["cj_indel"], stages=7, stream=s)
 torch.cuda.synchronize()
@@ -49,3 +52,10 @@ for rep in range(3):
     late = np.argsort(-end)[:8]
     print("  the eight last workgroups: end", np.round(end[late], 1), "last wave out of tiles", np.round(b1[late], 1), "then", np.round((end - b1)[late], 1))
     print("  from the barrier to the end, all workgroups: p10 %.1f median %.1f p90 %.1f max %.1f us" % tuple(np.percentile(end - b1, [10, 50, 90, 100])))
+    fq(qbuf.ctypes.data)
+    recs, tests = (qbuf[:256] & np.uint64(0xffffffff)).astype(np.int64), (qbuf[:256] >> np.uint64(32)).astype(np.int64)
+    print("  queue records per workgroup: min %d median %d p90 %d max %d | open tests: median %d max %d | corr(records, barrier-to-end) %.2f"
+          % (recs.min(), np.median(recs), np.percentile(recs, 90), recs.max(), np.median(tests), tests.max(), np.corrcoef(recs, end - b1)[0, 1]))
+    print("  the eight last: records", recs[late], "tests", tests[late])
+    print("  corr(last wave out of tiles, end) %.2f ; spread of 'last wave out of tiles': min %.1f median %.1f max %.1f"
+          % (np.corrcoef(b1, end)[0, 1], b1.min(), np.median(b1), b1.max()))
