@@ -476,7 +476,8 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
 //   ulp apart, as for the trinucleotide kernels).  Regions of up to 16 384 positions; a longer one is NOT evaluated: its
 //   n_valid is -1 and its pt NaN (the host-side callers refuse such regions before the launch: engine.check_tile_regions).
 // =======================================================================================
-constexpr int kCtxBlock = 512;            // threads per workgroup: 64 walkers of 8 lanes
+constexpr int kCtxBlock = 1024;           // threads per workgroup: kCtxWalkers walkers of 8 lanes (512: 5.5 ms where 1024 take 4.6)
+constexpr int kCtxWalkers = kCtxBlock / 8;
 constexpr int kCtxCoh = 8;                // cohorts per pass = lanes per walker
 constexpr int kCtxMaxPos = 16384;         // positions of a region whose codes are staged
 constexpr int kCtxSumTiles = 512;         // tile sums kept per walk
@@ -508,7 +509,7 @@ __device__ __forceinline__ CtxRegion ctx_region(const CtxRaw& a, int64_t len, in
 }
 
 constexpr int kCtxWordsPer = (kCtxMaxPos / 8 + 8 + kCtxBlock - 1) / kCtxBlock;       // packed words a thread stages per region
-constexpr int kCtxSplitSlots = 64;        // extra unit sums: the pieces of the last tiles of a region (below)
+constexpr int kCtxSplitSlots = kCtxWalkers;       // extra unit sums: the pieces of the last tiles of a region (below)
 
 template <int U>
 __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
     __shared__ uint32_t s_words[kCtxMaxPos / 8 + 8];
     __shared__ double s_sum[kCtxCoh][kCtxSumStride + kCtxSplitSlots];      // tile sums, then the pieces of split tiles
     __shared__ double s_part[kCtxBlock / 8][kCtxCoh];
-    __shared__ double s_T[kCtxCoh];
+    __shared__ double s_T[kCtxWalkers / 64][kCtxCoh];         // region totals: one partial per wave of the reduction
     const int tid = threadIdx.x, c = tid & 7, walker = tid >> 3;
 #ifdef DIG_TM_TIMING
     unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_last = __builtin_readcyclecounter();
@@ -661,17 +662,26 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
                     for (int i = 0; i < 16; ++i) acc += v[i];        // (+ 0.0 leaves the sum as it is)
                     p = p + 16 < p1 ? p + 16 : p1;
                 }
-                for (; p < p1; ++p) acc += s_S[s_code[p]][c];
+                if (p < p1) {                         // at most three positions left: codes, then rows, together as well
+                    unsigned k[3];
+                    double v[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) k[i] = p + i < p1 ? s_code[p + i] : (unsigned)K;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v[i] = s_S[k[i]][c];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc += v[i];
+                }
                 return acc;
             };
-            // 64 walkers take the tiles in rounds of 64.  The tiles of a last, short round (200 tiles: 8) are cut into pieces so
+            // The walkers take the tiles in rounds of kCtxWalkers.  The tiles of a last, short round are cut into pieces so
             // that every walker of that round has one -- a piece of seven positions is one trip where a tile of fifty is four: the
             // busiest walker then makes 13 trips instead of 16.  A split tile's value is the sum of its pieces in order.
-            const int64_t whole = q.tiles_valid & ~(int64_t)63, rest = q.tiles_valid - whole;
+            const int64_t whole = q.tiles_valid & ~(int64_t)(kCtxWalkers - 1), rest = q.tiles_valid - whole;
             int pieces = 1;
-            if (rest > 0 && rest <= 32 && binsize >= 8 && q.tiles_valid <= kCtxSumTiles) {
+            if (rest > 0 && rest <= kCtxWalkers / 2 && binsize >= 8 && q.tiles_valid <= kCtxSumTiles) {
                 pieces = 2;
-                while (pieces < 8 && pieces * 2 * rest <= 64 && pieces * 2 * 4 <= binsize) pieces *= 2;
+                while (pieces < 8 && pieces * 2 * rest <= kCtxWalkers && pieces * 2 * 4 <= binsize) pieces *= 2;
             }
             const int64_t piece_len = (binsize + pieces - 1) / pieces;
             const bool stash = q.tiles_valid <= kCtxSumTiles;
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
             TM_MARK(4);
             __syncthreads();
             TM_MARK(5);
-            if (tid < 64) {                           // lane (g, c): walkers 8 g .. 8 g + 7, then the eight g's
+            if (tid < kCtxWalkers) {                  // lane (g, c): walkers 8 g .. 8 g + 7, then the eight g's of the wave
                 const int g = tid >> 3;
                 double v = 0.0;
 #pragma unroll
@@ -707,18 +717,20 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
                 v += __shfl_xor(v, 8, 64);
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (tid < kCtxCoh) s_T[tid] = v;
+                if ((tid & 63) < kCtxCoh) s_T[tid >> 6][tid & 63] = v;
             }
             __syncthreads();
             TM_MARK(6);
             // ---- pt = sum / total: wave w writes cohort w's plane, a lane = a tile (with a thread = a tile for all eight cohorts
             // 200 of the 512 threads wrote and the rest waited at the next barrier) ----
             if (stash || q.too_long) {
-                const int co = tid >> 6;
+                const int co = (tid >> 6) & 7;        // (waves 8 .. 15: the second 64 tiles of every 128)
                 if (co < cc) {
-                    const double total = s_T[co];
+                    double total = s_T[0][co];
+#pragma unroll
+                    for (int w = 1; w < kCtxWalkers / 64; ++w) total += s_T[w][co];
                     double* plane = pt + ((c0 + co) * R + r) * n_tiles;
-                    for (int64_t t = tid & 63; t < n_tiles; t += 64) {
+                    for (int64_t t = (tid & 63) + 64 * (tid >> 9); t < n_tiles; t += kCtxBlock / 8) {
                         double v = nan;
                         if (t < tiles) {
                             if (pieces > 1 && t >= whole) {
@@ -751,7 +763,12 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
                     for (int64_t t = tb + tid; t < tn; t += kCtxBlock)
 #pragma unroll
                         for (int co = 0; co < kCtxCoh; ++co)
-                            if (co < cc) pt[((c0 + co) * R + r) * n_tiles + t] = t < tiles ? s_sum[co][t - tb] / s_T[co] : nan;
+                            if (co < cc) {
+                                double total = s_T[0][co];
+#pragma unroll
+                                for (int w = 1; w < kCtxWalkers / 64; ++w) total += s_T[w][co];
+                                pt[((c0 + co) * R + r) * n_tiles + t] = t < tiles ? s_sum[co][t - tb] / total : nan;
+                            }
                 }
             }
         }
