@@ -23,6 +23,8 @@
 //
 // dig_tile_mut_counts: k[c][region][tile] from the (mutation, region) pairs of dig_overlap_join_*: one atomic add per
 // pair whose START lies inside the region's positions.
+#include <type_traits>
+
 #include "dig_common.hpp"
 
 namespace dig {
@@ -278,7 +280,13 @@ __device__ unsigned long long g_tm_prof[8];
 #define TM_MARK(k) do {} while (0)
 #endif
 
-template <int MT>
+// MT full 16-cohort tiles (v_mfma_f64_16x16x4), then NQ quads of four cohorts (v_mfma_f64_4x4x4: its four 4x4 blocks take the
+// SAME four cohort rows against four different groups of four tiles, so the B operand is the register of the 16-row form and a
+// quad costs a quarter of a tile): 37 cohorts = 2 tiles + 2 quads pay for 2.5 tiles' worth of matrix time where three tiles
+// paid for 3.  Same bits as whole tiles (measured: the two instructions sum their four products alike), so a cohort's values
+// do not depend on the other cohorts of the call.  (A single cohort on the vector ALU -- sixteen FMAs per sixteen tiles --
+// was 1 % faster still but rounds differently: not kept.)
+template <int MT, int NQ = 0>
 __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_kernel(
     const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
     const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
@@ -293,15 +301,21 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const unsigned short* s_hist16 = reinterpret_cast<const unsigned short*>(s_hist32);
 
-    double A[MT][16];
+    constexpr int MTA = MT > 0 ? MT : 1, NQA = NQ > 0 ? NQ : 1;
+    double A[MTA][16], Aq[NQA][16];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int64_t c = c0 + 16 * m + li;
+    for (int ks = 0; ks < 16; ++ks) {
+        const int row = 4 * ks + lk;                                    // histogram row = b0 + 4 b1 + 16 b2 (walk order) ...
+        const int ctx = ((row & 3) << 4) | (row & 12) | (row >> 4);     // ... of context 16 b0 + 4 b1 + b2
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int row = 4 * ks + lk;                                    // histogram row = b0 + 4 b1 + 16 b2 (walk order) ...
-            const int ctx = ((row & 3) << 4) | (row & 12) | (row >> 4);     // ... of context 16 b0 + 4 b1 + b2
+        for (int m = 0; m < MT; ++m) {
+            const int64_t c = c0 + 16 * m + li;
             A[m][ks] = c < C ? s_prob[c * 64 + ctx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {                                  // A[i][k] of every block b: lane 16 k + 4 b + i
+            const int64_t c = c0 + 16 * MT + 4 * q + (lane & 3);
+            Aq[q][ks] = c < C ? s_prob[c * 64 + ctx] : 0.0;
         }
     }
     const int n_groups = (n_tiles + 15) >> 4;
@@ -401,16 +415,20 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
         __syncthreads();
         TM_MARK(5);
         // ---- 1 / T[c] (every wave for itself: no exchange), moved into the lane layout of D once per region ----
-        double rt[MT][4];
+        double rt[MTA][4], rtq[NQA];
         {
-            double t[MT];
+            double t[MTA], tq[NQA];
 #pragma unroll
             for (int m = 0; m < MT; ++m) t[m] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tq[q] = 0.0;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const double hv = (double)s_H[4 * ks + lk];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) t[m] = fma(hv, A[m][ks], t[m]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) tq[q] = fma(hv, Aq[q][ks], tq[q]);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -419,6 +437,12 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
                 const double inv = 1.0 / t[m];                 // lane i (any k) holds cohort 16 m + i
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rt[m][q] = __shfl(inv, 4 * q + lk, 64);     // D register q: cohort 16 m + 4 q + k
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                tq[q] += __shfl_xor(tq[q], 16, 64);
+                tq[q] += __shfl_xor(tq[q], 32, 64);
+                rtq[q] = __shfl(1.0 / tq[q], lk, 64);          // lane i % 4 (any k, b) holds cohort i of the quad; D: cohort k
             }
         }
         // ---- the product ----
@@ -438,6 +462,29 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
                     for (int q = 0; q < 4; ++q)
                         if (c0 + 16 * m + 4 * q + lk < C)
                             __builtin_nontemporal_store(t < nv ? acc[q] * rt[m][q] : nan, o + (16 * m + 4 * q) * cohort_stride);
+                }
+            }
+        }
+        if constexpr (NQ > 0) {
+            // the quads of a tile group share the converted histogram values
+            for (int n = (wave + MT) & 3; n < n_groups; n += 4) {
+                double accq[NQA];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) accq[q] = 0.0;
+                const unsigned short* hp = s_hist16 + lk * kTmStride + 16 * n + li;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const double b = (double)hp[4 * ks * kTmStride];       // B[k][j] of block b': lane 16 k + 4 b' + j = the 16-column register
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) accq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Aq[q][ks], b, accq[q], 0, 0, 0);
+                }
+                const int t = 16 * n + li;
+                if (t < n_tiles) {
+                    double* o = out_lane + 16 * n;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)                            // D[i][j] of block b': lane 16 i + 4 b' + j -- cohort k, tile i of this lane
+                        if (c0 + 16 * MT + 4 * q + lk < C)
+                            __builtin_nontemporal_store(t < nv ? accq[q] * rtq[q] : nan, o + (16 * MT + 4 * q) * cohort_stride);
                 }
             }
         }
@@ -836,15 +883,29 @@ int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int
     if (mfma) {
         const int grid = grid_for(R * kTileBlock, kTileBlock, DIG_TM_OCC);
         for (int64_t c0 = 0; c0 < C; c0 += kTmChunk) {
-            const int mt = (int)(((C - c0 < kTmChunk ? C - c0 : kTmChunk) + 15) / 16);
+            // the chunk's cohorts as full tiles + quads: a remainder of 1 .. 4 is one quad, 5 .. 8 two, 9 and more a (padded) tile.
+            // DIG_TILES_CUT=0 (developer switch): whole tiles only.
+            static const bool cut = !(getenv("DIG_TILES_CUT") && getenv("DIG_TILES_CUT")[0] == '0');
+            const int rem = (int)(C - c0 < kTmChunk ? C - c0 : kTmChunk);
+            int mt = rem >> 4, nq = 0;
+            const int r16 = rem & 15;
+            if (!cut || r16 >= 9) mt += r16 > 0;
+            else nq = (r16 + 3) >> 2;
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words, chrom_off,
                                    chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, (int)c0, binsize, (int)n_tiles, pt,
                                    first_pos, n_valid);
             };
-            if (mt == 3) go(base_tile_probs_mfma_kernel<3>);
-            else if (mt == 2) go(base_tile_probs_mfma_kernel<2>);
-            else go(base_tile_probs_mfma_kernel<1>);
+            auto pick = [&](auto mt_c) {
+                constexpr int M = decltype(mt_c)::value;
+                if (nq == 2) go(base_tile_probs_mfma_kernel<M, 2>);
+                else if (nq == 1) go(base_tile_probs_mfma_kernel<M, 1>);
+                else if constexpr (M > 0) go(base_tile_probs_mfma_kernel<M, 0>);
+            };
+            if (mt == 3) go(base_tile_probs_mfma_kernel<3, 0>);
+            else if (mt == 2) pick(std::integral_constant<int, 2>{});
+            else if (mt == 1) pick(std::integral_constant<int, 1>{});
+            else pick(std::integral_constant<int, 0>{});
         }
         DIG_HIP_TRY(hipGetLastError());
         return DIG_OK;
