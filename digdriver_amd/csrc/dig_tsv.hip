@@ -7,9 +7,13 @@
 // 20x everything else in the pipeline together).  dig_write_tsv_host produces the same bytes from the column arrays:
 // std::to_chars gives the shortest round-trip digits, the layout rules of float_repr_style 'short' are applied here; rows
 // are formatted in chunks by a few threads and written in order.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <charconv>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,22 +119,45 @@ int dig_write_tsv_host(const char* path, const char* header, const char* labels,
     DIG_REQUIRE(n_rows == 0 || (labels && label_off), "row labels");
     DIG_REQUIRE(n_cols == 0 || (col_ptr && col_kind), "columns");
     for (int j = 0; j < n_cols; ++j) DIG_REQUIRE(col_ptr[j] && col_kind[j] >= 0 && col_kind[j] <= 2, "column pointers and kinds (0 f64, 1 i64, 2 bool)");
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return ::dig::set_error(DIG_EINVAL, "dig_write_tsv_host: cannot open %s for writing", path);
-    std::fputs(header, f);
-    std::fputc('\n', f);
-    const int64_t chunk = 8192;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return ::dig::set_error(DIG_EINVAL, "dig_write_tsv_host: cannot open %s for writing", path);
+    // Rows are formatted in chunks by n_threads threads into buffers that are never cleared (a value-initialised buffer of the
+    // worst-case size was 77 MB of zeroing and page faults per file), then every thread writes its chunks at their offsets
+    // (one thread copying a 44 MB file into the page cache was half of the call).
+    const int64_t chunk = 4096;
     const int64_t n_chunks = (n_rows + chunk - 1) / chunk;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
     if ((int64_t)n_threads > n_chunks) n_threads = (int)(n_chunks > 0 ? n_chunks : 1);
-    std::vector<std::string> text((size_t)n_chunks);
-    auto work = [&](int t) {
+    auto put = [&](const char* src, int64_t n, int64_t at) {
+        while (n > 0) {
+            const ssize_t w = ::pwrite(fd, src, (size_t)n, (off_t)at);
+            if (w <= 0) return false;
+            src += w;
+            n -= w;
+            at += w;
+        }
+        return true;
+    };
+    bool stream_ok = true;
+    const int64_t head = (int64_t)std::strlen(header);
+    std::vector<std::unique_ptr<char[]>> text((size_t)n_chunks);
+    std::vector<int64_t> bytes((size_t)n_chunks, 0), offset((size_t)n_chunks + 1, 0);
+    offset[0] = head + 1;
+    auto chunk_cap = [&](int64_t r0, int64_t r1) { return (size_t)((label_off[r1] - label_off[r0]) + (r1 - r0) * (1 + (int64_t)n_cols * 26)); };
+    int64_t max_label = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
+        const int64_t r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
+        if (label_off[r1] - label_off[r0] > max_label) max_label = label_off[r1] - label_off[r0];
+    }
+    std::unique_ptr<char[]> scratch;                     // one thread: one buffer for every chunk, written as soon as it is full
+    if (n_threads == 1 && n_chunks > 0) scratch.reset(new char[(size_t)(max_label + chunk * (1 + (int64_t)n_cols * 26))]);
+    auto format = [&](int t) {
         for (int64_t c = t; c < n_chunks; c += n_threads) {
             const int64_t r0 = c * chunk, r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
-            std::string& out = text[(size_t)c];
-            out.resize((size_t)((label_off[r1] - label_off[r0]) + (r1 - r0) * (1 + (int64_t)n_cols * 26)));
-            char* p = &out[0];
+            if (!scratch) text[(size_t)c].reset(new char[chunk_cap(r0, r1)]);
+            char* const base = scratch ? scratch.get() : text[(size_t)c].get();
+            char* p = base;
             for (int64_t r = r0; r < r1; ++r) {
                 const int64_t ln = label_off[r + 1] - label_off[r];
                 std::memcpy(p, labels + label_off[r], (size_t)ln);
@@ -147,17 +174,303 @@ int dig_write_tsv_host(const char* path, const char* header, const char* labels,
                 }
                 *p++ = '\n';
             }
-            out.resize((size_t)(p - &out[0]));
+            bytes[(size_t)c] = (int64_t)(p - base);
+            if (scratch) {                              // (offset[c] is known: the chunks before this one are out)
+                if (!put(base, bytes[(size_t)c], offset[(size_t)c])) stream_ok = false;
+                offset[(size_t)c + 1] = offset[(size_t)c] + bytes[(size_t)c];
+            }
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
-    bool ok = true;
-    for (const auto& s : text) ok = ok && std::fwrite(s.data(), 1, s.size(), f) == s.size();
-    ok = (std::fclose(f) == 0) && ok;
+    std::vector<char> good((size_t)n_threads, 1);
+    auto write_out = [&](int t) {
+        for (int64_t c = t; c < n_chunks; c += n_threads) {
+            if (!put(text[(size_t)c].get(), bytes[(size_t)c], offset[(size_t)c])) good[(size_t)t] = 0;
+            text[(size_t)c].reset();
+        }
+    };
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn, t);
+        fn(0);
+        for (auto& th : pool) th.join();
+    };
+    bool ok = put(header, head, 0) && put("\n", 1, head);
+    if (scratch) {
+        format(0);
+        ok = ok && stream_ok;
+    } else {
+        run(format);
+        for (int64_t c = 0; c < n_chunks; ++c) offset[(size_t)c + 1] = offset[(size_t)c] + bytes[(size_t)c];
+        run(write_out);
+        for (char g : good) ok = ok && g;
+    }
+    ok = (::close(fd) == 0) && ok;
     if (!ok) return ::dig::set_error(DIG_EINVAL, "dig_write_tsv_host: short write to %s", path);
+    return DIG_OK;
+}
+
+}  // extern "C"
+
+// =======================================================================================
+// Annotated mutation files (ABI 7; host code only).
+//
+// The reference reads a cohort's mutations with pandas (mutation_tools.read_mutation_file, mutation_tools.py:45-104: tab-
+// separated, no header, CHROM START END REF ALT SAMPLE GENE ANNOT and any further columns) and hands the frame on; the
+// many-cohort driver (driver_model/cohort_batch.py) needs them as integer arrays for the interval join on the device.
+// pyarrow parses a 300 000-row file in 40 ms, but the dictionary / numpy steps behind it hold the interpreter lock: 37 files
+// side by side on 256 cores took 0.83 s (tools/parse_probe.py: 0.1 s of work per file, 11x inflated when run together).
+// dig_mutation_file_parse_host does the whole of tabulate_gpu.encode_mutation_file for one file without the interpreter:
+//   * rows whose CHROM, with one leading "chr" removed, is not one of "1" .. "22" are dropped;
+//   * REF, ALT, SAMPLE, GENE, ANNOT become ids in order of first appearance (over all rows, as a dictionary encoding does);
+//     the samples are then renumbered in order of first appearance among the KEPT rows (pandas.factorize on the kept frame);
+//   * uid = dense rank of (CHROM, START, END, REF id, ALT id) among the kept rows, in sorted order;
+//   * indel = (ANNOT == "INDEL").
+// The arrays are bit-identical to the Python path's (tests/test_host_tools.py).  Content the parser does not cover -- a double
+// quote anywhere (pyarrow would treat it as quoting), a START / END that is not a plain integer, rows with different numbers
+// of fields -- is reported as *n_rows = -1 with no handle: the caller falls back to the Python path, which raises or parses
+// as before.
+// =======================================================================================
+#include <algorithm>
+#include <cstdio>
+#include <string_view>
+#include <unordered_map>
+
+namespace {
+
+struct MutFile {
+    std::vector<int64_t> chrom, start, end, uid, sample, indel, gene;
+    std::string sample_names;      // '\n'-joined, in id order
+    int64_t n_samples = 0;
+};
+
+struct Interner {
+    std::unordered_map<std::string_view, int64_t> ids;
+    std::vector<std::string_view> labels;
+    std::string_view last{};
+    int64_t last_id = -1;
+    int64_t get(std::string_view s)
+    {
+        if (last_id >= 0 && s == last) return last_id;
+        auto it = ids.find(s);
+        int64_t id;
+        if (it == ids.end()) {
+            id = (int64_t)labels.size();
+            ids.emplace(s, id);
+            labels.push_back(s);
+        } else
+            id = it->second;
+        last = s;
+        last_id = id;
+        return id;
+    }
+};
+
+inline bool parse_i64(std::string_view s, int64_t& out)
+{
+    if (s.empty()) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (s[0] == '-') {
+        neg = true;
+        i = 1;
+        if (s.size() == 1) return false;
+    }
+    if (s.size() - i > 18) return false;
+    int64_t v = 0;
+    for (; i < s.size(); ++i) {
+        const unsigned d = (unsigned)(s[i] - '0');
+        if (d > 9u) return false;
+        v = v * 10 + (int64_t)d;
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+inline int64_t autosome(std::string_view s)      // "1" .. "22" -> 1 .. 22, else -1 (one leading "chr" allowed)
+{
+    if (s.size() >= 3 && s[0] == 'c' && s[1] == 'h' && s[2] == 'r') s.remove_prefix(3);
+    if (s.size() == 1 && s[0] >= '1' && s[0] <= '9') return s[0] - '0';
+    if (s.size() == 2 && s[0] >= '1' && s[0] <= '2' && s[1] >= '0' && s[1] <= '9') {
+        const int v = 10 * (s[0] - '0') + (s[1] - '0');
+        return v <= 22 ? v : -1;
+    }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dig_mutation_file_parse_host(const char* path, void** handle, int64_t* n_rows, int64_t* n_samples, int64_t* names_bytes)
+{
+    DIG_REQUIRE(path && handle && n_rows && n_samples && names_bytes, "non-null arguments");
+    *handle = nullptr;
+    *n_rows = -1;
+    *n_samples = 0;
+    *names_bytes = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return dig::set_error(DIG_EINVAL, "dig_mutation_file_parse_host: cannot open %s", path);
+    std::string buf;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), f);
+        fclose(f);
+        if (got != buf.size()) return dig::set_error(DIG_EINVAL, "dig_mutation_file_parse_host: short read of %s", path);
+    }
+    if (memchr(buf.data(), '"', buf.size())) return DIG_OK;          // quoting: not covered (caller falls back)
+    Interner ref, alt, samp, gene, annot;
+    std::vector<int64_t> ch, st, en, r_id, a_id, s_id, g_id, n_id;
+    const size_t guess = buf.size() / 40 + 16;
+    for (auto* v : {&ch, &st, &en, &r_id, &a_id, &s_id, &g_id, &n_id}) v->reserve(guess);
+    const char* p = buf.data();
+    const char* const stop = p + buf.size();
+    int n_fields = -1;
+    while (p < stop) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(stop - p));
+        const char* le = nl ? nl : stop;
+        const char* next = nl ? nl + 1 : stop;
+        if (le > p && le[-1] == '\r') --le;
+        if (le == p) {                                               // empty line: skipped, as the reader does
+            p = next;
+            continue;
+        }
+        std::string_view fld[8];
+        int nf = 0;
+        const char* q = p;
+        for (;;) {
+            const char* tab = (const char*)memchr(q, '\t', (size_t)(le - q));
+            const char* fe = tab ? tab : le;
+            if (nf < 8) fld[nf] = std::string_view(q, (size_t)(fe - q));
+            ++nf;
+            if (!tab) break;
+            q = tab + 1;
+        }
+        if (n_fields < 0) n_fields = nf;
+        if (nf != n_fields || nf < 8) return DIG_OK;                 // ragged or short rows: the Python path reports them
+        int64_t s0, e0;
+        if (!parse_i64(fld[1], s0) || !parse_i64(fld[2], e0)) return DIG_OK;
+        ch.push_back(autosome(fld[0]));
+        st.push_back(s0);
+        en.push_back(e0);
+        r_id.push_back(ref.get(fld[3]));
+        a_id.push_back(alt.get(fld[4]));
+        s_id.push_back(samp.get(fld[5]));
+        g_id.push_back(gene.get(fld[6]));
+        n_id.push_back(annot.get(fld[7]));
+        p = next;
+    }
+    int64_t indel_id = -1;
+    {
+        auto it = annot.ids.find(std::string_view("INDEL"));
+        if (it != annot.ids.end()) indel_id = it->second;
+    }
+    auto* m = new MutFile();
+    const size_t n_all = ch.size();
+    size_t n_keep = 0;
+    for (size_t i = 0; i < n_all; ++i) n_keep += ch[i] > 0;
+    for (auto* v : {&m->chrom, &m->start, &m->end, &m->uid, &m->sample, &m->indel, &m->gene}) v->resize(n_keep);
+    std::vector<int64_t> remap(samp.labels.size(), -1), kr(n_keep), ka(n_keep);
+    std::vector<std::string_view> order;
+    size_t k = 0;
+    for (size_t i = 0; i < n_all; ++i) {
+        if (ch[i] <= 0) continue;
+        m->chrom[k] = ch[i];
+        m->start[k] = st[i];
+        m->end[k] = en[i];
+        int64_t& rm = remap[(size_t)s_id[i]];
+        if (rm < 0) {
+            rm = (int64_t)order.size();
+            order.push_back(samp.labels[(size_t)s_id[i]]);
+        }
+        m->sample[k] = rm;
+        m->indel[k] = n_id[i] == indel_id ? 1 : 0;
+        m->gene[k] = g_id[i];
+        kr[k] = r_id[i];
+        ka[k] = a_id[i];
+        ++k;
+    }
+    // uid: dense rank of (chrom, start, end, ref id, alt id) in sorted order
+    std::vector<uint32_t> idx(n_keep);
+    for (size_t i = 0; i < n_keep; ++i) idx[i] = (uint32_t)i;
+    auto less = [&](uint32_t a, uint32_t b) {
+        if (m->chrom[a] != m->chrom[b]) return m->chrom[a] < m->chrom[b];
+        if (m->start[a] != m->start[b]) return m->start[a] < m->start[b];
+        if (m->end[a] != m->end[b]) return m->end[a] < m->end[b];
+        if (kr[a] != kr[b]) return kr[a] < kr[b];
+        return ka[a] < ka[b];
+    };
+    if (n_keep >= ((size_t)1 << 32)) {
+        delete m;
+        return DIG_OK;
+    }
+    bool packs = true;                                               // coordinates and ids that fit two 64-bit keys: a plain sort
+    for (size_t i = 0; i < n_keep && packs; ++i)
+        packs = m->start[i] >= 0 && m->start[i] < ((int64_t)1 << 40) && m->end[i] >= m->start[i] &&
+                m->end[i] - m->start[i] < ((int64_t)1 << 22) && kr[i] < (1 << 20) && ka[i] < (1 << 20);
+    if (packs) {
+        struct Key {
+            uint64_t a, b;
+            uint32_t i;
+        };
+        std::vector<Key> keys(n_keep);
+        for (size_t i = 0; i < n_keep; ++i)
+            keys[i] = Key{((uint64_t)m->chrom[i] << 40) | (uint64_t)m->start[i],
+                          ((uint64_t)(m->end[i] - m->start[i]) << 40) | ((uint64_t)kr[i] << 20) | (uint64_t)ka[i], (uint32_t)i};
+        std::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+        int64_t rank = -1;
+        for (size_t i = 0; i < n_keep; ++i) {
+            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) ++rank;
+            m->uid[keys[i].i] = rank;
+        }
+    } else {
+        std::sort(idx.begin(), idx.end(), less);
+        int64_t rank = -1;
+        for (size_t i = 0; i < n_keep; ++i) {
+            if (i == 0 || less(idx[i - 1], idx[i])) ++rank;
+            m->uid[idx[i]] = rank;
+        }
+    }
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (i) m->sample_names.push_back('\n');
+        m->sample_names.append(order[i].data(), order[i].size());
+    }
+    m->n_samples = (int64_t)order.size();
+    *handle = m;
+    *n_rows = (int64_t)n_keep;
+    *n_samples = m->n_samples;
+    *names_bytes = (int64_t)m->sample_names.size();
+    return DIG_OK;
+}
+
+int dig_mutation_file_fetch_host(void* handle, int64_t* chrom, int64_t* start, int64_t* end, int64_t* uid, int64_t* sample,
+                                 int64_t* indel, int64_t* gene, char* sample_names)
+{
+    DIG_REQUIRE(handle, "a handle of dig_mutation_file_parse_host");
+    const MutFile* m = static_cast<const MutFile*>(handle);
+    const size_t nb = m->chrom.size() * sizeof(int64_t);
+    if (nb) {
+        DIG_REQUIRE(chrom && start && end && uid && sample && indel && gene, "non-null arrays of n_rows int64");
+        memcpy(chrom, m->chrom.data(), nb);
+        memcpy(start, m->start.data(), nb);
+        memcpy(end, m->end.data(), nb);
+        memcpy(uid, m->uid.data(), nb);
+        memcpy(sample, m->sample.data(), nb);
+        memcpy(indel, m->indel.data(), nb);
+        memcpy(gene, m->gene.data(), nb);
+    }
+    if (!m->sample_names.empty()) {
+        DIG_REQUIRE(sample_names, "a buffer of names_bytes bytes");
+        memcpy(sample_names, m->sample_names.data(), m->sample_names.size());
+    }
+    return DIG_OK;
+}
+
+int dig_mutation_file_free_host(void* handle)
+{
+    delete static_cast<MutFile*>(handle);
     return DIG_OK;
 }
 

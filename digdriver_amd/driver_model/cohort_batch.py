@@ -184,14 +184,20 @@ def write_results(frames, outdir, prefixes, workers=None):
     os.makedirs(outdir, exist_ok=True)
     paths = [os.path.join(outdir, pfx + '.results.txt') for pfx in prefixes]
 
+    jobs = list(zip(frames, paths))
+    # Many files: one thread per file, every file formatted and written by that thread alone (threads the writer starts per call
+    # and the buffers they map and unmap contend for the process's address space: 8 workers x 8 threads and 32 x 8 both took
+    # 1.1 - 1.3 s for the 37 files of tools/write_probe.py).  Few files: the writer's own 8 threads per file.
+    cores = os.cpu_count() or 1
+    workers = min(len(jobs), cores) if workers is None else int(workers)
+    threads = 1 if workers >= 8 else max(1, min(8, cores // max(workers, 1)))
+
     def one(job):
         df, path = job
         ints = {col: df[col].astype(int) for col in ('OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL') if col in df.columns}
-        mapfile.write_results_tsv(df.assign(**ints), path)      # (same index object for every cohort: its text is encoded once)
+        mapfile.write_results_tsv(df.assign(**ints), path, threads=threads)      # (same index object for every cohort: its text is encoded once)
         return path
 
-    jobs = list(zip(frames, paths))
-    workers = min(len(jobs), 8, os.cpu_count() or 1) if workers is None else int(workers)
     if jobs:
         one(jobs[0])                                         # (fills the label cache)
     if workers <= 1:

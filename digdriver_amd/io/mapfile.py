@@ -317,6 +317,23 @@ def has_key(path, key):
 _LABEL_CACHE = {}
 
 
+def _cached_labels(index):
+    """(blob, offsets) of the encoded text of `index` if it is the one kept from the last call, else None.  The same object, or an equal index (DataFrame.assign and
+    .copy hand on a NEW Index object: an identity test alone missed every one of the 37 frames of a many-cohort run, and the
+    120 091 labels were turned into text 37 times under the interpreter lock -- 1.2 s of the 1.3 s the files took)."""
+    cached = _LABEL_CACHE.get("last")                   # (read once: other threads may replace the entry)
+    if cached is None:
+        return None
+    if cached[0] is not index:
+        try:
+            same = len(cached[0]) == len(index) and cached[0].dtype == index.dtype and cached[0].name == index.name and cached[0].equals(index)
+        except Exception:
+            same = False
+        if not same:
+            return None
+    return cached[1], cached[2]
+
+
 def write_results_tsv(frame, path, threads=8):
     """frame.to_csv(path, header=True, index=True, sep="\t") -- the text DigDriver.py writes (DigDriver.py:115-118) -- through
     the native writer dig_write_tsv_host: the same bytes (floats as Python's repr, NaN as the empty field, bools as True / False,
@@ -342,12 +359,12 @@ def write_results_tsv(frame, path, threads=8):
                 plain = False
             if not plain:
                 break
-    labels = None
+    labels, hit = None, None
     if plain:
         names = [str(frame.index.name) if frame.index.name is not None else ''] + [str(c) for c in frame.columns]
         special = ('\t', '"', '\n', '\r')
-        cached = _LABEL_CACHE.get("last")
-        if cached is None or cached[0] is not frame.index:
+        hit = _cached_labels(frame.index)
+        if hit is None:
             labels = [str(x) for x in frame.index]
             if frame.index.dtype == object and any(ch in s_ for s_ in labels for ch in special):
                 plain = False
@@ -357,9 +374,8 @@ def write_results_tsv(frame, path, threads=8):
         frame.to_csv(path, header=True, index=True, sep="\t")
         return path
     # (the 37 result frames of a many-cohort run share one index object: its text is encoded once)
-    cached = _LABEL_CACHE.get("last")
-    if cached is not None and cached[0] is frame.index:
-        blob, off = cached[1], cached[2]
+    if hit is not None:
+        blob, off = hit
     else:
         enc = [s_.encode() for s_ in labels]
         off = np.zeros(len(enc) + 1, np.int64)

@@ -34,9 +34,10 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 6   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 7   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
-                             * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome) */
+                             * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome), dig_write_tsv_host;
+                             * 7: + dig_mutation_file_*_host */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -383,6 +384,21 @@ int dig_count_contexts2_host(const uint32_t *words2, int64_t n_words2, const int
  *   n_threads: rows are formatted by up to 16 threads and written in order. */
 int dig_write_tsv_host(const char *path, const char *header, const char *labels, const int64_t *label_off, int64_t n_rows,
                        int n_cols, const void *const *col_ptr, const int *col_kind, int n_threads);
+
+/* ---- annotated mutation files (ABI 7; host code only) -------------------------------------- *
+ * What mutation_tools.read_mutation_file (mutation_tools.py:45-104) + the encoding of the many-cohort driver do for one file
+ * (tab-separated, no header: CHROM START END REF ALT SAMPLE GENE ANNOT [...]), without the interpreter:
+ *   rows whose CHROM (one leading "chr" removed) is not "1" .. "22" are dropped; sample = id in order of first appearance
+ *   among the kept rows; gene = id in order of first appearance in the file; indel = (ANNOT == "INDEL"); uid = dense rank of
+ *   (CHROM, START, END, REF, ALT) among the kept rows (REF / ALT compared as ids of first appearance).
+ * parse: *n_rows = kept rows, *n_samples, *names_bytes = length of the '\n'-joined sample names; *n_rows = -1 and no handle
+ *   when the file holds something the parser does not cover (a double quote, a non-integer coordinate, ragged rows): the
+ *   caller parses such a file as before.  fetch: copies the seven int64 columns and the names into the caller's buffers.
+ *   free: releases the handle (NULL allowed). */
+int dig_mutation_file_parse_host(const char *path, void **handle, int64_t *n_rows, int64_t *n_samples, int64_t *names_bytes);
+int dig_mutation_file_fetch_host(void *handle, int64_t *chrom, int64_t *start, int64_t *end, int64_t *uid, int64_t *sample,
+                                 int64_t *indel, int64_t *gene, char *sample_names);
+int dig_mutation_file_free_host(void *handle);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins

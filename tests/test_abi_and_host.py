@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), "libdig_hip.so does not export %s" % sym
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "python binding table and header disagree"
-    assert lib.dig_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.dig_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_library_abi_version_matches_header_and_binding():
@@ -120,9 +120,10 @@ def test_native_result_writer_writes_the_bytes_pandas_writes(tmp_path):
         'EDGE': np.resize(edge, n)}
     df = pd.DataFrame(cols, index=pd.Index(['ELT%06d' % i for i in range(n)], name='ELT'))
     a, b = tmp_path / "native.txt", tmp_path / "pandas.txt"
-    mapfile.write_results_tsv(df, str(a))
     df.to_csv(str(b), header=True, index=True, sep="\t")
-    assert a.read_bytes() == b.read_bytes()
+    for threads in (8, 1, 3):                             # several threads with their own chunks; one thread streaming chunk by chunk
+        mapfile.write_results_tsv(df, str(a), threads=threads)
+        assert a.read_bytes() == b.read_bytes(), threads
     back = pd.read_csv(str(a), sep="\t", index_col=0, float_precision="round_trip")
     assert np.array_equal(back.PVAL.values, df.PVAL.values) and np.array_equal(back.BITS.values, df.BITS.values, equal_nan=True)
     # an unnamed integer index, no rows, no columns

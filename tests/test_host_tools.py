@@ -176,3 +176,52 @@ def test_tabulation_matches_the_reference_functions(tmp_path):
         assert [str(i) for i in tab.index] == case["index"] and list(tab.columns) == case["columns"]
         for col in ("OBS_SAMPLES", "OBS_SNV", "OBS_INDEL"):
             assert tab[col].astype(int).tolist() == case[col], (case, col)
+
+
+def test_native_mutation_file_parser_gives_the_arrays_of_the_python_routes(tmp_path):
+    """dig_mutation_file_*_host (include/dig_hip.h, ABI 7) against the two Python routes of tabulate_gpu.encode_mutation_file /
+    encode_mutations_host on the reference-format golden file and on a file with the corner cases of the format: 'chr' prefixes,
+    contigs that are dropped, CRLF line ends, empty lines, repeated and out-of-order rows, extra columns.  Content the parser
+    does not cover is handed back to the Python route."""
+    from digdriver_amd.data_tools import tabulate_gpu as tg
+
+    def same(a, b):
+        assert a["sample_names"] == b["sample_names"]
+        for k in b:
+            if k != "sample_names":
+                assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+
+    small = os.path.join(GOLDEN, "mutations_small.tsv")
+    nat = tg._encode_mutation_file_native(small, 5)
+    assert nat is not None and len(nat["chrom"]) > 1000
+    same(nat, tg.encode_mutation_file(small, 5, native=False))
+    df = pd.read_csv(small, sep="\t", header=None, low_memory=False, dtype={0: str}).iloc[:, :8]
+    df.columns = ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT']
+    same(nat, tg.encode_mutations_host(df, 5))
+
+    rng = np.random.default_rng(11)
+    rows = []
+    for i in range(4000):
+        c = rng.choice(["1", "chr2", "22", "chr22", "X", "chrY", "MT", "23", "chr0", "GL000191.1", "7"])
+        s = int(rng.integers(0, 5000))
+        ln = int(rng.integers(1, 4))
+        ref, alt = rng.choice(["A", "C", "G", "T", "AT", "-"]), rng.choice(["A", "C", "G", "T", "-", "GG"])
+        rows.append("\t".join([c, str(s), str(s + ln), ref, alt, "S%d" % rng.integers(0, 40), rng.choice([".", "TP53", "KRAS"]),
+                               rng.choice(["SNV", "INDEL", "Missense", "Noncoding"]), "x", "ACG"]))
+    rows += rows[:300]                                      # exact duplicates
+    text = "\r\n".join(rows[:2000]) + "\r\n\r\n" + "\n".join(rows[2000:]) + "\n"
+    f = tmp_path / "corner.annot.txt"
+    f.write_bytes(text.encode())
+    nat = tg._encode_mutation_file_native(str(f), 0)
+    assert nat is not None
+    same(nat, tg.encode_mutation_file(str(f), 0, native=False))
+    assert set(np.unique(nat["chrom"])) <= {1, 2, 7, 22} and nat["indel"].sum() > 0
+    # not covered: left to the Python route
+    for bad in ('1\t5\t6\tA\tC\t"S1"\t.\tSNV\n', '1\t5\t6\tA\tC\tS1\t.\tSNV\n2\t7\t8\tA\tC\tS1\t.\n', '1\t5.0\t6\tA\tC\tS1\t.\tSNV\n'):
+        g = tmp_path / "bad.txt"
+        g.write_text(bad)
+        assert tg._encode_mutation_file_native(str(g), 0) is None
+    empty = tmp_path / "empty.txt"
+    empty.write_text("X\t1\t2\tA\tC\tS1\t.\tSNV\n")
+    nat = tg._encode_mutation_file_native(str(empty), 0)
+    assert nat is not None and len(nat["chrom"]) == 0 and nat["sample_names"] == []
