@@ -70,6 +70,11 @@ _SIGNATURES = {
     "dig_mutation_file_parse_host": [ctypes.c_char_p, _vp, _vp, _vp, _vp],
     "dig_mutation_file_fetch_host": [_vp] * 9,
     "dig_mutation_file_free_host": [_vp],
+    "dig_stage_timer_create": [_vp],
+    "dig_stage_timer_arm": [_vp, _int],
+    "dig_stage_timer_read": [_vp, _vp],
+    "dig_stage_timer_selftest": [_vp, _vp],
+    "dig_stage_timer_destroy": [_vp],
     "dig_overlap_join_count": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dig_overlap_join_fill": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dig_overlap_join_count_host": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int],
@@ -100,7 +105,7 @@ _SIZE_QUERIES = {
     "dig_bin_records_bytes": [_i64, _i64],
 }
 
-ABI_VERSION = 7          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 8          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

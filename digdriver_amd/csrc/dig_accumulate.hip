@@ -904,7 +904,7 @@ static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_
         const double* tab = w.tab + (int64_t)ch * kMfmaSteps * 3 * 64;
         auto go = [&](auto kern) -> int {
             DIG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaWaves * 64), lds, stream, w.rcp, L, tab, R_SIZE, gene_length, P,
+            DIG_LAUNCH_STAGE(DIG_PIPE_DOT, kern, dim3(grid), dim3(kMfmaWaves * 64), lds, stream, w.rcp, L, tab, R_SIZE, gene_length, P,
                                ELT_SIZE, P_INDEL, E, (int)C, c0, (int)(ch == 0));
             DIG_HIP_TRY(hipGetLastError());
             return DIG_OK;
@@ -1002,7 +1002,7 @@ int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, con
     for (int ch = 0; ch < n48; ++ch) {
         const ChunkCut cut = chunk_cut((int)C, ch);
         auto go = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kCtxWaves * 64), 0, (hipStream_t)stream, bin_ctx, ov_ptr, ov_idx, strand_minus,
+            DIG_LAUNCH_STAGE(DIG_PIPE_DOT, kern, dim3(grid), dim3(kCtxWaves * 64), 0, (hipStream_t)stream, bin_ctx, ov_ptr, ov_idx, strand_minus,
                                Lc, d_pr, gene_length, P, R_SIZE, ELT_SIZE, P_INDEL, E, (int)C, ch * kMfmaChunk, (int)(ch == 0),
                                ch == 0 ? zero_dwords : nullptr, n_zero);
             DIG_HIP_TRY(hipGetLastError());

@@ -38,9 +38,84 @@ int cu_count()
     return cached_cus;
 }
 
+static thread_local StageTimer* tl_armed[2] = {nullptr, nullptr};      // [0] the dot stage, [1] the statistics stage
+static int timer_slot(int stage) { return stage == DIG_PIPE_DOT ? 0 : stage == DIG_PIPE_STATISTICS ? 1 : -1; }
+
+StageTimer* take_armed_timer(int stage)
+{
+    const int k = timer_slot(stage);
+    if (k < 0) return nullptr;
+    StageTimer* t = tl_armed[k];
+    tl_armed[k] = nullptr;
+    return t;
+}
+
 }  // namespace dig
 
 extern "C" {
+
+int dig_stage_timer_create(void** timer)
+{
+    DIG_REQUIRE(timer, "non-null argument");
+    auto* t = new dig::StageTimer();
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) {
+        if (t->start) (void)hipEventDestroy(t->start);
+        delete t;
+        return dig::set_error(DIG_EHIP, "dig_stage_timer_create: hipEventCreate failed");
+    }
+    *timer = t;
+    return DIG_OK;
+}
+
+int dig_stage_timer_arm(void* timer, int stage)
+{
+    DIG_REQUIRE(timer, "a timer of dig_stage_timer_create");
+    const int k = dig::timer_slot(stage);
+    DIG_REQUIRE(k >= 0, "stage: DIG_PIPE_DOT or DIG_PIPE_STATISTICS");
+    auto* t = static_cast<dig::StageTimer*>(timer);
+    t->launched = 0;
+    dig::tl_armed[k] = t;
+    return DIG_OK;
+}
+
+int dig_stage_timer_read(void* timer, double* ms)
+{
+    DIG_REQUIRE(timer && ms, "non-null arguments");
+    auto* t = static_cast<dig::StageTimer*>(timer);
+    DIG_REQUIRE(t->launched, "no launch of the armed stage followed dig_stage_timer_arm on the arming thread");
+    DIG_HIP_TRY(hipEventSynchronize(t->stop));
+    float f = 0.f;
+    DIG_HIP_TRY(hipEventElapsedTime(&f, t->start, t->stop));
+    *ms = (double)f;
+    return DIG_OK;
+}
+
+__global__ void stage_timer_empty_kernel(int* sink)
+{
+    if (sink && threadIdx.x == 4096) *sink = 0;
+}
+
+int dig_stage_timer_selftest(void* timer, void* stream)
+{
+    DIG_REQUIRE(timer, "a timer of dig_stage_timer_create");
+    auto* t = static_cast<dig::StageTimer*>(timer);
+    hipExtLaunchKernelGGL(stage_timer_empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t->start, t->stop, 0, (int*)nullptr);
+    DIG_HIP_TRY(hipGetLastError());
+    t->launched = 1;
+    return DIG_OK;
+}
+
+int dig_stage_timer_destroy(void* timer)
+{
+    if (!timer) return DIG_OK;
+    auto* t = static_cast<dig::StageTimer*>(timer);
+    for (int k = 0; k < 2; ++k)
+        if (dig::tl_armed[k] == t) dig::tl_armed[k] = nullptr;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+    return DIG_OK;
+}
 
 int dig_abi_version(void) { return DIG_ABI_VERSION; }
 

@@ -1,6 +1,7 @@
 // dig_common.hpp -- error plumbing and launch helpers shared by the .hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -60,6 +61,23 @@ __device__ __forceinline__ int64_t fastdiv(int64_t i, const FastDiv& f)
 {
     return (int64_t)__umul64hi((uint64_t)i, f.magic);
 }
+
+// A stage timer (dig_stage_timer_*, include/dig_hip.h): two events that the next launch of a stage's kernel on the arming
+// thread fills with the kernel's own begin and end (hipExtLaunchKernelGGL: taken from the dispatch, no packet added to the stream).
+struct StageTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int launched = 0;
+};
+StageTimer* take_armed_timer(int stage);       // the timer armed for `stage` by this thread, or NULL; disarms it
+// launch `kernel` as hipLaunchKernelGGL does, through the armed timer of `stage` if there is one
+#define DIG_LAUNCH_STAGE(stage, kernel, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                                 \
+        if (::dig::StageTimer* _t = ::dig::take_armed_timer(stage)) {                                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, _t->start, _t->stop, 0, __VA_ARGS__);                \
+            _t->launched = 1;                                                                                            \
+        } else                                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                           \
+    } while (0)
 
 inline int grid_for(int64_t n, int block, int max_blocks_per_cu = 8)
 {

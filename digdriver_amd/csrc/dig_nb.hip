@@ -1226,9 +1226,9 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
             DIG_REQUIRE(!DIG_ES_INWAVE || cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
             if (a.bin_pack)
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 3>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 3>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
             else
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
             finished_in_wave = DIG_ES_INWAVE != 0;
         } else if (which == 2 && form == 1 && tickets == 256) {
             const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, true>, 256), stream_blocks_per_cu(8)));
@@ -1244,9 +1244,9 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
             // second pass inside): DIG_ES_GIVEN_FORM=0 keeps round 1's two-stage kernels + the compacted kernel
             DIG_REQUIRE(cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
             if (which == 1)
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 2>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 2>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
             else
-                hipLaunchKernelGGL((element_stats_stream_fused_kernel<1024, true, 1>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 1>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
             finished_in_wave = true;
         } else if (which == 1) {
             // (the two-stage forms are bound by VALU issue, not by latency hiding: slightly fewer than the maximum of

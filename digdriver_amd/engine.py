@@ -858,3 +858,35 @@ class ChunkedScaleFactorPlan:
             self.finish(self.all, cj, cj_indel, out_sum, stream)
         else:
             self.finish(part.unsqueeze(0), cj, cj_indel, out_sum, stream)
+
+
+class StageTimer:
+    """How long did the dot kernel / the statistics kernel of a dig_element_pipeline call run?  (dig_stage_timer_*, include/dig_hip.h:
+    the kernel's own begin and end, taken from its dispatch -- nothing is added to the stream.)
+
+        tm = StageTimer(); tm.arm(_lib.DIG_PIPE_STATISTICS); plan.run(...); ms = tm.read_ms(); tm.close()
+    """
+
+    def __init__(self):
+        import ctypes
+        self._h = ctypes.c_void_p()
+        _lib.call("dig_stage_timer_create", ctypes.byref(self._h))
+
+    def arm(self, stage):
+        _lib.call("dig_stage_timer_arm", self._h, int(stage))
+
+    def read_ms(self):
+        import ctypes
+        ms = ctypes.c_double()
+        _lib.call("dig_stage_timer_read", self._h, ctypes.byref(ms))
+        return float(ms.value)
+
+    def selftest(self, stream=None):
+        """Time a kernel that does nothing (then read_ms()): what of a reading is dispatch, not kernel."""
+        _lib.call("dig_stage_timer_selftest", self._h, _lib.stream_ptr(stream))
+
+    def close(self):
+        if self._h:
+            _lib.call("dig_stage_timer_destroy", self._h)
+            import ctypes
+            self._h = ctypes.c_void_p()

@@ -34,10 +34,10 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 7   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 8   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
                              * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome), dig_write_tsv_host;
-                             * 7: + dig_mutation_file_*_host */
+                             * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_* */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -190,6 +190,18 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
  *       a few ulp; tests/test_gpu_parity.py).  Without the flag the general K = 256 form runs, as before. */
 #define DIG_PIPE_COMPACT_L 16
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
+/* Stage timers (ABI 8; measurement only).  How long did the dot kernel / the statistics kernel of a dig_element_pipeline call
+ * run?  Two events around a stage on the stream measure more than the kernel (each is a packet of its own: ~6 us, and the
+ * packets change what runs beside the kernel on other streams).  A timer armed for DIG_PIPE_DOT or DIG_PIPE_STATISTICS makes
+ * the NEXT launch of that stage's kernel by the calling thread record its own begin and end (hipExtLaunchKernelGGL: the
+ * times of the dispatch itself, what rocprofv3's kernel trace shows; nothing is added to the stream).  dig_stage_timer_read
+ * waits for that kernel and returns its duration in milliseconds; DIG_EINVAL if no such launch followed the arming. */
+int dig_stage_timer_create(void **timer);
+int dig_stage_timer_arm(void *timer, int stage);
+int dig_stage_timer_read(void *timer, double *ms);
+/* what the timer reads for a kernel that does nothing (one wave, launched here on `stream`): the part of a reading that is dispatch, not kernel */
+int dig_stage_timer_selftest(void *timer, void *stream);
+int dig_stage_timer_destroy(void *timer);
 int dig_element_pipeline_prepare(const int32_t *L, int64_t E, int64_t C, void *workspace, int64_t workspace_bytes,
                                  int *compact_ok, void *stream);
 /* host twin: all pointers in host memory; stages the arrays, checks L (the compact form runs when it repeats), runs
