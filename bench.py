@@ -884,7 +884,7 @@ def main():
             stage_ms_raw[k], stage_n[k] = sum(got) / len(got), len(got)
     timed_by_stage_timers = bool(stage_ms_raw)
     # What such a timer reads for a kernel that does nothing (one wave): readings carry a dispatch share of that order.  Against
-    # rocprofv3's kernel trace of the same run (tools/_cmp.sh, profiles/r04_stage_timer_check.txt) the statistics kernel reads
+    # rocprofv3's kernel trace of the same run (tools/stage_timer_check.sh, profiles/r04_stage_timer_check.txt) the statistics kernel reads
     # 6 - 9 us high, the dot kernel 2 - 3 us: avg_launch_ms is the RAW mean reading (the roofline fraction is if anything
     # understated); the empty-kernel reading is in the line beside it.
     empty_kernel_us = None
