@@ -129,9 +129,11 @@ int dig_write_tsv_host(const char* path, const char* header, const char* labels,
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
     if ((int64_t)n_threads > n_chunks) n_threads = (int)(n_chunks > 0 ? n_chunks : 1);
+    const bool seekable = ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;      // (a pipe or a terminal: one thread, plain writes in order)
+    if (!seekable) n_threads = 1;
     auto put = [&](const char* src, int64_t n, int64_t at) {
         while (n > 0) {
-            const ssize_t w = ::pwrite(fd, src, (size_t)n, (off_t)at);
+            const ssize_t w = seekable ? ::pwrite(fd, src, (size_t)n, (off_t)at) : ::write(fd, src, (size_t)n);
             if (w <= 0) return false;
             src += w;
             n -= w;
