@@ -137,24 +137,28 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
     acc, st = engine.element_pipeline(*args, obs_snv, obs_smp, obs_ind, cj, cji)
     alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
     st_.mark("kernels")
+    # every [E, C] plane comes back cohort-major ([C, E], transposed on the device): a cohort's column is then one contiguous
+    # row -- read with a stride of C values, the 24 columns of 37 frames were 0.35 s of cache misses on the host
     host = lambda x: x.cpu().numpy()
-    A = {k: host(v) for k, v in acc.items()}
-    S, al, th = host(st), host(alpha), host(theta)
+    by_cohort = lambda x: host(x.transpose(-1, -2).contiguous())
+    A = {k: (by_cohort(v) if v.dim() >= 2 and v.shape[-1] == C else host(v)) for k, v in acc.items()}       # P: [E, 1, C] -> [E, C, 1]
+    S, al, th = by_cohort(st), by_cohort(alpha), by_cohort(theta)
+    P0 = host(acc['P'][:, 0, :].transpose(0, 1).contiguous())
     cj_h, cji_h = host(cj), host(cji)
-    o_snv, o_smp, o_ind = host(obs_snv), host(obs_smp), host(obs_ind)
+    o_snv, o_smp, o_ind = by_cohort(obs_snv), by_cohort(obs_smp), by_cohort(obs_ind)
     st_.mark("d2h")
     frames = []
     index = pd.Index(elts['names'], name='ELT')              # one object for all cohorts
     for c in range(C):
-        have_indel = o_ind[:, c].sum() != 0
-        d = {'ELT_SIZE': A['ELT_SIZE'], 'FLAG': A['FLAG'][:, c].astype(bool), 'R_SIZE': A['R_SIZE'], 'R_OBS': A['R_OBS'][:, c],
-             'R_INDEL': A['R_OBS'][:, c], 'MU': A['MU'][:, c], 'SIGMA': A['SIGMA'][:, c], 'ALPHA': al[:, c],
-             'THETA': th[:, c] * cj_h[c], 'MU_INDEL': A['MU'][:, c], 'SIGMA_INDEL': A['SIGMA'][:, c], 'ALPHA_INDEL': al[:, c],
-             'THETA_INDEL': S[3][:, c] if have_indel else th[:, c], 'Pi_SUM': A['P'][:, 0, c], 'Pi_INDEL': A['P_INDEL'],
-             'OBS_SAMPLES': o_smp[:, c].astype(float), 'OBS_SNV': o_snv[:, c].astype(float), 'OBS_INDEL': o_ind[:, c].astype(float),
-             'EXP_SNV': S[0][:, c], 'PVAL_SNV_BURDEN': S[1][:, c], 'PVAL_SAMPLE_BURDEN': S[2][:, c]}
+        have_indel = o_ind[c].sum() != 0
+        d = {'ELT_SIZE': A['ELT_SIZE'], 'FLAG': A['FLAG'][c].astype(bool), 'R_SIZE': A['R_SIZE'], 'R_OBS': A['R_OBS'][c],
+             'R_INDEL': A['R_OBS'][c], 'MU': A['MU'][c], 'SIGMA': A['SIGMA'][c], 'ALPHA': al[c],
+             'THETA': th[c] * cj_h[c], 'MU_INDEL': A['MU'][c], 'SIGMA_INDEL': A['SIGMA'][c], 'ALPHA_INDEL': al[c],
+             'THETA_INDEL': S[3][c] if have_indel else th[c], 'Pi_SUM': P0[c], 'Pi_INDEL': A['P_INDEL'],
+             'OBS_SAMPLES': o_smp[c].astype(float), 'OBS_SNV': o_snv[c].astype(float), 'OBS_INDEL': o_ind[c].astype(float),
+             'EXP_SNV': S[0][c], 'PVAL_SNV_BURDEN': S[1][c], 'PVAL_SAMPLE_BURDEN': S[2][c]}
         if have_indel:                                       # transfer_tools.py:1079-1087
-            d.update({'EXP_INDEL': S[4][:, c], 'PVAL_INDEL_BURDEN': S[5][:, c], 'PVAL_MUT_BURDEN': S[6][:, c]})
+            d.update({'EXP_INDEL': S[4][c], 'PVAL_INDEL_BURDEN': S[5][c], 'PVAL_MUT_BURDEN': S[6][c]})
         frames.append(pd.DataFrame(d, index=index))
     st_.mark("frames")
     return frames
