@@ -54,25 +54,49 @@ def get_elt_ideal_overlaps(chrom, start, end, window):
 # ---------------------------------------------------------------------------------------------
 # cohort tables
 # ---------------------------------------------------------------------------------------------
+def _columns_to_table(cols, dtype, block=2048):
+    """C columns of N values -> a contiguous [N, C] table.  np.stack(axis=1) writes every column with a stride of C values (0.22 s
+    for 288 000 x 37 doubles); rows are taken in blocks that stay in cache instead (0.06 s)."""
+    a = np.array(cols, dtype=dtype)                       # [C, N], contiguous copies
+    C, N = a.shape if a.ndim == 2 else (len(cols), 0)
+    out = np.empty((N, C), dtype)
+    for r0 in range(0, N, block):
+        out[r0:r0 + block] = a[:, r0:r0 + block].T
+    return out
+
+
 class RegionTables:
     """region_params of one or more cohorts as dense [N, C] tables on a common, (chrom, start)-sorted bin grid."""
 
     def __init__(self, frames):
-        base = frames[0].sort_values(['CHROM', 'START'])
-        self.chrom = base.CHROM.values.astype(np.int32)
-        self.start = base.START.values.astype(np.int64)
-        self.window = int(base.END.values[0] - base.START.values[0])     # genic_driver_tools.py:308
+        # one ordering for all cohorts: the (CHROM, START) order of the first map -- nothing to do when the map is stored in that
+        # order (the usual case: 1 ms to check where a 288 000-row sort_values took 25 ms per cohort); a cohort whose raw
+        # columns equal the first one's shares its ordering, any other is sorted on its own and must land on the same grid
+        chrom0, start0 = np.asarray(frames[0].CHROM.values), np.asarray(frames[0].START.values)
+        in_order = len(chrom0) < 2 or bool(np.all((chrom0[1:] > chrom0[:-1]) | ((chrom0[1:] == chrom0[:-1]) & (start0[1:] >= start0[:-1]))))
+        order0 = None if in_order else np.lexsort((start0, chrom0))
+        take = (lambda a, o: a) if in_order else (lambda a, o: a[o])
+        g_chrom, g_start = take(chrom0, order0), take(start0, order0)
+        self.chrom = g_chrom.astype(np.int32)
+        self.start = g_start.astype(np.int64)
+        end0 = np.asarray(frames[0].END.values)
+        self.window = int(take(end0, order0)[0] - g_start[0])                # genic_driver_tools.py:308
         cols = {k: [] for k in ('Y_PRED', 'STD', 'Y_TRUE', 'FLAG')}
         for f in frames:
-            f = f.sort_values(['CHROM', 'START'])
-            if not (np.array_equal(f.CHROM.values, base.CHROM.values) and np.array_equal(f.START.values, base.START.values)):
-                raise ValueError("all cohorts must share one bin grid")
+            fc, fs = np.asarray(f.CHROM.values), np.asarray(f.START.values)
+            if fc is chrom0 or (np.array_equal(fc, chrom0) and np.array_equal(fs, start0)):
+                order = order0
+            else:
+                order = np.lexsort((fs, fc))
+                if not (np.array_equal(fc[order], g_chrom) and np.array_equal(fs[order], g_start)):
+                    raise ValueError("all cohorts must share one bin grid")
             for k in cols:
-                cols[k].append(f[k].values)
-        self.mu = np.ascontiguousarray(np.stack(cols['Y_PRED'], axis=1), np.float64)
-        self.std = np.ascontiguousarray(np.stack(cols['STD'], axis=1), np.float64)
-        self.y = np.ascontiguousarray(np.stack(cols['Y_TRUE'], axis=1), np.int32)
-        self.flag = np.ascontiguousarray(np.stack(cols['FLAG'], axis=1).astype(bool), np.uint8)
+                v = np.asarray(f[k].values)
+                cols[k].append(v if order is None else v[order])
+        self.mu = _columns_to_table(cols['Y_PRED'], np.float64)
+        self.std = _columns_to_table(cols['STD'], np.float64)
+        self.y = _columns_to_table(cols['Y_TRUE'], np.int32)
+        self.flag = _columns_to_table([np.asarray(v).astype(bool) for v in cols['FLAG']], np.uint8)
 
     def aligned_context(self, si_index, si_values):
         """Rows of full_window_si_values re-ordered to this bin grid (a bin without context row is an error)."""
