@@ -141,7 +141,7 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
     # row -- read with a stride of C values, the 24 columns of 37 frames were 0.35 s of cache misses on the host
     host = lambda x: x.cpu().numpy()
     by_cohort = lambda x: host(x.transpose(-1, -2).contiguous())
-    A = {k: (by_cohort(v) if v.dim() >= 2 and v.shape[-1] == C else host(v)) for k, v in acc.items()}       # P: [E, 1, C] -> [E, C, 1]
+    A = {k: (by_cohort(v) if v.dim() == 2 else host(v)) for k, v in acc.items() if k != 'P'}                # (P [E, 1, C]: its one class below)
     S, al, th = by_cohort(st), by_cohort(alpha), by_cohort(theta)
     P0 = host(acc['P'][:, 0, :].transpose(0, 1).contiguous())
     cj_h, cji_h = host(cj), host(cji)
