@@ -225,3 +225,36 @@ def test_native_mutation_file_parser_gives_the_arrays_of_the_python_routes(tmp_p
     empty.write_text("X\t1\t2\tA\tC\tS1\t.\tSNV\n")
     nat = tg._encode_mutation_file_native(str(empty), 0)
     assert nat is not None and len(nat["chrom"]) == 0 and nat["sample_names"] == []
+
+
+def test_region_tables_take_any_row_order_and_refuse_another_grid():
+    """RegionTables (the [N, C] tables of C maps on one (CHROM, START)-ordered grid): a map stored in another row order, or in the
+    same shuffled order as the first, gives the tables of the sorted maps; a map on another grid is refused."""
+    from digdriver_amd.sequence_model import genic_driver_tools as g
+    rng = np.random.default_rng(4)
+    N = 3000
+    chrom = np.repeat(np.arange(1, 4), N // 3)
+    start = np.tile(np.arange(N // 3) * 10_000, 3)
+
+    def frame(seed):
+        r = np.random.default_rng(seed)
+        return pd.DataFrame({"CHROM": chrom, "START": start, "END": start + 10_000, "Y_TRUE": r.integers(0, 50, N),
+                             "Y_PRED": r.gamma(5, 2, N), "STD": r.gamma(2, 1, N), "FLAG": r.random(N) < 0.1})
+    frames = [frame(s) for s in range(5)]
+    want = g.RegionTables(frames)
+    assert want.mu.shape == (N, 5) and want.mu.flags.c_contiguous and want.y.dtype == np.int32 and want.flag.dtype == np.uint8
+    for c, f in enumerate(frames):
+        assert np.array_equal(want.mu[:, c], f.Y_PRED.values) and np.array_equal(want.y[:, c], f.Y_TRUE.values)
+        assert np.array_equal(want.flag[:, c], f.FLAG.values.astype(np.uint8)) and np.array_equal(want.std[:, c], f.STD.values)
+    perm = rng.permutation(N)
+    same_shuffle = g.RegionTables([f.iloc[perm].reset_index(drop=True) for f in frames])
+    mixed = g.RegionTables([frames[0]] + [f.iloc[rng.permutation(N)].reset_index(drop=True) for f in frames[1:]])
+    first_shuffled = g.RegionTables([frames[0].iloc[perm].reset_index(drop=True)] + frames[1:])
+    for got in (same_shuffle, mixed, first_shuffled):
+        for name in ("chrom", "start", "mu", "std", "y", "flag"):
+            assert np.array_equal(getattr(got, name), getattr(want, name)), name
+        assert got.window == want.window == 10_000
+    other = frames[1].copy()
+    other.loc[7, "START"] += 5
+    with pytest.raises(ValueError):
+        g.RegionTables([frames[0], other])
