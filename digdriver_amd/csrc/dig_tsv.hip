@@ -364,6 +364,7 @@ int dig_mutation_file_parse_host(const char* path, void** handle, int64_t* n_row
         n_id.push_back(annot.get(fld[7]));
         p = next;
     }
+    if (n_fields < 0) return DIG_OK;                                 // no row at all: the Python path says what it says about such a file
     int64_t indel_id = -1;
     {
         auto it = annot.ids.find(std::string_view("INDEL"));

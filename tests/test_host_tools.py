@@ -221,6 +221,11 @@ def test_native_mutation_file_parser_gives_the_arrays_of_the_python_routes(tmp_p
         g = tmp_path / "bad.txt"
         g.write_text(bad)
         assert tg._encode_mutation_file_native(str(g), 0) is None
+    nothing = tmp_path / "nothing.txt"
+    nothing.write_text("")
+    assert tg._encode_mutation_file_native(str(nothing), 0) is None       # an empty file: the Python route raises as before
+    with pytest.raises(ValueError):
+        tg.encode_mutation_file(str(nothing), 0)
     empty = tmp_path / "empty.txt"
     empty.write_text("X\t1\t2\tA\tC\tS1\t.\tSNV\n")
     nat = tg._encode_mutation_file_native(str(empty), 0)
