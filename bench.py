@@ -482,7 +482,7 @@ def aux_rooflines(dev):
     return out
 
 # --------------------------------------------------------------------------------------
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -492,8 +492,10 @@ def main():
     ap.add_argument("--cohorts", type=int, default=37)
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="elements in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--mode", choices=["sharded", "strong", "replicas"], default="sharded",
-                    help="how N > 1 ranks divide the work (see the module docstring); all three are configs[2] at N = 1")
+    ap.add_argument("--mode", choices=["both", "sharded", "strong", "replicas"], default="both",
+                    help="how N > 1 ranks divide the work (see the module docstring); all are configs[2] at N = 1.  both (default): "
+                         "`value` on the strong problem (BASELINE configs[3]: ONE 120 091-element problem cut over the N GPUs), then "
+                         "the weak curve (the element set grows with N) under `weak_scaling` in the same line")
     ap.add_argument("--contexts-on", choices=["main", "side"], default="main",
                     help="stream of the pipeline's context stage (it depends on the step's inputs only, like the scale factors)")
     ap.add_argument("--form", choices=["auto", "general"], default="auto",
@@ -518,14 +520,71 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed: the sequential evaluation the loop is checked against is repeated for this long before "
                          "the W warm-up steps (brings the GPU out of its idle power state; 0 = evaluate once)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    from digdriver_amd import _lib, engine, parallel
 
+def gpu_identity():
+    """Serial numbers of the visible GPUs (`rocm-smi --showserial`, run as a child BEFORE this process touches a device).  The
+    pool holds two kinds of MI355X that differ by 5-10 % on the statistics kernel: the line says which
+    card a number came from."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showserial"], capture_output=True, text=True, timeout=60).stdout
+        return {int(m.group(1)): m.group(2) for m in re.finditer(r"GPU\[(\d+)\]\s*:\s*Serial Number:\s*(\S+)", out)}
+    except Exception:                                     # (no rocm-smi: the line says so)
+        return {}
+
+
+# the statistics kernel's own time splits the pool's cards into two groups (round 5's kernel: see DESIGN.md section 8)
+STATS_KERNEL_KIND_SPLIT_US = 136.0
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves.  This parent has not
+    imported torch and never touches a GPU -- a process that has initialised HIP must not be replaced or forked into ranks --
+    it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD, relays
+    rank 0's one JSON line (the last line of the child's stdout that parses as JSON) and exits with the child's code."""
+    import socket
+    import subprocess
+    assert "torch" not in sys.modules, "the launching process must not have imported torch"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, BENCH_LAUNCHED_BY="bench.py", BENCH_PARENT_IMPORTED_TORCH="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for cand in reversed(p.stdout.splitlines()):
+        try:
+            json.loads(cand)
+            line = cand
+            break
+        except ValueError:
+            continue
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:])
+        raise SystemExit(p.returncode or 1)
+    print(line, flush=True)
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BENCH_LAUNCH_PROBE") == "1":
+        # launcher self-check (tests/test_bench_launcher.py, CPU): what a rank sees, before anything touches a device
+        if rank == 0:
+            peers = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                    "BENCH_LAUNCHED_BY", "BENCH_PARENT_IMPORTED_TORCH")}
+            print(json.dumps({"probe": peers, "gpus": args.gpus, "torch_imported_before_main": "torch" in sys.modules}), flush=True)
+        return
     saved_stdout = None
     if rank != 0:
         # only rank 0 reports: whatever the other ranks' libraries write to stdout (RCCL's banner) must not land after
@@ -538,10 +597,45 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch %d ranks (or leave WORLD_SIZE unset: bench.py starts them itself)"
+                         % (args.gpus, world, args.gpus))
+    ctx_gpu = gpu_identity() if rank == 0 else {}
+    modes = [args.mode] if args.mode != "both" else (["strong", "sharded"] if world > 1 else ["sharded"])
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "gpu_serials": ctx_gpu}
+    res = None
+    for i, mode in enumerate(modes):
+        r = run_workload(args, mode, ctx, primary=(i == 0))
+        if rank == 0:
+            if i == 0:
+                res = r
+            else:
+                res["weak_scaling" if mode == "sharded" else mode] = {
+                    k: r[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "roofline", "roofline_step",
+                                      "matches_sequential_evaluation", "finite_pvalues")}
+    # RCCL writes a version banner to the C stdout of the process, which is block-buffered when stdout is a pipe and would
+    # come out AFTER the result at exit: tear the process group down and flush the C streams first, so that the JSON
+    # line is the last line this process prints.
+    if ctx.get("use_dist"):
+        ctx["dist"].destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+def run_workload(args, mode, ctx, primary=True):
+    """One workload (`mode`) on this rank: build the rank's shard, W warm-up steps, K timed steps between barriers, max over
+    ranks; rank 0 returns the result dictionary.  The device and the process group are set up by the first call (ctx)."""
+    import torch
+    from digdriver_amd import _lib, engine, parallel
+    rank, local_rank, world = ctx["rank"], ctx["local_rank"], ctx["world"]
     # The global problem and this rank's shard of it (at N = 1 the shard is the whole problem)
-    sharded = args.mode != "replicas" and world > 1
-    n_elements_global = args.elements * (world if args.mode == "sharded" else 1)
+    sharded = mode != "replicas" and world > 1
+    n_elements_global = args.elements * (world if mode == "sharded" else 1)
     if sharded:
         # only this rank's shard is built: the cheap global tables + the element blocks that hold its elements
         w, plan = make_shard_workload(rank, world, args.bins, n_elements_global, args.cohorts, seed=args.seed)
@@ -554,24 +648,27 @@ def main():
     E_total = n_elements_global if sharded else args.elements * world
     # CPU baselines first: the all-core one forks workers, which must happen before this process touches the GPU
     cpu_res = (None, None)
-    if world == 1 and args.cpu_sample > 0:
+    if world == 1 and args.cpu_sample > 0 and primary:
         cpu_res = (cpu_baseline(w, args.cpu_sample), cpu_baseline_all_cores(w))
-    _lib.require_device()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    # BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, all-gather, barrier, max-reduce) with whatever world
-    # size the environment gives, also 1: a one-GPU check that the RCCL calls of the multi-GPU path work
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-        if os.environ.get("BENCH_FORCE_DIST") == "1":
-            parallel.FORCE_COLLECTIVES = True       # a world of one sends its all-gather through RCCL too
+    if "dev" not in ctx:
+        _lib.require_device()
+        torch.cuda.set_device(local_rank)
+        ctx["dev"] = torch.device("cuda", local_rank)
+        ctx["dist"] = None
+        # BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, all-gather, barrier, max-reduce) with whatever world
+        # size the environment gives, also 1: a one-GPU check that the RCCL calls of the multi-GPU path work
+        ctx["use_dist"] = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+        if ctx["use_dist"]:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=ctx["dev"])
+            ctx["dist"] = dist
+            if os.environ.get("BENCH_FORCE_DIST") == "1":
+                parallel.FORCE_COLLECTIVES = True       # a world of one sends its all-gather through RCCL too
+    dev, dist, use_dist = ctx["dev"], ctx["dist"], ctx["use_dist"]
 
     E, C = w["L"].shape[0], w["d_pr"].shape[0]
     N = w["bin_mu"].shape[0]                          # rows this rank holds (own range + halo)
@@ -595,7 +692,10 @@ def main():
     # main stream; that record is a barrier packet and cost a 7 us bubble per step in front of the dot kernel, and the
     # reduction, squeezed beside the dot kernel, finished 5 us after it: rocprofv3 kernel trace, 0.301 -> 0.290 ms.)
     SIDE_LEAD_STEPS = 3                      # the side stream is enqueued this many steps ahead of the main stream (slack for the all-gather at N > 1)
-    RING = args.steps + args.warmup + SIDE_LEAD_STEPS + 2      # one set of scale-factor buffers per step: the side stream never waits
+    # a short run (the driver's --steps 20 is 3.6 ms of GPU time) is followed by an UNTIMED-by-the-driver loop of 1 000 more steps of
+    # the same kind, reported beside it as ms_per_step_1000 (primary workload only)
+    EXTRA_STEPS = 1000 if (args.steps < 100 and primary) else 0
+    RING = args.steps + args.warmup + EXTRA_STEPS + SIDE_LEAD_STEPS + 2      # one set of scale-factor buffers per step: the side stream never waits
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
                for _ in range(RING)]
     main_stream = torch.cuda.current_stream(dev)
@@ -751,7 +851,7 @@ def main():
             if k >= 3:
                 throttle_events[(k - 3) % len(throttle_events)].synchronize()
         # this step's (first call only) and the coming steps' scale factors; nothing beyond the last step of the run
-        while queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps - 1):
+        while queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps + EXTRA_STEPS - 1):
             queued[0] += 1
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
@@ -874,12 +974,32 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_step = ev_begin.elapsed_time(ev_end) / args.steps
+    ms_step_1000 = None
+    if EXTRA_STEPS:
+        gc.disable()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(EXTRA_STEPS):
+            step()
+        barrier()
+        d1 = time.perf_counter() - t1
+        gc.enable()
+        if use_dist:
+            tmax = torch.tensor([d1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            d1 = float(tmax.item())
+        ms_step_1000 = d1 / EXTRA_STEPS * 1e3
     slack_us = sorted(slack_side[t].elapsed_time(slack_main[t]) * 1e3 for t in slack_main)
     stage_ms = {k: (sum(a.elapsed_time(b_) for a, b_ in v) / len(v) if v else None) for k, v in samples.items()}
     stage_n = {k: len(v) for k, v in samples.items()}
     stage_ms_raw = {}
     for k, tms in timer_samples.items():
-        got = [tm.read_ms() for tm in tms]
+        got = []
+        for tm in tms:
+            try:
+                got.append(tm.read_ms())
+            except _lib.DigHipError:         # the armed stage was not launched through the timed path (another kernel form): no sample
+                pass
         if got:
             stage_ms_raw[k], stage_n[k] = sum(got) / len(got), len(got)
     timed_by_stage_timers = bool(stage_ms_raw)
@@ -1010,7 +1130,7 @@ def main():
             "metric": "genomic elements tested/sec (whole node), whole-genome x 37 cohorts",
             "value": units / dt, "unit": "element-cohort tests/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if args.mode == "strong" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (mode == "strong" and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: whole genome, %d 10-kb bins, %d cohorts batched, %d elements, K=192 "
                                     "substitution types, mean %.2f bins/element" % (args.bins, C, E_total, nbar)) if world == 1 else
                                    {"sharded": "BASELINE configs[3]: ONE genome of %d 10-kb bins cut into %d contiguous bin ranges (one per "
@@ -1019,9 +1139,18 @@ def main():
                                     "strong": "BASELINE configs[3], strong form: ONE configs[2] problem (%d bins / %d ranks, %d cohorts, %d "
                                               "elements in all, about %d per GPU), all-gather of the per-cohort chunk sums every step",
                                     "replicas": "%d-bin genome replicated on each of %d GPUs, %d cohorts, %d elements in all (%d per GPU), "
-                                                "no exchange"}[args.mode] % (args.bins, world, C, E_total, E_total // world),
-                       "mode": args.mode, "contexts_on": args.contexts_on, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
-                       "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if args.mode != "replicas" else "replicas x%d" % world},
+                                                "no exchange"}[mode] % (args.bins, world, C, E_total, E_total // world),
+                       "mode": mode, "contexts_on": args.contexts_on, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
+                       "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if mode != "replicas" else "replicas x%d" % world},
+            "ms_per_step_1000": ms_step_1000,
+            "ms_per_step_1000_note": ("the same step, 1 000 more times after the timed region (own barriers, host clock, max over "
+                                      "ranks); NOT part of `value`: the asked %d steps are %.1f ms of GPU time" % (args.steps, dt * 1e3)
+                                      if ms_step_1000 is not None else None),
+            "gpu": {"serial": ctx["gpu_serials"].get(ctx["local_rank"]), "serials_visible": [ctx["gpu_serials"][k] for k in sorted(ctx["gpu_serials"])],
+                    "kind": (None if not stage_ms.get("statistics") or not default_shape else
+                             "fast" if stage_ms["statistics"] * 1e3 < STATS_KERNEL_KIND_SPLIT_US else "common"),
+                    "kind_note": "the pool's MI355X fall into two groups by the statistics kernel's own time on this workload (split at "
+                                 "%.0f us for this build; DESIGN.md section 8); `serial` from rocm-smi" % STATS_KERNEL_KIND_SPLIT_US},
             "roofline": dominant_roof,
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
@@ -1062,11 +1191,11 @@ def main():
             "untimed_settle": {"ms": settle_ms, "sequential_evaluations": n_settle, "two_stream_passes": args.settle_passes,
                                "what": "the sequential evaluation the loop is checked against, repeated before the warm-up steps"},
         }
-        if args.aux and world == 1:
+        if args.aux and world == 1 and primary:
             del td, pipes, seq_plan
             torch.cuda.empty_cache()
             res["aux_rooflines"] = aux_rooflines(dev)
-        if args.e2e and world == 1 and (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37):
+        if args.e2e and world == 1 and primary and (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37):
             # the number a user of the drop-in sees: files in, results.txt out; never mixed into `value`
             import tempfile
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -1087,19 +1216,8 @@ def main():
             res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu_res
         else:
             res["cpu_baseline"] = None
-    # RCCL writes a version banner to the C stdout of the process, which is block-buffered when stdout is a pipe and would
-    # come out AFTER the result at exit: tear the process group down and flush the C streams first, so that the JSON
-    # line is the last line this process prints.
-    if use_dist:
-        dist.destroy_process_group()
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    if saved_stdout is not None:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+    torch.cuda.empty_cache()
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_hip.so")
 
 DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
-DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS, DIG_PIPE_WORKLIST_CLEAN, DIG_PIPE_COMPACT_L = 1, 2, 4, 8, 16
+DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS, DIG_PIPE_WORKLIST_CLEAN, DIG_PIPE_COMPACT_L, DIG_PIPE_RECORDS = 1, 2, 4, 8, 16, 32
+DIG_REC_DOUBLES, DIG_REC_MU, DIG_REC_SIGMA, DIG_REC_ROBS_FLAG = 10, 7, 8, 9
 GENE_CLASSES = ("SYN", "MIS", "NONS", "SPL", "TRUNC", "NONSYN")
 GS_PLANES = tuple("EXP_" + c for c in GENE_CLASSES) + tuple("PVAL_%s_BURDEN" % c for c in GENE_CLASSES) + \
     tuple("PVAL_%s_BURDEN_SAMPLE" % c for c in GENE_CLASSES) + ("THETA_INDEL", "EXP_INDEL", "PVAL_INDEL_BURDEN", "PVAL_MUT_BURDEN")
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _vp, _int, _vp, _i64, _vp],
     "dig_bin_records_pack": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
+    "dig_element_records_unpack": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "dig_element_pipeline_host": [_vp] * 25 + [_i64, _i64, _i64, _int],
     "dig_gene_stats": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp],
@@ -103,9 +105,10 @@ _SIZE_QUERIES = {
     "dig_scale_suffstats_chunked_workspace": [_vp, _int, _i64],
     "dig_rbf_backward_partials": [_i64, _i64],
     "dig_bin_records_bytes": [_i64, _i64],
+    "dig_element_records_bytes": [_i64, _i64],
 }
 
-ABI_VERSION = 8          # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 9          # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

@@ -50,6 +50,13 @@ StageTimer* take_armed_timer(int stage)
     return t;
 }
 
+// a timer armed for a stage that the call did not launch through DIG_LAUNCH_STAGE (another form of the kernel, a stage the
+// call did not include) must not stay armed and attach to a later, unrelated call: dig_element_pipeline calls this on return
+void disarm_stage_timers()
+{
+    tl_armed[0] = tl_armed[1] = nullptr;
+}
+
 }  // namespace dig
 
 extern "C" {

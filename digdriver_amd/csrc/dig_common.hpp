@@ -68,7 +68,8 @@ struct StageTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     int launched = 0;
 };
-StageTimer* take_armed_timer(int stage);       // the timer armed for `stage` by this thread, or NULL; disarms it
+StageTimer* take_armed_timer(int stage);
+void disarm_stage_timers();                    // end of a dig_element_pipeline call: nothing stays armed       // the timer armed for `stage` by this thread, or NULL; disarms it
 // launch `kernel` as hipLaunchKernelGGL does, through the armed timer of `stage` if there is one
 #define DIG_LAUNCH_STAGE(stage, kernel, grid, block, lds, stream, ...)                                                   \
     do {                                                                                                                 \

@@ -58,7 +58,13 @@ __device__ __forceinline__ double nb_success_prob(double theta, double pi)
 #pragma clang fp contract(off)
     double t = theta * pi;
     double d = t + 1.0;
+#ifdef DIG_FAST_P          // developer A/B: hardware reciprocal + two Newton steps (p within an ulp) instead of the IEEE division
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+#else
     return 1.0 / d;
+#endif
 }
 
 __device__ __forceinline__ double mul_rn(double a, double b)

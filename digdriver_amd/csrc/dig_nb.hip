@@ -89,10 +89,30 @@ struct ElementStatsArgs {
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
     const double2* bin_pack;   // dig_bin_records_pack: {Y_PRED, STD^2} per (bin, cohort), or NULL
     const int32_t* bin_yf;     //                       Y_TRUE | (FLAG != 0) << 31
+    int rec;              // DIG_PIPE_RECORDS: out is [ceil(n / 64) * 64][kRecOut] doubles (one record per pair) instead of seven planes
 #ifdef DIG_DEV_ABLATE
     int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
 #endif
 };
+
+constexpr int kRecOut = 10;       // DIG_REC_DOUBLES: seven statistics, MU, SIGMA, {R_OBS, FLAG}
+// DIG_PIPE_RECORDS: field f of pair i lives in block i / 64 of 5 rows x 64 lanes x 2 doubles, at row f / 2, lane i % 64
+#ifndef DIG_REC_LAYOUT
+#define DIG_REC_LAYOUT 0
+#endif
+__device__ __forceinline__ int64_t rec_index(int64_t i, int f, int64_t n)
+{
+#if DIG_REC_LAYOUT == 1      // developer A/B: five "pair planes" [5][n_pad][2]
+    return (int64_t)(f >> 1) * (((n + 63) >> 6) << 7) + (i << 1) + (f & 1);
+#else
+    return (((i >> 6) * (kRecOut / 2) + (f >> 1)) << 7) + ((i & 63) << 1) + (f & 1);
+#endif
+}
+// where plane `pl` of pair `i` lives (n pairs): the plane form, or field pl of the pair's record
+__device__ __forceinline__ double* out_slot(const ElementStatsArgs& a, int pl, int64_t n, int64_t i)
+{
+    return a.rec ? a.out + rec_index(i, pl, n) : a.out + (int64_t)pl * n + i;
+}
 
 constexpr int kMaxDevices = 64;
 constexpr int kWorkHeader = 64;   // dwords reserved in front of the worklist (count lives in [0])
@@ -118,8 +138,8 @@ __device__ __forceinline__ PairRaw load_raw(const ElementStatsArgs& a, int64_t i
         r.q1 = a.ov_ptr[e + 1];
         r.mu = r.sigma = 0.0;
     } else {
-        r.mu = a.mu[i];
-        r.sigma = a.sigma[i];
+        r.mu = a.rec ? a.out[rec_index(i, 7, a.E * a.C)] : a.mu[i];
+        r.sigma = a.rec ? a.out[rec_index(i, 8, a.E * a.C)] : a.sigma[i];
         r.q0 = r.q1 = 0;
     }
     r.pi_s = a.pi_sum[i];
@@ -401,6 +421,7 @@ struct StageBin {            // tile t+1
 constexpr int kQueueCap = 1024;        // records per workgroup
 constexpr int kRecDoubles = 11;        // [0..2] p-value slots, [3..5] counts, [6] alpha, [7] p, [8] [9] the indel pair, [10] pair index
 __shared__ double g_queue[kQueueCap * kRecDoubles];
+typedef double v2d __attribute__((ext_vector_type(2)));
 __shared__ unsigned g_queue_list[16][48];
 __shared__ unsigned g_queue_len, g_ovf_len, g_ovf_next;
 __shared__ unsigned g_tests[3 * kQueueCap];      // the open tests of the queue: record * 4 + role
@@ -428,9 +449,12 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 // from the packed bin records of dig_bin_records_pack (two gathers per bin instead of four);
 // GIVEN = 1 / 2: dig_element_stats (mu / sigma handed in per pair; 2: separate indel parameters) -- the same pipeline,
 // tickets and in-kernel second pass without the CSR and bin stages.
-template <int TB, bool TICKETS, int GIVEN = 0>
+template <int TB, bool TICKETS, int GIVEN = 0, bool REC = false>
 __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
+    static_assert(!REC || (TB == 1024 && TICKETS && (GIVEN == 0 || GIVEN == 3)), "record outputs: the pipeline's kernel only");
+    double* const queue = g_queue;
+    constexpr int QCAP = kQueueCap;
 #ifdef DIG_ES_TIMING
     if (threadIdx.x == 0) g_es_t0[blockIdx.x & 1023] = wall_clock64();
 #endif
@@ -529,11 +553,19 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
                 r.sg_i = a.sigma_indel[s.i];
             }
         }
+#ifdef DIG_ES_NT_LOADS      // developer A/B: the streamed inputs (read once) as non-temporal loads
+        r.pi_s = __builtin_nontemporal_load(&a.pi_sum[s.i]);
+        r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
+        r.k_snv = __builtin_nontemporal_load(&a.obs_snv[s.i]);
+        r.k_smp = __builtin_nontemporal_load(&a.obs_samples[s.i]);
+        r.k_ind = __builtin_nontemporal_load(&a.obs_indel[s.i]);
+#else
         r.pi_s = a.pi_sum[s.i];
         r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
         r.k_snv = a.obs_snv[s.i];
         r.k_smp = a.obs_samples[s.i];
         r.k_ind = a.obs_indel[s.i];
+#endif
         r.cj = a.cj[s.c];
         r.cji = a.cj_indel[s.c];
         return r;
@@ -647,7 +679,10 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         w.k_snv = w.k_smp = w.k_ind = 0;
 #endif
 #if DIG_ES_ABL & 256                                   // counts capped at 28: what a sorted wave's trip count would cost (timing only)
-        w.k_snv = min(w.k_snv, 28); w.k_smp = min(w.k_smp, 28);
+#ifndef DIG_ES_CAPK
+#define DIG_ES_CAPK 28
+#endif
+        w.k_snv = min(w.k_snv, DIG_ES_CAPK); w.k_smp = min(w.k_smp, DIG_ES_CAPK);
 #endif
         w.q0 = w.q1 = 0; w.c = cur.c;
 #if DIG_ES_ABL & 8
@@ -676,9 +711,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             if (lane == 0) qb = atomicAdd(&g_queue_len, cnt);
             qb = (unsigned)__builtin_amdgcn_readfirstlane((int)qb);
             const unsigned slot = qb + (unsigned)__popcll(m & lanes_below);
-            const bool fits = slot < (unsigned)kQueueCap;
+            const bool fits = slot < (unsigned)QCAP;
             if (slow && fits) {
-                double* r = g_queue + slot * kRecDoubles;
+                double* r = queue + slot * kRecDoubles;
                 r[0] = pv_snv; r[1] = pv_smp; r[2] = pv_ind;
                 r[3] = q.k_snv; r[4] = q.k_smp; r[5] = q.k_ind;
                 r[6] = q.alpha; r[7] = q.p; r[8] = q.alpha_i; r[9] = q.p_i;
@@ -692,6 +727,30 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
 #if DIG_ES_ABL & 1
         if (pv_snv + pv_smp + pv_ind + pv_mut + q.exp_snv + q.exp_ind + q.theta_i + w.mu + w.sigma + robs + flag != 12345.678) continue;
 #endif
+        if (REC) {
+            // tile-blocked records: the tile's block is 5 rows of 64 x 16 bytes; lane l writes its fields (2 j, 2 j + 1) to row j --
+            // five store instructions of 1 KB each, one aligned 5 120-byte run per tile, one base address
+            const unsigned long long rf = (unsigned long long)(unsigned)robs | ((unsigned long long)(unsigned)flag << 32);
+#if DIG_REC_LAYOUT == 1
+            v2d* g = reinterpret_cast<v2d*>(a.out) + tile * 64 + lane;
+            const int64_t row = ((n + 63) >> 6);              // v2d elements per pair plane / 64
+#define DIG_REC_ROW(j) ((j) * row * 64)
+#else
+            v2d* g = reinterpret_cast<v2d*>(a.out + tile * (64 * kRecOut)) + lane;
+#define DIG_REC_ROW(j) ((j) * 64)
+#endif
+#ifdef DIG_REC_PLAIN_STORES                     // developer A/B: write-back stores
+#define DIG_REC_STORE(j, x, y) g[DIG_REC_ROW(j)] = v2d{(x), (y)}
+#else
+#define DIG_REC_STORE(j, x, y) __builtin_nontemporal_store(v2d{(x), (y)}, &g[DIG_REC_ROW(j)])
+#endif
+            DIG_REC_STORE(0, q.exp_snv, pv_snv);
+            DIG_REC_STORE(1, pv_smp, q.theta_i);
+            DIG_REC_STORE(2, q.exp_ind, pv_ind);
+            DIG_REC_STORE(3, pv_mut, w.mu);
+            DIG_REC_STORE(4, w.sigma, __longlong_as_double((long long)rf));
+            continue;
+        }
 #if !(DIG_ES_ABL & 64)
         if (FUSED) {
             DIG_STREAM_STORE(&a.mu_w[i], w.mu);
@@ -724,7 +783,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         }
 #endif
         __syncthreads();                                    // every wave of the workgroup is out of tiles: the queue is complete
-        const int total = (int)min(g_queue_len, (unsigned)kQueueCap);
+        const int total = (int)min(g_queue_len, (unsigned)QCAP);
         if (threadIdx.x == 0 && total) atomicAdd(&a.worklist[3], (unsigned)total);     // diagnostic: pairs finished here
         // The queue is taken apart TEST by test, not pair by pair: the workgroups that end last are the ones with the most
         // records (probe: 14-18 us from the barrier to the end against a median of 8), and with whole pairs dealt to
@@ -733,7 +792,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         // each, and put the p-value back into the record; (c) one thread per record combines and writes the four planes.
         if (total) {
             const int rec = (int)threadIdx.x;               // TB == kQueueCap
-            double* r = g_queue + rec * kRecDoubles;
+            double* r = queue + (rec < QCAP ? rec : 0) * kRecDoubles;
             unsigned open = 0;
             if (rec < total)
                 open = (__double_as_longlong(r[0]) < 0 ? 1u : 0u) | (__double_as_longlong(r[1]) < 0 ? 2u : 0u) |
@@ -760,7 +819,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
                 const bool active = t0 + (unsigned)quad < n_tests;
                 const unsigned id = g_tests[active ? t0 + (unsigned)quad : t0];
                 const int role = (int)(id & 3u);
-                double* sp = g_queue + (id >> 2) * kRecDoubles;
+                double* sp = queue + (id >> 2) * kRecDoubles;
                 const double marker = sp[role];             // -pmf(k), or -2: pmf(k) not known
                 const double pv = nb_midp_upper_quad(sp[3 + role], sp[role == 2 ? 8 : 6], sp[role == 2 ? 9 : 7],
                                                      marker == -2.0 ? -1.0 : -marker, sub);
@@ -770,10 +829,17 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             if (rec < total) {
                 const int64_t item = __double_as_longlong(r[10]);
                 const double pv_snv = r[0], pv_smp = r[1], pv_ind = r[2];
-                a.out[1 * n + item] = pv_snv;
-                a.out[2 * n + item] = pv_smp;
-                a.out[5 * n + item] = pv_ind;
-                a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+                if (REC) {
+                    a.out[rec_index(item, 1, n)] = pv_snv;
+                    a.out[rec_index(item, 2, n)] = pv_smp;
+                    a.out[rec_index(item, 5, n)] = pv_ind;
+                    a.out[rec_index(item, 6, n)] = fisher_combine_fast(pv_snv, pv_ind);
+                } else {
+                    a.out[1 * n + item] = pv_snv;
+                    a.out[2 * n + item] = pv_smp;
+                    a.out[5 * n + item] = pv_ind;
+                    a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+                }
             }
         }
         const unsigned ovf = g_ovf_len;                     // (final since the barrier above)
@@ -782,7 +848,7 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
             // planes -- written by this workgroup's waves, all of which have passed the barrier (vmcnt(0) in front of it)
             __syncthreads();                                // the queue's LDS is free: 80 doubles per wave of it become the pair buffers
             if (threadIdx.x == 0) atomicAdd(&a.worklist[2], ovf);
-            double (*sp)[10] = reinterpret_cast<double (*)[10]>(g_queue + (threadIdx.x >> 6) * (kSlowPairsPerWave * 10));
+            double (*sp)[10] = reinterpret_cast<double (*)[10]>(queue + (threadIdx.x >> 6) * (kSlowPairsPerWave * 10));
             for (;;) {
                 unsigned b = 0;
                 if (lane == 0) b = atomicAdd(&g_ovf_next, (unsigned)kSlowPairsPerWave);
@@ -819,7 +885,7 @@ __device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsi
     unsigned open = 0;
     if (owner) {
         item = have_first ? first_item : items[base + lane];
-        const double v1 = a.out[1 * n + item], v2 = a.out[2 * n + item], v5 = a.out[5 * n + item];
+        const double v1 = *out_slot(a, 1, n, item), v2 = *out_slot(a, 2, n, item), v5 = *out_slot(a, 5, n, item);
         const PairInputs q = load_pair(a, item);
         double* sp = sp_all[lane];
         sp[0] = v1; sp[1] = v2; sp[2] = v5;
@@ -855,10 +921,10 @@ __device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsi
     if (owner) {
         const double* sp = sp_all[lane];
         const double pv_snv = sp[0], pv_smp = sp[1], pv_ind = sp[2];
-        a.out[1 * n + item] = pv_snv;
-        a.out[2 * n + item] = pv_smp;
-        a.out[5 * n + item] = pv_ind;
-        a.out[6 * n + item] = fisher_combine_fast(pv_snv, pv_ind);
+        *out_slot(a, 1, n, item) = pv_snv;
+        *out_slot(a, 2, n, item) = pv_smp;
+        *out_slot(a, 5, n, item) = pv_ind;
+        *out_slot(a, 6, n, item) = fisher_combine_fast(pv_snv, pv_ind);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // (sp / list are rewritten in the next round)
     __builtin_amdgcn_wave_barrier();
@@ -1151,6 +1217,7 @@ struct FusedRates {
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
     const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
     const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
+    int records;               // DIG_PIPE_RECORDS: `out` holds one record of kRecOut doubles per pair
 };
 
 // DIG_ES_FORM / DIG_ES_BLOCKS_PER_CU are developer knobs for A/B runs (tools/variant_bench.py).
@@ -1183,7 +1250,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     const int use_fd = (C >= 2);   // exact: E * C * C < 2^64 for any problem that fits in memory
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0
 #ifdef DIG_DEV_ABLATE
                        , 0
 #endif
@@ -1194,10 +1261,13 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.mu_w = fused->mu_w; a.sigma_w = fused->sigma_w; a.r_obs = fused->r_obs; a.flag = fused->flag;
         a.small_index = fused->small_index;
         a.bin_pack = fused->bin_pack; a.bin_yf = fused->bin_yf;
+        a.rec = fused->records;
     }
 #ifdef DIG_DEV_ABLATE
     a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;
 #endif
+    DIG_REQUIRE(!a.rec || (wl && stream_form() == 1 && (!getenv("DIG_ES_TICKETS") || atoi(getenv("DIG_ES_TICKETS")) == 1024)),
+                "DIG_PIPE_RECORDS: only the default form of the statistics kernel writes records");
     if (wl && !worklist_already_zero) DIG_HIP_TRY(hipMemsetAsync(wl, 0, sizeof(unsigned) * kWorkHeader, s));
     bool finished_in_wave = false;
     const int64_t want_blocks = (E * C + kBlock - 1) / kBlock;
@@ -1222,13 +1292,23 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         };
         static const int form = stream_form(), tickets = getenv("DIG_ES_TICKETS") ? atoi(getenv("DIG_ES_TICKETS")) : 1024;
         static const int given_form = getenv("DIG_ES_GIVEN_FORM") ? atoi(getenv("DIG_ES_GIVEN_FORM")) : 1;
+        // the pipelined kernel (one 1024-thread workgroup per CU, tile tickets; it finishes its own parked pairs)
+        auto launch_fused = [&](auto kernel) -> int {
+            DIG_REQUIRE(cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
+            DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, kernel, dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            return DIG_OK;
+        };
         if (which == 2 && form == 1 && tickets == 1024) {
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
-            DIG_REQUIRE(!DIG_ES_INWAVE || cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
-            if (a.bin_pack)
-                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 3>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            int rc;
+            if (a.rec) {
+                DIG_REQUIRE(a.bin_pack && DIG_ES_INWAVE, "DIG_PIPE_RECORDS needs the packed bin records (dig_bin_records_pack)");
+                rc = launch_fused(element_stats_stream_fused_kernel<1024, true, 3, true>);
+            } else if (a.bin_pack)
+                rc = launch_fused(element_stats_stream_fused_kernel<1024, true, 3>);
             else
-                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+                rc = launch_fused(element_stats_stream_fused_kernel<1024, true>);
+            if (rc) return rc;
             finished_in_wave = DIG_ES_INWAVE != 0;
         } else if (which == 2 && form == 1 && tickets == 256) {
             const int g = grid_for(E * C, 256, std::min(occupancy(3, element_stats_stream_fused_kernel<256, true>, 256), stream_blocks_per_cu(8)));
@@ -1242,11 +1322,9 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         } else if (which != 2 && DIG_ES_INWAVE && given_form) {
             // dig_element_stats on the pipelined kernel of dig_element_pipeline (one 1024-thread workgroup per CU, tickets,
             // second pass inside): DIG_ES_GIVEN_FORM=0 keeps round 1's two-stage kernels + the compacted kernel
-            DIG_REQUIRE(cu_count() <= 1024, "at most 1024 workgroups (overflow segments)");
-            if (which == 1)
-                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 2>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
-            else
-                DIG_LAUNCH_STAGE(DIG_PIPE_STATISTICS, (element_stats_stream_fused_kernel<1024, true, 1>), dim3(grid_for(E * C, 1024, 1)), dim3(1024), 0, s, a);
+            const int rc = which == 1 ? launch_fused(element_stats_stream_fused_kernel<1024, true, 2>)
+                                      : launch_fused(element_stats_stream_fused_kernel<1024, true, 1>);
+            if (rc) return rc;
             finished_in_wave = true;
         } else if (which == 1) {
             // (the two-stage forms are bound by VALU issue, not by latency hiding: slightly fewer than the maximum of

@@ -27,6 +27,7 @@ struct FusedRates {
     int small_index;      // bin rows < 2^24 and rows * C < 2^32: bin-table offsets from one 24-bit multiply-add
     const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
     const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
+    int records;               // DIG_PIPE_RECORDS: `out` holds one record of DIG_REC_DOUBLES doubles per pair
 };
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
@@ -80,6 +81,38 @@ __global__ __launch_bounds__(256) void pack_bins_kernel(const double* __restrict
     if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
+// DIG_PIPE_RECORDS -> the plane form.  One workgroup per 64 x 64 block of the [E, C] grid when cohort_major (planes [C, E]:
+// a result frame's column is then one contiguous row), else a straight copy out of the records.
+__global__ __launch_bounds__(256) void records_unpack_kernel(const double* __restrict__ rec, int64_t E, int64_t C, double* __restrict__ out7,
+                                                             double* __restrict__ MU, double* __restrict__ SIGMA, int32_t* __restrict__ R_OBS,
+                                                             int32_t* __restrict__ FLAG, int cohort_major)
+{
+    const int64_t n = E * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t o = i;
+        if (cohort_major) {
+            const int64_t e = i / C, c = i - e * C;
+            o = c * E + e;
+        }
+        // field f of pair i: block i / 64 (5 rows x 64 lanes x 2 doubles), row f / 2, lane i % 64, half f % 2
+#if defined(DIG_REC_LAYOUT) && DIG_REC_LAYOUT == 1
+        const int64_t plane2 = ((n + 63) >> 6) << 7;
+        auto field = [&](int f) { return rec[(int64_t)(f >> 1) * plane2 + (i << 1) + (f & 1)]; };
+#else
+        const double* blk = rec + (i >> 6) * (64 * DIG_REC_DOUBLES) + ((i & 63) << 1);
+        auto field = [&](int f) { return blk[((f >> 1) << 7) + (f & 1)]; };
+#endif
+        if (out7)
+#pragma unroll
+            for (int pl = 0; pl < DIG_ES_NPLANES; ++pl) out7[(int64_t)pl * n + o] = field(pl);
+        if (MU) MU[o] = field(DIG_REC_MU);
+        if (SIGMA) SIGMA[o] = field(DIG_REC_SIGMA);
+        const long long rf = __double_as_longlong(field(DIG_REC_ROBS_FLAG));
+        if (R_OBS) R_OBS[o] = (int32_t)(rf & 0xffffffffll);
+        if (FLAG) FLAG[o] = (int32_t)(rf >> 32);
+    }
+}
+
 struct BinRecords {
     int64_t yf_off, flag_off, bytes;
 };
@@ -131,6 +164,24 @@ int dig_element_pipeline_prepare(const int32_t* L, int64_t E, int64_t C, void* w
     return DIG_OK;
 }
 
+int64_t dig_element_records_bytes(int64_t E, int64_t C)
+{
+    if (E <= 0 || C <= 0) return 0;
+    return (E * C + 63) / 64 * 64 * DIG_REC_DOUBLES * (int64_t)sizeof(double);
+}
+
+int dig_element_records_unpack(const double* records, int64_t E, int64_t C, double* out7, double* MU, double* SIGMA,
+                               int32_t* R_OBS, int32_t* FLAG, int cohort_major, void* stream)
+{
+    DIG_REQUIRE(E >= 0 && C >= 0, "E, C >= 0");
+    if (E == 0 || C == 0) return DIG_OK;
+    DIG_REQUIRE(records, "records non-null");
+    hipLaunchKernelGGL(records_unpack_kernel, dim3(grid_for(E * C, 256)), dim3(256), 0, (hipStream_t)stream, records, E, C, out7, MU,
+                       SIGMA, R_OBS, FLAG, cohort_major);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
 int64_t dig_bin_records_bytes(int64_t N, int64_t C)
 {
     if (N <= 0 || C <= 0) return 0;
@@ -158,7 +209,34 @@ int dig_bin_records_pack(const double* bin_mu, const double* bin_std, const int3
     return DIG_OK;
 }
 
+static int element_pipeline_impl(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                         const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
+                         const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
+                         const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
+                         const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
+                         int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
+                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream);
+
 int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+                         const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
+                         const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
+                         const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
+                         const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
+                         int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
+                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    const int rc = element_pipeline_impl(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
+                                         obs_snv, obs_samples, obs_indel, cj, cj_indel, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE,
+                                         P_INDEL, out, N, E, C, bin_records, stages, workspace, workspace_bytes, stream);
+    // a stage timer armed for a stage this call did not launch through the timed path (another form of the kernel, a stage
+    // the call did not include, C > 48: only the FIRST chunk's dot launch takes the timer) does not stay armed
+    dig::disarm_stage_timers();
+    return rc;
+}
+
+}  // extern "C"
+
+static int element_pipeline_impl(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                          const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
                          const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
                          const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
@@ -168,7 +246,8 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
 {
     const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
     const int compact = (stages & DIG_PIPE_COMPACT_L) != 0 && N >= 1;
-    stages &= ~(DIG_PIPE_WORKLIST_CLEAN | DIG_PIPE_COMPACT_L);
+    const int records = (stages & DIG_PIPE_RECORDS) != 0;
+    stages &= ~(DIG_PIPE_WORKLIST_CLEAN | DIG_PIPE_COMPACT_L | DIG_PIPE_RECORDS);
     DIG_REQUIRE(stages >= 1 && stages <= 7, "stages: bit mask of DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS");
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
@@ -199,7 +278,11 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
     }
     if (!(stages & 4)) return DIG_OK;
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
-    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr};
+    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records};
+    if (records) {
+        DIG_REQUIRE(bin_records, "DIG_PIPE_RECORDS needs bin_records (dig_bin_records_pack)");
+        DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");
+    }
     if (bin_records) {
         const BinRecords lay_r = bin_records_layout(N, C);
         f.bin_pack = (const double2*)bin_records;
@@ -211,5 +294,3 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                                    (new scale factors on an existing accumulation) clears it itself */
                                 (compact ? (stages & DIG_PIPE_DOT) != 0 : (stages & 1) != 0) || worklist_clean);
 }
-
-}  // extern "C"

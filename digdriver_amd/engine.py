@@ -407,7 +407,7 @@ class PipelinePlan:
 
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
                  obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None,
-                 pack_bins=True):
+                 pack_bins=True, records_out=False):
         """compact: "auto" (default) checks ONCE, here, on the device whether L repeats every context count three times
         (sequence_tools.py:560-564: true for every elementModel / tiledModel / quickDriver set) and, if so, runs the
         64-context form of the accumulation (contexts + dot in one kernel, half the matrix work); False forces the
@@ -415,7 +415,11 @@ class PipelinePlan:
         pack_bins: rewrite the four bin tables ONCE, here, as the packed records the statistics stage gathers from
         (dig_bin_records_pack: 20 bytes per (bin, cohort) of plan-owned memory, two gathers per bin instead of four, same
         bits).  The plan then reads the records, not the tables: call `repack_bins()` after changing a table in place.
-        Another PipelinePlan over the same tables may be given instead of True: its records are shared."""
+        Another PipelinePlan over the same tables may be given instead of True: its records are shared.
+        records_out: the statistics stage writes tile-blocked records (DIG_PIPE_RECORDS: the ten outputs of a pair -- seven
+        statistics, MU, SIGMA, R_OBS | FLAG -- as field f of block i / 64 at [f / 2, i % 64, f % 2]: one aligned 5 120-byte run
+        per 64-pair tile instead of eleven store streams) into `self.out_records` [ceil(E C / 64), 5, 64, 2]; `self.stats` and
+        MU / SIGMA / R_OBS / FLAG of `self.acc` are filled by `unpack()` (same bits).  Needs the packed bin records (pack_bins)."""
         import ctypes
         import torch
         dev = bin_mu.device
@@ -462,8 +466,17 @@ class PipelinePlan:
             nb = int(_lib.load().dig_bin_records_bytes(self.N, self.C))
             self.records = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.repack_bins()
+        self.records_out = bool(records_out)
+        self.out_records = None
+        if self.records_out:
+            if self.records is None:
+                raise ValueError("records_out needs the packed bin records (pack_bins)")
+            nrec = (self.E * self.C + 63) // 64 * 64
+            self.out_records = torch.empty((nrec // 64, _lib.DIG_REC_DOUBLES // 2, 64, 2), dtype=f64, device=dev)
+            assert self.out_records.data_ptr() % 256 == 0
         self._tail = [p(o["MU"]), p(o["SIGMA"]), p(o["R_OBS"]), p(o["FLAG"]), p(o["P"]), p(o["R_SIZE"]), p(o["ELT_SIZE"]),
-                      p(o["P_INDEL"]), p(self.stats), self.N, self.E, self.C, p(self.records)]
+                      p(o["P_INDEL"]), p(self.out_records if self.records_out else self.stats), self.N, self.E, self.C,
+                      p(self.records)]
         self._ws = p(self.ws)
         self._fn = getattr(_lib.load(), "dig_element_pipeline")
         self.compact = False
@@ -473,7 +486,26 @@ class PipelinePlan:
                 _lib.call("dig_element_pipeline_prepare", p(L), self.E, self.C, self._ws, self.wsb, ctypes.byref(ok),
                           _lib.stream_ptr())
             self.compact = bool(ok.value)
-        self._flags = _lib.DIG_PIPE_COMPACT_L if self.compact else 0
+        self._flags = (_lib.DIG_PIPE_COMPACT_L if self.compact else 0) | (_lib.DIG_PIPE_RECORDS if self.records_out else 0)
+
+    def unpack(self, cohort_major=False, stream=None, stats=None):
+        """records_out plans: out_records -> the plane form (self.stats [7, E, C] and MU, SIGMA, R_OBS, FLAG of self.acc) on
+        `stream`; cohort_major=True writes every plane as [C, E] instead (a result frame's column is then one contiguous row)
+        into `stats` [7, C, E] (required then) and leaves self.acc alone."""
+        import torch
+        assert self.records_out
+        p = _lib.dev_ptr
+        o = self.acc
+        with torch.cuda.device(self.dev):
+            if cohort_major:
+                assert stats is not None and tuple(stats.shape) == (len(ES_PLANES), self.C, self.E)
+                _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(stats), None, None, None, None, 1,
+                          _lib.stream_ptr(stream))
+                return stats
+            st = self.stats if stats is None else stats
+            _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(st), p(o["MU"]), p(o["SIGMA"]),
+                      p(o["R_OBS"]), p(o["FLAG"]), 0, _lib.stream_ptr(stream))
+        return o, st
 
     def repack_bins(self):
         """(Re)build the packed bin records from the plan's bin tables on torch's current stream (waits for it)."""

@@ -34,10 +34,10 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 8   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 9   /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
                              * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome), dig_write_tsv_host;
-                             * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_* */
+                             * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_*; 9: + DIG_PIPE_RECORDS, dig_element_records_* */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -189,6 +189,27 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
  *       Denominators are bit-identical to the general form, numerators differ by the rounding of a regrouped sum (P within
  *       a few ulp; tests/test_gpu_parity.py).  Without the flag the general K = 256 form runs, as before. */
 #define DIG_PIPE_COMPACT_L 16
+/* Record-major outputs of the statistics stage (ABI 9).  The stage has eleven outputs per (element, cohort) pair -- the seven
+ * planes of dig_element_stats and MU, SIGMA, R_OBS, FLAG of the accumulation (transfer_tools.py:343-344,473-482,594-615,
+ * 731-747,1086-1087; genic_driver_tools.py:404-417) -- i.e. eleven store streams whose tile starts fall on odd 8-byte
+ * boundaries (E * C is rarely a multiple of 16).  With DIG_PIPE_RECORDS in `stages`, `out` is instead TILE-BLOCKED RECORDS:
+ *     double out[ceil(E * C / 64)][DIG_REC_DOUBLES / 2][64][2]      (256-byte aligned)
+ * the ten fields of pair i = e * C + c -- [DIG_ES_EXP_SNV .. DIG_ES_PVAL_MUT_BURDEN] the seven statistics in plane order,
+ * [DIG_REC_MU], [DIG_REC_SIGMA], and at [DIG_REC_ROBS_FLAG] the two int32 R_OBS (low word) and FLAG (high word) -- live in
+ * block i / 64: field f at out[i / 64][f / 2][i % 64][f % 2].  A lane of the kernel writes its ten fields as five 16-byte
+ * pieces; a wave's five store instructions write 1 KB each, ONE aligned 5 120-byte run per 64-pair tile from one base
+ * address, and nothing passes through LDS.  MU / SIGMA / R_OBS / FLAG arguments are not written (may be NULL); the lanes
+ * past E * C of the last block are scratch.  Needs `bin_records`.  Values are bit-identical to the plane form.
+ * dig_element_records_unpack turns the blocks into the plane form (out7 [7, E, C], MU, SIGMA [E, C] doubles, R_OBS, FLAG
+ * [E, C] int32; any destination may be NULL; cohort_major: every plane as [C, E]). */
+#define DIG_PIPE_RECORDS 32
+#define DIG_REC_DOUBLES 10
+#define DIG_REC_MU 7
+#define DIG_REC_SIGMA 8
+#define DIG_REC_ROBS_FLAG 9
+int64_t dig_element_records_bytes(int64_t E, int64_t C);
+int dig_element_records_unpack(const double *records, int64_t E, int64_t C, double *out7, double *MU, double *SIGMA,
+                               int32_t *R_OBS, int32_t *FLAG, int cohort_major, void *stream);
 int64_t dig_element_pipeline_workspace(int64_t E, int64_t C);
 /* Stage timers (ABI 8; measurement only).  How long did the dot kernel / the statistics kernel of a dig_element_pipeline call
  * run?  Two events around a stage on the stream measure more than the kernel (each is a packet of its own: ~6 us, and the

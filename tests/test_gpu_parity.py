@@ -781,6 +781,44 @@ def test_packed_bin_records_give_the_same_bits(torch_dev):
         engine.PipelinePlan(*args)
 
 
+def test_record_major_outputs_give_the_same_bits(torch_dev):
+    """DIG_PIPE_RECORDS (ABI 9): the statistics stage writes the ten outputs of a pair -- the seven statistics, MU, SIGMA,
+    R_OBS | FLAG -- as tile-blocked records, one aligned 5 120-byte run per 64-pair tile instead of eleven store streams.
+    Unpacked (dig_element_records_unpack, both orders) they are the planes of the plane form bit for bit: shapes whose
+    pair count is and is not a multiple of 64, C on both sides of 37, elements over 0 ... 12 bins, a workload in which
+    most pairs take the queue and the overflow segment behind it."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine
+    cases = ((900, 700, 37, 2, 3, 0), (400, 333, 1, 3, 9, 0), (700, 1601, 40, 9, 12, 0), (300, 260, 104, 6, 3, 0), (64, 1, 37, 8, 1, 0),
+             (512, 64, 64, 4, 2, 0), (20000, 20000, 37, 31, 3, 300), (9000, 12000, 37, 32, 3, 0))
+    for (nb, E, C, seed, mb, bump) in cases:
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed, max_blocks=mb)
+        w["bin_flag"][::7] = 1
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        td["obs_snv"] += bump
+        td["obs_samples"] += bump // 2
+        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+        planes = engine.PipelinePlan(*args)
+        recs = engine.PipelinePlan(*args, records_out=True, pack_bins=planes)
+        assert recs.out_records.shape == ((E * C + 63) // 64, 5, 64, 2)
+        recs.out_records.fill_(float("nan"))
+        a0, s0 = planes.run(td["cj"], td["cj_indel"])
+        recs.run(td["cj"], td["cj_indel"])
+        a1, s1 = recs.unpack()
+        sc = recs.unpack(cohort_major=True, stats=torch.empty((7, C, E), dtype=torch.float64, device=torch_dev))
+        torch.cuda.synchronize()
+        for k in a0:
+            assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, E, C)
+        assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (E, C)
+        assert torch.equal(torch.nan_to_num(s0, nan=-7.0).transpose(1, 2), torch.nan_to_num(sc, nan=-7.0)), (E, C)
+        if bump:
+            assert torch.isfinite(s1[1]).all() and (s1[1] >= 0).all() and (s1[6] >= 0).all()      # no marker left behind
+    with pytest.raises(ValueError, match="packed bin records"):
+        engine.PipelinePlan(*args, records_out=True, pack_bins=False)
+
+
 def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
     """The fused stream pass finishes its unfinished pairs itself: through the workgroup's LDS queue (1024 records) and, beyond
     that, through the workgroup's own segment of the worklist.  With every SNV count raised past the recurrence's range

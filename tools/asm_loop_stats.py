@@ -11,7 +11,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
        ROOT + "/digdriver_amd/csrc/dig_nb.hip"] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3dig33element_stats_stream_fused_kernelILi1024ELb1ELi0E"))
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3dig33element_stats_stream_fused_kernelILi1024ELb1ELi3ELb1E"))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 k = lines[start:end]
 stores = [i for i, l in enumerate(k) if "global_store" in l and " nt" in l]

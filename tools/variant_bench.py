@@ -28,7 +28,7 @@ def child(ref_path, write_ref):
     st = torch.empty((7, E, C), dtype=torch.float64, device=dev)
     plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"],
                                td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"],
-                               out_acc=oa, out_stats=st)
+                               out_acc=oa, out_stats=st, records_out=os.environ.get("DIG_PLAN_RECORDS", "0") == "1")
     s = torch.cuda.current_stream(dev)
 
     def timed(stages, n):
@@ -58,9 +58,21 @@ def child(ref_path, write_ref):
         res["stats"].append(timed(4, 40))
         res["acc"].append(timed(3, 100))
         res["pipe"].append(timed(7, 100))
-    out = {k: min(v) for k, v in res.items()}
-    out.update({k + "_med": sorted(v)[len(v) // 2] for k, v in res.items()})
+    out = {k: round(min(v), 2) for k, v in res.items()}
+    out.update({k + "_med": round(sorted(v)[len(v) // 2], 2) for k, v in res.items()})
+    off = (engine._lib.workspace_bytes("accumulate", E, C) + 255) // 256 * 256
+    hdr = plan.ws[off:off + 16].view(torch.int32).cpu().numpy()
+    out["finished_from_overflow_segment"], out["finished_from_lds_queue"] = int(hdr[2]), int(hdr[3])
+    if plan.records_out:
+        plan.unpack()
+        torch.cuda.synchronize()
     got = st.cpu().numpy()
+    extra = np.concatenate([oa["MU"].cpu().numpy().ravel(), oa["SIGMA"].cpu().numpy().ravel(), oa["R_OBS"].cpu().numpy().ravel().astype(np.float64),
+                            oa["FLAG"].cpu().numpy().ravel().astype(np.float64)])
+    if write_ref:
+        np.save(ref_path + ".extra.npy", extra)
+    else:
+        out["rate_outputs_bit_equal"] = bool(np.array_equal(extra, np.load(ref_path + ".extra.npy"), equal_nan=True))
     if write_ref:
         np.save(ref_path, got)
     else:
