@@ -64,6 +64,23 @@ __device__ __forceinline__ int revcomp_ctx(int c)
     return ((3 - b2) << 4) | ((3 - b1) << 2) | (3 - b0);
 }
 
+// A cohort whose table d_pr itself holds an exact zero (or a NaN, or entries of both signs) gives NaN whatever L is: t_pi holds
+// 0 / 0 = NaN (or +inf and -inf) at those substitutions (round 5; rounds 3-4 said inf there).  `cohort_table_bad` reads the cohort's
+// 192 frequencies from global memory -- only on this path, i.e. only when some denominator of the tile IS zero.
+__device__ __noinline__ bool cohort_table_bad(const double* __restrict__ d_pr, int c, int C)
+{
+    if (c >= C) return false;
+    const double* d = d_pr + (int64_t)c * 192;
+    bool pos = false, neg = false, bad = false;
+    for (int j = 0; j < 192; ++j) {
+        const double v = d[j];
+        pos |= v > 0.0;
+        neg |= v < 0.0;
+        bad |= !(v > 0.0 || v < 0.0);           // an exact zero or a NaN
+    }
+    return bad || (pos && neg);
+}
+
 template <int NCLASS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
 {
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
                         n3 = fma(Ls[j + 3], dprT[(j + 3) * Cc + lane], n3);
                     }
                     // (denominator 0: the reference forms t_pi = d_pr / 0 = inf first, and inf * 0 is NaN -- see fix_zero_denominators)
-                    const double numer = (denom == 0.0 && ((class_has_zero >> q) & 1u)) ? __longlong_as_double(0x7ff8000000000000ll)
+                    const double numer = (denom == 0.0 && (((class_has_zero >> q) & 1u) || cohort_table_bad(a.d_pr, a.c0 + lane, (int)a.C)))
+                                             ? __longlong_as_double(0x7ff8000000000000ll)
                                                                                         : (n0 + n1) + (n2 + n3);
                     a.P[(e * NCLASS + q) * a.C + col] = numer / denom;
                 }
@@ -443,13 +461,10 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 // (inf * 0) and inf otherwise; numerator / 0 alone would say inf in both cases.  `lzero`: this lane's slices of the row's L
 // hold a zero.  The numerators of such rows are replaced so that the quotient that follows gives the reference's value.
 // Rare: one wave-uniform test per tile in front of it.
-// (Known deviation, ADVICE r3: a cohort whose SIGNATURE d_pr holds an exact zero makes the reference's t_pi hold 0 / 0 = NaN
-//  at that substitution whatever L is, so the reference says NaN for such a cohort even when every L[j] > 0; this kernel says
-//  inf there.  It takes a zero denominator AND an exact zero in a fitted 192-frequency table AND no zero in L: not reproduced.)
 template <int NT, int NQ>
 __device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT > 0 ? NT : 1], const double (&denq)[NQ > 0 ? NQ : 1],
                                                       double4_t (&num)[NT > 0 ? NT : 1], double (&numq)[NQ > 0 ? NQ : 1],
-                                                      int lzero, int lane)
+                                                      int lzero, int lane, const double* __restrict__ d_pr, int c0, int C)
 {
     bool z = false;
 #pragma unroll
@@ -468,13 +483,13 @@ __device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT 
         const int rowzero = __shfl(lzero, 4 * r + kq, 64);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            if (den[nt][r] == 0.0 && rowzero) num[nt][r] = nan;
+            if (den[nt][r] == 0.0 && (rowzero || cohort_table_bad(d_pr, c0 + nt * 16 + (lane & 15), C))) num[nt][r] = nan;
     }
     if constexpr (NQ > 0) {
         const int rowzero = __shfl(lzero, 4 * ((lane >> 2) & 3) + kq, 64);   // D[i][j] of block b: row 4 b + i
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (denq[q] == 0.0 && rowzero) numq[q] = nan;
+            if (denq[q] == 0.0 && (rowzero || cohort_table_bad(d_pr, c0 + NT * 16 + 4 * q + (lane & 3), C))) numq[q] = nan;
     }
 }
 
@@ -482,7 +497,8 @@ template <int NCLASS, int NT, int NQ>
 __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_mfma_kernel(
     const int32_t* __restrict__ rcp, const int32_t* __restrict__ L, const double* __restrict__ tab_g,
     const int32_t* __restrict__ R_SIZE, const int32_t* __restrict__ gene_length, double* __restrict__ P,
-    int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes)
+    int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes,
+    const double* __restrict__ d_pr)
 {
     extern __shared__ double tab[];           // [kMfmaSteps][SL][64]
     constexpr int SL = NT + (NQ > 0 ? 1 : 0);
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
                 }
                 mfma_group<NT, NQ>(cur, tabq, 16 + 16 * g, lane, toff, num, numq, lsum, lzero);
             }
-            fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
+            fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane, d_pr, c0, C);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t e = e0 + 4 * r + kq;                      // D[i][j]: lane 16 (i % 4) + j, register i / 4
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
         steps(std::integral_constant<int, 0>{});
         r_c = load_rows(b_n, x_n);                               // tile t+1: context rows + L (indices have arrived meanwhile)
         steps(std::integral_constant<int, 2>{});
-        fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
+        fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane, d_pr, c0, C);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t e = e0 + 4 * r + kq;                   // D[i][j]: lane 16 (i % 4) + j, register i / 4
@@ -893,7 +909,7 @@ static AccWorkspace acc_workspace_layout(void* base, int64_t E, int64_t C)
 
 template <int NCLASS>
 static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_t* R_SIZE, const int32_t* gene_length,
-                           double* P, int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, hipStream_t stream)
+                           double* P, int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, hipStream_t stream, const double* d_pr)
 {
     const int64_t n_tiles = (E + 15) / 16;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cu_count(), (n_tiles + kMfmaWaves - 1) / kMfmaWaves));
@@ -905,7 +921,7 @@ static int launch_dot_mfma(const AccWorkspace& w, const int32_t* L, const int32_
         auto go = [&](auto kern) -> int {
             DIG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             DIG_LAUNCH_STAGE(DIG_PIPE_DOT, kern, dim3(grid), dim3(kMfmaWaves * 64), lds, stream, w.rcp, L, tab, R_SIZE, gene_length, P,
-                               ELT_SIZE, P_INDEL, E, (int)C, c0, (int)(ch == 0));
+                               ELT_SIZE, P_INDEL, E, (int)C, c0, (int)(ch == 0), d_pr);
             DIG_HIP_TRY(hipGetLastError());
             return DIG_OK;
         };
@@ -982,8 +998,8 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
         DIG_HIP_TRY(hipGetLastError());
     }
     if (!(parts & 2)) return DIG_OK;
-    return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s)
-                          : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s);
+    return (n_class == 1) ? launch_dot_mfma<1>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s, d_pr)
+                          : launch_dot_mfma<4>(w, L, R_SIZE, gene_length, P, ELT_SIZE, P_INDEL, E, C, s, d_pr);
 }
 
 // Compact form of the dot + context stages (dig_element_pipeline with DIG_PIPE_COMPACT_L): one kernel per 48-cohort chunk.

@@ -553,19 +553,13 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
                 r.sg_i = a.sigma_indel[s.i];
             }
         }
-#ifdef DIG_ES_NT_LOADS      // developer A/B: the streamed inputs (read once) as non-temporal loads
+        // the streamed inputs are read once: non-temporal loads keep them from displacing the bin records, which neighbouring
+        // elements re-read, in L2 (same-box A/B, two pairs of runs: whole pass 172.8 -> 171.1 us; profiles/r05_stats_kernel_probes.txt)
         r.pi_s = __builtin_nontemporal_load(&a.pi_sum[s.i]);
         r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
         r.k_snv = __builtin_nontemporal_load(&a.obs_snv[s.i]);
         r.k_smp = __builtin_nontemporal_load(&a.obs_samples[s.i]);
         r.k_ind = __builtin_nontemporal_load(&a.obs_indel[s.i]);
-#else
-        r.pi_s = a.pi_sum[s.i];
-        r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
-        r.k_snv = a.obs_snv[s.i];
-        r.k_smp = a.obs_samples[s.i];
-        r.k_ind = a.obs_indel[s.i];
-#endif
         r.cj = a.cj[s.c];
         r.cji = a.cj_indel[s.c];
         return r;

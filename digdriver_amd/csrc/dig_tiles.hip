@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
     constexpr int W = 2 * U + 1;                      // window
     constexpr int K = 1 << (2 * W);                   // contexts
     __shared__ double s_S[K + 1][kCtxCoh];            // row K: zeros (a window with a non-ACGT base)
-    __shared__ alignas(16) unsigned short s_code[kCtxMaxPos + 8];
+    __shared__ alignas(16) unsigned short s_code[kCtxMaxPos + 16];       // (+ 16: a trip of the walk reads sixteen codes from any p < n_pos - 3)
     __shared__ uint32_t s_words[kCtxMaxPos / 8 + 8];
     __shared__ double s_sum[kCtxCoh][kCtxSumStride + kCtxSplitSlots];      // tile sums, then the pieces of split tiles
     __shared__ double s_part[kCtxBlock / 8][kCtxCoh];

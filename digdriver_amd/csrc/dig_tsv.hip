@@ -365,6 +365,17 @@ int dig_mutation_file_parse_host(const char* path, void** handle, int64_t* n_row
         p = next;
     }
     if (n_fields < 0) return DIG_OK;                                 // no row at all: the Python path says what it says about such a file
+    // the reference picks the schema by the column count (mutation_tools.py:56-78): GENE and ANNOT sit in columns 6 and 7 of
+    // files with 8, 10 or 11 columns only (a 9-column file has ANNOT in column 6 and no GENE): anything else is the Python path's
+    if (n_fields != 8 && n_fields != 10 && n_fields != 11) return DIG_OK;
+    // pandas.read_csv turns these spellings of "missing" into NaN (and the reference's groupby then drops such samples): a file
+    // with one of them in a label column goes the Python path, which reads it with pandas
+    static const char* const kNa[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                                      "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+    for (const Interner* in : {&ref, &alt, &samp, &gene, &annot})
+        for (const std::string_view lab : in->labels)
+            for (const char* na : kNa)
+                if (lab == std::string_view(na)) return DIG_OK;
     int64_t indel_id = -1;
     {
         auto it = annot.ids.find(std::string_view("INDEL"));

@@ -51,7 +51,9 @@ class PackedGenome:
         f_cache = f_fasta + ".dig4.npz"
         if cache and os.path.exists(f_cache) and os.path.getmtime(f_cache) >= os.path.getmtime(f_fasta):
             d = np.load(f_cache, allow_pickle=False)
-            return cls([str(n) for n in d["names"]], d["offsets"], d["lengths"], d["words"])
+            g = cls([str(n) for n in d["names"]], d["offsets"], d["lengths"], d["words"])
+            g._cache2 = f_fasta + ".dig2.npz"
+            return g
         seqs, name, parts = {}, None, []
         opener = gzip.open if f_fasta.endswith(".gz") else open
         with opener(f_fasta, "rb") as f:
@@ -68,6 +70,9 @@ class PackedGenome:
         if cache:
             try:
                 np.savez(f_cache, names=np.array(g.names), offsets=g.offsets, lengths=g.lengths, words=g.words)
+                g._cache2 = f_fasta + ".dig2.npz"
+                if os.path.exists(g._cache2):
+                    os.remove(g._cache2)                  # (a 2-bit cache of an older FASTA)
             except OSError:
                 pass
         return g
@@ -124,41 +129,68 @@ class PackedGenome:
     PAD2_BASES = 64            # bases in front of the chromosome data of the 2-bit array
     BUCKET_SHIFT = 12
 
-    def two_bit(self):
+    def two_bit(self, cache_path=None):
         """(words2, nint_start, nint_end, nint_bucket): the genome at 2 bits per base (every letter other than ACGT stored as
         A), the maximal runs of such letters as sorted intervals of ARRAY bases (array base = 64 + offset + position; the
         alignment padding between chromosomes counts as such letters) and the bucket index of the interval list.
-        Derived from the 4-bit words once, 32 M bases at a time."""
+        Derived from the 4-bit words once per genome: byte-wise through 256-entry tables (a byte of the 4-bit form is two
+        bases: their 2-bit codes and their two "other letter" flags), 64 M bases at a time -- about 1 s per 100 Mb -- and kept
+        next to the 4-bit cache as <fasta>.dig2.npz (from_fasta passes the path), so a process pays for it once per FASTA."""
         if getattr(self, "_two_bit", None) is not None:
             return self._two_bit
+        cache_path = cache_path or getattr(self, "_cache2", None)
+        if cache_path and os.path.exists(cache_path):
+            try:
+                d = np.load(cache_path, allow_pickle=False)
+                if int(d["n_words4"]) == int(self.words.size):
+                    self._two_bit = (d["words2"], d["nint_start"], d["nint_end"], d["nint_bucket"])
+                    return self._two_bit
+            except (OSError, KeyError, ValueError):
+                pass
         body = self.words[1:-1]                                   # without the two pad words
         total = int(body.size) * 8
         words2 = np.zeros(4 + (total + 15) // 16 + 24, np.uint32)
-        shifts4 = (4 * np.arange(8, dtype=np.uint32))[None, :]
-        shifts2 = (2 * np.arange(16, dtype=np.uint32))[None, :]
+        b = np.arange(256, dtype=np.uint32)
+        lo, hi = b & 15, b >> 4
+        lut_code = (np.where(lo > 3, 0, lo & 3) | (np.where(hi > 3, 0, hi & 3) << 2)).astype(np.uint16)    # 4 bits: two bases
+        lut_lo, lut_hi = (lo > 3).astype(np.int8), (hi > 3).astype(np.int8)
+        by = body.view(np.uint8)                                  # little endian: byte k of a word holds bases 2 k, 2 k + 1
         starts, ends = [], []
-        chunk = 1 << 22                                           # 4-bit words per pass (an even number: whole 2-bit words)
-        for w0 in range(0, body.size, chunk):
-            nib = ((body[w0:w0 + chunk, None] >> shifts4) & np.uint32(15)).astype(np.uint8).reshape(-1)
-            base0 = w0 * 8                                        # offset + position of nib[0]
-            isn = nib > 3
-            code = np.where(isn, 0, nib & 3).astype(np.uint32)
-            if len(code) % 16:
-                code = np.concatenate([code, np.zeros(16 - len(code) % 16, np.uint32)])
-            packed = (code.reshape(-1, 16) << shifts2).sum(axis=1, dtype=np.uint64).astype(np.uint32)
-            words2[4 + base0 // 16: 4 + base0 // 16 + len(packed)] = packed
-            edge = np.diff(np.concatenate([[0], isn.astype(np.int8), [0]]))       # runs cut at the chunk's ends are joined below
-            starts.append(base0 + np.flatnonzero(edge == 1).astype(np.int64))
-            ends.append(base0 + np.flatnonzero(edge == -1).astype(np.int64))
+        chunk = 1 << 25                                           # bytes per pass (a multiple of 8: whole 2-bit words)
+        prev = np.int8(0)                                         # flag of the base in front of the chunk
+        for b0 in range(0, by.size, chunk):
+            seg = by[b0:b0 + chunk]
+            c = lut_code[seg]
+            if len(c) % 8:
+                c = np.concatenate([c, np.zeros(8 - len(c) % 8, np.uint16)])
+            c = c.reshape(-1, 4)
+            w16 = (c[:, 0] | (c[:, 1] << 4) | (c[:, 2] << 8) | (c[:, 3] << 12)).astype(np.uint32)          # one 4-bit word = 8 bases
+            packed = w16[0::2] | (w16[1::2] << 16)
+            words2[4 + b0 // 8: 4 + b0 // 8 + len(packed)] = packed
+            fl, fh = lut_lo[seg], lut_hi[seg]                     # flags of bases 2 i and 2 i + 1 of the chunk
+            before = np.empty_like(fl)                            # flag of the base in front of base 2 i
+            before[0] = prev
+            before[1:] = fh[:-1]
+            base0 = 2 * b0
+            d_lo, d_hi = fl - before, fh - fl                     # +1: a run starts at that base, -1: it ended in front of it
+            s_lo, s_hi = np.flatnonzero(d_lo == 1), np.flatnonzero(d_hi == 1)
+            e_lo, e_hi = np.flatnonzero(d_lo == -1), np.flatnonzero(d_hi == -1)
+            starts.append(np.sort(np.concatenate([base0 + 2 * s_lo, base0 + 2 * s_hi + 1]).astype(np.int64)))
+            ends.append(np.sort(np.concatenate([base0 + 2 * e_lo, base0 + 2 * e_hi + 1]).astype(np.int64)))
+            prev = fh[-1]
         ns = np.concatenate(starts) if starts else np.zeros(0, np.int64)
         ne = np.concatenate(ends) if ends else np.zeros(0, np.int64)
-        if len(ns) > 1:                                           # a run that crosses a chunk boundary: end == next start
-            glue = ne[:-1] == ns[1:]
-            ns, ne = ns[np.concatenate([[True], ~glue])], ne[np.concatenate([~glue, [True]])]
+        if prev:                                                  # the genome ends inside a run
+            ne = np.concatenate([ne, [total]])
         ns, ne = ns + self.PAD2_BASES, ne + self.PAD2_BASES
         n_buckets = ((total + self.PAD2_BASES) >> self.BUCKET_SHIFT) + 2
         bucket = np.searchsorted(ne, np.arange(n_buckets, dtype=np.int64) << self.BUCKET_SHIFT, side="right").astype(np.int32)
         self._two_bit = (words2, ns, ne, bucket)
+        if cache_path:
+            try:
+                np.savez(cache_path, words2=words2, nint_start=ns, nint_end=ne, nint_bucket=bucket, n_words4=np.int64(self.words.size))
+            except OSError:
+                pass
         return self._two_bit
 
     def on_device2(self, device):

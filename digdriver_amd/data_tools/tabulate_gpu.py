@@ -88,8 +88,8 @@ def encode_mutations_host(df_mut, cohort_id=0, chrom_ids=None):
         keep = ch.notna()
         df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
     else:
-        ch = df_mut.CHROM.astype(str).str.replace("chr", "", regex=False)
-        keep = ch.isin([str(i) for i in range(1, 23)])
+        ch = df_mut.CHROM.astype(str).map(_strip_chr)           # (ONE leading "chr", the rule of all three file routes)
+        keep = ch.isin(_AUTOSOME_LABELS) & df_mut.SAMPLE.notna()      # (a missing SAMPLE: the reference's groupby drops such rows)
         df_mut, ch = df_mut[keep], ch[keep].astype(np.int64)
     ref_id = pd.factorize(df_mut.REF.astype(str).values)[0]
     alt_id = pd.factorize(df_mut.ALT.astype(str).values)[0]
@@ -150,47 +150,64 @@ def _encode_mutation_file_native(path, cohort_id):
 
 
 def encode_mutation_file(path, cohort_id=0, native=True):
-    """An annotated mutation file (>= 8 tab-separated columns, no header) -> the host arrays of encode_mutations_host,
-    without a pandas frame in between.  The library's own parser does it when it covers the file (`native`); otherwise
-    pyarrow's multi-threaded reader parses the file and dictionary-encodes the label columns (0.12 s per 300 000 rows where
-    pandas.read_csv + factorize take 0.45 s), autosome labels '1' ... '22' ('chr' prefix allowed) as in
-    encode_mutations_host; pandas when pyarrow is not installed.  The three routes give the same arrays."""
+    """An annotated mutation file (tab-separated, no header; GENE and ANNOT in columns 6 and 7: the reference's 8-, 10- and
+    11-column schemas, mutation_tools.py:56-78) -> the host arrays of encode_mutations_host, without a pandas frame in between.
+    Three routes, tried in this order, that give the same arrays on the files all of them take:
+      * the library's own parser (`native`; it leaves quotes, ragged rows, non-integer coordinates, other column counts and
+        label fields that pandas reads as missing -- '', 'NA', 'nan', 'NULL', ... -- to the next routes);
+      * pyarrow's multi-threaded reader + dictionary encoding (0.12 s per 300 000 rows; leaves the same files to pandas);
+      * pandas, with the reference's schema for the file's column count (what read_mutation_file does: the fall-back that
+        defines the semantics -- missing labels are NaN, a row whose SAMPLE is missing is dropped as the reference's groupby does).
+    Chromosome labels '1' ... '22', ONE leading 'chr' allowed, in every route."""
     if native:
         enc = _encode_mutation_file_native(path, cohort_id)
         if enc is not None:
             return enc
+
+    def pandas_route():
+        from . import mutation_tools
+        try:
+            df = mutation_tools.read_mutation_file(path, drop_sex=False, drop_duplicates=False, unique_indels=False)
+        except StopIteration:                    # (the reference's next(reader) on an empty file)
+            raise ValueError("%s: no rows (an annotated mutation file has 7 or more tab-separated columns, mutation_tools.py:45-104)" % path) from None
+        if 'ANNOT' not in df.columns:
+            raise ValueError("%s: an annotated mutation file has an ANNOT column (7 or more columns, mutation_tools.py:45-104)" % path)
+        return encode_mutations_host(df, cohort_id)
+
     try:
         import pyarrow as pa
-        import pyarrow.compute as pc
         import pyarrow.csv as pcsv
     except ImportError:
-        import pandas as pd
-        df = pd.read_csv(path, sep="\t", header=None, low_memory=False, dtype={0: str}).iloc[:, :8]
-        df.columns = ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT']
-        return encode_mutations_host(df, cohort_id)
+        return pandas_route()
     names = ['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT']
     with open(path, 'rb') as f:
         n_cols = f.readline().count(b"\t") + 1
-    if n_cols < 8:
-        raise ValueError("%s: an annotated mutation file has at least 8 columns (mutation_tools.py:45-104), found %d" % (path, n_cols))
+    if n_cols not in (8, 10, 11):
+        return pandas_route()
     all_names = names + ['X%d' % i for i in range(n_cols - 8)]
     text = {k: pa.string() for k in ('CHROM', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT')}
-    tb = pcsv.read_csv(path, read_options=pcsv.ReadOptions(column_names=all_names, use_threads=True, block_size=8 << 20),
-                       parse_options=pcsv.ParseOptions(delimiter="\t"),
-                       convert_options=pcsv.ConvertOptions(column_types=dict(text, START=pa.int64(), END=pa.int64()), include_columns=names,
-                                                           strings_can_be_null=False))
+    try:
+        tb = pcsv.read_csv(path, read_options=pcsv.ReadOptions(column_names=all_names, use_threads=True, block_size=8 << 20),
+                           parse_options=pcsv.ParseOptions(delimiter="\t"),
+                           convert_options=pcsv.ConvertOptions(column_types=dict(text, START=pa.int64(), END=pa.int64()), include_columns=names,
+                                                               strings_can_be_null=False))
+    except pa.ArrowInvalid:                      # a header line, a coordinate that is not an integer: pandas says what it says
+        return pandas_route()
+
     def ids(col):
         d = tb[col].combine_chunks().dictionary_encode()
         return d.indices.to_numpy(zero_copy_only=False).astype(np.int64), d.dictionary.to_pylist()
     ch_idx, ch_labels = ids('CHROM')
-    label_to_int = np.array([int(l.replace("chr", "", 1)) if l.replace("chr", "", 1) in _AUTOSOME_LABELS else -1 for l in ch_labels] or [-1], np.int64)
+    label_to_int = np.array([int(_strip_chr(l)) if _strip_chr(l) in _AUTOSOME_LABELS else -1 for l in ch_labels] or [-1], np.int64)
     ch = label_to_int[ch_idx] if len(ch_idx) else np.zeros(0, np.int64)
     keep = ch > 0
-    ref_id, _ = ids('REF')
-    alt_id, _ = ids('ALT')
+    ref_id, ref_labels = ids('REF')
+    alt_id, alt_labels = ids('ALT')
     samp, sample_labels = ids('SAMPLE')
-    gene, _ = ids('GENE')
+    gene, gene_labels = ids('GENE')
     annot_idx, annot_labels = ids('ANNOT')
+    if any(l in _PANDAS_NA for labels in (ref_labels, alt_labels, sample_labels, gene_labels, annot_labels) for l in labels):
+        return pandas_route()                    # pandas reads such a label as missing
     indel = (np.array([l == 'INDEL' for l in annot_labels] or [False])[annot_idx]) if len(annot_idx) else np.zeros(0, bool)
     start = tb['START'].combine_chunks().to_numpy(zero_copy_only=False)
     end = tb['END'].combine_chunks().to_numpy(zero_copy_only=False)
@@ -207,6 +224,14 @@ def encode_mutation_file(path, cohort_id=0, native=True):
 
 
 _AUTOSOME_LABELS = frozenset(str(i) for i in range(1, 23))
+# what pandas.read_csv reads as a missing value (its default na_values)
+_PANDAS_NA = frozenset(["", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA",
+                        "NULL", "NaN", "None", "n/a", "nan", "null"])
+
+
+def _strip_chr(label):
+    """ONE leading 'chr' off a chromosome label (the rule of the native parser's autosome())."""
+    return label[3:] if label.startswith("chr") else label
 
 
 def to_device(enc, device):

@@ -347,7 +347,9 @@ def write_results_tsv(frame, path, threads=8):
     if plain:
         for name in frame.columns:
             v = frame[name].values
-            if v.dtype == np.float64:
+            if not isinstance(v, np.ndarray):          # (a nullable / extension column: pandas knows how its NA prints)
+                plain = False
+            elif v.dtype == np.float64:
                 kinds.append(0); cols.append(np.ascontiguousarray(v))
             elif v.dtype.kind == 'f':
                 plain = False                          # (float32 prints differently: left to pandas)
@@ -361,14 +363,25 @@ def write_results_tsv(frame, path, threads=8):
                 break
     labels, hit = None, None
     if plain:
-        names = [str(frame.index.name) if frame.index.name is not None else ''] + [str(c) for c in frame.columns]
+        # the native path takes integer indexes and object indexes of plain str only: None / NaN labels (pandas writes an empty
+        # field), datetimes (pandas drops a zero time of day), floats and mixed objects (1 and 1.0 compare equal but print
+        # differently -- the label cache below matches on Index.equals) are pandas' business
+        idx = frame.index
+        names = [str(idx.name) if idx.name is not None else ''] + [str(c) for c in frame.columns]
         special = ('\t', '"', '\n', '\r')
-        hit = _cached_labels(frame.index)
-        if hit is None:
-            labels = [str(x) for x in frame.index]
-            if frame.index.dtype == object and any(ch in s_ for s_ in labels for ch in special):
-                plain = False
-        if any(ch in s_ for s_ in names for ch in special) or frame.index.dtype.kind == 'f':
+        int_index = isinstance(idx.dtype, np.dtype) and idx.dtype.kind in 'iu'
+        if not int_index and idx.dtype != object:
+            plain = False
+        if plain:
+            hit = _cached_labels(idx)
+        if plain and hit is None:
+            if int_index:
+                labels = [str(x) for x in idx]
+            else:
+                labels = list(idx)
+                if not all(type(x) is str for x in labels) or any(ch in s_ for s_ in labels for ch in special):
+                    plain = False
+        if any(ch in s_ for s_ in names for ch in special):
             plain = False
     if not plain:
         frame.to_csv(path, header=True, index=True, sep="\t")

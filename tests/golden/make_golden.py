@@ -576,6 +576,85 @@ def gen_accumulate(subst_idx, ctx64, df_empty):
 # ----------------------------------------------------------------------------
 # (viii) integer mutation tabulation helpers
 # ----------------------------------------------------------------------------
+def gen_accumulate_zero_den(subst_idx, df_empty):
+    """Zero denominators (round 5): the reference's own nonc_model where prob_sum.sum() == 0 (genic_driver_tools.py:361-364:
+    t_pi = d_pr / 0).  With bins that hold no countable context at all the reference does not get that far (R_size = 0:
+    ZeroDivisionError at :381), so the reachable case is the one in which the cohort's FREQ table is exactly zero at every
+    context the element's bins hold: t_pi is 0 / 0 = NaN at those substitutions and P_SUM is NaN whatever L is -- rows of L with and
+    without a zero.  Three FREQ tables: all positive (finite everywhere); zero at the six substitutions of the two contexts the
+    first five bins consist of (NaN for the elements inside them); zero at one other substitution only (finite everywhere)."""
+    rng = np.random.default_rng(77)
+    window = 10000
+    chroms = [1]
+    idx, df_reg = synth_region_params(rng, chroms, 14, window)
+    n = len(idx)
+    ctx_p = rng.dirichlet(np.ones(64))
+    bin_ctx = rng.multinomial(window, ctx_p, size=n).astype(np.int64)
+    only = [3, 10]                                         # the first five bins consist of two contexts only
+    bin_ctx[:5] = 0
+    bin_ctx[:5, only] = rng.integers(1000, 5000, (5, 2))
+    idx_dict = {tuple(int(v) for v in r): i for i, r in enumerate(idx)}
+    revc = [ref_seq.reverse_complement(s.split('>')[0]) + '>' + ref_seq.reverse_complement(s.split('>')[-1]) for s in subst_idx]
+    revc_dic = dict(zip(subst_idx, revc))
+    f_pre, f_dat = "mem://pretrained_zero.h5", "mem://element_data_zero.h5"
+    _HDF_FRAMES[(f_pre, "region_params")] = df_reg
+    save_key = "elts"
+    tree = {"window_%d" % window: {save_key: {}, "full_window_si_values": bin_ctx, "full_window_si_index": idx}}
+    E = 36
+    names, strands, L_all, ov_all = [], [], [], []
+    for e in range(E):
+        zero_bins = e % 3 != 2                             # two elements in three lie in the empty bins
+        b0 = int(rng.integers(0, 4)) if zero_bins else int(rng.integers(6, 12))
+        s0 = b0 * window + int(rng.integers(0, 4000))
+        ln = int(rng.integers(300, 9000 if e % 4 == 0 else 3000))      # some reach into a second bin
+        if zero_bins and (s0 + ln) // window > 4:
+            ln = 5 * window - s0 - 1
+        iv = np.array([[s0], [s0 + ln]])
+        overlaps = ref_gdt.get_ideal_overlaps(1, iv, window)
+        region_counts = np.array([np.repeat(bin_ctx[idx_dict[r], :], 3) for r in overlaps]).sum(axis=0)
+        strand = "+" if e % 2 == 0 else "-"
+        if strand == '-':
+            region_counts = np.asarray([r[1] for r in sorted(enumerate(region_counts), key=lambda k: revc_dic[subst_idx[k[0]]])])
+        L64 = rng.multinomial(ln, ctx_p)
+        if e % 6 < 3:
+            L64 = L64 + 1                                   # no zero anywhere in L
+        else:
+            L64[int(rng.integers(0, 64))] = 0               # a zero in L
+        L = np.repeat(L64, 3).astype(np.float64)
+        name = "z_%03d" % e
+        tree["window_%d" % window][save_key][name] = {"L_counts": L, "region_counts": region_counts,
+                                                      "__attrs__": {"overlaps": np.array(overlaps)}}
+        names.append(name); strands.append(strand); L_all.append(L)
+        ov_all.append(sorted([idx_dict[tuple(int(v) for v in r)] for r in overlaps]))
+    _H5_FILES[f_dat] = tree
+    freqs = []
+    f0 = rng.dirichlet(np.ones(192)) * 1e-6 * 192
+    ctx_names = sorted(set(df_empty.CONTEXT.values))       # context index 16 b0 + 4 b1 + b2 <-> sorted trinucleotides
+    f1 = f0.copy()
+    for c in only:
+        f1[df_empty.CONTEXT.values == ctx_names[c]] = 0.0
+    f2 = f0.copy(); f2[17] = 0.0
+    outs = []
+    for fr in (f0, f1, f2):
+        df_seq = df_empty.copy()
+        df_seq["COUNT"] = 1
+        df_seq["FREQ"] = fr
+        _HDF_FRAMES[(f_pre, "sequence_model_192")] = df_seq
+        with np.errstate(all="ignore"):
+            df_out = ref_gdt.nonc_model(names, f_pre, f_dat, save_key, False)
+        outs.append(df_out["P_SUM"].values.astype(float))
+        freqs.append(fr)
+    max_ov = max(len(o) for o in ov_all)
+    ov_pad = -np.ones((E, max_ov), dtype=np.int64)
+    for i, o in enumerate(ov_all):
+        ov_pad[i, :len(o)] = o
+    save_npz("accumulate_zero_golden.npz", bin_y_pred=df_reg.Y_PRED.values, bin_std=df_reg.STD.values,
+             bin_y_true=df_reg.Y_TRUE.values.astype(np.int64), bin_flag=df_reg.FLAG.values, bin_ctx=bin_ctx,
+             seq_mut_type=df_empty.MUT_TYPE.values.astype(str), seq_context=df_empty.CONTEXT.values.astype(str),
+             seq_freq=np.array(freqs), elt_strand=np.array(strands), elt_L=np.array(L_all), elt_overlap_bins=ov_pad,
+             p_sum=np.array(outs))
+
+
 def gen_mutation_tools():
     rng = np.random.default_rng(13)
     m = 5000
@@ -1273,6 +1352,10 @@ def main():
     if "--only-collapse" in sys.argv:
         gen_collapse()
         return
+    if "--only-zero-den" in sys.argv:
+        subst_idx, ctx64, df_empty = gen_subst_index()
+        gen_accumulate_zero_den(subst_idx, df_empty)
+        return
     if "--only-tabulate" in sys.argv:
         gen_tabulate()
         return
@@ -1307,6 +1390,7 @@ def main():
     gen_overlaps()
     subst_idx, ctx64, df_empty = gen_subst_index()
     gen_accumulate(subst_idx, ctx64, df_empty)
+    gen_accumulate_zero_den(subst_idx, df_empty)
     gen_mutation_tools()
     gen_sequence_model(df_empty)
     gen_cnn()

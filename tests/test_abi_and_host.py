@@ -136,3 +136,15 @@ def test_native_result_writer_writes_the_bytes_pandas_writes(tmp_path):
         mapfile.write_results_tsv(frame, str(a))
         frame.to_csv(str(b), header=True, index=True, sep="\t")
         assert a.read_bytes() == b.read_bytes()
+    # indexes the native path must leave to pandas: an object index of integers FOLLOWED by the equal index of
+    # floats (Index.equals says "same": the label cache must not hand 1 / 2 / 3 to a frame that prints 1.0 / 2.0 / 3.0), a None /
+    # NaN label, dates, a float index, a nullable integer column with a missing value
+    small = df.iloc[:3, :4]
+    frames = [small.set_axis(pd.Index([1, 2, 3], dtype=object)), small.set_axis(pd.Index([1.0, 2.0, 3.0], dtype=object)),
+              small.set_axis(pd.Index(['a', None, 'c'], dtype=object)), small.set_axis(pd.Index(['a', np.nan, 'c'], dtype=object)),
+              small.set_axis(pd.to_datetime(['2020-01-01', '2020-01-02', '2020-01-03'])), small.set_axis(pd.Index([0.5, 1.5, 2.5])),
+              small.assign(NA_INT=pd.array([1, None, 3], dtype="Int64")), small.set_axis(pd.Index([7, 8, 9], name='ID'))]
+    for frame in frames:
+        mapfile.write_results_tsv(frame, str(a))
+        frame.to_csv(str(b), header=True, index=True, sep="\t")
+        assert a.read_bytes() == b.read_bytes(), frame.index

@@ -1,0 +1,41 @@
+"""bench.py starts its own ranks: `python bench.py --gpus N` with WORLD_SIZE unset launches N ranks as
+CHILD processes (torch.distributed.run), from a parent that has not imported torch and never touches a device.  CPU tests:
+BENCH_LAUNCH_PROBE=1 makes a rank report what it sees and return before anything reaches the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_parent_launches_n_ranks_without_touching_a_device():
+    p = _run(["--gpus", "2", "--steps", "3"], {"BENCH_LAUNCH_PROBE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                         # rank 0's line, relayed once
+    d = json.loads(lines[0])
+    pr = d["probe"]
+    assert pr["WORLD_SIZE"] == "2" and pr["RANK"] == "0" and pr["LOCAL_RANK"] == "0" and pr["MASTER_ADDR"] == "127.0.0.1"
+    assert pr["BENCH_LAUNCHED_BY"] == "bench.py" and pr["BENCH_PARENT_IMPORTED_TORCH"] == "0"
+    assert d["gpus"] == 2 and d["torch_imported_before_main"] is False
+
+
+def test_a_failing_rank_gives_a_non_zero_exit_code_and_no_line():
+    # no GPU here: the ranks fail at require_device(); the parent must relay the failure, not print a line
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bins", "2000", "--elements", "500", "--cohorts", "3", "--cpu-sample", "0"], {})
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_launcher_module_does_not_import_torch_at_import_time():
+    code = "import sys; sys.path.insert(0, %r); import bench; assert 'torch' not in sys.modules; print('ok')" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-1000:]

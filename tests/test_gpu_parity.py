@@ -247,6 +247,63 @@ def test_accumulate_nonc_model_golden(torch_dev):
         assert np.array_equal(r[name], v[:, col[name]].astype(np.int32)), name
 
 
+def test_zero_denominators_with_zeros_in_the_frequency_table(torch_dev):
+    """The one known output difference of rounds 3-4, closed: a cohort whose FREQ table is exactly zero at
+    every context an element's bins hold has sum(region_counts * d_pr) == 0 AND 0 / 0 in t_pi, so the reference's P_SUM is NaN
+    whatever L is (genic_driver_tools.py:361-366; rounds 3-4 said inf when L held no zero).  Golden: the reference's own
+    nonc_model (accumulate_zero_golden.npz), three tables as three cohorts of ONE call -- general form, the no-workspace form
+    and the compact pipeline form (the cohort test runs only on the zero-denominator path)."""
+    import torch
+    from digdriver_amd import engine
+    from oracle import dig_oracle as O
+    d = np.load(os.path.join(GOLDEN, "accumulate_zero_golden.npz"))
+    ptr, idx = _csr(d["elt_overlap_bins"])
+    C = d["seq_freq"].shape[0]
+    E = len(d["elt_L"])
+    rep = lambda v: np.ascontiguousarray(np.repeat(np.asarray(v)[:, None], C, axis=1))
+    d_pr = np.ascontiguousarray(d["seq_freq"][:, O.model_rows_to_sorted_perm()])
+    want = d["p_sum"].T                                   # [E, 3 tables]
+    assert np.isnan(want[:, 1]).sum() >= 8
+    ins = (rep(d["bin_y_pred"]), rep(d["bin_std"]), rep(d["bin_y_true"]).astype(np.int32), rep(d["bin_flag"]).astype(np.uint8),
+           d["bin_ctx"].astype(np.int32), ptr, idx, d["elt_L"].astype(np.int32), (d["elt_strand"] == "-"), d_pr)
+
+    def check(P, what):
+        P = np.asarray(P)
+        assert np.array_equal(np.isnan(P), np.isnan(want)), what
+        ok = ~np.isnan(want)
+        rel_close(P[ok], want[ok], 1e-11)
+
+    r = engine.accumulate_elements(*ins)
+    check(r["P"][:, 0, :], "general form")
+    td = [torch.as_tensor(np.ascontiguousarray(x), device=torch_dev) for x in ins]
+    zeros = torch.zeros((E, C), dtype=torch.int32, device=torch_dev)
+    one = torch.ones(C, dtype=torch.float64, device=torch_dev)
+    plan = engine.PipelinePlan(*td, zeros, zeros, zeros)
+    assert plan.compact
+    acc, _ = plan.run(one, one)
+    torch.cuda.synchronize()
+    check(acc["P"].cpu().numpy().reshape(E, C), "compact pipeline form")
+    plan_g = engine.PipelinePlan(*td, zeros, zeros, zeros, compact=False)
+    acc, _ = plan_g.run(one, one)
+    torch.cuda.synchronize()
+    check(acc["P"].cpu().numpy().reshape(E, C), "general pipeline form")
+    # more cohorts than one 16-column tile and the 4-column quads: the three tables cycled over 37 cohorts
+    C2 = 37
+    cyc = np.arange(C2) % C
+    ins2 = (np.ascontiguousarray(ins[0][:, cyc]), np.ascontiguousarray(ins[1][:, cyc]), np.ascontiguousarray(ins[2][:, cyc]),
+            np.ascontiguousarray(ins[3][:, cyc]), ins[4], ptr, idx, ins[7], ins[8], np.ascontiguousarray(d_pr[cyc]))
+    td2 = [torch.as_tensor(np.ascontiguousarray(x), device=torch_dev) for x in ins2]
+    z2 = torch.zeros((E, C2), dtype=torch.int32, device=torch_dev)
+    o2 = torch.ones(C2, dtype=torch.float64, device=torch_dev)
+    for compact in ("auto", False):
+        acc, _ = engine.PipelinePlan(*td2, z2, z2, z2, compact=compact).run(o2, o2)
+        torch.cuda.synchronize()
+        P = acc["P"].cpu().numpy().reshape(E, C2)
+        assert np.array_equal(np.isnan(P), np.isnan(want[:, cyc])), compact
+        ok = ~np.isnan(want[:, cyc])
+        rel_close(P[ok], want[:, cyc][ok], 1e-11)
+
+
 def test_accumulate_tiled_and_genic_golden(torch_dev):
     from digdriver_amd import engine
     d = np.load(os.path.join(GOLDEN, "accumulate_golden.npz"))

@@ -230,6 +230,31 @@ def test_native_mutation_file_parser_gives_the_arrays_of_the_python_routes(tmp_p
     empty.write_text("X\t1\t2\tA\tC\tS1\t.\tSNV\n")
     nat = tg._encode_mutation_file_native(str(empty), 0)
     assert nat is not None and len(nat["chrom"]) == 0 and nat["sample_names"] == []
+    # labels pandas reads as missing, other column counts, a header line and the 'chr' rule go the same way in all routes
+    na = tmp_path / "na.txt"
+    na.write_text("1\t5\t6\tA\tC\tS1\t.\tSNV\n1\t7\t8\tA\tC\tNA\t.\tSNV\n2\t9\t10\tA\tG\tS2\t\tINDEL\n")
+    assert tg._encode_mutation_file_native(str(na), 0) is None                 # 'NA' and '' in label columns
+    via_file = tg.encode_mutation_file(str(na), 0)
+    frame = pd.read_csv(str(na), sep="\t", names=['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT'], dtype={'CHROM': str})
+    same(via_file, tg.encode_mutations_host(frame, 0))
+    assert via_file["sample_names"] == ["S1", "S2"] and len(via_file["chrom"]) == 2     # the row without a SAMPLE is dropped (the reference's groupby)
+    nine = tmp_path / "nine.txt"                                                # 9 columns: ANNOT is column 6, there is no GENE (mutation_tools.py:68-70)
+    nine.write_text("1\t5\t6\tA\tC\tS1\tINDEL\tC>A\tACG\n3\t7\t8\tA\tC\tS2\tSNV\tC>A\tACG\n")
+    assert tg._encode_mutation_file_native(str(nine), 0) is None
+    enc9 = tg.encode_mutation_file(str(nine), 0)
+    assert enc9["indel"].tolist() == [1, 0] and enc9["gene"].tolist() == [0, 0]
+    head = tmp_path / "header.txt"
+    head.write_text("CHROM\tSTART\tEND\tREF\tALT\tSAMPLE\tGENE\tANNOT\n1\t5\t6\tA\tC\tS1\t.\tSNV\n")
+    assert tg._encode_mutation_file_native(str(head), 0) is None
+    with pytest.raises(ValueError):                                             # what pandas says about START = 'START' under dtype int
+        tg.encode_mutation_file(str(head), 0)
+    chrs = tmp_path / "chr.txt"
+    chrs.write_text("".join("%s\t5\t6\tA\tC\tS1\t.\tSNV\n" % c for c in ("chr1", "chrchr1", "1chr", "2", "chr22", "chr23")))
+    want = [1, 2, 22]
+    assert tg._encode_mutation_file_native(str(chrs), 0)["chrom"].tolist() == want
+    assert tg.encode_mutation_file(str(chrs), 0, native=False)["chrom"].tolist() == want
+    frame = pd.read_csv(str(chrs), sep="\t", names=['CHROM', 'START', 'END', 'REF', 'ALT', 'SAMPLE', 'GENE', 'ANNOT'], dtype={'CHROM': str})
+    assert tg.encode_mutations_host(frame, 0)["chrom"].tolist() == want
 
 
 def test_region_tables_take_any_row_order_and_refuse_another_grid():
@@ -263,3 +288,61 @@ def test_region_tables_take_any_row_order_and_refuse_another_grid():
     other.loc[7, "START"] += 5
     with pytest.raises(ValueError):
         g.RegionTables([frames[0], other])
+
+
+def test_two_bit_genome_against_a_brute_force_walk_and_its_disk_cache(tmp_path):
+    """PackedGenome.two_bit (the form dig_count_contexts2 reads): 2-bit codes, runs of letters other than ACGT and
+    their bucket index against a per-base walk -- runs at the chromosome ends, across the alignment padding, of length 1, letters
+    in lower case -- and the cache next to the FASTA: the second process-worth of calls reads <fasta>.dig2.npz instead of
+    converting again, and a rewritten FASTA invalidates it."""
+    from digdriver_amd.data_tools.genome import PackedGenome
+    rng = np.random.default_rng(11)
+    seqs = {}
+    for name, L in (("1", 40_013), ("2", 9_999), ("X", 517)):
+        s = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, L)].copy()
+        for _ in range(25):
+            p = int(rng.integers(0, L))
+            s[p:min(L, p + int(rng.integers(1, 300)))] = ord("N")
+        s[:5] = ord("N")
+        s[-1:] = ord("R")
+        s[100] = ord("n")
+        seqs[name] = s.tobytes()
+    g = PackedGenome.from_sequences(seqs)
+    w2, ns, ne, bucket = g.two_bit()
+    total = (g.words.size - 2) * 8
+    flat = np.ones(total, bool)                                      # "other letter" per array base (padding counts as such)
+    code = np.zeros(total, np.uint32)
+    lut = {ord(c): i for i, c in enumerate("ACGT")}
+    lut.update({ord(c): i for i, c in enumerate("acgt")})
+    for name, off in zip(g.names, g.offsets):
+        b = np.frombuffer(seqs[name], np.uint8)
+        known = np.isin(b, list(lut))
+        flat[off:off + len(b)] = ~known
+        code[off:off + len(b)] = np.where(known, np.vectorize(lambda x: lut.get(x, 0))(b), 0)
+    edge = np.diff(np.concatenate([[0], flat.astype(np.int8), [0]]))
+    assert np.array_equal(ns, np.flatnonzero(edge == 1) + g.PAD2_BASES) and np.array_equal(ne, np.flatnonzero(edge == -1) + g.PAD2_BASES)
+    got = (w2[4:4 + (total + 15) // 16, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3
+    assert np.array_equal(got.reshape(-1)[:total], code)
+    want_bucket = np.searchsorted(ne, np.arange(len(bucket), dtype=np.int64) << g.BUCKET_SHIFT, side="right")
+    assert np.array_equal(bucket, want_bucket)
+    # the disk cache
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b"".join(b">" + n.encode() + b"\n" + s + b"\n" for n, s in seqs.items()))
+    g1 = PackedGenome.from_fasta(str(fa))
+    r1 = g1.two_bit()
+    assert os.path.exists(str(fa) + ".dig2.npz")
+    g2 = PackedGenome.from_fasta(str(fa))
+    calls = []
+    orig = np.savez
+    np.savez = lambda *a, **k: calls.append(a[0])                    # a second conversion would write the cache again
+    try:
+        r2 = g2.two_bit()
+    finally:
+        np.savez = orig
+    assert not calls and all(np.array_equal(a, b) for a, b in zip(r1, r2)) and all(np.array_equal(a, b) for a, b in zip(r1, (w2, ns, ne, bucket)))
+    import time
+    time.sleep(0.05)
+    fa.write_bytes(b">1\nACGTNNACGT\n")
+    os.utime(str(fa), None)
+    g3 = PackedGenome.from_fasta(str(fa))
+    assert len(g3.two_bit()[1]) == 2 and g3.lengths.tolist() == [10]  # the run of two N and the alignment padding behind the chromosome

@@ -176,6 +176,28 @@ def test_py_oracle_accumulate_elements():
     assert np.array_equal(f["R_SIZE"], r["R_SIZE"]) and np.array_equal(f["FLAG"], r["FLAG"])
 
 
+def test_py_oracle_zero_denominators_follow_the_reference():
+    """accumulate_zero_golden.npz (make_golden.py::gen_accumulate_zero_den): the reference's own nonc_model where
+    sum(region_counts * d_pr) == 0 because the cohort's FREQ table is exactly zero at every context the element's bins hold --
+    t_pi = d_pr / 0 holds 0 / 0 = NaN there, so P_SUM is NaN whatever L is (genic_driver_tools.py:361-366); a zero in FREQ that
+    leaves the denominator positive changes nothing."""
+    d = np.load(os.path.join(GOLDEN, "accumulate_zero_golden.npz"))
+    ovp = d["elt_overlap_bins"]
+    ptr = np.concatenate([[0], np.cumsum((ovp >= 0).sum(axis=1))]).astype(np.int64)
+    idx = ovp[ovp >= 0].astype(np.int32)
+    perm = O.model_rows_to_sorted_perm()
+    C = d["seq_freq"].shape[0]
+    rep = lambda v: np.repeat(v[:, None], C, axis=1)
+    r = O.accumulate_elements(rep(d["bin_y_pred"]), rep(d["bin_std"]), rep(d["bin_y_true"]), rep(d["bin_flag"]), d["bin_ctx"], ptr, idx,
+                              d["elt_L"][:, None, :], d["elt_strand"] == "-", d["seq_freq"][:, perm])
+    want = d["p_sum"]                                     # [3 tables, E]
+    got = r["P"][:, 0, :].T
+    assert np.isnan(want[1]).sum() >= 8 and np.isfinite(want[0]).all() and np.isfinite(want[2]).all()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13)
+
+
 def test_py_oracle_tiled_model():
     d = np.load(os.path.join(GOLDEN, "accumulate_golden.npz"))
     window = int(d["window"])
