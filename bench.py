@@ -403,7 +403,33 @@ def aux_rooflines(dev):
                 "achieved": fl / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": fl / dt / 157.3e12,
                 "algorithmic_flops_per_launch": fl, "avg_launch_ms": dt * 1e3, "workload": "%d bins, T = 735, 37 heads" % Bc,
                 "bins_per_s": Bc / dt})
-    del net, store, x16
+    del net
+    # f4: one NNTrainer training step -- gather-fed, T = 735, 37 heads, batch 128: the defaults of kfold_mutations_main.py:52-76 --
+    # train-mode forward, summed per-task MSE, backward, Adam (nn_trainer.py:40-91), by the REAL trainer object over 64 batches
+    from digdriver_amd.region_model.trainers.nn_trainer import NNTrainer
+    import contextlib
+    import io
+    bs_t, n_tr = 128, 64 * 128
+    torch.manual_seed(0)
+    net_t = SimpleMultiTaskResNet((bs_t, L, T), C_heads).to(dev)
+    opt = torch.optim.Adam(net_t.parameters(), lr=1e-4)
+    lab = [np.random.default_rng(9 + c).gamma(9.0, 3.0, N) for c in range(C_heads)]
+    tr = NNTrainer(net_t, opt, torch.nn.MSELoss(), bs_t, list(range(C_heads)), store, np.arange(n_tr), np.arange(n_tr, n_tr + 256), lab, dev, seed=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(0)                                   # warm-up epoch (kernel selection, allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train(1)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (n_tr // bs_t)
+    fl = 3.0 * float(flops_per_bin(T, C_heads)) * bs_t
+    out.append({"kernel": "NNTrainer.train step: dig_gather_bins + SimpleMultiTaskResNet train-mode forward + 37 MSE losses + backward + Adam "
+                          "(fp32, batch 128: the reference's defaults)", "bound": "mfma", "achieved": fl / dt / 1e12, "peak": 157.3,
+                "unit": "TFLOP/s", "frac": fl / dt / 157.3e12, "algorithmic_flops_per_launch": fl, "avg_launch_ms": dt * 1e3,
+                "flops_note": "3 x the forward's algorithmic flops (forward, input-gradient and weight-gradient products)",
+                "workload": "one epoch of 64 batches of 128 bins, T = 735, 37 heads, host clock over the whole epoch (the trainer's "
+                            "per-epoch bookkeeping included)", "bins_per_s": bs_t / dt, "epoch_288000_bins_s": 288_000 / (bs_t / dt)})
+    del net_t, opt, tr, store, x16
     torch.cuda.empty_cache()
     # a18 back half: per-tile exact NB test, 37 cohorts x 8 000 bins x 200 tiles
     Cc, nb, nt = 37, 8000, 200
@@ -479,6 +505,53 @@ def aux_rooflines(dev):
                 "times_the_trinucleotide_kernel": dt / dt3, "table_reads_per_s": reads / dt,
                 "workload": "36 000 bins x 200 tiles x 37 cohorts per launch; 13.3 G table reads",
                 "whole_genome_x37_ms": dt * 1e3 * nwin / chunk})
+    del words, ptile, first, nval, S, S5
+    torch.cuda.empty_cache()
+    # BASELINE configs[4] as a ROUTE (nb_model.py:126-234,340-342): tile probabilities -> interval join + dig_tile_mut_counts ->
+    # dig_tiled_nb_test -> Benjamini-Hochberg q-values of every cohort, for an eighth of the genome (what one of 8 GPUs holds),
+    # in tiles per second; trinucleotide tables and the reference's DEFAULT penta-nucleotide tables (n_up = n_down = 2)
+    from digdriver_amd import parallel
+    Rr, Cr, Wr, Br = 36_000, 37, 10_000, 50
+    n_chrom = 3
+    per = Rr // n_chrom
+    rng = np.random.default_rng(4)
+    wh = rng.integers(0, 2 ** 32, (per * Wr * n_chrom) // 8 + 2, dtype=np.uint64).astype(np.uint32) & np.uint32(0x33333333)
+    wh[0] = wh[-1] = 0x44444444
+    names = ["chr%d" % (i + 1) for i in range(n_chrom)]
+    genome = PackedGenome(names, np.arange(n_chrom, dtype=np.int64) * per * Wr, np.full(n_chrom, per * Wr, np.int64), wh)
+    chroms = np.repeat(names, per)
+    starts = np.tile(np.arange(per, dtype=np.int64) * Wr, n_chrom)
+    mu_r, sg_r = rng.uniform(5, 45, (Cr, Rr)), rng.uniform(1, 7, (Cr, Rr))
+    M = 500_000                                                   # (4 M mutations per genome x 37 cohorts: an eighth)
+    mci, msr, cor = rng.integers(0, n_chrom, M), rng.integers(0, per * Wr, M).astype(np.int64), rng.integers(0, Cr, M).astype(np.int32)
+    for n_up, width in ((1, 64), (2, 1024)):
+        Sr = rng.uniform(0, 1e-2, (Cr, width))
+        sh = parallel.ShardedTiles(genome, chroms, starts, starts + Wr, Sr, mu_r, sg_r, np.array(names)[mci], msr, msr + 1, cor, Br, dev, 0, 1)
+        sh.run()
+        sh.q_values(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sh.run()
+        torch.cuda.synchronize()
+        t_run = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for c in range(Cr):
+            sh.q_values(c)
+        torch.cuda.synchronize()
+        t_q = time.perf_counter() - t0
+        tiles_r = float(Rr) * (Wr // Br) * Cr
+        out.append({"kernel": "per-base route (BASELINE configs[4], an eighth of the genome): dig_base_tile_probs_ctx(n_up = %d) + interval "
+                              "join + dig_tile_mut_counts + dig_tiled_nb_test + Benjamini-Hochberg q-values of all 37 cohorts" % n_up,
+                    "bound": "hbm", "achieved": 28.0 * tiles_r / (t_run + t_q) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": 28.0 * tiles_r / (t_run + t_q) / HBM_PEAK, "algorithmic_bytes_per_launch": 28.0 * tiles_r,
+                    "avg_launch_ms": (t_run + t_q) * 1e3, "kernels_ms": t_run * 1e3, "q_values_ms": t_q * 1e3,
+                    "tile_cohort_tests_per_s": tiles_r / (t_run + t_q),
+                    "contexts": "trinucleotide (64-entry tables)" if n_up == 1 else "penta-nucleotide (1 024-entry tables: the reference's default)",
+                    "workload": "36 000 10-kb bins x 200 tiles of 50 positions x 37 cohorts, 500 000 mutations; host clock, device drained "
+                                "after the kernels and after the q-values; 28 B per (tile, cohort) by SURVEY 8d",
+                    "whole_genome_x37_ms_on_one_gpu": (t_run + t_q) * 1e3 * 8})
+        del sh
+        torch.cuda.empty_cache()
     return out
 
 # --------------------------------------------------------------------------------------

@@ -98,6 +98,55 @@ class SimpleMultiTaskResNet(nn.Module):
         """x: [B, L, T] as stored (cnn_predictors.py:130-131 transposes first)."""
         return self.forward_channels_first(x.transpose(1, 2))
 
+    # ---- GEMM formulation, differentiable (training and evaluation epochs) --------------------
+    def _block_rows(self, x, name):
+        """conv + BatchNorm + ReLU on channels-last activations x [B, L, C] as k accumulated GEMMs (one per filter tap, no
+        im2col copy: see _conv_gemm), out of place so that autograd differentiates it: the backward pass is GEMMs too
+        (input gradients w.r.t. the strided row slices, weight gradients as flat[tap::s]^T @ dY) instead of MIOpen's fp32
+        weight-gradient convolutions, which fall back to slow solvers at these shapes (54.8 ms per batch of 128 bins at
+        T = 735, measured; profiles/r05_aux.json).  BatchNorm sees the [B * Lout, C] matrix: per-channel statistics over batch
+        and positions, exactly BatchNorm1d on [B, C, Lout]."""
+        conv, bn = getattr(self, "conv" + name), getattr(self, "bn" + name)
+        k, pad, stride = conv.kernel_size[0], conv.padding[0], conv.stride[0]
+        B, L, C = x.shape
+        Lout = (L + 2 * pad - k) // stride + 1
+        extra = (-(L + 2 * pad)) % stride
+        Lp = L + 2 * pad + extra
+        flat = F.pad(x, (0, 0, pad, pad + extra)).reshape(B * Lp, C)
+        m = (B * Lp - (k - 1) + stride - 1) // stride          # output rows that have all k taps inside `flat`
+        w = conv.weight.permute(2, 1, 0)                       # [k, Cin, Cout] (a view: gradients reach conv.weight)
+        y = torch.addmm(conv.bias, flat[0:(m - 1) * stride + 1:stride], w[0])
+        for tap in range(1, k):
+            y = torch.addmm(y, flat[tap:tap + (m - 1) * stride + 1:stride], w[tap])
+        rows_out = B * Lp // stride
+        if m < rows_out:
+            y = F.pad(y, (0, 0, 0, rows_out - m))
+        y = y.view(B, Lp // stride, -1)[:, :Lout].reshape(B * Lout, -1)     # the valid output positions
+        if not self._folded:
+            y = bn(y)
+        return F.relu(y).view(B, Lout, -1)
+
+    def forward_rows_stacked(self, x):
+        """x [B, L, T] row-major (what dig_gather_bins produces without a transpose) -> (outputs [C, B], features [C, B, 16]),
+        in train or eval mode, differentiable: the trunk in channels-last GEMM form (_block_rows), the heads as batched
+        matmuls on the reference's flatten order (channel-major).  The task dimension is kept: a trainer scores all tasks
+        with one chain of kernels instead of one per task."""
+        assert not self.get_attention_maps, "the attention branch runs through forward() / forward_channels_first()"
+        blk = self._block_rows
+        x = blk(blk(x, "11"), "12")
+        x = blk(blk(x, "21"), "22") + x
+        x = blk(x, "3")
+        x = blk(blk(x, "41"), "42") + x
+        x = blk(x, "5")
+        x = blk(blk(x, "61"), "62") + x
+        flat = x.transpose(1, 2).reshape(x.shape[0], _FLAT)    # reference flatten index = c * 13 + l
+        return self.heads(flat)
+
+    def forward_rows(self, x):
+        """forward_rows_stacked with the (outputs, feature_vecs, None) contract of forward()."""
+        out, feats = self.forward_rows_stacked(x)
+        return [out[i] for i in range(self.task_num)], [feats[i] for i in range(self.task_num)], None
+
     # ---- GEMM formulation (inference) -------------------------------------------------------
     def _gemm_weights(self):
         """Conv weights as [k*Cin, Cout] matrices for channels-last windows, head weights with the flatten order

@@ -18,6 +18,20 @@ def r2_score(y_true, y_pred):
 
 
 @torch.no_grad()
+def r2_rows(y_true, y_pred):
+    """r2_score for every row of two [C, n] device tensors at once (float64 on the device, no host round trip): squared
+    Pearson correlation, 0 where it is undefined (fewer than two values, a constant row)."""
+    t, q = y_true.double(), y_pred.double()
+    if t.shape[1] < 2:
+        return torch.zeros(t.shape[0], dtype=torch.float64, device=t.device)
+    tm, qm = t - t.mean(dim=1, keepdim=True), q - q.mean(dim=1, keepdim=True)
+    den = (tm * tm).sum(dim=1) * (qm * qm).sum(dim=1)
+    r = (tm * qm).sum(dim=1) / torch.sqrt(den)
+    r2 = r * r
+    return torch.where(torch.isfinite(r2) & (den > 0), r2, torch.zeros_like(r2))
+
+
+@torch.no_grad()
 def predict(model, store, bin_rows, labels=None, batch_size=2048, fold_bn=True, dtype=torch.float32):
     """Returns (preds [C, n], features [C, n, 16], r2 [C] or None).  `store` is a BinTrackStore; the batch
     arrives channels-first straight from dig_gather_bins."""

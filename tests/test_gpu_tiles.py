@@ -71,11 +71,13 @@ def test_two_cohorts_in_one_call_equal_single_cohort_calls():
 
 
 @pytest.mark.timeout(900)
-def test_full_size_configs4_properties():
+@pytest.mark.parametrize("n_up", [1, 2])
+def test_full_size_configs4_properties(n_up):
     """BASELINE configs[4] on one GPU at full size: 288 000 bins of 10 kb x 37 cohorts x 200 tiles of 50 positions =
-    2.13 G tile tests from a 2.88 Gb genome.  Oracle-free properties: tile probabilities of a bin sum to 1, tile counts
-    sum to the mutations inside the bins' positions, pt agrees with an independent torch evaluation on sampled bins,
-    p-values are finite probabilities, and a sample of tiles agrees with the elementwise entry point dig_nb_exact."""
+    2.13 G tile tests from a 2.88 Gb genome -- with trinucleotide tables and with the reference's DEFAULT penta-nucleotide
+    tables (n_up = n_down = 2: nb_model.py:126,188; 1 024 contexts).  Oracle-free properties: tile probabilities of a bin
+    sum to 1, tile counts sum to the mutations inside the bins' positions, pt agrees with an independent torch evaluation on
+    sampled bins, p-values are finite probabilities, and a sample of tiles agrees with the elementwise entry point dig_nb_exact."""
     import torch
     from digdriver_amd import engine
     from digdriver_amd.data_tools.genome import PackedGenome
@@ -96,7 +98,7 @@ def test_full_size_configs4_properties():
     chroms = np.repeat(["chr%d" % i for i in range(n_chrom)], per)
     starts = np.tile(np.arange(per) * W, n_chrom).astype(np.int64)
     ends = starts + W
-    S = torch.rand((C, 64), generator=gen, device=dev, dtype=torch.float64) * 1e-2
+    S = torch.rand((C, 4 ** (2 * n_up + 1)), generator=gen, device=dev, dtype=torch.float64) * 1e-2
     mu = torch.rand((C, R), generator=gen, device=dev, dtype=torch.float64) * 40 + 5
     sg = torch.rand((C, R), generator=gen, device=dev, dtype=torch.float64) * 6 + 1
     M = 4_000_000
@@ -111,9 +113,9 @@ def test_full_size_configs4_properties():
     assert int(nval.min()) == 200 and int(nval.max()) == 200
     sums = pt.sum(dim=2)
     assert float((sums - 1).abs().max()) < 1e-12
-    # every mutation lies in exactly one bin; those at a chromosome's position 0 or last position have no window
+    # every mutation lies in exactly one bin; those within n_up of a chromosome's end have no window
     pos_in_chrom = m_start
-    inside = (pos_in_chrom >= 1) & (pos_in_chrom <= per * W - 2)
+    inside = (pos_in_chrom >= n_up) & (pos_in_chrom <= per * W - 1 - n_up)
     assert int(k.sum()) == int(inside.sum())
     per_cohort = torch.bincount(m_coh[inside].long(), minlength=C)
     assert torch.equal(k.sum(dim=(1, 2)), per_cohort)
@@ -121,11 +123,12 @@ def test_full_size_configs4_properties():
     code = torch.stack([(words >> (4 * j)) & 15 for j in range(8)], dim=1).reshape(-1)[8:]      # bases from word 1 on
     for r in (0, 1, per - 1, per, 17 * per + 123, R - 1):
         ci, s = r // per, (r % per) * W
-        f = max(s, 1)
-        stop = min(s + W, per * W - 1)
+        f = max(s, n_up)
+        stop = min(s + W, per * W - n_up)
         g0 = ci * per * W
-        a, b, c_ = code[g0 + f - 1:g0 + stop - 1], code[g0 + f:g0 + stop], code[g0 + f + 1:g0 + stop + 1]
-        ctx = (16 * a + 4 * b + c_).long()
+        ctx = torch.zeros(stop - f, dtype=torch.int64, device=dev)
+        for o in range(-n_up, n_up + 1):                                    # index in itertools.product('ACGT', repeat = 2 n_up + 1) order
+            ctx = ctx * 4 + code[g0 + f + o:g0 + stop + o].long()
         probs = S[:, ctx]                                                   # [C, n_pos]
         tot = probs.sum(dim=1, keepdim=True)
         n_pos = probs.shape[1]
@@ -188,23 +191,27 @@ def _tile_problem(seed=3, C=3):
     return seqs, genome, np.array(chroms), np.array(starts), np.array(ends), S, mu, sg, mc, ms, me, co
 
 
-def test_sharded_tiles_equal_unsharded_bit_for_bit():
+@pytest.mark.parametrize("n_up", [1, 2])
+def test_sharded_tiles_equal_unsharded_bit_for_bit(n_up):
     """parallel.ShardedTiles (BASELINE configs[4]: the per-base route sharded by bins): the ranks of a 2-, 3- and 8-rank
     plan, walked one after the other on one device -- each on its own slab of the genome, with shifted coordinates and its
     own mutations -- reproduce the single-device result bit for bit (pt, k, exp, pval, first positions), and so do the
-    Benjamini-Hochberg q-values formed from the rank-ordered concatenation of the ranks' p-values."""
+    Benjamini-Hochberg q-values formed from the rank-ordered concatenation of the ranks' p-values.  n_up = 2: the reference's
+    default penta-nucleotide tables (a slab's margin must then cover two bases on either side of its first and last bin)."""
     import torch
     from digdriver_amd import engine, parallel
     from digdriver_amd.sequence_model import nb_model
     dev = torch.device("cuda:0")
     seqs, genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co = _tile_problem()
+    if n_up == 2:
+        S = np.random.default_rng(8).uniform(1e-3, 1e-2, (S.shape[0], 1024))
     C, R = S.shape[0], len(chroms)
     whole = engine.tiled_nb_model(genome, chroms, starts, ends, S, mu, sg, mc[mc != "chrX"], ms[mc != "chrX"], me[mc != "chrX"],
                                   co[mc != "chrX"], binsize=50, device=0)
     assert int(whole["k"].sum()) > 1000
     T = whole["pt"].shape[2]
     valid = torch.arange(T, device=dev)[None, :] < whole["n_valid"][:, None]
-    for world in (2, 3, 8, 40):                               # 40 ranks for 35 bins: some ranks hold no bin at all
+    for world in ((2, 3, 8, 40) if n_up == 1 else (3, 8)):    # 40 ranks for 35 bins: some ranks hold no bin at all
         ranks = [parallel.ShardedTiles(genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co, 50, dev, r, world) for r in range(world)]
         res = [r.run() for r in ranks]
         assert sum(len(r.genome.words) for r in ranks if r.hi > r.lo) < len(genome.words) + 6 * world
