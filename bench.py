@@ -412,7 +412,7 @@ def aux_rooflines(dev):
     bs_t, n_tr = 128, 64 * 128
     torch.manual_seed(0)
     net_t = SimpleMultiTaskResNet((bs_t, L, T), C_heads).to(dev)
-    opt = torch.optim.Adam(net_t.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net_t.parameters(), lr=1e-4, fused=True)
     lab = [np.random.default_rng(9 + c).gamma(9.0, 3.0, N) for c in range(C_heads)]
     tr = NNTrainer(net_t, opt, torch.nn.MSELoss(), bs_t, list(range(C_heads)), store, np.arange(n_tr), np.arange(n_tr, n_tr + 256), lab, dev, seed=1)
     with contextlib.redirect_stdout(io.StringIO()):

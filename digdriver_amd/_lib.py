@@ -71,6 +71,7 @@ _SIGNATURES = {
     "dig_write_tsv_host": [ctypes.c_char_p, ctypes.c_char_p, _vp, _vp, _i64, _int, _vp, _vp, _int],
     "dig_mutation_file_parse_host": [ctypes.c_char_p, _vp, _vp, _vp, _vp],
     "dig_mutation_file_fetch_host": [_vp] * 9,
+    "dig_mutation_file_flags_host": [_vp, _vp, _vp],
     "dig_mutation_file_free_host": [_vp],
     "dig_stage_timer_create": [_vp],
     "dig_stage_timer_arm": [_vp, _int],

@@ -121,14 +121,16 @@ int dig_write_tsv_host(const char* path, const char* header, const char* labels,
     for (int j = 0; j < n_cols; ++j) DIG_REQUIRE(col_ptr[j] && col_kind[j] >= 0 && col_kind[j] <= 2, "column pointers and kinds (0 f64, 1 i64, 2 bool)");
     const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) return ::dig::set_error(DIG_EINVAL, "dig_write_tsv_host: cannot open %s for writing", path);
-    // Rows are formatted in chunks by n_threads threads into buffers that are never cleared (a value-initialised buffer of the
-    // worst-case size was 77 MB of zeroing and page faults per file), then every thread writes its chunks at their offsets
-    // (one thread copying a 44 MB file into the page cache was half of the call).
+    // One thread: chunks of 4 096 rows through one scratch buffer, written as soon as each is full.  Several threads: thread t
+    // formats ONE contiguous range of rows into ONE buffer of its own (never cleared: a value-initialised buffer of the
+    // worst-case size was 77 MB of zeroing and page faults per file), the byte counts give the ranges' offsets, then every
+    // thread writes its range where it belongs.  (Round 4 gave every 4 096-row chunk a buffer of its own: with several files
+    // written side by side the hundreds of mappings and unmappings contended for the process's address space -- 8 files x 8
+    // threads took longer than 37 x 1; one mapping per thread does not.)
     const int64_t chunk = 4096;
-    const int64_t n_chunks = (n_rows + chunk - 1) / chunk;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
-    if ((int64_t)n_threads > n_chunks) n_threads = (int)(n_chunks > 0 ? n_chunks : 1);
+    if ((int64_t)n_threads * chunk > n_rows) n_threads = (int)std::max<int64_t>(1, n_rows / chunk);
     const bool seekable = ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;      // (a pipe or a terminal: one thread, plain writes in order)
     if (!seekable) n_threads = 1;
     auto put = [&](const char* src, int64_t n, int64_t at) {
@@ -141,68 +143,61 @@ int dig_write_tsv_host(const char* path, const char* header, const char* labels,
         }
         return true;
     };
-    bool stream_ok = true;
     const int64_t head = (int64_t)std::strlen(header);
-    std::vector<std::unique_ptr<char[]>> text((size_t)n_chunks);
-    std::vector<int64_t> bytes((size_t)n_chunks, 0), offset((size_t)n_chunks + 1, 0);
-    offset[0] = head + 1;
-    auto chunk_cap = [&](int64_t r0, int64_t r1) { return (size_t)((label_off[r1] - label_off[r0]) + (r1 - r0) * (1 + (int64_t)n_cols * 26)); };
-    int64_t max_label = 0;
-    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
-        const int64_t r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
-        if (label_off[r1] - label_off[r0] > max_label) max_label = label_off[r1] - label_off[r0];
-    }
-    std::unique_ptr<char[]> scratch;                     // one thread: one buffer for every chunk, written as soon as it is full
-    if (n_threads == 1 && n_chunks > 0) scratch.reset(new char[(size_t)(max_label + chunk * (1 + (int64_t)n_cols * 26))]);
-    auto format = [&](int t) {
-        for (int64_t c = t; c < n_chunks; c += n_threads) {
-            const int64_t r0 = c * chunk, r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
-            if (!scratch) text[(size_t)c].reset(new char[chunk_cap(r0, r1)]);
-            char* const base = scratch ? scratch.get() : text[(size_t)c].get();
-            char* p = base;
-            for (int64_t r = r0; r < r1; ++r) {
-                const int64_t ln = label_off[r + 1] - label_off[r];
-                std::memcpy(p, labels + label_off[r], (size_t)ln);
-                p += ln;
-                for (int j = 0; j < n_cols; ++j) {
-                    *p++ = '\t';
-                    if (col_kind[j] == 0) p = put_float(p, static_cast<const double*>(col_ptr[j])[r]);
-                    else if (col_kind[j] == 1) p = put_int(p, static_cast<const int64_t*>(col_ptr[j])[r]);
-                    else {
-                        const bool b = static_cast<const uint8_t*>(col_ptr[j])[r] != 0;
-                        std::memcpy(p, b ? "True" : "False", b ? 4 : 5);
-                        p += b ? 4 : 5;
-                    }
+    auto cap = [&](int64_t r0, int64_t r1) { return (size_t)((label_off[r1] - label_off[r0]) + (r1 - r0) * (1 + (int64_t)n_cols * 26) + 64); };
+    auto format_rows = [&](int64_t r0, int64_t r1, char* p) -> char* {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t ln = label_off[r + 1] - label_off[r];
+            std::memcpy(p, labels + label_off[r], (size_t)ln);
+            p += ln;
+            for (int j = 0; j < n_cols; ++j) {
+                *p++ = '\t';
+                if (col_kind[j] == 0) p = put_float(p, static_cast<const double*>(col_ptr[j])[r]);
+                else if (col_kind[j] == 1) p = put_int(p, static_cast<const int64_t*>(col_ptr[j])[r]);
+                else {
+                    const bool b = static_cast<const uint8_t*>(col_ptr[j])[r] != 0;
+                    std::memcpy(p, b ? "True" : "False", b ? 4 : 5);
+                    p += b ? 4 : 5;
                 }
-                *p++ = '\n';
             }
-            bytes[(size_t)c] = (int64_t)(p - base);
-            if (scratch) {                              // (offset[c] is known: the chunks before this one are out)
-                if (!put(base, bytes[(size_t)c], offset[(size_t)c])) stream_ok = false;
-                offset[(size_t)c + 1] = offset[(size_t)c] + bytes[(size_t)c];
-            }
+            *p++ = '\n';
         }
-    };
-    std::vector<char> good((size_t)n_threads, 1);
-    auto write_out = [&](int t) {
-        for (int64_t c = t; c < n_chunks; c += n_threads) {
-            if (!put(text[(size_t)c].get(), bytes[(size_t)c], offset[(size_t)c])) good[(size_t)t] = 0;
-            text[(size_t)c].reset();
-        }
-    };
-    auto run = [&](auto&& fn) {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn, t);
-        fn(0);
-        for (auto& th : pool) th.join();
+        return p;
     };
     bool ok = put(header, head, 0) && put("\n", 1, head);
-    if (scratch) {
-        format(0);
-        ok = ok && stream_ok;
+    if (n_threads == 1) {
+        int64_t max_cap = 0;
+        for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) max_cap = std::max<int64_t>(max_cap, (int64_t)cap(r0, std::min(r0 + chunk, n_rows)));
+        std::unique_ptr<char[]> scratch(n_rows ? new char[(size_t)max_cap] : nullptr);
+        int64_t at = head + 1;
+        for (int64_t r0 = 0; r0 < n_rows && ok; r0 += chunk) {
+            const int64_t r1 = std::min(r0 + chunk, n_rows);
+            const int64_t nb = (int64_t)(format_rows(r0, r1, scratch.get()) - scratch.get());
+            ok = put(scratch.get(), nb, at);
+            at += nb;
+        }
     } else {
+        std::vector<std::unique_ptr<char[]>> text((size_t)n_threads);
+        std::vector<int64_t> bytes((size_t)n_threads, 0), offset((size_t)n_threads + 1, head + 1);
+        std::vector<char> good((size_t)n_threads, 1);
+        auto rows_of = [&](int t) { return std::make_pair(n_rows * t / n_threads, n_rows * (t + 1) / n_threads); };
+        auto format = [&](int t) {
+            const auto [r0, r1] = rows_of(t);
+            text[(size_t)t].reset(new char[cap(r0, r1)]);
+            bytes[(size_t)t] = (int64_t)(format_rows(r0, r1, text[(size_t)t].get()) - text[(size_t)t].get());
+        };
+        auto write_out = [&](int t) {
+            if (!put(text[(size_t)t].get(), bytes[(size_t)t], offset[(size_t)t])) good[(size_t)t] = 0;
+            text[(size_t)t].reset();
+        };
+        auto run = [&](auto&& fn) {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn, t);
+            fn(0);
+            for (auto& th : pool) th.join();
+        };
         run(format);
-        for (int64_t c = 0; c < n_chunks; ++c) offset[(size_t)c + 1] = offset[(size_t)c] + bytes[(size_t)c];
+        for (int t = 0; t < n_threads; ++t) offset[(size_t)t + 1] = offset[(size_t)t] + bytes[(size_t)t];
         run(write_out);
         for (char g : good) ok = ok && g;
     }
@@ -479,6 +474,36 @@ int dig_mutation_file_fetch_host(void* handle, int64_t* chrom, int64_t* start, i
         DIG_REQUIRE(sample_names, "a buffer of names_bytes bytes");
         memcpy(sample_names, m->sample_names.data(), m->sample_names.size());
     }
+    return DIG_OK;
+}
+
+int dig_mutation_file_flags_host(void* handle, int64_t* first_row, int64_t* first_indel)
+{
+    // The two de-duplications the reference runs one after the other on a cohort's rows (read_mutation_file(drop_duplicates=True,
+    // unique_indels=True), mutation_tools.py:106-117), as per-row flags in file order:
+    //   first_row[i]   = 1: no earlier row has the same mutation (uid) AND sample       (drop_duplicate_mutations keeps it)
+    //   first_indel[i] = 1: row i is kept, is an INDEL, and no earlier kept INDEL row has the same mutation AND gene label
+    //                       (get_unique_indels keeps it)
+    // A caller that counts kept rows (the genome-mode scale factors, transfer_tools.py:129-159) needs no sort on the device.
+    DIG_REQUIRE(handle && first_row && first_indel, "a handle of dig_mutation_file_parse_host and two arrays of n_rows int64");
+    const MutFile* m = static_cast<const MutFile*>(handle);
+    const size_t n = m->chrom.size();
+    struct Key {
+        uint64_t k;
+        uint32_t i;
+    };
+    std::vector<Key> keys(n);
+    for (size_t i = 0; i < n; ++i) keys[i] = Key{((uint64_t)m->uid[i] << 32) | (uint64_t)(uint32_t)m->sample[i], (uint32_t)i};
+    auto by_key_then_row = [](const Key& x, const Key& y) { return x.k != y.k ? x.k < y.k : x.i < y.i; };
+    std::sort(keys.begin(), keys.end(), by_key_then_row);
+    for (size_t j = 0; j < n; ++j) first_row[keys[j].i] = (j == 0 || keys[j].k != keys[j - 1].k) ? 1 : 0;
+    size_t ni = 0;
+    for (size_t i = 0; i < n; ++i) {
+        first_indel[i] = 0;
+        if (first_row[i] && m->indel[i]) keys[ni++] = Key{((uint64_t)m->uid[i] << 32) | (uint64_t)(uint32_t)m->gene[i], (uint32_t)i};
+    }
+    std::sort(keys.begin(), keys.begin() + (ptrdiff_t)ni, by_key_then_row);
+    for (size_t j = 0; j < ni; ++j) first_indel[keys[j].i] = (j == 0 || keys[j].k != keys[j - 1].k) ? 1 : 0;
     return DIG_OK;
 }
 

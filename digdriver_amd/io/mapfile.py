@@ -215,6 +215,23 @@ def read_frame(path, key, index=True):
     return df if index else df.reset_index(drop=True)
 
 
+def read_columns(path, key, columns):
+    """{name: 1-D array} of the named columns of a frame, contiguous, without building the DataFrame (HDF5 maps: straight from
+    the stored blocks)."""
+    import numpy as np
+    if _is_h5(path):
+        root = _h5_tree(path)
+        if key not in root:
+            raise KeyError("no frame %r in %s" % (key, path))
+        try:
+            got = pandas_fixed.decode_columns(root[key], list(columns))
+        except pandas_fixed.FrameFormatError as exc:
+            raise MapFileError("%s:%s: %s" % (path, key, exc)) from exc
+        return {k: np.ascontiguousarray(v) for k, v in got.items()}
+    df = _dir_read_frame(path, key)
+    return {k: np.ascontiguousarray(df[k].values) for k in columns}
+
+
 def write_frame(path, key, df):
     return _h5_write_frame(path, key, df) if _is_h5(path) else _dir_write_frame(path, key, df)
 
@@ -332,6 +349,54 @@ def _cached_labels(index):
         if not same:
             return None
     return cached[1], cached[2]
+
+
+def encode_labels(index):
+    """(blob, offsets) of the text of a str / integer index, or None if it holds something the native writer must leave to pandas
+    (see write_results_tsv)."""
+    import numpy as np
+    int_index = isinstance(index.dtype, np.dtype) and index.dtype.kind in 'iu'
+    if not int_index and index.dtype != object:
+        return None
+    labels = [str(x) for x in index] if int_index else list(index)
+    if not int_index and (not all(type(x) is str for x in labels) or any(ch in s_ for s_ in labels for ch in ('\t', '"', '\n', '\r'))):
+        return None
+    enc = [s_.encode() for s_ in labels]
+    off = np.zeros(len(enc) + 1, np.int64)
+    np.cumsum([len(b) for b in enc], out=off[1:])
+    return b"".join(enc), off
+
+
+def write_columns_tsv(path, index_name, labels, columns, threads=8):
+    """The text of DataFrame(dict(columns), index).to_csv(path, sep="\t") from the column arrays themselves: `labels` =
+    encode_labels(index), `columns` = [(name, 1-D array)] of float64 / integer / bool arrays.  The bulk path of the many-cohort
+    driver (no pandas object involved); raises ValueError for anything else -- write_results_tsv is the general entry."""
+    import ctypes
+    import numpy as np
+    from .. import _lib
+    if labels is None:
+        raise ValueError("row labels the native writer does not cover")
+    blob, off = labels
+    kinds, cols, names = [], [], [str(index_name) if index_name is not None else '']
+    for name, v in columns:
+        names.append(str(name))
+        if v.dtype == np.float64:
+            kinds.append(0); cols.append(np.ascontiguousarray(v))
+        elif v.dtype.kind in 'iu' and v.dtype != np.uint64:
+            kinds.append(1); cols.append(np.ascontiguousarray(v, np.int64))
+        elif v.dtype == np.bool_:
+            kinds.append(2); cols.append(np.ascontiguousarray(v, np.uint8))
+        else:
+            raise ValueError("column %s: dtype %s" % (name, v.dtype))
+        if len(v) != len(off) - 1:
+            raise ValueError("column %s: %d rows, %d labels" % (name, len(v), len(off) - 1))
+    if any(ch in s_ for s_ in names for ch in ('\t', '"', '\n', '\r')):
+        raise ValueError("a column name the native writer does not cover")
+    ptrs = (ctypes.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+    kind_arr = np.asarray(kinds or [0], np.int32)
+    _lib.call("dig_write_tsv_host", os.fspath(path).encode(), "\t".join(names).encode(), ctypes.c_char_p(blob) if blob else ctypes.c_char_p(b""),
+              _lib.host_ptr(off), len(off) - 1, len(cols), ctypes.cast(ptrs, ctypes.c_void_p), _lib.host_ptr(kind_arr), int(threads))
+    return path
 
 
 def write_results_tsv(frame, path, threads=8):

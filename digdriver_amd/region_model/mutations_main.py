@@ -35,6 +35,18 @@ from .trainers import gp_trainer
 from .trainers.nn_trainer import NNTrainer
 
 
+def _adam(model, device):
+    """Adam(lr = 1e-3) as the reference builds it (mutations_main.py:256 / kfold_mutations_main.py:160); on the GPU the fused
+    multi-tensor form (one kernel for the 75 M parameters of a 37-task model instead of a chain of foreach kernels: 1.8 ->
+    0.5 ms of a 9.8 ms step) -- the model must already be on the device then."""
+    import torch
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        model.to(dev)
+        return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False, fused=True)
+    return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+
+
 def _say(*message):
     """Progress lines on stdout, worded as the reference words them."""
     print(*message, flush=True)
@@ -251,7 +263,7 @@ def main(input_args=None):
         _say('Setting model and optimizers for run {}/{}...'.format(r + 1, args.nn_reruns))
         torch.manual_seed(args.seed + 1000 * r + 10 * re)
         model = SimpleMultiTaskResNet(shape, C)
-        trainer = NNTrainer(model, optim.Adam(model.parameters(), lr=1e-3, amsgrad=False), nn.MSELoss(), args.bs, args.label_ids,
+        trainer = NNTrainer(model, _adam(model, device), nn.MSELoss(), args.bs, args.label_ids,
                             data.store, train_rows, val_rows, data.labels, device, seed=args.seed + 7919 * r + re)
         best = dict(accs=np.zeros(C))
         for epoch in range(1, args.epochs + 1):

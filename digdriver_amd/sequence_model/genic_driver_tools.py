@@ -57,7 +57,7 @@ def get_elt_ideal_overlaps(chrom, start, end, window):
 def _columns_to_table(cols, dtype, block=2048):
     """C columns of N values -> a contiguous [N, C] table.  np.stack(axis=1) writes every column with a stride of C values (0.22 s
     for 288 000 x 37 doubles); rows are taken in blocks that stay in cache instead (0.06 s)."""
-    a = np.array(cols, dtype=dtype)                       # [C, N], contiguous copies
+    a = cols if isinstance(cols, np.ndarray) and cols.ndim == 2 and cols.dtype == dtype else np.array(cols, dtype=dtype)   # [C, N]
     C, N = a.shape if a.ndim == 2 else (len(cols), 0)
     out = np.empty((N, C), dtype)
     for r0 in range(0, N, block):
@@ -66,24 +66,30 @@ def _columns_to_table(cols, dtype, block=2048):
 
 
 class RegionTables:
-    """region_params of one or more cohorts as dense [N, C] tables on a common, (chrom, start)-sorted bin grid."""
+    """region_params of one or more cohorts on a common, (chrom, start)-sorted bin grid.  `frames`: per cohort a DataFrame or a
+    dict of column arrays (mapfile.read_columns) with CHROM, START, END, Y_PRED, STD, Y_TRUE, FLAG.
+    The tables are kept COHORT-MAJOR ([C, N]: a cohort's column as it was read is one contiguous row -- `mu_cm`, `std_cm`,
+    `y_cm`, `flag_cm`); the [N, C] layout of the kernels (`mu`, `std`, `y`, `flag`) is formed on first use on the host, or by
+    `on_device(dev)`: the cohort-major tables uploaded and transposed on the device (a blocked host transpose of four 288 000 x
+    37 tables was 0.15 s of a 37-cohort run, the device does it in under a millisecond)."""
 
     def __init__(self, frames):
+        col = lambda f, k: np.asarray(f[k].values if hasattr(f[k], "values") else f[k])
         # one ordering for all cohorts: the (CHROM, START) order of the first map -- nothing to do when the map is stored in that
         # order (the usual case: 1 ms to check where a 288 000-row sort_values took 25 ms per cohort); a cohort whose raw
         # columns equal the first one's shares its ordering, any other is sorted on its own and must land on the same grid
-        chrom0, start0 = np.asarray(frames[0].CHROM.values), np.asarray(frames[0].START.values)
+        chrom0, start0 = col(frames[0], 'CHROM'), col(frames[0], 'START')
         in_order = len(chrom0) < 2 or bool(np.all((chrom0[1:] > chrom0[:-1]) | ((chrom0[1:] == chrom0[:-1]) & (start0[1:] >= start0[:-1]))))
         order0 = None if in_order else np.lexsort((start0, chrom0))
         take = (lambda a, o: a) if in_order else (lambda a, o: a[o])
         g_chrom, g_start = take(chrom0, order0), take(start0, order0)
         self.chrom = g_chrom.astype(np.int32)
         self.start = g_start.astype(np.int64)
-        end0 = np.asarray(frames[0].END.values)
+        end0 = col(frames[0], 'END')
         self.window = int(take(end0, order0)[0] - g_start[0])                # genic_driver_tools.py:308
         cols = {k: [] for k in ('Y_PRED', 'STD', 'Y_TRUE', 'FLAG')}
         for f in frames:
-            fc, fs = np.asarray(f.CHROM.values), np.asarray(f.START.values)
+            fc, fs = col(f, 'CHROM'), col(f, 'START')
             if fc is chrom0 or (np.array_equal(fc, chrom0) and np.array_equal(fs, start0)):
                 order = order0
             else:
@@ -91,21 +97,47 @@ class RegionTables:
                 if not (np.array_equal(fc[order], g_chrom) and np.array_equal(fs[order], g_start)):
                     raise ValueError("all cohorts must share one bin grid")
             for k in cols:
-                v = np.asarray(f[k].values)
+                v = col(f, k)
                 cols[k].append(v if order is None else v[order])
-        self.mu = _columns_to_table(cols['Y_PRED'], np.float64)
-        self.std = _columns_to_table(cols['STD'], np.float64)
-        self.y = _columns_to_table(cols['Y_TRUE'], np.int32)
-        self.flag = _columns_to_table([np.asarray(v).astype(bool) for v in cols['FLAG']], np.uint8)
+        C, N = len(frames), len(self.chrom)
+        stack = lambda vs, dt: np.array(vs, dtype=dt).reshape(C, N)          # [C, N]: contiguous row copies
+        self.mu_cm, self.std_cm = stack(cols['Y_PRED'], np.float64), stack(cols['STD'], np.float64)
+        self.y_cm = stack(cols['Y_TRUE'], np.int32)
+        self.flag_cm = stack([np.asarray(v).astype(bool) for v in cols['FLAG']], np.uint8)
+        self._nc = {}
+
+    def _table(self, name):
+        if name not in self._nc:
+            cm = getattr(self, name + "_cm")
+            self._nc[name] = _columns_to_table(cm, cm.dtype)
+        return self._nc[name]
+
+    mu = property(lambda self: self._table("mu"))
+    std = property(lambda self: self._table("std"))
+    y = property(lambda self: self._table("y"))
+    flag = property(lambda self: self._table("flag"))
+
+    def on_device(self, device):
+        """(mu, std, y, flag) as [N, C] device tensors: the cohort-major tables uploaded, transposed there."""
+        import torch
+        up = lambda a: torch.as_tensor(a, device=device).t().contiguous()
+        return up(self.mu_cm), up(self.std_cm), up(self.y_cm), up(self.flag_cm)
 
     def aligned_context(self, si_index, si_values):
         """Rows of full_window_si_values re-ordered to this bin grid (a bin without context row is an error)."""
-        key = {(int(c), int(s)): i for i, (c, s) in enumerate(zip(si_index[:, 0], si_index[:, 1]))}
-        try:
-            rows = [key[(int(c), int(s))] for c, s in zip(self.chrom, self.start)]
-        except KeyError as exc:
-            raise KeyError("bin chr%s:%s of region_params has no context counts" % exc.args[0]) from exc
-        return np.ascontiguousarray(si_values[rows], np.int32)
+        si_index = np.asarray(si_index)
+        key = (si_index[:, 0].astype(np.int64) << 40) | si_index[:, 1].astype(np.int64)
+        want = (self.chrom.astype(np.int64) << 40) | self.start
+        if len(key) == len(want) and np.array_equal(key, want):           # the usual case: the container lists the map's own bins
+            return np.ascontiguousarray(si_values, np.int32)
+        order = np.argsort(key, kind="stable")
+        pos = np.searchsorted(key[order], want)
+        pos = np.minimum(pos, max(len(key) - 1, 0))
+        ok = key[order][pos] == want if len(key) else np.zeros(len(want), bool)
+        if not ok.all():
+            bad = int(np.flatnonzero(~ok)[0])
+            raise KeyError("bin chr%s:%s of region_params has no context counts" % (int(self.chrom[bad]), int(self.start[bad])))
+        return np.ascontiguousarray(np.asarray(si_values)[order[pos]], np.int32)
 
 
 def sorted_d_pr(df_seq):
@@ -117,9 +149,8 @@ def sorted_d_pr(df_seq):
 
 def _read_cohort_frames(args):
     f, key = args
-    df = mapfile.read_frame(f, key, index=False)
-    # only what RegionTables takes: a process that read the map for another hands back six columns, not the whole frame
-    return df[['CHROM', 'START', 'END', 'Y_PRED', 'STD', 'Y_TRUE', 'FLAG']], mapfile.read_frame(f, 'sequence_model_192')
+    # only what RegionTables takes, as column arrays straight from the stored blocks (no DataFrame: see mapfile.read_columns)
+    return mapfile.read_columns(f, key, ['CHROM', 'START', 'END', 'Y_PRED', 'STD', 'Y_TRUE', 'FLAG']), mapfile.read_frame(f, 'sequence_model_192')
 
 
 def _load_cohorts(f_pretrained, key='region_params', workers=1):
@@ -175,23 +206,24 @@ def _element_set(f_data, window, save_key, names=None):
     if not mapfile.has_key(f_data, base + 'names') and mapfile._is_h5(f_data) and mapfile.has_key(f_data, base.rstrip('/')):
         return _element_set_reference_layout(f_data, window, save_key, names)
     all_names = mapfile.read_array(f_data, base + 'names').astype(str)
-    sel = np.arange(len(all_names))
-    if names is not None:
-        pos = {n: i for i, n in enumerate(all_names)}
-        sel = np.array([pos[n] for n in names], dtype=np.int64)
     blk_ptr = mapfile.read_array(f_data, base + 'blk_ptr').astype(np.int64)
     bs = mapfile.read_array(f_data, base + 'blk_start').astype(np.int64)
     be = mapfile.read_array(f_data, base + 'blk_end').astype(np.int64)
-    cnt = (blk_ptr[1:] - blk_ptr[:-1])[sel]
-    new_ptr = np.concatenate([[0], np.cumsum(cnt)])
-    take = np.concatenate([np.arange(blk_ptr[i], blk_ptr[i + 1]) for i in sel]) if len(sel) else np.zeros(0, np.int64)
-    strand = mapfile.read_array(f_data, base + 'strand').astype(str)[sel]
-    L = mapfile.read_array(f_data, base + 'L')[sel]
+    strand = mapfile.read_array(f_data, base + 'strand')
+    chrom = mapfile.read_array(f_data, base + 'chrom')
+    L = mapfile.read_array(f_data, base + 'L')
+    if names is not None:                                    # a subset, in the caller's order (no Python loop over the elements)
+        pos = {n: i for i, n in enumerate(all_names)}
+        sel = np.array([pos[n] for n in names], dtype=np.int64)
+        cnt = (blk_ptr[1:] - blk_ptr[:-1])[sel]
+        new_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        take = np.repeat(blk_ptr[sel] - new_ptr[:-1], cnt) + np.arange(int(new_ptr[-1]), dtype=np.int64)
+        all_names, strand, chrom, L, bs, be, blk_ptr = all_names[sel], strand[sel], chrom[sel], L[sel], bs[take], be[take], new_ptr
     if L.ndim == 2:
         L = L[:, None, :]
-    return dict(names=all_names[sel], chrom=mapfile.read_array(f_data, base + 'chrom')[sel].astype(np.int32),
-                strand_minus=np.isin(strand, ['-', '-1']).astype(np.uint8), blk_ptr=new_ptr, blk_start=bs[take],
-                blk_end=be[take], L=np.ascontiguousarray(L, np.int32))
+    strand = strand.astype(str)
+    return dict(names=all_names, chrom=chrom.astype(np.int32), strand_minus=((strand == '-') | (strand == '-1')).astype(np.uint8),
+                blk_ptr=blk_ptr, blk_start=bs, blk_end=be, L=np.ascontiguousarray(L, np.int32))
 
 
 def _accumulate(tables, d_pr, f_data, elts, gene_length=None):

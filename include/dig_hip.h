@@ -431,6 +431,11 @@ int dig_write_tsv_host(const char *path, const char *header, const char *labels,
 int dig_mutation_file_parse_host(const char *path, void **handle, int64_t *n_rows, int64_t *n_samples, int64_t *names_bytes);
 int dig_mutation_file_fetch_host(void *handle, int64_t *chrom, int64_t *start, int64_t *end, int64_t *uid, int64_t *sample,
                                  int64_t *indel, int64_t *gene, char *sample_names);
+/* flags (round 5): the reference's two de-duplications of a cohort's rows -- drop_duplicate_mutations, then get_unique_indels
+ * (mutation_tools.py:106-117) -- as per-row 0 / 1 flags in file order: first_row[i] = no earlier row has the same mutation and
+ * sample; first_indel[i] = row i is such a row, is an INDEL, and no earlier such row has the same mutation and GENE label.  The
+ * genome-mode scale factors (calc_scale_factor_efficient, transfer_tools.py:129-159) count flagged rows: no sort on the device. */
+int dig_mutation_file_flags_host(void *handle, int64_t *first_row, int64_t *first_indel);
 int dig_mutation_file_free_host(void *handle);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of

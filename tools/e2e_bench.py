@@ -107,7 +107,7 @@ def write_inputs(args, work):
 
 
 def run_e2e(bins=288_000, elements=120_091, cohorts=37, mut_rows=300_000, seed=3, workdir="/tmp/dig_e2e", read_workers=None,
-            skip_cli=False, reps=2, keep=False):
+            skip_cli=False, reps=5, keep=False):
     """Write the inputs (untimed), run the many-cohort pipeline `reps` times with stage timings, then the two per-cohort command
     lines once; returns the record tools/e2e_bench.py prints and bench.py embeds as `e2e`."""
     import shutil
@@ -126,8 +126,9 @@ def run_e2e(bins=288_000, elements=120_091, cohorts=37, mut_rows=300_000, seed=3
     _lib.require_device()
     torch.zeros(1, device="cuda:0")                      # device and library initialisation are not the pipeline's
     torch.cuda.synchronize()
-    res = {"what": "BASELINE configs[2] as FILES -> %d results.txt: driver_model.cohort_batch.run_element_cohorts + write_results, wall-clock "
-                   "by stage (the device is drained at every stage boundary); inputs written beforehand, untimed" % cohorts,
+    res = {"what": "BASELINE configs[2] as FILES -> %d results.txt: driver_model.cohort_batch.run_and_write_element_cohorts (the maps, the element "
+                   "container and the mutation files read side by side; the result files written while the frames behind them are assembled), "
+                   "wall-clock by stage (the device is drained at every stage boundary); inputs written beforehand, untimed" % cohorts,
            "config": {"bins": bins, "elements": elements, "cohorts": cohorts, "mutation_rows_per_cohort": int(mut_rows * 1.03)},
            "host_cores": os.cpu_count(), "input_files": sizes, "inputs_written_s": t_inputs, "runs": []}
     outdir = os.path.join(workdir, "results")
@@ -135,16 +136,26 @@ def run_e2e(bins=288_000, elements=120_091, cohorts=37, mut_rows=300_000, seed=3
     for rep in range(reps):                               # the second run has the files in the page cache and the kernels loaded
         stages = {}
         t0 = time.perf_counter()
-        frames = cohort_batch.run_element_cohorts(paths["mut"], paths["pre"], paths["ed"], "elts", timings=stages, read_workers=read_workers)
-        t1 = time.perf_counter()
-        out = cohort_batch.write_results(frames, outdir, ["cohort%02d" % c for c in range(cohorts)])
+        frames, out = cohort_batch.run_and_write_element_cohorts(paths["mut"], paths["pre"], paths["ed"], "elts", outdir,
+                                                                 ["cohort%02d" % c for c in range(cohorts)], timings=stages,
+                                                                 read_workers=read_workers)
         t2 = time.perf_counter()
-        stages["write_results_txt"] = t2 - t1
         total = t2 - t0
+        inside = stages.pop("inside_read_parse_upload", None)
+        stages["results_txt_behind_the_last_frame"] = total - sum(stages.values())
         res["runs"].append({"total_s": total, "stages_s": {k: round(v, 4) for k, v in stages.items()},
+                            "inside_read_parse_upload_s": inside,
                             "element_cohort_tests_per_s": elements * cohorts / total, "seconds_per_cohort": total / cohorts})
         del frames
     res["results_files"] = len(out)
+    tot = sorted(r["total_s"] for r in res["runs"])
+    res["total_s_median"] = tot[len(tot) // 2]
+    # the overlapped route writes the bytes the plain route writes (run_element_cohorts, then write_results; untimed)
+    serial_dir = os.path.join(workdir, "results_serial")
+    frames = cohort_batch.run_element_cohorts(paths["mut"], paths["pre"], paths["ed"], "elts", read_workers=1)
+    ser = cohort_batch.write_results(frames, serial_dir, ["cohort%02d" % c for c in range(cohorts)])
+    del frames
+    res["results_identical_to_the_serial_route"] = all(open(a_, "rb").read() == open(b_, "rb").read() for a_, b_ in zip(out, ser))
     if not skip_cli:
         # the per-cohort command lines of the reference's workflow, one cohort, fresh processes
         env = dict(os.environ, PYTHONPATH=ROOT)
