@@ -64,22 +64,12 @@ __device__ __forceinline__ int revcomp_ctx(int c)
     return ((3 - b2) << 4) | ((3 - b1) << 2) | (3 - b0);
 }
 
-// A cohort whose table d_pr itself holds an exact zero (or a NaN, or entries of both signs) gives NaN whatever L is: t_pi holds
-// 0 / 0 = NaN (or +inf and -inf) at those substitutions (round 5; rounds 3-4 said inf there).  `cohort_table_bad` reads the cohort's
-// 192 frequencies from global memory -- only on this path, i.e. only when some denominator of the tile IS zero.
-__device__ __noinline__ bool cohort_table_bad(const double* __restrict__ d_pr, int c, int C)
-{
-    if (c >= C) return false;
-    const double* d = d_pr + (int64_t)c * 192;
-    bool pos = false, neg = false, bad = false;
-    for (int j = 0; j < 192; ++j) {
-        const double v = d[j];
-        pos |= v > 0.0;
-        neg |= v < 0.0;
-        bad |= !(v > 0.0 || v < 0.0);           // an exact zero or a NaN
-    }
-    return bad || (pos && neg);
-}
+// A cohort whose table d_pr itself holds an entry that is not positive -- an exact zero (0 / 0 in t_pi = d_pr / 0), a NaN, a
+// negative value (-inf beside +inf) -- gives NaN for a zero denominator whatever L is (genic_driver_tools.py:361-366; round 5:
+// rounds 3-4 said inf when L held no zero).  Every kernel notes such cohorts of its chunk in LDS (g_cohort_bad) while it stages
+// the table -- one compare per staged entry, an LDS atomic only when one is found -- and the zero-denominator path reads the note.
+constexpr int kChunkCohorts = 64;       // (the matrix kernels take 48 cohorts per launch, the no-workspace kernel up to 64)
+__shared__ unsigned g_cohort_bad[kChunkCohorts];
 
 template <int NCLASS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
@@ -95,9 +85,13 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
     const int wave = tid >> 6, lane = tid & 63;
 
     // ---- stage the per-cohort trinucleotide parameters (once per workgroup) ----
+    if (tid < kChunkCohorts) g_cohort_bad[tid] = 0u;
+    __syncthreads();
     for (int idx = tid; idx < Cc * 192; idx += WAVES * 64) {
         const int c = idx / 192, j = idx - c * 192;
-        dprT[j * Cc + c] = a.d_pr[(int64_t)(a.c0 + c) * 192 + j];
+        const double v = a.d_pr[(int64_t)(a.c0 + c) * 192 + j];
+        dprT[j * Cc + c] = v;
+        if (!(v > 0.0)) atomicOr(&g_cohort_bad[c], 1u);
     }
     __syncthreads();
     for (int idx = tid; idx < Cc * 64; idx += WAVES * 64) {
@@ -186,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) void accumulate_kernel(AccArgs a)
                         n3 = fma(Ls[j + 3], dprT[(j + 3) * Cc + lane], n3);
                     }
                     // (denominator 0: the reference forms t_pi = d_pr / 0 = inf first, and inf * 0 is NaN -- see fix_zero_denominators)
-                    const double numer = (denom == 0.0 && (((class_has_zero >> q) & 1u) || cohort_table_bad(a.d_pr, a.c0 + lane, (int)a.C)))
+                    const double numer = (denom == 0.0 && (((class_has_zero >> q) & 1u) || g_cohort_bad[lane]))
                                              ? __longlong_as_double(0x7ff8000000000000ll)
                                                                                         : (n0 + n1) + (n2 + n3);
                     a.P[(e * NCLASS + q) * a.C + col] = numer / denom;
@@ -464,7 +458,7 @@ __device__ __forceinline__ void mfma_group(const int4 (&a)[4], const double* __r
 template <int NT, int NQ>
 __device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT > 0 ? NT : 1], const double (&denq)[NQ > 0 ? NQ : 1],
                                                       double4_t (&num)[NT > 0 ? NT : 1], double (&numq)[NQ > 0 ? NQ : 1],
-                                                      int lzero, int lane, const double* __restrict__ d_pr, int c0, int C)
+                                                      int lzero, int lane)
 {
     bool z = false;
 #pragma unroll
@@ -483,13 +477,13 @@ __device__ __forceinline__ void fix_zero_denominators(const double4_t (&den)[NT 
         const int rowzero = __shfl(lzero, 4 * r + kq, 64);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            if (den[nt][r] == 0.0 && (rowzero || cohort_table_bad(d_pr, c0 + nt * 16 + (lane & 15), C))) num[nt][r] = nan;
+            if (den[nt][r] == 0.0 && (rowzero || g_cohort_bad[nt * 16 + (lane & 15)])) num[nt][r] = nan;
     }
     if constexpr (NQ > 0) {
         const int rowzero = __shfl(lzero, 4 * ((lane >> 2) & 3) + kq, 64);   // D[i][j] of block b: row 4 b + i
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (denq[q] == 0.0 && (rowzero || cohort_table_bad(d_pr, c0 + NT * 16 + 4 * q + (lane & 3), C))) numq[q] = nan;
+            if (denq[q] == 0.0 && (rowzero || g_cohort_bad[NT * 16 + 4 * q + (lane & 3)])) numq[q] = nan;
     }
 }
 
@@ -503,6 +497,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
     extern __shared__ double tab[];           // [kMfmaSteps][SL][64]
     constexpr int SL = NT + (NQ > 0 ? 1 : 0);
     constexpr int NTA = NT > 0 ? NT : 1, NQA = NQ > 0 ? NQ : 1;
+    if (threadIdx.x < kChunkCohorts) g_cohort_bad[threadIdx.x] = 0u;
+    __syncthreads();
+    {   // the chunk's cohorts whose frequency table holds an entry that is not positive (see g_cohort_bad): the table this kernel
+        // stages is the pre-swizzled one, so the raw frequencies are looked at here (9 216 values per workgroup, L2-resident)
+        const int cc = min(C - c0, kMfmaChunk);
+        for (int idx = threadIdx.x; idx < cc * 192; idx += kMfmaWaves * 64)
+            if (!(d_pr[(int64_t)c0 * 192 + idx] > 0.0)) atomicOr(&g_cohort_bad[idx / 192], 1u);
+    }
     {
         // stage this chunk's NT tiles of the pre-swizzled table (global layout: 3 tiles per step); all loads of a
         // thread are issued before its first LDS write
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, DIG_MFMA_MINBLOCKS) void acc_dot_m
                 }
                 mfma_group<NT, NQ>(cur, tabq, 16 + 16 * g, lane, toff, num, numq, lsum, lzero);
             }
-            fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane, d_pr, c0, C);
+            fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t e = e0 + 4 * r + kq;                      // D[i][j]: lane 16 (i % 4) + j, register i / 4
@@ -683,6 +685,8 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
 
     // (pipeline only) clear the worklist header of the statistics stage that follows on the stream
     if (zero_dwords && blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_dwords[threadIdx.x] = 0u;
+    if (threadIdx.x < kChunkCohorts) g_cohort_bad[threadIdx.x] = 0u;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -760,6 +764,7 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
                 d0[j] = d[0];
                 d1[j] = d[1];
                 d2[j] = d[2];
+                if (!(d0[j] > 0.0 && d1[j] > 0.0 && d2[j] > 0.0)) atomicOr(&g_cohort_bad[c - c0], 1u);
             }
         }
 #pragma unroll
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
         steps(std::integral_constant<int, 0>{});
         r_c = load_rows(b_n, x_n);                               // tile t+1: context rows + L (indices have arrived meanwhile)
         steps(std::integral_constant<int, 2>{});
-        fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane, d_pr, c0, C);
+        fix_zero_denominators<NT, NQ>(den, denq, num, numq, lzero, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t e = e0 + 4 * r + kq;                   // D[i][j]: lane 16 (i % 4) + j, register i / 4

@@ -441,6 +441,9 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 #ifndef DIG_ES_XCD
 #define DIG_ES_XCD 1
 #endif
+#ifndef DIG_ES_CONTIG
+#define DIG_ES_CONTIG 0
+#endif
 #ifndef DIG_ES_ABL
 #define DIG_ES_ABL 0     // developer ablation builds (tools/build_variant.sh): 1 no stores, 2 counts forced to 0, 8 no arithmetic, 16 no bin gathers,
                          // 32 no CSR / index loads, 64 no stores of the four rate outputs, 128 no stores of the seven planes
@@ -486,6 +489,12 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         unsigned t = 0;
         if (lane == 0) t = atomicAdd(&s_ticket, 1u);
         t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+#if DIG_ES_CONTIG      // developer A/B: every workgroup walks ONE contiguous range of tiles
+        {
+            const int64_t lo = n_tiles * blockIdx.x / gridDim.x, hi = n_tiles * (blockIdx.x + 1) / gridDim.x;
+            return lo + t < hi ? lo + t : n_tiles;
+        }
+#endif
 #if DIG_ES_XCD
         // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the group that shares an L2).  A tile is 64
         // pairs = 1.7 elements at 37 cohorts, so neighbouring tiles read the same bin rows: the 8 groups take runs of
