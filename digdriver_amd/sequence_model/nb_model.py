@@ -211,10 +211,14 @@ def get_q_vals(pvals_lst):
         if n == 0:
             return p.clone()
         ps, order = torch.sort(p, stable=True)
-        # (the divisor as a DEVICE tensor: torch turns a division by a host scalar into a multiplication by its reciprocal)
-        q = ps / (torch.arange(1, n + 1, device=p.device, dtype=torch.float64) / torch.full((), float(n), device=p.device, dtype=torch.float64))
-        q = torch.flip(torch.cummin(torch.flip(q, [0]), 0).values, [0])
-        q = torch.clamp(q, max=1.0)
+        # p / (rank / n), the reverse running minimum and the cap in one pass of the library (dig_bh_qvalues_sorted: torch.cummin
+        # took 21 of the 22 ms of a cohort's 7.2 M p-values)
+        from .. import _lib
+        q = torch.empty_like(ps)
+        wsb = int(_lib.load().dig_bh_workspace(n))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.call("dig_bh_qvalues_sorted", _lib.dev_ptr(ps), n, _lib.dev_ptr(q), _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
         out = torch.empty_like(q)
         out[order] = q
         return out.reshape(pvals_lst.shape)

@@ -339,3 +339,27 @@ def test_collapsed_contexts_k96_per_base_route_and_counts_match_reference():
         np.testing.assert_allclose(df.Pi.values, run["Pi"], rtol=1e-12, atol=0)
         np.testing.assert_allclose(df.EXP.values, run["EXP"], rtol=1e-12, atol=0)
         rel_close(df.PVAL.values, np.array(run["PVAL"]), rtol=1e-6)
+
+
+def test_bh_pass_of_the_library_equals_the_host_form_at_every_size():
+    """dig_bh_qvalues_sorted (round 5: p / (rank / n), reverse running minimum and cap in one pass behind torch's sort -- torch.cummin
+    was 97 % of a cohort's q-values) against the host form of get_q_vals = statsmodels' operations, bit for bit: sizes around the
+    thread, workgroup and chunk boundaries of the kernel, ties at 0 and 1, and a NaN, which makes every q-value NaN as it does
+    in statsmodels."""
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 8193, 100_003, 1_048_577, 7_200_001):
+        p = rng.uniform(0, 1, n) ** 3
+        if n > 10:
+            p[rng.integers(0, n, 5)] = 1.0
+            p[rng.integers(0, n, 5)] = 0.0
+        want = nb_model.get_q_vals(p)
+        got = nb_model.get_q_vals(torch.as_tensor(p, device=dev)).cpu().numpy()
+        assert np.array_equal(want, got), n
+        if n > 3:
+            p[n // 2] = np.nan
+            want = nb_model.get_q_vals(p)
+            got = nb_model.get_q_vals(torch.as_tensor(p, device=dev)).cpu().numpy()
+            assert np.isnan(want).all() and np.isnan(got).all(), n
