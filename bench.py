@@ -528,15 +528,14 @@ def aux_rooflines(dev):
         Sr = rng.uniform(0, 1e-2, (Cr, width))
         sh = parallel.ShardedTiles(genome, chroms, starts, starts + Wr, Sr, mu_r, sg_r, np.array(names)[mci], msr, msr + 1, cor, Br, dev, 0, 1)
         sh.run()
-        sh.q_values(0)
+        sh.q_values_all()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sh.run()
         torch.cuda.synchronize()
         t_run = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for c in range(Cr):
-            sh.q_values(c)
+        sh.q_values_all()
         torch.cuda.synchronize()
         t_q = time.perf_counter() - t0
         tiles_r = float(Rr) * (Wr // Br) * Cr

@@ -93,7 +93,7 @@ _SIGNATURES = {
     "dig_base_tile_probs_host": [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64, _int, _i64, _vp, _vp, _vp, _int],
     "dig_tile_mut_counts_host": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
-    "dig_bh_qvalues_sorted": [_vp, _i64, _vp, _vp, _i64, _vp],
+    "dig_bh_qvalues_sorted": [_vp, _i64, _i64, _vp, _vp, _i64, _vp],
     "dig_rbf_cross": [_vp, _vp, _i64, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "dig_rbf_backward": [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp],
 }
@@ -108,7 +108,7 @@ _SIZE_QUERIES = {
     "dig_rbf_backward_partials": [_i64, _i64],
     "dig_bin_records_bytes": [_i64, _i64],
     "dig_element_records_bytes": [_i64, _i64],
-    "dig_bh_workspace": [_i64],
+    "dig_bh_workspace": [_i64, _i64],
 }
 
 ABI_VERSION = 9          # include/dig_hip.h: DIG_ABI_VERSION

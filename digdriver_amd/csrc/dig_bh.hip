@@ -28,10 +28,18 @@ __device__ __forceinline__ double bh_value(const double* __restrict__ ps, int64_
 }
 
 // reverse inclusive running minimum over the workgroup's chunk: thread t holds items [t * kBhItems, (t + 1) * kBhItems) of the chunk
+// (blockIdx.y: the row of a batch -- one cohort's sorted p-values -- rows n apart)
 template <bool WRITE>
 __global__ __launch_bounds__(kBhBlock) void bh_chunk_kernel(const double* __restrict__ ps, int64_t n, double* __restrict__ chunk_min,
                                                             const double* __restrict__ suffix, double* __restrict__ q)
 {
+    const int64_t n_chunks_ = (n + kBhChunk - 1) / kBhChunk;
+    ps += (int64_t)blockIdx.y * n;
+    if (WRITE) {
+        q += (int64_t)blockIdx.y * n;
+        suffix += (int64_t)blockIdx.y * n_chunks_;
+    } else
+        chunk_min += (int64_t)blockIdx.y * n_chunks_;
     __shared__ double s_tot[kBhBlock];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     const double n_f = (double)n;
@@ -68,6 +76,8 @@ __global__ __launch_bounds__(kBhBlock) void bh_chunk_kernel(const double* __rest
 // suffix[b] = min of chunk_min[b + 1 ..] (inf for the last chunk), one workgroup, chunks walked from the end
 __global__ __launch_bounds__(kBhBlock) void bh_suffix_kernel(const double* __restrict__ chunk_min, int64_t n_chunks, double* __restrict__ suffix)
 {
+    chunk_min += (int64_t)blockIdx.x * n_chunks;      // (one workgroup per row of the batch)
+    suffix += (int64_t)blockIdx.x * n_chunks;
     __shared__ double s_tot[kBhBlock];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double carry = inf;                                   // minimum of everything behind the current stretch of kBhBlock chunks
@@ -97,25 +107,27 @@ using namespace dig;
 
 extern "C" {
 
-int64_t dig_bh_workspace(int64_t n)
+int64_t dig_bh_workspace(int64_t n, int64_t rows)
 {
-    if (n <= 0) return 0;
-    return 2 * ((n + kBhChunk - 1) / kBhChunk) * (int64_t)sizeof(double);
+    if (n <= 0 || rows <= 0) return 0;
+    return 2 * rows * ((n + kBhChunk - 1) / kBhChunk) * (int64_t)sizeof(double);
 }
 
-int dig_bh_qvalues_sorted(const double* p_sorted, int64_t n, double* q_sorted, void* workspace, int64_t workspace_bytes, void* stream)
+int dig_bh_qvalues_sorted(const double* p_sorted, int64_t n, int64_t rows, double* q_sorted, void* workspace, int64_t workspace_bytes,
+                          void* stream)
 {
-    DIG_REQUIRE(n >= 0, "n >= 0");
-    if (n == 0) return DIG_OK;
-    DIG_REQUIRE(p_sorted && q_sorted && workspace && workspace_bytes >= dig_bh_workspace(n), "non-null pointers, workspace of dig_bh_workspace(n) bytes");
+    DIG_REQUIRE(n >= 0 && rows >= 0, "n, rows >= 0");
+    if (n == 0 || rows == 0) return DIG_OK;
+    DIG_REQUIRE(p_sorted && q_sorted && workspace && workspace_bytes >= dig_bh_workspace(n, rows),
+                "non-null pointers, workspace of dig_bh_workspace(n, rows) bytes");
     const int64_t n_chunks = (n + kBhChunk - 1) / kBhChunk;
-    DIG_REQUIRE(n_chunks <= 0x7fffffff, "n too large for one launch");
+    DIG_REQUIRE(n_chunks <= 0x7fffffff && rows <= 65535, "n or rows too large for one launch");
     double* chunk_min = (double*)workspace;
-    double* suffix = chunk_min + n_chunks;
+    double* suffix = chunk_min + rows * n_chunks;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((bh_chunk_kernel<false>), dim3((unsigned)n_chunks), dim3(kBhBlock), 0, s, p_sorted, n, chunk_min, nullptr, nullptr);
-    hipLaunchKernelGGL(bh_suffix_kernel, dim3(1), dim3(kBhBlock), 0, s, chunk_min, n_chunks, suffix);
-    hipLaunchKernelGGL((bh_chunk_kernel<true>), dim3((unsigned)n_chunks), dim3(kBhBlock), 0, s, p_sorted, n, nullptr, suffix, q_sorted);
+    hipLaunchKernelGGL((bh_chunk_kernel<false>), dim3((unsigned)n_chunks, (unsigned)rows), dim3(kBhBlock), 0, s, p_sorted, n, chunk_min, nullptr, nullptr);
+    hipLaunchKernelGGL(bh_suffix_kernel, dim3((unsigned)rows), dim3(kBhBlock), 0, s, chunk_min, n_chunks, suffix);
+    hipLaunchKernelGGL((bh_chunk_kernel<true>), dim3((unsigned)n_chunks, (unsigned)rows), dim3(kBhBlock), 0, s, p_sorted, n, nullptr, suffix, q_sorted);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

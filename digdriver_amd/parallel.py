@@ -481,6 +481,32 @@ class ShardedTiles:
         return out
 
 
+def _sharded_tiles_q_values_all(self, max_elements=1 << 28):
+    """q_values() for ALL cohorts at once: [C, R_r, n_tiles] (NaN where a bin has no such tile).  One exchange (the ranks'
+    valid-tile p-values of every cohort, [n_valid, C] rows in rank order), then the cohorts' lists are sorted and taken through
+    the Benjamini-Hochberg pass in batches of whole cohorts (nb_model.get_q_vals_rows; at most `max_elements` values per batch)
+    instead of one cohort at a time: the same bits as q_values(c) for every c."""
+    import torch
+    from .sequence_model import nb_model
+    r = self.result
+    t = torch.arange(self.n_tiles, device=r["pval"].device)[None, :]
+    mask = t < r["n_valid"][:, None]
+    mine = r["pval"][:, mask]                                   # [C, n_mine]
+    counts = all_gather_rows(torch.tensor([mine.shape[1]], dtype=torch.int64, device=mine.device), self.group)
+    everything = all_gather_rows(mine.t().contiguous(), self.group).t()      # [C, n_all] (a view: the batches below make it contiguous)
+    before = int(counts[: self.rank].sum().item()) if counts.numel() > 1 else 0
+    C, n_all = everything.shape
+    out = torch.full((C,) + tuple(mask.shape), float("nan"), dtype=torch.float64, device=mine.device)
+    step = max(1, int(max_elements // max(n_all, 1)))
+    for c0 in range(0, C, step):
+        q = nb_model.get_q_vals_rows(everything[c0:c0 + step])
+        out[c0:c0 + step][:, mask] = q[:, before:before + mine.shape[1]]
+    return out
+
+
+ShardedTiles.q_values_all = _sharded_tiles_q_values_all
+
+
 def standardisation_stats(X, y, group=None, comm=None):
     """Feature means / population standard deviations and label mean / std over the rows of ALL ranks -- what sklearn's
     StandardScaler and y.mean() / y.std() give the reference on the whole training set (gp_trainer.py:107-120) -- from

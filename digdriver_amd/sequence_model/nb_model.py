@@ -198,6 +198,26 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=2, n_down=2, b
         "MU": np.asarray(mu_lst, float)[reg], "SIGMA": np.asarray(sigma_lst, float)[reg], "REGION": labels[reg]})[cols]
 
 
+def get_q_vals_rows(p_rows):
+    """get_q_vals for every row of a [rows, n] device tensor at once (the cohorts of the per-base route: one segmented sort, one
+    pass of dig_bh_qvalues_sorted, one scatter instead of `rows` times five launches)."""
+    import torch
+    from .. import _lib
+    p = p_rows.to(torch.float64).contiguous()
+    rows, n = p.shape
+    if n == 0 or rows == 0:
+        return p.clone()
+    ps, order = torch.sort(p, dim=1, stable=True)
+    q = torch.empty_like(ps)
+    wsb = int(_lib.load().dig_bh_workspace(n, rows))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.call("dig_bh_qvalues_sorted", _lib.dev_ptr(ps), n, rows, _lib.dev_ptr(q), _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
+    out = torch.empty_like(q)
+    out.scatter_(1, order, q)
+    return out
+
+
 def get_q_vals(pvals_lst):
     """nb_model.py:340-342: Benjamini-Hochberg q-values, statsmodels.stats.multitest.fdrcorrection(pvals)[1] (method
     'indep'): q_(i) = min_{j >= i} p_(j) n / j in ascending order of p, capped at 1.  NaNs propagate the way the sort
@@ -205,23 +225,7 @@ def get_q_vals(pvals_lst):
     if type(pvals_lst).__module__.startswith("torch") and pvals_lst.is_cuda:
         # device form for whole-genome tile sets (57.6 M p-values per cohort): the same IEEE operations in the same order
         # (p / (rank / n), reverse running minimum, cap), so the same bits as the host form and as statsmodels
-        import torch
-        p = pvals_lst.reshape(-1).to(torch.float64)
-        n = p.numel()
-        if n == 0:
-            return p.clone()
-        ps, order = torch.sort(p, stable=True)
-        # p / (rank / n), the reverse running minimum and the cap in one pass of the library (dig_bh_qvalues_sorted: torch.cummin
-        # took 21 of the 22 ms of a cohort's 7.2 M p-values)
-        from .. import _lib
-        q = torch.empty_like(ps)
-        wsb = int(_lib.load().dig_bh_workspace(n))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
-        with torch.cuda.device(p.device):
-            _lib.call("dig_bh_qvalues_sorted", _lib.dev_ptr(ps), n, _lib.dev_ptr(q), _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
-        out = torch.empty_like(q)
-        out[order] = q
-        return out.reshape(pvals_lst.shape)
+        return get_q_vals_rows(pvals_lst.reshape(1, -1)).reshape(pvals_lst.shape)
     p = np.asarray(pvals_lst, dtype=np.float64)
     n = p.size
     if n == 0:

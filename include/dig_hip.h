@@ -439,12 +439,13 @@ int dig_mutation_file_flags_host(void *handle, int64_t *first_row, int64_t *firs
 int dig_mutation_file_free_host(void *handle);
 
 /* ---- Benjamini-Hochberg q-values (nb_model.get_q_vals, nb_model.py:340-342 = statsmodels fdrcorrection, method 'indep') ---- *
- * For p-values ALREADY in ascending order (the caller sorts: torch.sort / rocPRIM): q_sorted[i] = min(1, min_{j >= i} p[j] / ((j + 1) / n)),
- * the same IEEE operations in the same order as the host form (a NaN -- sorted last -- makes every q NaN, as statsmodels does).
- * workspace: dig_bh_workspace(n) bytes.  One HBM-bound pass (round 5: torch.cummin took 21 ms per 7.2 M values, 99 % of the
+ * For `rows` lists of n p-values each, every list ALREADY in ascending order (the caller sorts: torch.sort / rocPRIM; row r at
+ * p_sorted + r n): q_sorted[i] = min(1, min_{j >= i} p[j] / ((j + 1) / n)), the same IEEE operations in the same order as the host
+ * form (a NaN -- sorted last -- makes every q of its list NaN, as statsmodels does).  workspace: dig_bh_workspace(n, rows) bytes.  One HBM-bound pass (round 5: torch.cummin took 21 ms per 7.2 M values, 99 % of the
  * per-base route of BASELINE configs[4]). */
-int64_t dig_bh_workspace(int64_t n);
-int dig_bh_qvalues_sorted(const double *p_sorted, int64_t n, double *q_sorted, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t dig_bh_workspace(int64_t n, int64_t rows);
+int dig_bh_qvalues_sorted(const double *p_sorted, int64_t n, int64_t rows, double *q_sorted, void *workspace, int64_t workspace_bytes,
+                          void *stream);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of
  * elements (host-side index construction, integer only): block b of element e covers bins

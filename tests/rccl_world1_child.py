@@ -116,10 +116,11 @@ def main(port, out_path):
         r = {k: v.clone() for k, v in r.items()}
         r["pval"] = torch.nan_to_num(r["pval"], nan=0.5)       # (an all-N bin's NaN makes every q-value NaN: also compare finite ones)
         sh.result = r
-        res[flag] = (r, [sh.q_values(c) for c in range(3)])
+        res[flag] = (r, [sh.q_values(c) for c in range(3)], sh.q_values_all())
     ok["ShardedTiles.run"] = all(_eq(res[True][0][k], res[False][0][k]) for k in res[False][0])
     ok["ShardedTiles.q_values"] = all(_eq(a, b) for a, b in zip(res[True][1], res[False][1])) and \
         bool(torch.isfinite(res[True][1][0][res[True][0]["n_valid"] > 0][:, 0]).all())
+    ok["ShardedTiles.q_values_all"] = _eq(res[True][2], res[False][2]) and _eq(res[True][2], torch.stack(res[True][1]))
 
     # ---- 3. predict_sharded on the real BinTrackStore ---------------------------------------------------------------
     from test_region_and_sequence_models import _golden_net

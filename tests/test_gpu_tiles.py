@@ -239,6 +239,14 @@ def test_sharded_tiles_equal_unsharded_bit_for_bit(n_up):
             assert torch.equal(torch.cat(got), want), (world, c)
         with pytest.raises(ValueError):
             ranks[0].q_values(0, gathered=allp)                                    # the caller's exchange needs the rank's offset
+    # all cohorts at once (one segmented sort, one batched pass): the bits of the per-cohort calls, with batches of one, two and all cohorts
+    one = parallel.ShardedTiles(genome, chroms, starts, ends, S, mu, sg, mc, ms, me, co, 50, dev, 0, 1)
+    res1 = one.run()
+    res1["pval"] = torch.nan_to_num(res1["pval"], nan=0.5)
+    per_cohort = torch.stack([one.q_values(c) for c in range(C)])
+    for cap in (1, 2 * int(valid.sum()), 1 << 28):
+        got = one.q_values_all(max_elements=cap)
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(per_cohort, nan=-7.0)), cap
 
 
 @pytest.mark.parametrize("binsize", [50, 1])
