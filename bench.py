@@ -204,7 +204,7 @@ class _Rebased:
         return self.rows[pos]
 
 
-def committed_traffic(kernel_prefixes):
+def committed_traffic(kernel_prefixes, exclude=()):
     """HBM bytes per launch of the dominant operation from the committed rocprofv3 PMC summary of this same
     command (profiles/rNN_traffic.json, made by tools/make_profile_summary.py: separate --pmc FETCH_SIZE /
     WRITE_SIZE passes, KiB units, FETCH_SIZE x2 on gfx950).  None when no summary is committed."""
@@ -213,7 +213,7 @@ def committed_traffic(kernel_prefixes):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    tot = sum(v["hbm_bytes"] for k, v in d["kernels"].items() if any(p in k for p in kernel_prefixes))
+    tot = sum(v["hbm_bytes"] for k, v in d["kernels"].items() if any(p in k for p in kernel_prefixes) and not any(x in k for x in exclude))
     return (tot or None), os.path.basename(files[-1])
 
 
@@ -576,6 +576,11 @@ def parse_args(argv=None):
     ap.add_argument("--pack-bins", type=int, default=1,
                     help="1 (default): the plans gather from the packed bin records built at plan time (dig_bin_records_pack); "
                          "0: from the four bin tables as handed in (A/B)")
+    ap.add_argument("--outputs", choices=["auto", "planes", "records"], default="auto",
+                    help="layout of the statistics stage's ten outputs per pair: planes (eleven arrays, the form of dig_element_stats), "
+                         "records (DIG_PIPE_RECORDS: one aligned 5 120-byte run per 64-pair tile, unpacked by dig_element_records_unpack), "
+                         "auto (default): the plan times both on THIS card before the run (untimed, reported as output_form) and keeps "
+                         "the faster -- the pool's two kinds of MI355X differ (profiles/r05_stats_kernel_probes.txt)")
     ap.add_argument("--aux", type=int, default=1,
                     help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
                          "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
@@ -596,16 +601,36 @@ def parse_args(argv=None):
 
 
 def gpu_identity():
-    """Serial numbers of the visible GPUs (`rocm-smi --showserial`, run as a child BEFORE this process touches a device).  The
-    pool holds two kinds of MI355X that differ by 5-10 % on the statistics kernel: the line says which
-    card a number came from."""
-    import re
-    import subprocess
+    """{PCI address: serial number} of the GPUs in sysfs (what `rocm-smi --showserial` prints) -- no child process: under
+    rocprofv3 --pmc the profiler's library has initialised the GPU before this program starts, and a process in that state
+    must not start another program.  The pool holds two kinds of MI355X that differ by 5-10 % on the statistics kernel
+    (DESIGN.md section 8): the line says which card a number came from."""
+    import glob
+    out = {}
+    for c in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        pci = os.path.basename(os.path.realpath(c)).lower()           # 0000:c5:00.0
+        for name in ("serial_number", "unique_id"):
+            try:
+                v = open(os.path.join(c, name)).read().strip()
+            except OSError:
+                continue
+            if v:
+                out[pci] = v
+                break
+    return out
+
+
+def gpu_serial_of(dev, serials):
+    """Serial number of torch device `dev`: sysfs entry with the device's PCI address (one entry: that one)."""
+    import torch
+    if len(serials) == 1:
+        return next(iter(serials.values()))
     try:
-        out = subprocess.run(["rocm-smi", "--showserial"], capture_output=True, text=True, timeout=60).stdout
-        return {int(m.group(1)): m.group(2) for m in re.finditer(r"GPU\[(\d+)\]\s*:\s*Serial Number:\s*(\S+)", out)}
-    except Exception:                                     # (no rocm-smi: the line says so)
-        return {}
+        p = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        return serials.get(pci)
+    except Exception:
+        return None
 
 
 # the statistics kernel's own time splits the pool's cards into two groups (round 5's kernel: see DESIGN.md section 8)
@@ -785,12 +810,15 @@ def run_workload(args, mode, ctx, primary=True):
     ctx_side = args.contexts_on == "side"
     PLAN_RING = 32 if ctx_side else 1
 
-    def make_plan(k):
+    use_records = [args.outputs == "records" and bool(args.pack_bins)]
+
+    def make_plan(k, records=None):
         acc_k = out_acc if k == 0 else dict(out_acc, R_SIZE=torch.empty_like(out_acc["R_SIZE"]))
         return engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"],
                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
                                    td["obs_indel"], out_acc=acc_k, out_stats=out_stats, compact=args.form == "auto",
-                                   pack_bins=(pipes[0] if pipes else True) if args.pack_bins else False)      # (plan time; shared)
+                                   pack_bins=(pipes[0] if pipes else True) if args.pack_bins else False,      # (plan time; shared)
+                                   records_out=use_records[0] if records is None else records)
     pipes = []
     torch.cuda.synchronize()
     t_one = time.perf_counter()
@@ -804,6 +832,37 @@ def run_workload(args, mode, ctx, primary=True):
     one_shot["total_ms"] = one_shot["h2d_ms"] + one_shot["plan_ms"] + one_shot["first_run_ms"]
     one_shot["what"] = ("fresh process, inputs in host memory: upload of every input (h2d), engine.PipelinePlan (plan), one dig_element_pipeline call "
                         "with given scale factors and its synchronisation (first_run); the timed loop below runs on warm plans")
+    # --outputs auto: which layout of the statistics stage's outputs is faster on THIS card (untimed, a property of the plan
+    # like the compact form: the statistics stage alone, three rounds of 25 launches of each form, HIP events)
+    output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs %s" % args.outputs}
+    if args.outputs == "auto" and args.pack_bins:
+        try:
+            alt = make_plan(0, records=True)
+            cal = {}
+            for name, pl in (("planes", pipes[0]), ("records", alt)):
+                pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
+                best = []
+                for _ in range(3):
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    for _w in range(5):
+                        pl.run(td["cj"], td["cj_indel"], stages=4, stream=main_stream)
+                    ea.record(main_stream)
+                    for _r in range(25):
+                        pl.run(td["cj"], td["cj_indel"], stages=4, stream=main_stream)
+                    eb.record(main_stream)
+                    torch.cuda.synchronize()
+                    best.append(ea.elapsed_time(eb) / 25 * 1e3)
+                cal[name] = min(best)
+            use_records[0] = cal["records"] < cal["planes"] - 1.5           # (us; a tie keeps the plane form)
+            output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs auto: statistics stage alone, best of "
+                           "three rounds of 25 launches of each form on this card, before the run (untimed)",
+                           "statistics_stage_us": {k: round(v, 1) for k, v in cal.items()}}
+            if use_records[0]:
+                pipes[0] = alt
+            del alt
+        except Exception as exc:                            # (the calibration must never cost the bench line)
+            output_form = {"chosen": "planes", "how": "--outputs auto: calibration failed (%r)" % (exc,)}
+            use_records[0] = False
     for k in range(1, PLAN_RING):
         pipes.append(make_plan(k))
     pipe = pipes[0]
@@ -1105,6 +1164,9 @@ def run_workload(args, mode, ctx, primary=True):
     if trace is not None and rank == 0:
         print("BENCH_TRACE statistics-stage brackets (us):", [round(a.elapsed_time(b_) * 1e3, 1) for a, b_ in samples["statistics"]][:40],
               file=sys.stderr)
+    if pipe.records_out:                                     # the loop's last result: blocks -> planes (dig_element_records_unpack), then checked like the plane form
+        pipes[(step_no[0] - 1) % PLAN_RING].unpack()
+        torch.cuda.synchronize()
     ok = bool(torch.isfinite(out_stats[1]).all().item())
     # the overlapped loop must have produced what a plain sequential evaluation produces (bit for bit)
     torch.cuda.synchronize()
@@ -1137,7 +1199,10 @@ def run_workload(args, mode, ctx, primary=True):
         def roof(name, by, ms, prefixes, n):
             if not ms:
                 return None
-            traffic, src = committed_traffic(prefixes) if default_shape else (None, None)
+            # (the trace of the command holds BOTH forms of the statistics kernel -- the sequential reference evaluation runs the plane
+            #  form: only the form the timed steps ran is counted)
+            other_form = ("3, false>", "0, false>") if pipe.records_out else ("3, true>",)
+            traffic, src = committed_traffic(prefixes, other_form) if default_shape else (None, None)
             ach = by / (ms * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": ach / (HBM_PEAK / 1e9), "traffic": traffic, "traffic_source": src,
@@ -1145,7 +1210,9 @@ def run_workload(args, mode, ctx, primary=True):
 
         stage_names = {
             "statistics": "dig_element_pipeline statistics stage: element_stats_stream_fused_kernel (one launch: the "
-                          "stream pass and, at the end of every workgroup, the pairs it could not finish in passing)",
+                          "stream pass and, at the end of every workgroup, the pairs it could not finish in passing); outputs as %s"
+                          % ("tile-blocked records (DIG_PIPE_RECORDS: one aligned 5 120-byte run per 64-pair tile)" if pipe.records_out else
+                             "eleven planes"),
             "contexts": "dig_element_pipeline contexts stage: acc_region_kernel",
             "dot": ("dig_element_pipeline accumulation (contexts + dot in one launch): acc_dot_ctx_kernel, the 64-context form for "
                     "context-repeated L -- checked and compacted to [E, 64] ONCE at plan time (dig_element_pipeline_prepare), "
@@ -1179,7 +1246,7 @@ def run_workload(args, mode, ctx, primary=True):
         if dominant_roof is stage_roofs["statistics"] and default_shape:
             # SURVEY 8d asks for both figures of this kernel: the HBM fraction above and the FP64-VALU utilisation of its
             # streaming pass (what actually bounds it)
-            vf, src = committed_valu_frac("element_stats_stream")
+            vf, src = committed_valu_frac("element_stats_stream_fused_kernel<1024, true, 3, %s>" % ("true" if pipe.records_out else "false"))
             dominant_roof["valu_frac"], dominant_roof["valu_frac_source"] = vf, src
         if dominant_roof is stage_roofs["statistics"]:
             if timed_by_stage_timers:
@@ -1218,11 +1285,13 @@ def run_workload(args, mode, ctx, primary=True):
             "ms_per_step_1000_note": ("the same step, 1 000 more times after the timed region (own barriers, host clock, max over "
                                       "ranks); NOT part of `value`: the asked %d steps are %.1f ms of GPU time" % (args.steps, dt * 1e3)
                                       if ms_step_1000 is not None else None),
-            "gpu": {"serial": ctx["gpu_serials"].get(ctx["local_rank"]), "serials_visible": [ctx["gpu_serials"][k] for k in sorted(ctx["gpu_serials"])],
-                    "kind": (None if not stage_ms.get("statistics") or not default_shape else
+            "gpu": {"serial": gpu_serial_of(dev, ctx["gpu_serials"]), "cards_in_sysfs": len(ctx["gpu_serials"]),
+                    "kind": (None if pipe.records_out or not stage_ms.get("statistics") or not default_shape else
                              "fast" if stage_ms["statistics"] * 1e3 < STATS_KERNEL_KIND_SPLIT_US else "common"),
-                    "kind_note": "the pool's MI355X fall into two groups by the statistics kernel's own time on this workload (split at "
-                                 "%.0f us for this build; DESIGN.md section 8); `serial` from rocm-smi" % STATS_KERNEL_KIND_SPLIT_US},
+                    "kind_note": "the pool's MI355X fall into two groups by the statistics kernel's own time WITH PLANE OUTPUTS on this "
+                                 "workload (split at %.0f us; DESIGN.md section 8): given when the run used that form; with the record "
+                                 "form both groups run alike (output_form.statistics_stage_us has this card's two times); `serial`: "
+                                 "sysfs, the number rocm-smi --showserial prints" % STATS_KERNEL_KIND_SPLIT_US},
             "roofline": dominant_roof,
             "roofline_step": step_roof,
             "roofline_other_stages": [stage_roofs["contexts"], stage_roofs["dot"]],
@@ -1253,6 +1322,7 @@ def run_workload(args, mode, ctx, primary=True):
                              % (args.contexts_on, SAMPLE_EVERY, "one of the smaller stages on every %d-th timed step" % SAMPLE_EVERY
                                 if SAMPLE_EVERY != 4 else "the smaller stages on the warm-up steps (a run this short keeps them out of "
                                                           "its timed steps)", args.steps),
+            "output_form": output_form,
             "one_shot": one_shot,
             "finite_pvalues": ok, "matches_sequential_evaluation": same, "slow_pair_fraction": slow_frac,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,

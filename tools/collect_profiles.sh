@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r03        -> gpurun_out/r03{a,f,w,v/*} ; then `python tools/make_profile_summary.py r03` here.
 # Kernel trace and counters in SEPARATE runs (counters with --kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
