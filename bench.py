@@ -697,7 +697,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch %d ranks (or leave WORLD_SIZE unset: bench.py starts them itself)"
                          % (args.gpus, world, args.gpus))
     ctx_gpu = gpu_identity() if rank == 0 else {}
-    modes = [args.mode] if args.mode != "both" else (["strong", "sharded"] if world > 1 else ["sharded"])
+    # (BENCH_FORCE_BOTH=1: a one-GPU check of the N > 1 control flow -- two workloads timed one after the other in one process)
+    modes = [args.mode] if args.mode != "both" else (["strong", "sharded"] if world > 1 or os.environ.get("BENCH_FORCE_BOTH") == "1"
+                                                     else ["sharded"])
     ctx = {"rank": rank, "local_rank": local_rank, "world": world, "gpu_serials": ctx_gpu}
     res = None
     for i, mode in enumerate(modes):
