@@ -53,6 +53,21 @@ for case in range(n_cases):
     torch.cuda.synchronize()
     ok = ok and torch.equal(torch.nan_to_num(st3, nan=-7.0), torch.nan_to_num(st2, nan=-7.0))
     ok = ok and all(torch.equal(torch.nan_to_num(acc[k].double(), nan=-7.0), torch.nan_to_num(acc3[k].double(), nan=-7.0)) for k in acc)
+    # the record form of the statistics stage (DIG_PIPE_RECORDS, round 5), general and compact accumulation: unpacked, the bits of the planes
+    for compact in (False, "auto"):
+        ref = plan if compact is False else engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"],
+                                                                td["ov_ptr"], td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"],
+                                                                td["obs_samples"], td["obs_indel"], pack_bins=plan)
+        acc_r, st_r = ref.run(td["cj"], td["cj_indel"])
+        rec = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                                  td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"], compact=compact,
+                                  pack_bins=plan, records_out=True)
+        rec.out_records.fill_(float("nan"))
+        rec.run(td["cj"], td["cj_indel"])
+        acc4, st4 = rec.unpack()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(torch.nan_to_num(st4, nan=-7.0), torch.nan_to_num(st_r, nan=-7.0))
+        ok = ok and all(torch.equal(torch.nan_to_num(acc_r[k].double(), nan=-7.0), torch.nan_to_num(acc4[k].double(), nan=-7.0)) for k in acc_r)
     neg = int((torch.nan_to_num(st2[1], nan=0.0) < 0).sum() + (torch.nan_to_num(st2[5], nan=0.0) < 0).sum())
     if not ok or neg:
         bad += 1
