@@ -241,7 +241,9 @@ constexpr int kTmChunk = 48;                   // cohorts per launch
 #define DIG_TM_OCC 2                           // workgroups per CU (register budget 256)
 #endif
 
-// One packed word of a tile's walk: contexts centred on nibbles centre0 .. centre0 + 7 (centre0 = 8 word - 1).
+// One packed word of a tile's walk: contexts centred on nibbles centre0 .. centre0 + 7 (centre0 = 8 word - 1).  GUARD: the
+// word holds a non-ACGT base or straddles the tile's ends -- the centres that count are one 8-bit mask (inside [lo, hi), no
+// non-ACGT base in the window), and a centre that does not count adds zero.
 template <bool GUARD>
 __device__ __forceinline__ void tile_word(unsigned w, unsigned& carry, unsigned& icarry, int centre0, int lo, int hi,
                                           unsigned* col, unsigned inc)
@@ -252,25 +254,64 @@ __device__ __forceinline__ void tile_word(unsigned w, unsigned& carry, unsigned&
     x = (x | (x >> 8)) & 0xFFFFu;
     const unsigned win = (x << 4) | carry;                         // the two bases before the word, then its eight
     carry = win >> 16;
-    unsigned iwin = 0;
+    unsigned okm = 0xFFu;
     if (GUARD) {
         unsigned f = ((w >> 2) | (w >> 3)) & 0x11111111u;          // non-ACGT flags, squeezed: base n at bit n
         f = (f | (f >> 3)) & 0x03030303u;
         f = (f | (f >> 6)) & 0x000F000Fu;
         f = (f | (f >> 12)) & 0xFFu;
-        iwin = (f << 2) | icarry;
+        const unsigned iwin = (f << 2) | icarry;                   // bit n + 2: base n of the word; bits n .. n + 2: the window of centre n
         icarry = iwin >> 8;
+        const int a = lo - centre0, b = hi - centre0;              // centres a .. b - 1 of the word lie inside the tile
+        const unsigned below_b = b >= 8 ? 0xFFu : (b <= 0 ? 0u : (1u << b) - 1u);
+        const unsigned below_a = a >= 8 ? 0xFFu : (a <= 0 ? 0u : (1u << a) - 1u);
+        okm = below_b & ~below_a & ~(iwin | (iwin >> 1) | (iwin >> 2));
     }
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const unsigned ctx = (win >> (2 * n)) & 63u;
-        unsigned add = inc;
-        if (GUARD) {
-            const int centre = centre0 + n;
-            add = (centre >= lo && centre < hi && ((iwin >> n) & 7u) == 0u) ? inc : 0u;
-        }
+        const unsigned add = GUARD ? ((okm >> n) & 1u) * inc : inc;
         atomicAdd(col + ctx * kTmStride32, add);
     }
+}
+
+// The walk of one region: thread t owns tile t (positions t binsize .. of the n_cov tiled ones; lo0 = staged nibble
+// coordinate of the region's first position) and counts its contexts into column t of the histogram.
+__device__ __forceinline__ void tile_histograms(const uint32_t* s_words, uint32_t* s_hist32, int t, int nv, int binsize, int n_cov,
+                                                int lo0)
+{
+    const bool live = t < nv;
+    const int tp = t * binsize;
+    int cnt = binsize;
+    if (cnt > n_cov - tp) cnt = n_cov - tp;
+    const int lo = live ? lo0 + tp : 0;                             // centres [lo, hi) in staged nibble coordinates
+    const int hi = live ? lo + cnt : 0;
+    const int w_last = live ? hi >> 3 : -1;                         // word of the right neighbour of the last position
+    unsigned carry = 0, icarry = 0;
+    const unsigned inc = 1u << (16 * (t & 1));
+    unsigned* col = s_hist32 + (t >> 1);
+    int wi = live ? (lo - 1) >> 3 : 0;
+    unsigned w_next = s_words[wi];                                 // (a word ahead: its wait does not drain the atomics behind it)
+    for (;; ++wi) {
+        const bool go = wi <= w_last;
+        if (!__any(go)) break;
+        const unsigned w = go ? w_next : 0u;
+        w_next = s_words[wi < kTileMaxWords ? wi + 1 : wi];
+        const int centre0 = 8 * wi - 1;
+        const bool plain = centre0 >= lo && centre0 + 7 < hi && (w & 0xCCCCCCCCu) == 0u && icarry == 0u;
+        if (__all(plain || !go)) {                                 // (wave-uniform: the middle words of every tile)
+            if (go) tile_word<false>(w, carry, icarry, centre0, lo, hi, col, inc);
+        } else if (go) {
+            tile_word<true>(w, carry, icarry, centre0, lo, hi, col, inc);
+        }
+    }
+}
+
+// 4-bit code of global base g straight from the packed array (array word = genome word + 1; clamped to the trailing pad word)
+__device__ __forceinline__ unsigned tile_base_global(const uint32_t* __restrict__ words, int64_t n_words, int64_t g)
+{
+    const int64_t w = (g >> 3) + 1;
+    return (words[w < n_words ? w : n_words - 1] >> (4 * (int)(g & 7))) & 15u;
 }
 
 #ifdef DIG_TM_TIMING                            // developer build: cycles per phase (wave 0 of every workgroup), tools/tile_variant_bench.py
@@ -351,30 +392,7 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
         __syncthreads();
         TM_MARK(1);
         // ---- per-tile context histograms ----
-        {
-            const bool live = tid < nv;
-            const int tp = tid * binsize;
-            int cnt = binsize;
-            if (cnt > n_cov - tp) cnt = n_cov - tp;
-            const int lo = live ? (int)(ga - g_lds0) + 1 + tp : 0;          // centres [lo, hi) in staged nibble coordinates
-            const int hi = live ? lo + cnt : 0;
-            const int w_last = live ? hi >> 3 : -1;                        // word of the right neighbour of the last position
-            unsigned carry = 0, icarry = 0;
-            const unsigned inc = 1u << (16 * (tid & 1));
-            unsigned* col = s_hist32 + (tid >> 1);
-            for (int wi = live ? (lo - 1) >> 3 : 0;; ++wi) {
-                const bool go = wi <= w_last;
-                if (!__any(go)) break;
-                const unsigned w = go ? s_words[wi] : 0u;
-                const int centre0 = 8 * wi - 1;
-                const bool plain = centre0 >= lo && centre0 + 7 < hi && (w & 0xCCCCCCCCu) == 0u && icarry == 0u;
-                if (__all(plain || !go)) {                     // (wave-uniform: the middle words of every tile)
-                    if (go) tile_word<false>(w, carry, icarry, centre0, lo, hi, col, inc);
-                } else if (go) {
-                    tile_word<true>(w, carry, icarry, centre0, lo, hi, col, inc);
-                }
-            }
-        }
+        tile_histograms(s_words, s_hist32, tid, nv, binsize, n_cov, (int)(ga - g_lds0) + 1);
         TM_MARK(2);
         __syncthreads();
         TM_MARK(3);
@@ -494,6 +512,325 @@ __global__ __launch_bounds__(kTileBlock, DIG_TM_OCC) void base_tile_probs_mfma_k
     }
 #ifdef DIG_TM_TIMING
     if (tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_tm_prof[k], tm_acc[k]);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two-role form of the matrix kernel (round 5; what dig_base_tile_probs launches).  tools/probe/mfma_f64_mix.hip: a chain of
+// DEPENDENT v_mfma_f64_16x16x4 issues every 64 clocks (the pipe's rate) whatever a second wave of the SIMD does, an FP64 vector
+// instruction of that second wave waits for a whole matrix instruction (73 clocks each) and an integer one gets about every
+// second slot.  The kernel above ran its matrix instructions 130 - 160 clocks apart because every one of them waited for the
+// v_cvt_f64_u32 of its B operand (an FP64 vector instruction behind the previous matrix instruction), and all four waves of a
+// workgroup sat in the same phase: global-load latency, LDS atomics and barriers were nobody's matrix time.  Here:
+//   * one workgroup of EIGHT waves per CU, two roles: waves 4-7 ("walkers", one per SIMD) build the histograms of region i + 1
+//     while waves 0-3 ("multipliers", one per SIMD) run the product of region i out of the other histogram buffer: ONE barrier
+//     per region, the walkers' latencies (packed words two regions ahead, region descriptions three ahead, 10 000 LDS atomics)
+//     are filled by the multipliers' matrix instructions;
+//   * no FP64 vector instruction in the product: a count becomes a double with three integer instructions (the high word of
+//     the double of n < 2^20 is the float's exponent and mantissa moved by three bits; the low word is zero), once per
+//     (histogram row group, tile group) for ALL cohort tiles and quads of the chunk (up to four independent chains);
+//   * no barrier inside a role: a walker wave zeroes, fills and sums the histogram columns of ITS 64 tiles (LDS operations of a
+//     wave execute in order), the region histogram H arrives as four partial rows per context; every multiplier wave forms
+//     T and 1 / T for itself;
+//   * whole tile groups go round the four multipliers, the cohort tiles / the quads of the last G mod 4 groups one by one
+//     (13 groups x (2 tiles + 2 quads): 8.5 / 8.5 / 8 / 7.5 tile-times instead of 10 / 7.5 / 7.5 / 7.5).
+// Same bits as the kernel above (same chains, same order; tests/test_gpu_tiles.py compares the two forms).
+constexpr int kTsBlock = 512;
+constexpr int kTsPer = (kTileMaxWords + 2 + 255) / 256;         // packed words a walker thread carries for the next region
+
+__device__ __forceinline__ double count_as_double(unsigned n)   // n < 2^20, exact, integer instructions only
+{
+    const unsigned f = __float_as_uint((float)n);
+    const unsigned hi = n ? (f >> 3) + 0x38000000u : 0u;        // exponent 127 -> 1023; the 20 mantissa bits in use fit the high word
+    return __hiloint2double((int)hi, 0);
+}
+
+__device__ __forceinline__ TileRegion tile_region_of(int64_t len, int64_t off, int64_t start, int64_t end)
+{
+    TileRegion t;
+    t.first = start == 0 ? 1 : start;
+    const int64_t stop = end < len - 1 ? end : len - 1;
+    t.n_pos = stop > t.first ? stop - t.first : 0;
+    t.g0 = off + t.first;
+    return t;
+}
+
+// One tile group: the chains named by MASK (bit m = cohort tile m, bit MT = the quads) share the converted histogram values.
+// The counts travel two steps ahead of the matrix instructions that take them (read at ks - 2, converted at ks - 1 behind the
+// issue of step ks - 1's matrix instructions, i.e. while the last of them runs): written as it stands, the sequence
+// read -> wait -> convert -> multiply left the matrix pipe idle for the LDS round trip and five dependent vector instructions
+// in every step.  The plane stride reaches the stores through an opaque scalar so that the ten plane addresses are formed at the
+// store (one 64-bit add each) instead of living in twenty registers across the loop.
+template <int MT, int NQ, unsigned MASK>
+__device__ __forceinline__ void ts_group(const double (&A)[MT > 0 ? MT : 1][16], const double (&Aq)[NQ > 0 ? NQ : 1][16],
+                                         const unsigned short* hp, double* o, bool col_ok, bool tile_ok,
+                                         const double (&rt)[MT > 0 ? MT : 1][4], const double (&rtq)[NQ > 0 ? NQ : 1], int c0, int64_t C,
+                                         int lk, int64_t cohort_stride)
+{
+    constexpr int MTA = MT > 0 ? MT : 1, NQA = NQ > 0 ? NQ : 1;
+    constexpr bool QUADS = NQ > 0 && ((MASK >> MT) & 1u);
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    tile_double4 acc[MTA];
+    double accq[NQA];
+#pragma unroll
+    for (int m = 0; m < MTA; ++m) acc[m] = tile_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) accq[q] = 0.0;
+    unsigned raw = hp[0];
+    double b = count_as_double(raw);
+    raw = hp[4 * kTmStride];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if ((MASK >> m) & 1u) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[m][ks], b, acc[m], 0, 0, 0);
+        if (QUADS) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) accq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Aq[q][ks], b, accq[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < 15) b = count_as_double(raw);
+        if (ks < 14) raw = hp[4 * (ks + 2) * kTmStride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (col_ok) {
+        int64_t cs = cohort_stride;
+        asm volatile("" : "+s"(cs));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if ((MASK >> m) & 1u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + 16 * m + 4 * q + lk < C)
+                        __builtin_nontemporal_store(tile_ok ? acc[m][q] * rt[m][q] : nan, o + (16 * m + 4 * q) * cs);
+            }
+        if (QUADS) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (c0 + 16 * MT + 4 * q + lk < C)
+                    __builtin_nontemporal_store(tile_ok ? accq[q] * rtq[q] : nan, o + (16 * MT + 4 * q) * cs);
+        }
+    }
+}
+
+template <int MT, int NQ = 0>
+__global__ __launch_bounds__(kTsBlock, 1) void base_tile_probs_roles_kernel(
+    const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
+    const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
+    const int64_t* __restrict__ reg_end, int64_t R, const double* __restrict__ s_prob, int64_t C, int c0, int binsize, int n_tiles,
+    double* __restrict__ pt, int64_t* __restrict__ first_pos, int32_t* __restrict__ n_valid)
+{
+    __shared__ uint32_t s_words[2][kTileMaxWords + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist32[2][64 * kTmStride32];
+    __shared__ __attribute__((aligned(16))) unsigned s_Hp[2][64][4];      // region histogram: one partial per walker wave
+    __shared__ int s_nv[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool walker = wave >= 4;
+    const int li = lane & 15, lk = lane >> 4;
+    constexpr int MTA = MT > 0 ? MT : 1, NQA = NQ > 0 ? NQ : 1;
+    constexpr int P = MT + (NQ > 0 ? 1 : 0);                               // chains of a tile group that can be dealt singly
+    constexpr unsigned ALL = (1u << P) - 1u;
+    const int64_t n_my = blockIdx.x < R ? (R - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int n_groups = (n_tiles + 15) >> 4;
+    const int64_t cohort_stride = R * n_tiles;
+    const int64_t tiled = (int64_t)n_tiles * binsize;
+
+    double A[MTA][16], Aq[NQA][16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int row = 4 * ks + lk;                                    // histogram row = b0 + 4 b1 + 16 b2 (walk order) ...
+        const int ctx = ((row & 3) << 4) | (row & 12) | (row >> 4);     // ... of context 16 b0 + 4 b1 + b2
+#pragma unroll
+        for (int m = 0; m < MTA; ++m) {
+            const int64_t c = c0 + 16 * m + li;
+            A[m][ks] = (!walker && m < MT && c < C) ? s_prob[c * 64 + ctx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+            const int64_t c = c0 + 16 * MT + 4 * q + (lane & 3);
+            Aq[q][ks] = (!walker && q < NQ && c < C) ? s_prob[c * 64 + ctx] : 0.0;
+        }
+    }
+
+    // ---- walker state: region i (d_cur), i + 1 (d_nxt: its words travel during the walk of i), i + 2 (raw: chromosome, start, end) ----
+    const int ht = tid - 256, hw = wave - 4;
+    auto region_index = [&](int64_t i) { const int64_t r = blockIdx.x + i * gridDim.x; return r < R ? r : R - 1; };
+    TileRegion d_cur = {0, 0, 0}, d_nxt = {0, 0, 0};
+    int raw_chrom = 0;
+    int64_t raw_start = 0, raw_end = 0;
+    auto words_of = [&](const TileRegion& d, int64_t& w0, int& nw, int& n_cov) {
+        n_cov = (int)(d.n_pos < tiled ? d.n_pos : tiled);
+        const int64_t ga = d.g0 - 1;
+        w0 = (ga >> 3) + 1;
+        nw = (int)(((ga + n_cov + 1) >> 3) + 1 - w0 + 1);
+    };
+    if (walker && n_my > 0) {
+        const int64_t r0 = region_index(0), r1 = region_index(1), r2 = region_index(2);
+        const int ch0 = reg_chrom[r0], ch1 = reg_chrom[r1];
+        d_cur = tile_region_of(chrom_len[ch0], chrom_off[ch0], reg_start[r0], reg_end[r0]);
+        d_nxt = tile_region_of(chrom_len[ch1], chrom_off[ch1], reg_start[r1], reg_end[r1]);
+        raw_chrom = reg_chrom[r2];
+        raw_start = reg_start[r2];
+        raw_end = reg_end[r2];
+        int64_t w0;
+        int nw, n_cov;
+        words_of(d_cur, w0, nw, n_cov);
+        stage_words<256>(s_words[0], words, n_words, w0, nw, ht);
+    }
+    __syncthreads();
+
+#ifdef DIG_TM_TIMING                            // walker leader: 0 loads issued | 1 zero | 2 walk | 3 sums | 4 words + description | 5 barrier;
+    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_last = __builtin_readcyclecounter();      // multiplier leader: 6 product | 7 barrier
+#define TS_MARK(k) do { if (lane == 0 && (wave == 0 || wave == 4)) { const unsigned long long now_ = __builtin_readcyclecounter(); tm_acc[k] += now_ - tm_last; tm_last = now_; } } while (0)
+#else
+#define TS_MARK(k) do {} while (0)
+#endif
+    for (int64_t i = 0; i <= n_my; ++i) {
+        const int b = (int)(i & 1);
+        if (walker) {
+            if (i < n_my) {
+                const int64_t r = blockIdx.x + i * gridDim.x;
+                // the next region's packed words: loads now, LDS writes behind the walk
+                uint32_t wreg[kTsPer];
+                int64_t w0n;
+                int nwn, n_cov_n;
+                words_of(d_nxt, w0n, nwn, n_cov_n);
+                if (i + 1 >= n_my) nwn = 0;
+#pragma unroll
+                for (int j = 0; j < kTsPer; ++j) {
+                    const int64_t k = ht + (int64_t)j * 256;
+                    wreg[j] = k < nwn ? __builtin_nontemporal_load(&words[(w0n + k < n_words ? w0n + k : n_words - 1)]) : 0u;
+                }
+                // the description of region i + 2 (its chromosome's row) and the raw row of region i + 3
+                const int64_t len2 = chrom_len[raw_chrom], off2 = chrom_off[raw_chrom];
+                const int64_t r3 = region_index(i + 3);
+                const int ch3 = reg_chrom[r3];
+                const int64_t st3 = reg_start[r3], en3 = reg_end[r3];
+
+                const TileRegion reg = d_cur;
+                const int64_t tiles_valid = (reg.n_pos + binsize - 1) / binsize;
+                const int nv = (int)(tiles_valid < n_tiles ? tiles_valid : n_tiles);
+                const int n_cov = (int)(reg.n_pos < tiled ? reg.n_pos : tiled);
+                if (ht == 0) {
+                    first_pos[r] = reg.first;
+                    n_valid[r] = nv;
+                    s_nv[b] = nv;
+                }
+                uint32_t* hist = s_hist32[b];
+                TS_MARK(0);
+                {   // zero the columns of this wave's tiles (32 dwords of every row): eight rows per 16-byte store
+                    uint4* z = reinterpret_cast<uint4*>(hist + 32 * hw + 4 * (lane & 7)) ;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) z[((lane >> 3) + 8 * k) * (kTmStride32 / 4)] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                TS_MARK(1);
+                const int64_t ga = reg.g0 - 1;
+                const int64_t g_lds0 = (((ga >> 3) + 1) - 1) << 3;
+                tile_histograms(s_words[b], hist, ht, nv, binsize, n_cov, (int)(ga - g_lds0) + 1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                TS_MARK(2);
+                {   // this wave's share of H: lane = histogram row
+                    const uint4* rowp = reinterpret_cast<const uint4*>(hist + lane * kTmStride32 + 32 * hw);
+                    unsigned sum = 0;                                   // two 16-bit sums side by side
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint4 v = rowp[j];
+                        sum += (v.x + v.y) + (v.z + v.w);
+                    }
+                    s_Hp[b][lane][hw] = (sum & 0xffffu) + (sum >> 16);
+                }
+                if (reg.n_pos > n_cov) {                              // positions behind the last tile count for the normalisation only
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    for (int64_t j = n_cov + ht; j < reg.n_pos; j += 256) {
+                        const int64_t g = reg.g0 + j;
+                        const unsigned a = tile_base_global(words, n_words, g - 1), bb = tile_base_global(words, n_words, g),
+                                       c = tile_base_global(words, n_words, g + 1);
+                        if (!((a | bb | c) & 12u)) atomicAdd(&s_Hp[b][a + 4 * bb + 16 * c][hw], 1u);
+                    }
+                }
+                TS_MARK(3);
+                // the next region's words (the buffer was last read in iteration i - 1)
+#pragma unroll
+                for (int j = 0; j < kTsPer; ++j) {
+                    const int k = ht + j * 256;
+                    if (k < nwn) s_words[b ^ 1][k] = wreg[j];
+                }
+                d_cur = d_nxt;
+                d_nxt = tile_region_of(len2, off2, raw_start, raw_end);
+                raw_chrom = ch3;
+                raw_start = st3;
+                raw_end = en3;
+                TS_MARK(4);
+            }
+        } else if (i > 0) {
+            const int bp = b ^ 1;
+            const int64_t r = blockIdx.x + (i - 1) * gridDim.x;
+            const int nv = s_nv[bp];
+            // ---- 1 / T[c] (every wave for itself), moved into the lane layout of D ----
+            double rt[MTA][4], rtq[NQA];
+            {
+                double t[MTA], tq[NQA];
+#pragma unroll
+                for (int m = 0; m < MTA; ++m) t[m] = 0.0;
+#pragma unroll
+                for (int q = 0; q < NQA; ++q) tq[q] = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const uint4 h4 = *reinterpret_cast<const uint4*>(&s_Hp[bp][4 * ks + lk][0]);
+                    const double hv = (double)((h4.x + h4.y) + (h4.z + h4.w));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) t[m] = fma(hv, A[m][ks], t[m]);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) tq[q] = fma(hv, Aq[q][ks], tq[q]);
+                }
+#pragma unroll
+                for (int m = 0; m < MTA; ++m) {
+                    t[m] += __shfl_xor(t[m], 16, 64);
+                    t[m] += __shfl_xor(t[m], 32, 64);
+                    const double inv = 1.0 / t[m];                 // lane i (any k) holds cohort 16 m + i
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rt[m][q] = __shfl(inv, 4 * q + lk, 64);     // D register q: cohort 16 m + 4 q + k
+                }
+#pragma unroll
+                for (int q = 0; q < NQA; ++q) {
+                    tq[q] += __shfl_xor(tq[q], 16, 64);
+                    tq[q] += __shfl_xor(tq[q], 32, 64);
+                    rtq[q] = __shfl(1.0 / tq[q], lk, 64);          // lane i % 4 (any k, b) holds cohort i of the quad; D: cohort k
+                }
+            }
+            // ---- the product ----
+            const unsigned short* s_hist16 = reinterpret_cast<const unsigned short*>(s_hist32[bp]);
+            double* const out_lane = pt + ((int64_t)(c0 + lk) * R + r) * n_tiles + li;       // cohort c0 + k, tile i
+            const int g_full = n_groups & ~3;
+            for (int n = wave; n < g_full; n += 4) {
+                const int t = 16 * n + li;
+                ts_group<MT, NQ, ALL>(A, Aq, s_hist16 + lk * kTmStride + 16 * n + li, out_lane + 16 * n, t < n_tiles, t < nv, rt, rtq, c0,
+                                      C, lk, cohort_stride);
+            }
+            for (int u = wave; u < (n_groups - g_full) * P; u += 4) {
+                const int n = g_full + u / P, part = u % P;
+                const int t = 16 * n + li;
+                const unsigned short* hp = s_hist16 + lk * kTmStride + 16 * n + li;
+                double* o = out_lane + 16 * n;
+                if (part == 0) ts_group<MT, NQ, 1u>(A, Aq, hp, o, t < n_tiles, t < nv, rt, rtq, c0, C, lk, cohort_stride);
+                if constexpr (P > 1)
+                    if (part == 1) ts_group<MT, NQ, 2u>(A, Aq, hp, o, t < n_tiles, t < nv, rt, rtq, c0, C, lk, cohort_stride);
+                if constexpr (P > 2)
+                    if (part == 2) ts_group<MT, NQ, 4u>(A, Aq, hp, o, t < n_tiles, t < nv, rt, rtq, c0, C, lk, cohort_stride);
+                if constexpr (P > 3)
+                    if (part == 3) ts_group<MT, NQ, 8u>(A, Aq, hp, o, t < n_tiles, t < nv, rt, rtq, c0, C, lk, cohort_stride);
+            }
+            TS_MARK(6);
+        }
+        __syncthreads();
+        if (walker) TS_MARK(5);
+        else TS_MARK(7);
+    }
+#ifdef DIG_TM_TIMING
+    if (lane == 0 && (wave == 0 || wave == 4))
         for (int k = 0; k < 8; ++k) atomicAdd(&g_tm_prof[k], tm_acc[k]);
 #endif
 }
@@ -881,7 +1218,14 @@ int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int
     const bool mfma = !classic && binsize >= 2 && n_tiles >= 1 && n_tiles <= kTileBlock && C >= 1 &&
                       n_tiles * binsize <= (int64_t)(kTileMaxWords - 1) * 8;
     if (mfma) {
-        const int grid = grid_for(R * kTileBlock, kTileBlock, DIG_TM_OCC);
+        // Which matrix kernel: the two-role one for a chunk of two or more cohort tiles (32 cohorts and up: 1.28 -> 1.22 ms at
+        // 37, 1.41 -> 1.34 at 48), the one-role one below that (its two workgroups per CU walk twice as fast when the product
+        // is short: 0.93 against 0.95 ms at 21 cohorts, 0.60 against 0.69 at 5).  DIG_TILES_FORM = "one-role" / "two-role"
+        // (developer switch) forces either.
+        static const int forced = []() {
+            const char* e = getenv("DIG_TILES_FORM");
+            return e && e[0] == 'o' ? 1 : (e && e[0] == 't' ? 2 : 0);
+        }();
         for (int64_t c0 = 0; c0 < C; c0 += kTmChunk) {
             // the chunk's cohorts as full tiles + quads: a remainder of 1 .. 4 is one quad, 5 .. 8 two, 9 and more a (padded) tile.
             // DIG_TILES_CUT=0 (developer switch): whole tiles only.
@@ -891,18 +1235,25 @@ int dig_base_tile_probs(const uint32_t* genome_words, int64_t n_words, const int
             const int r16 = rem & 15;
             if (!cut || r16 >= 9) mt += r16 > 0;
             else nq = (r16 + 3) >> 2;
-            auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words, chrom_off,
-                                   chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, (int)c0, binsize, (int)n_tiles, pt,
-                                   first_pos, n_valid);
+            const bool one_role = forced ? forced == 1 : mt < 2;
+            const int grid = one_role ? grid_for(R * kTileBlock, kTileBlock, DIG_TM_OCC) : grid_for(R * kTsBlock, kTsBlock, 1);
+            auto go = [&](auto kern, auto kern_roles) {
+                if (one_role)
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), 0, (hipStream_t)stream, genome_words, n_words, chrom_off,
+                                       chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, (int)c0, binsize, (int)n_tiles, pt,
+                                       first_pos, n_valid);
+                else
+                    hipLaunchKernelGGL(kern_roles, dim3(grid), dim3(kTsBlock), 0, (hipStream_t)stream, genome_words, n_words,
+                                       chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, (int)c0, binsize,
+                                       (int)n_tiles, pt, first_pos, n_valid);
             };
             auto pick = [&](auto mt_c) {
                 constexpr int M = decltype(mt_c)::value;
-                if (nq == 2) go(base_tile_probs_mfma_kernel<M, 2>);
-                else if (nq == 1) go(base_tile_probs_mfma_kernel<M, 1>);
-                else if constexpr (M > 0) go(base_tile_probs_mfma_kernel<M, 0>);
+                if (nq == 2) go(base_tile_probs_mfma_kernel<M, 2>, base_tile_probs_roles_kernel<M, 2>);
+                else if (nq == 1) go(base_tile_probs_mfma_kernel<M, 1>, base_tile_probs_roles_kernel<M, 1>);
+                else if constexpr (M > 0) go(base_tile_probs_mfma_kernel<M, 0>, base_tile_probs_roles_kernel<M, 0>);
             };
-            if (mt == 3) go(base_tile_probs_mfma_kernel<3, 0>);
+            if (mt == 3) go(base_tile_probs_mfma_kernel<3, 0>, base_tile_probs_roles_kernel<3, 0>);
             else if (mt == 2) pick(std::integral_constant<int, 2>{});
             else if (mt == 1) pick(std::integral_constant<int, 1>{});
             else pick(std::integral_constant<int, 0>{});

@@ -323,6 +323,44 @@ def test_general_context_kernel_many_cohorts_against_oracle_and_trinucleotide_ke
         np.testing.assert_allclose(out["general"]["pt"], out["mfma"]["pt"], rtol=1e-12, equal_nan=True)
 
 
+def test_two_role_matrix_kernel_gives_the_bits_of_the_one_role_kernel():
+    """base_tile_probs_roles_kernel (walker waves + multiplier waves, what dig_base_tile_probs launches for 32 cohorts and more)
+    against base_tile_probs_mfma_kernel (DIG_TILES_FORM=one-role, own process): 37 and 48 cohorts, a single region and more
+    regions than workgroups, ragged last tiles, N runs, regions at a chromosome's start and over its end, fewer tiles asked
+    for than a region has (positions behind the last tile), binsize 7 -- every value bit for bit, NaN for NaN."""
+    import subprocess
+    import sys
+    import tempfile
+    rng = np.random.default_rng(23)
+    seqs = {"chr1": "".join(rng.choice(list("ACGTN"), 60211, p=[.24, .25, .25, .24, .02])), "chr2": "".join(rng.choice(list("ACGT"), 1803))}
+    n1 = 600                                                   # more regions than the 256 workgroups of the two-role kernel
+    chroms = ["chr1"] * n1 + ["chr2"] * 2
+    starts = np.r_[np.arange(n1, dtype=np.int64) * 100, [0, 1000]]
+    ends = np.r_[starts[:n1] + rng.integers(1, 1000, n1), [1000, 2000]]
+    ends[n1 - 1] = 70000                                       # over the chromosome's end
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from digdriver_amd import engine; "
+            "from digdriver_amd.data_tools.genome import PackedGenome; d = np.load(sys.argv[1], allow_pickle=True); "
+            "g = PackedGenome.from_sequences(d['seqs'].item()); out = {}\n"
+            "for k, (C, binsize, n_tiles, nreg) in enumerate(((37, 50, None, None), (48, 50, 11, None), (37, 7, 120, None), (33, 50, None, 1), (64, 25, None, 300))):\n"
+            "    n = nreg or len(d['chroms'])\n"
+            "    pt, f, nv = engine.base_tile_probs(g, list(d['chroms'][:n]), d['starts'][:n], d['ends'][:n], d['S'][:C], binsize, n_tiles=n_tiles, device=0)\n"
+            "    out['pt%%d' %% k], out['f%%d' %% k], out['n%%d' %% k] = pt.cpu().numpy(), f.cpu().numpy(), nv.cpu().numpy()\n"
+            "np.savez(sys.argv[2], **out)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), seqs=np.array(seqs, dtype=object), chroms=np.array(chroms), starts=starts, ends=ends,
+                 S=rng.uniform(1e-4, 1e-2, (64, 64)))
+        out = {}
+        for form in ("one-role", "two-role"):
+            env = dict(os.environ, DIG_TILES_FORM=form)
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, form + ".npz")], env=env)
+            out[form] = np.load(os.path.join(tmp, form + ".npz"))
+        assert len(out["one-role"].files) == 15
+        for key in out["one-role"].files:
+            a, b = out["one-role"][key], out["two-role"][key]
+            assert a.shape == b.shape and a.tobytes() == b.tobytes(), key
+        assert np.isfinite(out["two-role"]["pt0"]).sum() > 1000
+
+
 def test_collapsed_contexts_k96_per_base_route_and_counts_match_reference():
     """collapse=True (the north star's "96-trinucleotide-context" wording; no live caller of the reference passes it): the
     per-base route nb_model(..., collapse=True) for trinucleotide (32-context S_prob) and penta-nucleotide (512) tables and

@@ -74,7 +74,8 @@ def child(ref_path, write_ref):
         tot = float(sum(buf))
         out["phase_cycles_per_region_block"] = [round(v / nwin, 1) for v in buf]
         out["phase_share"] = [round(v / tot, 3) for v in buf]
-        out["phases"] = "stage+zero | barrier | hist | barrier | Hsum(+tail) | barrier | T+product+stores | barrier"
+        out["phases"] = ("one-role kernel: stage+zero | barrier | hist | barrier | Hsum(+tail) | barrier | T+product+stores | barrier; "
+                         "two-role kernel: walker loads | zero | walk | sums | words+description | barrier, multiplier product | barrier")
     except AttributeError:
         pass
     sel = np.unique(np.clip(np.r_[0:40, 495:505, 1995:2005, nwin - 20:nwin], 0, nwin - 1))
