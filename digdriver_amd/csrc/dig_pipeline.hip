@@ -28,7 +28,14 @@ struct FusedRates {
     const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
     const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
     int records;               // DIG_PIPE_RECORDS: `out` holds one record of DIG_REC_DOUBLES doubles per pair
+    // one-kernel form (dot stage inside the statistics kernel): set dot_P, else all NULL
+    const int32_t *dot_bin_ctx, *dot_Lc, *dot_gene_length;
+    const uint8_t* dot_strand;
+    const double* dot_d_pr;
+    double *dot_P, *dot_P_INDEL;
+    int32_t *dot_R_SIZE, *dot_ELT_SIZE;
 };
+bool one_kernel_form_fits(int64_t E, int64_t C);
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                       const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L, int n_class,
@@ -260,6 +267,24 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     const int64_t acc_bytes = lay.acc_bytes;
     // the first kernel also clears the worklist header of the statistics stage (64 dwords): no separate memset node
     unsigned* wl = (unsigned*)((char*)workspace + acc_bytes);
+    // DIG_PIPE_FORM=one (developer switch, tools/variant_bench.py): dot + statistics stages of one call as ONE kernel -- record
+    // outputs, compact L, packed bin records, 33 - 37 cohorts; same bits (tests/test_gpu_parity.py)
+    static const bool want_one = []() {
+        const char* e = getenv("DIG_PIPE_FORM");
+        return e && e[0] == 'o';
+    }();
+    const bool one_kernel = want_one && compact && records && bin_records && (stages & 6) == 6 && one_kernel_form_fits(E, C);
+    if (one_kernel) {
+        DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && d_pr && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null accumulation arguments");
+        DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");
+        const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
+        const BinRecords lay_r = bin_records_layout(N, C);
+        FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, (const double2*)bin_records,
+                     (const int32_t*)((const char*)bin_records + lay_r.yf_off), 1,
+                     bin_ctx, (const int32_t*)((char*)workspace + lay.lc_off), gene_length, strand_minus, d_pr, P, P_INDEL, R_SIZE, ELT_SIZE};
+        return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel, out, E, C,
+                                    (char*)workspace + acc_bytes, lay.stats_bytes, stream, &f, /* the kernel clears the header itself */ 1);
+    }
     if (compact) {
         // context-repeated L, compacted by dig_element_pipeline_prepare: contexts + dot are ONE kernel (the DOT stage; a
         // CONTEXTS-only call has nothing to enqueue)
@@ -278,7 +303,8 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     }
     if (!(stages & 4)) return DIG_OK;
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
-    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records};
+    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records,
+                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (records) {
         DIG_REQUIRE(bin_records, "DIG_PIPE_RECORDS needs bin_records (dig_bin_records_pack)");
         DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");
