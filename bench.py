@@ -486,7 +486,7 @@ def aux_rooflines(dev):
                                   50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=3, warm=1)
     tiles = chunk * 200
     fl = 2.0 * 64 * 37 * tiles
-    out.append({"kernel": "dig_base_tile_probs (base_tile_probs_mfma_kernel, v_mfma_f64_16x16x4)", "bound": "mfma", "achieved": fl / dt / 1e12,
+    out.append({"kernel": "dig_base_tile_probs (base_tile_probs_roles_kernel: walker + multiplier waves, v_mfma_f64_16x16x4 + 4x4x4 quads)", "bound": "mfma", "achieved": fl / dt / 1e12,
                 "peak": 78.6, "unit": "TFLOP/s", "frac": fl / dt / 78.6e12, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": chunk * window * 0.5 + tiles * 37 * 8.0,
                 "hbm_frac": (chunk * window * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK, "avg_launch_ms": dt * 1e3,
