@@ -589,6 +589,11 @@ def parse_args(argv=None):
                          "files) and time the drop-in from files to 37 results.txt, stage by stage (tools/e2e_bench.py; ~40 s, 1.7 GB "
                          "under --e2e-dir); reported as e2e; 0: skip")
     ap.add_argument("--e2e-dir", default=None, help="scratch directory of the e2e leg (default: a fresh directory under the system's temp)")
+    ap.add_argument("--scale-factors", choices=["auto", "inside", "side"], default="auto",
+                    help="where the cohort scale factors of a step are formed: inside = in the pipeline's own two kernels "
+                         "(dig_element_pipeline_scaled: the dot kernel's waves sum the rate table, the statistics kernel divides; one "
+                         "GPU, same bits; measured slower at this size), side = kernels of their own on a side stream (the only form when "
+                         "the bins are sharded: the chunk sums are all-gathered); auto = side")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -798,7 +803,7 @@ def run_workload(args, mode, ctx, primary=True):
     cj_outs = [(torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
                for _ in range(RING)]
     main_stream = torch.cuda.current_stream(dev)
-    side_stream = torch.cuda.Stream(device=dev, priority=-1)     # own hardware queue even when RCCL holds streams too
+    side_stream = torch.cuda.Stream(device=dev, priority=-1 if use_dist else 0)     # (-1: a hardware queue of its own even when RCCL holds streams too; alone, the normal priority is 1 - 2 us better)
     side_done = [torch.cuda.Event() for _ in range(RING)]   # scale factors of a step are ready
     main_done = [torch.cuda.Event() for _ in range(RING)]   # the main stream has finished a step (paces the side stream)
     step_no = [0]
@@ -847,18 +852,18 @@ def run_workload(args, mode, ctx, primary=True):
                 for _ in range(3):
                     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     for _w in range(5):
-                        pl.run(td["cj"], td["cj_indel"], stages=4, stream=main_stream)
+                        pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
                     ea.record(main_stream)
                     for _r in range(25):
-                        pl.run(td["cj"], td["cj_indel"], stages=4, stream=main_stream)
+                        pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
                     eb.record(main_stream)
                     torch.cuda.synchronize()
                     best.append(ea.elapsed_time(eb) / 25 * 1e3)
                 cal[name] = min(best)
             use_records[0] = cal["records"] < cal["planes"] - 1.5           # (us; a tie keeps the plane form)
-            output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs auto: statistics stage alone, best of "
-                           "three rounds of 25 launches of each form on this card, before the run (untimed)",
-                           "statistics_stage_us": {k: round(v, 1) for k, v in cal.items()}}
+            output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs auto: whole passes (dot + statistics kernel, "
+                           "given scale factors), best of three rounds of 25 of each form on this card, before the run (untimed)",
+                           "pass_us": {k: round(v, 1) for k, v in cal.items()}}
             if use_records[0]:
                 pipes[0] = alt
             del alt
@@ -874,6 +879,20 @@ def run_workload(args, mode, ctx, primary=True):
     scale_plan = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"],
                                                parallel.N_CHUNKS, world=None if exchange else 1)
 
+    # (auto = side: at the whole-genome size the rate table's 85 MB cost the dot kernel more inside it -- +27 us -- than the background
+    #  kernel costs the statistics kernel beside it -- 10 - 17 us; profiles/r05_stats_kernel_probes.txt item 10)
+    scale_inside = args.scale_factors == "inside" and not (use_dist and exchange)
+    if scale_inside:
+        assert pipe.compact and args.contexts_on == "main" and C <= 48, "--scale-factors inside: the compact accumulation, --contexts-on main, C <= 48"
+        for pl in pipes:
+            pl.attach_scale_factors(scale_plan)
+
+    def run_pipe(plan, cj, cji, stages, stream):
+        """One dig_element_pipeline call (given scale factors) or one dig_element_pipeline_scaled call (cj, cji are written)."""
+        if scale_inside:
+            return plan.run_scaled(cj, cji, stages=stages, stream=stream)
+        return plan.run(cj, cji, stages=stages, stream=stream)
+
     def enqueue_scale_factors(t):
         """Side stream: (1) chunk sums of the per-cohort sufficient statistics of this rank's bins (transfer_tools.py:148-156)
         -> (2) all-gather of [chunk sums ; observed counts] over RCCL when the bins are sharded ((64 / N + 2) x C doubles per
@@ -883,7 +902,10 @@ def run_workload(args, mode, ctx, primary=True):
         with torch.cuda.stream(side_stream):
             if args.side_lead > 0 and t >= args.side_lead:
                 side_stream.wait_event(main_done[(t - args.side_lead) % RING])
-            scale_plan.run(cj_out[0], cj_out[1], stream=side_stream)
+            if t == 0 or not os.environ.get("BENCH_NO_SIDE"):
+                scale_plan.run(cj_out[0], cj_out[1], stream=side_stream)
+            else:                                   # developer probe (the line says so): the first step's factors for every step
+                cj_outs[b] = cj_outs[0]
             if ctx_side:
                 # plan t % 32 was last used by step t - 32: the main stream's throttle event of step t - 16 (recorded
                 # in front of that step) says that everything up to step t - 17 has run
@@ -984,7 +1006,7 @@ def run_workload(args, mode, ctx, primary=True):
             if k >= 3:
                 throttle_events[(k - 3) % len(throttle_events)].synchronize()
         # this step's (first call only) and the coming steps' scale factors; nothing beyond the last step of the run
-        while queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps + EXTRA_STEPS - 1):
+        while not scale_inside and queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps + EXTRA_STEPS - 1):
             queued[0] += 1
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
@@ -992,7 +1014,8 @@ def run_workload(args, mode, ctx, primary=True):
             ev = slack_events.pop()
             ev.record(main_stream)
             slack_main[t] = ev
-        main_stream.wait_event(side_done[b])
+        if not scale_inside:
+            main_stream.wait_event(side_done[b])
         which = sample_which(t)
         plan = pipes[t % PLAN_RING]
         if which in ("dot", "statistics") and len(timer_pool) >= 3:      # (one timer stays for the self-test after the loop)
@@ -1009,11 +1032,11 @@ def run_workload(args, mode, ctx, primary=True):
                 staged("dot", which, lambda: plan.run(cj, cji, stages=2, stream=main_stream))
                 staged("statistics", which, lambda: plan.run(cj, cji, stages=4 | 8, stream=main_stream))
         elif which is None:
-            plan.run(cj, cji, stages=7, stream=main_stream)
+            run_pipe(plan, cj, cji, 7, main_stream)
         else:
-            staged("contexts", which, lambda: plan.run(cj, cji, stages=1, stream=main_stream))    # context kernel
-            staged("dot", which, lambda: plan.run(cj, cji, stages=2, stream=main_stream))         # dot kernel
-            staged("statistics", which, lambda: plan.run(cj, cji, stages=4 | 8, stream=main_stream))  # statistics (header cleared by the stages=1 call)
+            staged("contexts", which, lambda: run_pipe(plan, cj, cji, 1, main_stream))    # context kernel
+            staged("dot", which, lambda: run_pipe(plan, cj, cji, 2, main_stream))         # dot kernel
+            staged("statistics", which, lambda: run_pipe(plan, cj, cji, 4 | 8, main_stream))  # statistics (header cleared by the stages=1 call)
         if args.side_lead > 0:
             main_done[b].record(main_stream)
 
@@ -1065,6 +1088,9 @@ def run_workload(args, mode, ctx, primary=True):
     reh_cj, reh_cji = torch.empty_like(seq_cj), torch.empty_like(seq_cji)
     reh_ev = torch.cuda.Event()
     for _ in range(args.settle_passes):
+        if scale_inside:
+            run_pipe(pipe, reh_cj, reh_cji, 7, main_stream)
+            continue
         with torch.cuda.stream(side_stream):
             scale_plan.run(reh_cj, reh_cji, stream=side_stream)
             reh_ev.record(side_stream)
@@ -1195,6 +1221,8 @@ def run_workload(args, mode, ctx, primary=True):
                        "statistics": E * C * (21.0 * nbar + 24 + 100)}
         if pipe.compact:            # one launch does the work of both accumulation stages (SURVEY's unfused count is kept)
             stage_bytes["dot"] += stage_bytes["contexts"]
+        if scale_inside:            # ... and sums the rate table for the scale factors (8 bytes per (bin, cohort): the pre-masked table)
+            stage_bytes["dot"] += 8.0 * N_own * C
         stage_kernels = {"contexts": ["acc_region"], "dot": ["acc_dot"], "statistics": ["element_stats_"]}
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37) and world == 1
 
@@ -1203,7 +1231,7 @@ def run_workload(args, mode, ctx, primary=True):
                 return None
             # (the trace of the command holds BOTH forms of the statistics kernel -- the sequential reference evaluation runs the plane
             #  form: only the form the timed steps ran is counted)
-            other_form = ("3, false>", "0, false>") if pipe.records_out else ("3, true>",)
+            other_form = ("3, false", "0, false") if pipe.records_out else ("3, true",)      # (template arguments follow the flag)
             traffic, src = committed_traffic(prefixes, other_form) if default_shape else (None, None)
             ach = by / (ms * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -1248,7 +1276,7 @@ def run_workload(args, mode, ctx, primary=True):
         if dominant_roof is stage_roofs["statistics"] and default_shape:
             # SURVEY 8d asks for both figures of this kernel: the HBM fraction above and the FP64-VALU utilisation of its
             # streaming pass (what actually bounds it)
-            vf, src = committed_valu_frac("element_stats_stream_fused_kernel<1024, true, 3, %s>" % ("true" if pipe.records_out else "false"))
+            vf, src = committed_valu_frac("element_stats_stream_fused_kernel<1024, true, 3, %s" % ("true" if pipe.records_out else "false"))
             dominant_roof["valu_frac"], dominant_roof["valu_frac_source"] = vf, src
         if dominant_roof is stage_roofs["statistics"]:
             if timed_by_stage_timers:
@@ -1281,7 +1309,11 @@ def run_workload(args, mode, ctx, primary=True):
                                               "elements in all, about %d per GPU), all-gather of the per-cohort chunk sums every step",
                                     "replicas": "%d-bin genome replicated on each of %d GPUs, %d cohorts, %d elements in all (%d per GPU), "
                                                 "no exchange"}[mode] % (args.bins, world, C, E_total, E_total // world),
-                       "mode": mode, "contexts_on": args.contexts_on, "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
+                       "mode": mode, "contexts_on": args.contexts_on,
+                       "scale_factors": "DEVELOPER PROBE (BENCH_NO_SIDE): formed ONCE, not per step -- not a valid bench line" if os.environ.get("BENCH_NO_SIDE") and not scale_inside else ("inside the pipeline's two kernels (dig_element_pipeline_scaled): the dot kernel's waves sum the rate table, "
+                                         "the statistics kernel divides before its first tile" if scale_inside else
+                                         "kernels of their own on a side stream, several steps ahead" + (" (chunk sums all-gathered over RCCL)" if use_dist and exchange else "")),
+                       "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
                        "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if mode != "replicas" else "replicas x%d" % world},
             "ms_per_step_1000": ms_step_1000,
             "ms_per_step_1000_note": ("the same step, 1 000 more times after the timed region (own barriers, host clock, max over "
@@ -1292,7 +1324,7 @@ def run_workload(args, mode, ctx, primary=True):
                              "fast" if stage_ms["statistics"] * 1e3 < STATS_KERNEL_KIND_SPLIT_US else "common"),
                     "kind_note": "the pool's MI355X fall into two groups by the statistics kernel's own time WITH PLANE OUTPUTS on this "
                                  "workload (split at %.0f us; DESIGN.md section 8): given when the run used that form; with the record "
-                                 "form both groups run alike (output_form.statistics_stage_us has this card's two times); `serial`: "
+                                 "form both groups run alike (output_form.pass_us has this card's two whole-pass times); `serial`: "
                                  "sysfs, the number rocm-smi --showserial prints" % STATS_KERNEL_KIND_SPLIT_US},
             "roofline": dominant_roof,
             "roofline_step": step_roof,

@@ -97,6 +97,10 @@ struct ElementStatsArgs {
     const double* dot_d_pr;
     double *dot_P, *dot_P_INDEL;
     int32_t *dot_R_SIZE, *dot_ELT_SIZE;
+    // dig_element_pipeline_scaled: the scale factors cj / cj_indel are formed here, before the first tile, from the chunk sums the
+    // dot kernel left (ss.chunk_sums) and the observed totals, exactly as scale_factors_chunked_kernel forms them; every workgroup
+    // keeps them in LDS and writes them to cj / cj_indel above (which then point at OUTPUT arrays)
+    ScaleInside ss;
 #ifdef DIG_DEV_ABLATE
     int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
 #endif
@@ -434,6 +438,7 @@ __shared__ unsigned g_queue_list[16][48];
 __shared__ unsigned g_queue_len, g_ovf_len, g_ovf_next;
 __shared__ unsigned g_tests[3 * kQueueCap];      // the open tests of the queue: record * 4 + role
 __shared__ unsigned g_n_tests, g_next_test;
+__shared__ double g_cj[2][256];             // dig_element_pipeline_scaled: the workgroup's copy of the scale factors
 constexpr int kSlowBlock = 256;
 constexpr int kSlowWaves = kSlowBlock / 64;
 constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
@@ -767,6 +772,27 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     const int64_t dot_lo = DOT ? n_tiles * blockIdx.x / gridDim.x : 0, dot_hi = DOT ? n_tiles * (blockIdx.x + 1) / gridDim.x : 0;
     const int64_t dot_k_lo = DOT ? dot_lo / a.C : 0;
     const int dot_nk = DOT && dot_hi > dot_lo ? (int)((dot_hi - 1) / a.C - dot_k_lo + 1) : 0;
+    const bool scaled = FUSED && a.ss.chunk_sums != nullptr;
+    if (FUSED && scaled) {
+        // (the chunk sums go through the queue's LDS, which nothing uses yet: all loads at once, then one thread per cohort
+        //  adds its column first to last -- a loop of dependent-looking global loads per thread was 17 us of every launch)
+        const int nsum = a.ss.n_chunks * (int)a.C;             // <= 256 x 48 doubles = the first 96 KB... of at most kQueueCap x 11
+        double* stage = queue;
+        for (int i = threadIdx.x; i < nsum; i += TB) stage[i] = a.ss.chunk_sums[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < (int)a.C; c += TB) {
+            double e = 0.0, sn = 0.0, dn = 0.0;
+            for (int j = 0; j < a.ss.n_chunks; ++j) e += stage[j * (int)a.C + c];
+            sn += a.ss.obs[c];
+            dn += a.ss.obs[a.C + c];
+            const double cj = sn / e, cji = dn / e;            // transfer_tools.py:153-154
+            g_cj[0][c] = cj;
+            g_cj[1][c] = cji;
+            a.ss.cj[c] = cj;                                    // (every workgroup the same values: its own later reads of them hit its own writes)
+            a.ss.cj_indel[c] = cji;
+            if (a.ss.sum_out) a.ss.sum_out[c] = e;
+        }
+    }
     if constexpr (DOT) {
         if (threadIdx.x < 2) f_prod[threadIdx.x] = f_cons[threadIdx.x] = 0u;
         if (threadIdx.x < 64) f_cohort_bad[threadIdx.x] = 0u;
@@ -882,8 +908,13 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         r.k_snv = __builtin_nontemporal_load(&a.obs_snv[s.i]);
         r.k_smp = __builtin_nontemporal_load(&a.obs_samples[s.i]);
         r.k_ind = __builtin_nontemporal_load(&a.obs_indel[s.i]);
+        if (FUSED && scaled) {
+            r.cj = g_cj[0][s.c];
+            r.cji = g_cj[1][s.c];
+        } else {
         r.cj = a.cj[s.c];
         r.cji = a.cj_indel[s.c];
+        }
         return r;
     };
     auto fetch_bin = [&](const StageIn& r) {
@@ -1543,6 +1574,7 @@ struct FusedRates {
     const double* dot_d_pr;
     double *dot_P, *dot_P_INDEL;
     int32_t *dot_R_SIZE, *dot_ELT_SIZE;
+    ScaleInside ss;            // dig_element_pipeline_scaled (chunk_sums NULL: not in use)
 };
 
 // The shapes the one-kernel form is built for: the bench workload's 37 cohorts (two cohort tiles + two quads) down to 33.
@@ -1556,6 +1588,10 @@ static int stream_form()      // 1 = three-deep pipelined fused kernel (default)
 {
     const char* e = getenv("DIG_ES_FORM");
     return e ? atoi(e) : 1;
+}
+static bool which_form_takes_scale()      // the 1024-thread ticket kernel (the default form)
+{
+    return stream_form() == 1 && (!getenv("DIG_ES_TICKETS") || atoi(getenv("DIG_ES_TICKETS")) == 1024);
 }
 static int stream_blocks_per_cu(int dflt)
 {
@@ -1582,7 +1618,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ScaleInside{}
 #ifdef DIG_DEV_ABLATE
                        , 0
 #endif
@@ -1597,6 +1633,12 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.dot_bin_ctx = fused->dot_bin_ctx; a.dot_Lc = fused->dot_Lc; a.dot_gene_length = fused->dot_gene_length;
         a.dot_strand = fused->dot_strand; a.dot_d_pr = fused->dot_d_pr;
         a.dot_P = fused->dot_P; a.dot_P_INDEL = fused->dot_P_INDEL; a.dot_R_SIZE = fused->dot_R_SIZE; a.dot_ELT_SIZE = fused->dot_ELT_SIZE;
+        a.ss = fused->ss;
+        if (a.ss.chunk_sums) {
+            DIG_REQUIRE(C <= 256 && which_form_takes_scale(), "scale factors inside the pipeline: C <= 256, the default form of the statistics kernel");
+            a.cj = a.ss.cj;
+            a.cj_indel = a.ss.cj_indel;
+        }
     }
 #ifdef DIG_DEV_ABLATE
     a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;

@@ -876,6 +876,50 @@ def test_record_major_outputs_give_the_same_bits(torch_dev):
         engine.PipelinePlan(*args, records_out=True, pack_bins=False)
 
 
+def test_scale_factors_formed_inside_the_pipeline_give_the_same_bits(torch_dev):
+    """dig_element_pipeline_scaled (ABI 10): the dot kernel's waves also form the chunk sums of the rate table, the statistics
+    kernel divides -- against ChunkedScaleFactorPlan.run() (own kernels) followed by the plain pipeline: cj, cj_indel, the sum and
+    every output of the pipeline bit for bit; plane and record form, 1 ... 48 cohorts, 1 ... 64 chunks, tables with fewer rows than
+    chunks (empty chunks), chunks shorter than a block, flagged bins; a second call on the same scratch (the counters are back
+    at zero); dot stage and statistics stage as two calls."""
+    import torch
+    from bench import make_workload
+    from digdriver_amd import engine, parallel
+    cases = ((9000, 7000, 37, 2, 64), (333, 900, 5, 3, 64), (40, 300, 48, 4, 64), (5000, 6000, 37, 5, 1), (2000, 1500, 17, 6, 7),
+             (70000, 20000, 37, 7, 64))
+    for (nb, E, C, seed, n_chunks) in cases:
+        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
+        w["bin_flag"][::5] = 1
+        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
+        chunk_rows = parallel.canonical_chunks(nb, n_chunks)
+        sp = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], chunk_rows, n_chunks, world=1)
+        cj, cji, tot = (torch.empty(C, dtype=torch.float64, device=torch_dev) for _ in range(3))
+        sp.run(cj, cji, out_sum=tot)
+        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
+                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
+        ref = engine.PipelinePlan(*args)
+        assert ref.compact
+        a0, s0 = ref.run(cj, cji)
+        torch.cuda.synchronize()
+        for records in (False, True):
+            plan = engine.PipelinePlan(*args, records_out=records, pack_bins=ref).attach_scale_factors(sp)
+            for rep in range(2):
+                cj2, cji2, tot2 = (torch.full((C,), -3.0, dtype=torch.float64, device=torch_dev) for _ in range(3))
+                for v in plan.acc.values():
+                    v.fill_(-5)
+                if rep == 0:
+                    plan.run_scaled(cj2, cji2, out_sum=tot2)
+                else:                                   # the two stages as two calls
+                    plan.run_scaled(cj2, cji2, out_sum=tot2, stages=3)
+                    plan.run_scaled(cj2, cji2, out_sum=tot2, stages=4)
+                a1, s1 = plan.unpack() if records else (plan.acc, plan.stats)
+                torch.cuda.synchronize()
+                assert torch.equal(cj, cj2) and torch.equal(cji, cji2) and torch.equal(tot, tot2), (nb, C, n_chunks, records, rep)
+                for k in a0:
+                    assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, nb, C)
+                assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (nb, C, records, rep)
+
+
 _ONE_KERNEL_CHILD = r"""
 import sys
 import numpy as np
