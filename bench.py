@@ -879,8 +879,8 @@ def run_workload(args, mode, ctx, primary=True):
     scale_plan = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"],
                                                parallel.N_CHUNKS, world=None if exchange else 1)
 
-    # (auto = side: at the whole-genome size the rate table's 85 MB cost the dot kernel more inside it -- +27 us -- than the background
-    #  kernel costs the statistics kernel beside it -- 10 - 17 us; profiles/r05_stats_kernel_probes.txt item 10)
+    # (auto = side: at the whole-genome size the rate table's 85 MB cost the dot kernel 12 us inside it and give the statistics kernel
+    #  4 - 9 us back: +1 ... +4 us per step; profiles/r05_stats_kernel_probes.txt item 10)
     scale_inside = args.scale_factors == "inside" and not (use_dist and exchange)
     if scale_inside:
         assert pipe.compact and args.contexts_on == "main" and C <= 48, "--scale-factors inside: the compact accumulation, --contexts-on main, C <= 48"

@@ -679,6 +679,10 @@ __global__ __launch_bounds__(256) void compact_L_kernel(const int32_t* __restric
 // the other -- a pass is rpp * C consecutive doubles; then column c adds its rpp row-group sums first to last.  The wave that
 // completes a chunk (a device-scope counter per chunk) adds the chunk's block sums first to last as suffstats_chunk_stage2 does.
 // Block sums cross XCDs: written and read with device-scope atomic operations (no cache-wide fences).
+#ifndef DIG_SCALE_KB
+#define DIG_SCALE_KB 8      // (32 loads per lane in flight: 4 -> 56.4 us, 8 -> 54.4, 16 spills -> 74.5; the kernel without the sums: 42.7)
+#endif
+template <int KB>      // KB passes of the block in flight at once (4 KB loads per lane): 16 = the whole block
 __device__ __forceinline__ void scale_inside_blocks(const ScaleInside& ss, int C, double* part, int lane, int64_t first, int64_t step)
 {
     const int rpp = 256 / C, nacc = rpp * C;
@@ -690,25 +694,30 @@ __device__ __forceinline__ void scale_inside_blocks(const ScaleInside& ss, int C
         const int n_rows = (int)(ss.blk_rows[2 * blk + 1] - r0);
         const double* base = ss.table + r0 * C;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        // (thirty-two unconditional loads in flight -- an entry outside the block replays the block's first one and is not added;
-        //  a load under its own condition is a round trip of its own: 64 of them made the kernel 46 us longer)
+        // (sixteen unconditional loads in flight -- an entry outside the block replays the block's first one and is not added; a
+        //  load under its own condition is a round trip of its own: 64 of them made the kernel 46 us longer.  The offsets are formed
+        //  per block from an opaque zero: as loop invariants the compiler keeps all 64 addresses, spills them at 128 registers and
+        //  reloads one in front of every load.)
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        const int lim = n_rows * C;                              // entries of the block
 #pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += 8) {
-            double v[8][4];
+        for (int k0 = 0; k0 < 16; k0 += KB) {
+            double v[KB][4];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int a = lane + 64 * q;
-                    const bool in = a < nacc && rg[q] + (k0 + kk) * rpp < n_rows;
-                    v[kk][q] = __builtin_nontemporal_load(base + (in ? (k0 + kk) * nacc + a : 0));
+                    const int off = (k0 + kk) * nacc + a + oz;   // = (row group + (k0 + kk) rpp) C + column
+                    v[kk][q] = __builtin_nontemporal_load(base + (a < nacc && off < lim ? off : 0));
                 }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int a = lane + 64 * q;
-                    if (a < nacc && rg[q] + (k0 + kk) * rpp < n_rows) acc[q] += v[kk][q];
+                    if (a < nacc && (k0 + kk) * nacc + a < lim) acc[q] += v[kk][q];
                 }
         }
 #pragma unroll
@@ -729,13 +738,13 @@ __device__ __forceinline__ void scale_inside_blocks(const ScaleInside& ss, int C
         if (__shfl(last, 0, 64)) {
             if (lane < C) {
                 double s = 0.0;
-                for (int b = b0; b < b1; b += 16) {            // sixteen loads in flight, then their additions first to last
-                    double v[16];
+                for (int b = b0; b < b1; b += 3 * KB) {        // 3 KB loads in flight, then their additions first to last
+                    double v[3 * KB];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
+                    for (int i = 0; i < 3 * KB; ++i)
                         v[i] = __hip_atomic_load(&ss.partial[(int64_t)(b + i < b1 ? b + i : b0) * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
+                    for (int i = 0; i < 3 * KB; ++i)
                         if (b + i < b1) s += v[i];
                 }
                 ss.chunk_sums[(int64_t)j * C + lane] = s;
@@ -965,10 +974,11 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
         b_n = b_nn;
         tile += stride;
     }
-    // (dealt to all waves behind their tiles.  Measured at the bench size: the kernel 37 -> 64 us, i.e. the 85 MB do NOT hide behind
-    //  the matrix work -- the waves reach this point together, when the tiles are done; only the waves with one tile fewer than the
-    //  others, or blocks drawn from one device-wide counter, were slower still: profiles/r05_stats_kernel_probes.txt item 10)
-    if (ss.table) scale_inside_blocks(ss, C, ss_part[wave], lane, (int64_t)blockIdx.x * kCtxWaves + wave, (int64_t)gridDim.x * kCtxWaves);
+    // (dealt to all waves behind their tiles.  Measured at the bench size: the kernel 42.7 -> 54.4 us by its stage timer -- the
+    //  85 MB do not hide behind the matrix work, the waves reach this point together when the tiles are done.  Slower still: the waves
+    //  with one tile fewer taking all blocks, blocks drawn from one device-wide counter, a 128-register form of the kernel with a
+    //  fourth wave per SIMD that only streams the table (71 us): profiles/r05_stats_kernel_probes.txt item 10)
+    if (ss.table) scale_inside_blocks<DIG_SCALE_KB>(ss, C, ss_part[wave], lane, (int64_t)blockIdx.x * kCtxWaves + wave, (int64_t)gridDim.x * kCtxWaves);
 }
 
 struct AccWorkspace {
