@@ -927,7 +927,13 @@ def run_workload(args, mode, ctx, primary=True):
     # most one pair and seven steps in eight carry none (< 1 % of the loop time).
     # (short runs -- the driver's 20 steps -- bracket the dominant stage on every 4th step, 5 samples instead of 2, and the
     #  two smaller stages in turn on another: one bracket on every second step, about 1 % of the loop)
-    SAMPLE_EVERY = 8 if args.steps >= 100 else 4
+    # (a sampled step costs the loop ~30 us -- the timed launches wait for their own begin and end signals: every 8th step sampled was
+    #  0.1845 ms per step where every 64th is 0.1815 and none 0.1807, same box -- so long runs sample every 32nd step and a short
+    #  run two of its timed steps)
+    SHORT = args.steps < 100
+    SAMPLE_EVERY = 32 if not SHORT else 10
+    if os.environ.get("BENCH_SAMPLE_EVERY"):                 # developer probe: what the stage timers cost the loop
+        SAMPLE_EVERY = int(os.environ["BENCH_SAMPLE_EVERY"])
     sample_slot = {1: "contexts", 3: "dot", 5: "statistics"}
     samples = {"contexts": [], "dot": [], "statistics": []}
     sampling = [False]
@@ -975,12 +981,12 @@ def run_workload(args, mode, ctx, primary=True):
         if not sampling[0]:
             # short runs bracket the two SMALLER stages on their (untimed) warm-up steps instead of inside the K timed ones: a
             # bracket splits the step's one call into three and adds two event packets, ~10 us of a 200-us step
-            if SAMPLE_EVERY == 4 and warming[0]:
+            if SHORT and warming[0]:
                 which = ("dot", "contexts")[t % 2]
                 return "dot" if which == "contexts" and pipe.compact else which
             return None
-        if SAMPLE_EVERY == 4:       # short runs: statistics (the `roofline` kernel) on the timed steps 1 mod 4
-            which = "statistics" if t % 4 == 1 else None
+        if SHORT:                   # short runs: statistics (the `roofline` kernel) on the timed steps 1 mod SAMPLE_EVERY
+            which = "statistics" if t % SAMPLE_EVERY == 1 else None
         else:
             which = sample_slot.get(t % SAMPLE_EVERY)
         if which == "contexts" and pipe.compact:       # the compact form has no context kernel: contexts + dot are one launch
@@ -1355,7 +1361,7 @@ def run_workload(args, mode, ctx, primary=True):
                              "`roofline_step` brackets all %d timed steps on the main stream (side-stream work overlapped); rocprofv3 "
                              "per-kernel averages of the same command: profiles/"
                              % (args.contexts_on, SAMPLE_EVERY, "one of the smaller stages on every %d-th timed step" % SAMPLE_EVERY
-                                if SAMPLE_EVERY != 4 else "the smaller stages on the warm-up steps (a run this short keeps them out of "
+                                if not SHORT else "the smaller stages on the warm-up steps (a run this short keeps them out of "
                                                           "its timed steps)", args.steps),
             "output_form": output_form,
             "one_shot": one_shot,
