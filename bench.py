@@ -843,27 +843,43 @@ def run_workload(args, mode, ctx, primary=True):
     # --outputs auto: which layout of the statistics stage's outputs is faster on THIS card (untimed, a property of the plan
     # like the compact form: the statistics stage alone, three rounds of 25 launches of each form, HIP events)
     output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs %s" % args.outputs}
+    # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
+    # exchanges nothing (its plan has world = 1)
+    exchange = use_dist and (sharded or world == 1)
+    scale_plan = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"],
+                                               parallel.N_CHUNKS, world=None if exchange else 1)
+
     if args.outputs == "auto" and args.pack_bins:
         try:
             alt = make_plan(0, records=True)
             cal = {}
-            for name, pl in (("planes", pipes[0]), ("records", alt)):
+            cal_cj = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
+            beside = not exchange                            # (the sharded plan's run() is a collective: kept out of the calibration)
+
+            def cal_pass(pl):
+                # what a step of the loop puts on the device: the scale factors' kernels on the side stream, free-running, and one
+                # whole pass on the main stream (which form is faster depends on what runs beside it: in isolation the two tie on
+                # cards where the record form is 5 - 8 us per step ahead in the loop)
+                if beside:
+                    scale_plan.run(cal_cj[0], cal_cj[1], stream=side_stream)
                 pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
+            for name, pl in (("planes", pipes[0]), ("records", alt)):
                 best = []
                 for _ in range(3):
                     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    for _w in range(5):
-                        pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
+                    for _w in range(8):
+                        cal_pass(pl)
                     ea.record(main_stream)
                     for _r in range(25):
-                        pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
+                        cal_pass(pl)
                     eb.record(main_stream)
                     torch.cuda.synchronize()
                     best.append(ea.elapsed_time(eb) / 25 * 1e3)
                 cal[name] = min(best)
             use_records[0] = cal["records"] < cal["planes"] - 1.5           # (us; a tie keeps the plane form)
             output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs auto: whole passes (dot + statistics kernel, "
-                           "given scale factors), best of three rounds of 25 of each form on this card, before the run (untimed)",
+                           "given scale factors%s), best of three rounds of 25 of each form on this card, before the run (untimed)"
+                           % (", the scale factors' kernels running beside them on the side stream as in the loop" if beside else ""),
                            "pass_us": {k: round(v, 1) for k, v in cal.items()}}
             if use_records[0]:
                 pipes[0] = alt
@@ -874,12 +890,6 @@ def run_workload(args, mode, ctx, primary=True):
     for k in range(1, PLAN_RING):
         pipes.append(make_plan(k))
     pipe = pipes[0]
-    # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
-    # exchanges nothing (its plan has world = 1)
-    exchange = use_dist and (sharded or world == 1)
-    scale_plan = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], w["chunk_rows"],
-                                               parallel.N_CHUNKS, world=None if exchange else 1)
-
     # (auto = side: at the whole-genome size the rate table's 85 MB cost the dot kernel 12 us inside it and give the statistics kernel
     #  4 - 9 us back: +1 ... +4 us per step; profiles/r05_stats_kernel_probes.txt item 10)
     scale_inside = args.scale_factors == "inside" and not (use_dist and exchange)
