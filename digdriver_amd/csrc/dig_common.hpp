@@ -96,6 +96,13 @@ struct ScaleInside {
     double *cj, *cj_indel, *sum_out;     // outputs ([C] each; sum_out may be NULL)
 };
 
+// dig_tiles_rows.hip: the row walk of the tile probabilities, one launch per cohort pass; regions it does not take are left with
+// n_valid = -2 for the general kernel (dig_tiles.hip)
+int launch_tile_probs_rows(const uint32_t* words, int64_t n_words, const int64_t* chrom_off, const int64_t* chrom_len,
+                           const int32_t* reg_chrom, const int64_t* reg_start, const int64_t* reg_end, int64_t R, const double* s_prob,
+                           int64_t C, int n_up, int binsize, int64_t n_tiles, double* pt, int64_t* first_pos, int32_t* n_valid,
+                           hipStream_t stream);
+
 inline int grid_for(int64_t n, int block, int max_blocks_per_cu = 8)
 {
     int64_t want = (n + block - 1) / block;

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
     const uint32_t* __restrict__ words, int64_t n_words, const int64_t* __restrict__ chrom_off,
     const int64_t* __restrict__ chrom_len, const int32_t* __restrict__ reg_chrom, const int64_t* __restrict__ reg_start,
     const int64_t* __restrict__ reg_end, int64_t R, const double* __restrict__ s_prob, int64_t C, int binsize, int64_t n_tiles,
-    double* __restrict__ pt, int64_t* __restrict__ first_pos, int32_t* __restrict__ n_valid)
+    double* __restrict__ pt, int64_t* __restrict__ first_pos, int32_t* __restrict__ n_valid, int only_deferred)
 {
     constexpr int W = 2 * U + 1;                      // window
     constexpr int K = 1 << (2 * W);                   // contexts
@@ -936,8 +936,19 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
         return a;
     };
     const int64_t G = gridDim.x;
+    // only_deferred: behind the row walk (dig_tiles_rows.hip), which leaves n_valid = -2 at the regions it did not take: a
+    // workgroup visits those of its regions only (and leaves at once when it has none); the mark is replaced in the last pass.
+    auto next_region = [&](int64_t r) {
+        r += G;
+        if (only_deferred)
+            while (r < R && n_valid[r] != -2) r += G;
+        return r;
+    };
+    const int64_t r_first = only_deferred ? next_region((int64_t)blockIdx.x - G) : (int64_t)blockIdx.x;
+    if (r_first >= R) return;
     for (int64_t c0 = 0; c0 < C; c0 += kCtxCoh) {
         const int cc = (int)(C - c0 < kCtxCoh ? C - c0 : kCtxCoh);
+        const bool meta_pass = only_deferred ? c0 + kCtxCoh >= C : c0 == 0;
         __syncthreads();
         for (int idx = tid; idx < (K + 1) * kCtxCoh; idx += kCtxBlock) {
             const int code = idx >> 3, co = idx & 7;
@@ -949,23 +960,22 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
         }
         CtxRegion nxt{};
         uint32_t staged[kCtxWordsPer];
-        CtxRaw raw1 = raw_of(blockIdx.x);
-        if ((int64_t)blockIdx.x < R) {
-            nxt = ctx_region<U>(raw1, chrom_len[raw1.chrom], chrom_off[raw1.chrom], binsize);
-            request(nxt, staged);
-        }
-        raw1 = raw_of(blockIdx.x + G);                // the region after this workgroup's first
-        for (int64_t r = blockIdx.x; r < R; r += G) {
+        CtxRaw raw1 = raw_of(r_first);
+        nxt = ctx_region<U>(raw1, chrom_len[raw1.chrom], chrom_off[raw1.chrom], binsize);
+        request(nxt, staged);
+        int64_t r1 = next_region(r_first), r2 = next_region(r1);      // the regions after this one
+        raw1 = raw_of(r1);
+        for (int64_t r = r_first; r < R; r = r1, r1 = r2, r2 = next_region(r2)) {
             const CtxRegion q = nxt;
             const int64_t tiles = q.too_long ? 0 : (q.tiles_valid < n_tiles ? q.tiles_valid : n_tiles);     // tiles written with values
-            if (tid == 0 && c0 == 0) {
+            if (tid == 0 && meta_pass) {
                 first_pos[r] = q.first;
                 n_valid[r] = q.too_long ? -1 : (int32_t)tiles;
             }
             // (requested now, used after the codes: the description of the region after the next, the chromosome of the next)
-            const CtxRaw raw2 = raw_of(r + 2 * G);
+            const CtxRaw raw2 = raw_of(r2);
             int64_t len1 = 0, off1 = 0;
-            if (r + G < R) {
+            if (r1 < R) {
                 len1 = chrom_len[raw1.chrom];
                 off1 = chrom_off[raw1.chrom];
             }
@@ -1009,7 +1019,7 @@ __global__ __launch_bounds__(kCtxBlock) void base_tile_probs_ctx_kernel(
             }
             __syncthreads();
             TM_MARK(3);
-            if (r + G < R) {                          // the next region's words travel during this region's walk
+            if (r1 < R) {                             // the next region's words travel during this region's walk
                 nxt = ctx_region<U>(raw1, len1, off1, binsize);
                 request(nxt, staged);
             }
@@ -1278,11 +1288,13 @@ int dig_base_tile_probs_ctx(const uint32_t* genome_words, int64_t n_words, const
                             int32_t* n_valid, void* stream)
 {
     DIG_REQUIRE(n_up == 1 || n_up == 2, "n_up = n_down = 1 (trinucleotide) or 2 (penta-nucleotide)");
-    static const bool general = []() {
-        const char* e = getenv("DIG_TILES_FORM");        // developer switch: "general" sends n_up = 1 through this kernel too
-        return e && e[0] == 'g';
+    // developer switches: DIG_TILES_FORM = "general": the general kernel for every region, n_up = 1 too; "rows": the row walk for
+    // n_up = 1 too (both cross-check the trinucleotide kernels)
+    static const int form = []() {
+        const char* e = getenv("DIG_TILES_FORM");
+        return e && e[0] == 'g' ? 1 : (e && e[0] == 'r' ? 2 : 0);
     }();
-    if (n_up == 1 && !general)
+    if (n_up == 1 && form == 0)
         return dig_base_tile_probs(genome_words, n_words, chrom_off, chrom_len, n_chrom, reg_chrom, reg_start, reg_end, R, s_prob, C,
                                    binsize, n_tiles, pt, first_pos, n_valid, stream);
     DIG_REQUIRE(R >= 0 && C >= 0 && n_words >= 2 && n_chrom >= 0 && n_tiles >= 0, "non-negative sizes, n_words >= 2 (pad words)");
@@ -1290,15 +1302,24 @@ int dig_base_tile_probs_ctx(const uint32_t* genome_words, int64_t n_words, const
     if (R == 0) return DIG_OK;
     DIG_REQUIRE(genome_words && chrom_off && chrom_len && reg_chrom && reg_start && reg_end && first_pos && n_valid, "non-null pointers");
     DIG_REQUIRE(C == 0 || n_tiles == 0 || (s_prob && pt), "s_prob and pt");
-    // (a region of more than kCtxMaxPos positions is not evaluated -- n_valid -1, pt NaN; the host wrappers, which know the
-    //  coordinates, refuse such regions before the launch)
+    // The row walk (dig_tiles_rows.hip) takes every region its LDS budget covers and marks the others n_valid = -2; the general
+    // kernel behind it takes those (a region of more than kCtxMaxPos positions is not evaluated -- n_valid -1, pt NaN; the host
+    // wrappers, which know the coordinates, refuse such regions before the launch).
+    const int only_deferred = form == 1 ? 0 : 1;
+    if (only_deferred) {
+        const int rc = launch_tile_probs_rows(genome_words, n_words, chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, n_up,
+                                              binsize, n_tiles, pt, first_pos, n_valid, (hipStream_t)stream);
+        if (rc != DIG_OK) return rc;
+    }
     const int grid = grid_for(R * kCtxBlock, kCtxBlock, 1);
     if (n_up == 1)
         hipLaunchKernelGGL((base_tile_probs_ctx_kernel<1>), dim3(grid), dim3(kCtxBlock), 0, (hipStream_t)stream, genome_words, n_words,
-                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
+                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid,
+                           only_deferred);
     else
         hipLaunchKernelGGL((base_tile_probs_ctx_kernel<2>), dim3(grid), dim3(kCtxBlock), 0, (hipStream_t)stream, genome_words, n_words,
-                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid);
+                           chrom_off, chrom_len, reg_chrom, reg_start, reg_end, R, s_prob, C, binsize, n_tiles, pt, first_pos, n_valid,
+                           only_deferred);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

@@ -315,12 +315,73 @@ def test_general_context_kernel_many_cohorts_against_oracle_and_trinucleotide_ke
         S3 = rng.uniform(1e-4, 1e-2, (5, 64))
         np.savez(os.path.join(tmp, "in.npz"), seqs=np.array(seqs, dtype=object), chroms=np.array(chroms), starts=starts, ends=ends, S=S3)
         out = {}
-        for form in ("mfma", "general"):
+        for form in ("mfma", "general", "rows"):
             env = dict(os.environ, DIG_TILES_FORM=form)
             subprocess.check_call([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, form + ".npz")], env=env)
             out[form] = np.load(os.path.join(tmp, form + ".npz"))
-        assert np.array_equal(out["mfma"]["f"], out["general"]["f"]) and np.array_equal(out["mfma"]["n"], out["general"]["n"])
-        np.testing.assert_allclose(out["general"]["pt"], out["mfma"]["pt"], rtol=1e-12, equal_nan=True)
+        for form in ("general", "rows"):                 # (rows: the row walk of dig_tiles_rows.hip at n_up = 1)
+            assert np.array_equal(out["mfma"]["f"], out[form]["f"]) and np.array_equal(out["mfma"]["n"], out[form]["n"])
+            np.testing.assert_allclose(out[form]["pt"], out["mfma"]["pt"], rtol=1e-12, equal_nan=True)
+
+
+def test_row_walk_on_ten_kb_bins_against_the_general_kernel_and_the_oracle():
+    """base_tile_probs_rows_kernel (dig_tiles_rows.hip: what dig_base_tile_probs_ctx runs at n_up = 2) on 10-kb bins, the
+    shape of BASELINE configs[4]: more regions than workgroups, 37 cohorts (passes of 16 + 16 + 5), N runs and single N,
+    a bin at a chromosome's start and one over its end, a 12-kb region (more positions than the walk stages: left to the general
+    kernel by the n_valid = -2 mark), binsize 50 / 64 / 60 (trips of 10 / 8 / 12 positions; fewer tiles asked for than a region has) and 1 (every region deferred);
+    against the general kernel (DIG_TILES_FORM=general, own process) and, for a sample, the oracle."""
+    import subprocess
+    import sys
+    import tempfile
+    import torch
+    from digdriver_amd import engine
+    from digdriver_amd.data_tools.genome import PackedGenome
+    from oracle import dig_oracle as O
+    rng = np.random.default_rng(23)
+    n1, n2 = 3_000_000 + 4321, 612_345
+    a = rng.choice(list("ACGT"), n1)
+    a[rng.integers(0, n1, 300)] = "N"
+    for s0 in rng.integers(0, n1 - 3000, 12):
+        a[s0:s0 + int(rng.integers(1, 2500))] = "N"
+    a[20_000:30_000] = "N"                                       # a bin without any window
+    seqs = {"chr1": "".join(a), "chr2": "".join(rng.choice(list("ACGT"), n2))}
+    genome = PackedGenome.from_sequences(seqs)
+    chroms = ["chr1"] * 301 + ["chr2"] * 62 + ["chr1"]
+    starts = np.concatenate([np.arange(301) * 10_000, np.arange(62) * 10_000, [1_000_000]]).astype(np.int64)
+    ends = starts + 10_000
+    ends[-1] = starts[-1] + 12_000                               # deferred: 12 000 positions
+    C = 37
+    S5 = rng.uniform(1e-4, 1e-2, (C, 1024))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from digdriver_amd import engine; "
+            "from digdriver_amd.data_tools.genome import PackedGenome; d = np.load(sys.argv[1], allow_pickle=True); "
+            "g = PackedGenome.from_sequences(d['seqs'].item()); "
+            "pt, f, n = engine.base_tile_probs(g, list(d['chroms']), d['starts'], d['ends'], d['S'], int(sys.argv[3]), "
+            "n_tiles=(int(sys.argv[4]) or None), device=0); "
+            "np.savez(sys.argv[2], pt=pt.cpu().numpy(), f=f.cpu().numpy(), n=n.cpu().numpy())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), seqs=np.array(seqs, dtype=object), chroms=np.array(chroms), starts=starts, ends=ends, S=S5)
+        for binsize, n_tiles, sel in ((50, 0, slice(None)), (64, 0, slice(None)), (60, 100, slice(None)), (1, 0, slice(0, 3))):
+            sub = os.path.join(tmp, "sub.npz")
+            np.savez(sub, seqs=np.array(seqs, dtype=object), chroms=np.array(chroms)[sel], starts=starts[sel], ends=ends[sel], S=S5)
+            env = dict(os.environ, DIG_TILES_FORM="general")
+            subprocess.check_call([sys.executable, "-c", code, sub, os.path.join(tmp, "general.npz"), str(binsize), str(n_tiles)], env=env)
+            want = np.load(os.path.join(tmp, "general.npz"))
+            pt, first, nval = engine.base_tile_probs(genome, list(np.array(chroms)[sel]), starts[sel], ends[sel], S5, binsize,
+                                                     n_tiles=n_tiles or None, device=0)
+            pt, first, nval = pt.cpu().numpy(), first.cpu().numpy(), nval.cpu().numpy()
+            assert np.array_equal(first, want["f"]) and np.array_equal(nval, want["n"]) and nval.min() >= 0
+            assert np.array_equal(np.isnan(pt), np.isnan(want["pt"]))
+            np.testing.assert_allclose(pt, want["pt"], rtol=1e-13, equal_nan=True)
+            if binsize == 50:
+                assert np.isnan(pt[:, 2]).all() and nval[2] == 200                      # the all-N bin: 0 / 0
+                for r in (0, 1, 7, 300, 301, 362, 363):
+                    for c in (0, 15, 16, 31, 32, 36):
+                        probs, poss = O.base_probabilities_by_region(seqs[chroms[r]], S5[c], int(starts[r]), int(ends[r]), n_up=2)
+                        assert first[r] == poss[0]
+                        ref = np.array([probs[i:i + binsize].sum() for i in range(0, len(probs), binsize)])
+                        assert nval[r] == min(len(ref), pt.shape[2])
+                        np.testing.assert_allclose(pt[c, r, :nval[r]], ref[:nval[r]], rtol=1e-12)
+                        assert np.isnan(pt[c, r, nval[r]:]).all()
 
 
 def test_two_role_matrix_kernel_gives_the_bits_of_the_one_role_kernel():

@@ -38,8 +38,21 @@ try:
     fn(buf)
     _lib.call("dig_base_tile_probs_ctx", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S5), C, 2, 50, 200, p(pt), p(first), p(nval), _lib.stream_ptr())
     fn(buf)
-    tot = float(sum(buf))
+    tot = float(sum(buf)) or 1.0
     print("phase share (output+loop | barrier | words->LDS+request | codes+barrier | walk | barrier | reduce+barrier | -):", [round(v / tot, 3) for v in buf],
           "cycles per region-pass:", round(tot / (chunk * ((C + 7) // 8)), 1))
+except AttributeError:
+    pass
+try:                                    # the row walk (dig_tiles_rows.hip), -DDIG_TM_TIMING build
+    import ctypes
+    fn = _lib.load().dig_debug_rows_profile
+    buf = (ctypes.c_ulonglong * 8)()
+    fn(buf)
+    _lib.call("dig_base_tile_probs_ctx", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S5), C, 2, 50, 200, p(pt), p(first), p(nval), _lib.stream_ptr())
+    fn(buf)
+    for name, part in (("first wave", buf[0:4]), ("last wave", buf[4:8])):
+        tot = float(sum(part))
+        print("row walk,", name, "phase share (walk | barrier | bases -> LDS + output | barrier):", [round(v / tot, 3) for v in part],
+              "cycles per region (all passes):", round(tot / chunk, 1))
 except AttributeError:
     pass
