@@ -91,8 +91,10 @@ __device__ __forceinline__ uint2 rw_entry(uint32_t wa, uint32_t wb)
         f = (f | (f >> 6)) & 0x000F000Fu;
         return (f | (f >> 12)) & 0xFFu;
     };
-    const uint32_t z = squeeze(wa) | (squeeze(wb) << 16), f = flags(wa) | (flags(wb) << 8);
-    return make_uint2(__builtin_bitreverse32(z), __builtin_bitreverse32(f));
+    const uint32_t z = squeeze(wa) | (squeeze(wb) << 16);
+    uint32_t f = 0u;
+    if ((wa | wb) & 0xCCCCCCCCu) f = __builtin_bitreverse32(flags(wa) | (flags(wb) << 8));       // (rare: most words skip it)
+    return make_uint2(__builtin_bitreverse32(z), f);
 }
 
 // sum of a value over the wave, the same in every lane: quads, half rows and rows by DPP (xor 1, xor 2, mirror of 8, mirror of
@@ -239,7 +241,6 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
     load_raw(blockIdx.x + 2 * G, chrom1, start1, end1);
     __syncthreads();                                    // table and the first region's bases are in LDS
 
-    const double2* tab2 = reinterpret_cast<const double2*>(s_tab);
 #ifdef DIG_TM_TIMING
     unsigned long long rw_acc[4] = {0, 0, 0, 0}, rw_last = __builtin_readcyclecounter();
 #endif
@@ -269,6 +270,9 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
         auto walk = [&](auto hasn_c) {
             constexpr bool HASN = decltype(hasn_c)::value;
             constexpr int kPerTicket = 64 / LW;
+            constexpr int kRowLog = LW == 8 ? 7 : (LW == 4 ? 6 : 5);           // log2 of the bytes of a table row
+            const int n_trips = (binsize + TP - 1) / TP;                        // of a full tile (wave-uniform)
+            const int b_last = (q.ne - 2) << 4;                                 // (windows are read from entries b >> 4 and the next)
             int ticket = wave;
             while (ticket * kPerTicket < tiles_valid) {
                 int next = 0;
@@ -276,68 +280,69 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
                 const int t = ticket * kPerTicket + slot / LW;
                 const bool mine = t < tiles_valid;
                 const int p0 = t * binsize;
-                int cnt = mine ? binsize : 0;
-                if (mine && cnt > n_pos - p0) cnt = n_pos - p0;
+                // positions of the tile; a walker without a tile in this ticket rides along: its address mask is 0 and its column
+                // stands in the zero row, whatever window it decodes, and it never sends its wave to the careful branch
+                int rem = mine ? (binsize < n_pos - p0 ? binsize : n_pos - p0) : (1 << 30);
+                const uint32_t amask = mine ? (uint32_t)(K - 1) << kRowLog : 0u;
+                const uint32_t abase = (mine ? 0u : (uint32_t)K << kRowLog) | ((uint32_t)col << 4);
+                int b = mine ? q.sh0 + p0 : 0;                                  // staged base index of the trip's first window
                 double acc0 = 0.0, acc1 = 0.0;
-                constexpr int kRowLog = LW == 8 ? 7 : (LW == 4 ? 6 : 5);       // log2 of the bytes of a table row
-                const bool idle = !mine;
-                const uint32_t amask = idle ? 0u : (uint32_t)(K - 1) << kRowLog;
-                const uint32_t abase = (idle ? (uint32_t)K << kRowLog : 0u) | ((uint32_t)col << 4);
                 // A trip's window is read a trip ahead (it returns in front of the row reads issued behind it); two register sets
                 // take turns, so that no copy -- and no wait -- stands between the read and its use a trip later.
-                auto window = [&](int qq, uint32_t (&z)[4]) {
-                    const int m = cnt - qq > 0 ? (q.sh0 + p0 + qq) >> 4 : 0;
+                auto window = [&](int bb, uint32_t (&z)[4]) {
+                    const int m = (bb < b_last ? bb : b_last) >> 4;
                     z[0] = s_ent[m].x, z[1] = s_ent[m + 1].x;
                     if (HASN) z[2] = s_ent[m].y, z[3] = s_ent[m + 1].y;
                 };
-                auto trip = [&](int qq, const uint32_t (&z)[4], uint32_t (&zn)[4]) {
-                    const int rem = cnt - qq;           // positions of the tile left (<= 0: this walker is done)
-                    const int o = rem > 0 ? (q.sh0 + p0 + qq) & 15 : 0;
+                auto row_of = [&](uint32_t win, int i) {                      // the row of position i, this lane's two cohorts
+                    const int sh = (32 - 2 * W - 2 * i) - kRowLog;              // the field sits at bits [32 - 2 W - 2 i, 32 - 2 i)
+                    const uint32_t x = sh >= 0 ? win >> (sh >= 0 ? sh : 0) : win << (sh < 0 ? -sh : 0);
+                    uint32_t off;                                               // (the compiler turns the | of disjoint bits into an add
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(x), "v"(amask), "v"(abase));       //  and then has no fused form)
+#if defined(DIG_RW_ABL) && DIG_RW_ABL == 1         // timing builds: every walker reads row 0 / paired walkers rows of different parity / of the same parity
+                    off = abase;
+#elif defined(DIG_RW_ABL) && DIG_RW_ABL == 2
+                    off = (off & ~(1u << kRowLog)) | (((unsigned)(slot / LW) & 1u) << kRowLog);
+#elif defined(DIG_RW_ABL) && DIG_RW_ABL == 3
+                    off = off & ~(1u << kRowLog);
+#endif
+                    return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(s_all) + off);
+                };
+                auto trip = [&](const uint32_t (&z)[4], uint32_t (&zn)[4]) {
+                    const int o = b & 15;
                     const uint32_t win = (uint32_t)(((((uint64_t)z[0] << 32) | z[1]) << (2 * o)) >> 32);      // base i of the trip at bits 31 - 2 i
                     const uint32_t fw = HASN ? (z[2] | (z[3] >> 16)) << o : 0u;                                // flag of base i at bit 31 - i
-                    window(qq + TP, zn);
-                    const bool clean = idle || ((fw >> (32 - TP - 2 * U)) == 0u && rem >= TP);
+                    b += TP;
+                    window(b, zn);                      // (also behind the last trip: a read that depends on nothing costs less than a branch around it)
+                    const bool clean = (fw >> (32 - TP - 2 * U)) == 0u && rem >= TP;
                     if (__all(clean)) {
                         double2 v[TP];
 #pragma unroll
-                        for (int i = 0; i < TP; ++i) {
-                            // row address = field of position i moved to the row bits, masked, | the lane's column (a walker without a
-                            // tile in this ticket: mask 0 and the zero row -- it rides along without sending its wave to the other branch)
-                            const int sh = (32 - 2 * W - 2 * i) - kRowLog;              // field at bits [32 - 2 W - 2 i, 32 - 2 i)
-                            const uint32_t x = sh >= 0 ? win >> (sh >= 0 ? sh : 0) : win << (sh < 0 ? -sh : 0);
-                            uint32_t off = (x & amask) | abase;
-#if defined(DIG_RW_ABL) && DIG_RW_ABL == 1         // timing builds: every walker reads row 0 / paired walkers rows of different parity / of the same parity
-                            off = abase;
-#elif defined(DIG_RW_ABL) && DIG_RW_ABL == 2
-                            off = (off & ~(1u << kRowLog)) | (((unsigned)(slot / LW) & 1u) << kRowLog);
-#elif defined(DIG_RW_ABL) && DIG_RW_ABL == 3
-                            off = off & ~(1u << kRowLog);
-#endif
-                            v[i] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(s_all) + off);
-                        }
+                        for (int i = 0; i < TP; ++i) v[i] = row_of(win, i);
 #pragma unroll
                         for (int i = 0; i < TP; ++i) {
                             acc0 += v[i].x;
                             acc1 += v[i].y;
                         }
-                    } else {                            // a short last trip, a window with a non-ACGT base, or a walker that rides along
-                        uint32_t w2 = win, f2 = fw;     // with its wave: position by position, what does not count adds nothing
+                    } else {                            // a short last trip or a window with a non-ACGT base: position by position,
+                        uint32_t w2 = win, f2 = fw;     // what does not count adds nothing
 #pragma unroll 1
                         for (int i = 0; i < TP; ++i, w2 <<= 2, f2 <<= 1) {
                             if (i < rem && (f2 >> (32 - W)) == 0u) {
-                                const double2 v = tab2[(w2 >> (32 - 2 * W)) * LW + col];
+                                const double2 v = row_of(w2, 0);
                                 acc0 += v.x;
                                 acc1 += v.y;
                             }
                         }
                     }
+                    rem -= TP;
                 };
                 uint32_t za[4] = {0u, 0u, 0u, 0u}, zb[4] = {0u, 0u, 0u, 0u};
-                window(0, za);
-                for (int qq = 0; __any(qq < cnt); qq += 2 * TP) {
-                    trip(qq, za, zb);
-                    if (!__any(qq + TP < cnt)) break;
-                    trip(qq + TP, zb, za);
+                window(b, za);
+                for (int k = 0; k < n_trips; k += 2) {
+                    trip(za, zb);
+                    if (k + 1 >= n_trips) break;
+                    trip(zb, za);
                 }
                 if (mine) {
                     s_sum[t * SS + 2 * col] = acc0;
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
         //  dependent LDS round trips --, the quotient as a multiplication by 1 / total, as in the trinucleotide matrix kernels)
         // (a lane's four sums -- tiles lane, lane + 64, ... : the sum buffer holds at most 202 -- are read once, all in flight)
         if (!q.deferred) {
+            const bool whole = tiles_valid == (int)n_tiles;     // (the usual case: every tile asked for exists and none beyond)
             for (int co = wave; co < cc; co += n_waves) {
                 double sv[4];
 #pragma unroll
@@ -377,13 +383,19 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) part += lane + 64 * k < tiles_valid ? sv[k] : 0.0;
                 const double inv = 1.0 / rw_wave_sum(part);
-                double* plane = pt + ((int64_t)(c0 + co) * R + r) * n_tiles;
+                double* plane = pt + ((int64_t)(c0 + co) * R + r) * n_tiles + lane;
+                if (whole) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = lane + 64 * k;
-                    if (t < n_tiles) plane[t] = t < tiles ? sv[k] * inv : nan;
+                    for (int k = 0; k < 4; ++k)
+                        if (lane + 64 * k < tiles_valid) plane[64 * k] = sv[k] * inv;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int t = lane + 64 * k;
+                        if (t < n_tiles) plane[64 * k] = t < tiles ? sv[k] * inv : nan;
+                    }
+                    for (int64_t t = lane + 256; t < n_tiles; t += 64) plane[t - lane] = nan;
                 }
-                for (int64_t t = lane + 256; t < n_tiles; t += 64) plane[t] = nan;
             }
         }
         RW_MARK(2);
