@@ -98,6 +98,8 @@ _SIGNATURES = {
     "dig_tile_mut_counts_host": [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _int],
     "dig_tiled_nb_test_host": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
     "dig_bh_qvalues_sorted": [_vp, _i64, _i64, _vp, _vp, _i64, _vp],
+    "dig_sort_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
+    "dig_bh_qvalues_ragged": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp],
     "dig_rbf_cross": [_vp, _vp, _i64, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "dig_rbf_backward": [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp],
 }
@@ -114,9 +116,10 @@ _SIZE_QUERIES = {
     "dig_element_records_bytes": [_i64, _i64],
     "dig_element_pipeline_scaled_scratch": [_vp, _int, _i64],
     "dig_bh_workspace": [_i64, _i64],
+    "dig_bh_ragged_workspace": [_vp, _i64],
 }
 
-ABI_VERSION = 10         # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 11         # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

@@ -1,0 +1,621 @@
+// dig_sort.hip -- ranking the p-values of many lists at once on gfx950: a batched LSD radix sort written for this step, and the
+// Benjamini-Hochberg pass behind it (nb_model.get_q_vals, nb_model.py:340-342 = statsmodels' fdrcorrection, method 'indep').
+//
+// Until round 5 the per-base route of BASELINE configs[4] ended in torch.sort (rocPRIM: 64-bit keys + 64-bit indices, eight
+// 8-bit passes) + dig_bh_qvalues_sorted + scatter_: 40 of the route's 43 ms per eighth of the genome x 37 cohorts.  Here:
+//   * rows = lists (cohorts), ragged (row_ptr): all rows in one launch sequence; a row's keys never leave its range;
+//   * key = the double's bits made monotone (sign handled; every NaN = the largest key, as torch.sort places it); p-values are
+//     not negative, so the top bit of every key is set and SEVEN passes of 9-bit digits sort bits 0 .. 62; an eighth pass over
+//     bit 63 runs only when the histogram pass saw a negative value (a flag on the device, no host round trip);
+//   * payload = the 32-bit position in the row (n < 2^32): 12 bytes per element and pass instead of 16;
+//   * a pass is ONE kernel: a workgroup takes the next tile of 4 096 elements by ticket, ranks its elements stably (wave-wide
+//     match of the digit by ballots, per-wave digit counters in LDS), publishes its digit counts, finds the counts of the tiles
+//     in front of it by decoupled look-back over 4-byte {flag, count} words (one relaxed agent-scope store / load per word: the
+//     word is its own flag, nothing else has to be ordered), regroups the tile by digit in LDS and writes every digit's run
+//     contiguously; the digit histograms of all passes come from one pass over the input in front;
+//   * the Benjamini-Hochberg pass reads the sorted keys, and the q-values leave through the payload to their places: no
+//     separate scatter.  The same IEEE operations in the same order as the host form -- p / (rank / n), reverse running
+//     minimum (NaN-propagating), cap at 1 -- so the same bits as statsmodels' operations (q depends on the VALUE of p only:
+//     equal p-values get equal q whatever order a sort leaves them in).
+//   * rank0 / n_global / carry per row: a rank of parallel.ShardedTiles holds one contiguous range of the global order (sample
+//     sort) and finishes it with the minimum of the ranks behind it.
+#include "dig_common.hpp"
+
+namespace dig {
+
+constexpr int kSortBits = 9, kSortBins = 1 << kSortBits;        // digit
+constexpr int kSortBlock = 512, kSortItems = 8;                 // threads per workgroup, elements per thread
+constexpr int kSortTile = kSortBlock * kSortItems;              // elements per tile
+constexpr int kSortWaves = kSortBlock / 64;
+static_assert(kSortBlock == kSortBins, "a thread of the pass kernel = a digit");
+constexpr int kSortPasses = 8;                                  // 7 x 9 bits + the sign bit
+constexpr int kSortHistChunk = 16 * kSortTile;                  // elements a workgroup of the histogram pass takes
+
+__device__ __forceinline__ uint64_t sort_key(double p)
+{
+    const int64_t b = __double_as_longlong(p);
+    if (p != p) return ~0ull;                                    // every NaN: the largest key
+    if (p == 0.0) return 0x8000000000000000ull;                  // -0.0 = +0.0, as a comparison sort has it
+    return b < 0 ? ~(uint64_t)b : (uint64_t)b | 0x8000000000000000ull;
+}
+__device__ __forceinline__ double sort_value(uint64_t k)
+{
+    if (k == ~0ull) return __longlong_as_double(0x7ff8000000000000LL);
+    return __longlong_as_double((int64_t)((k >> 63) ? k ^ 0x8000000000000000ull : ~k));
+}
+__device__ __forceinline__ unsigned sort_digit(uint64_t k, int pass)
+{
+    return pass < 7 ? (unsigned)(k >> (kSortBits * pass)) & (kSortBins - 1) : (unsigned)(k >> 63);
+}
+
+// row of a global tile number: tile_start[r] <= tile < tile_start[r + 1] (rows without elements have no tiles)
+__device__ __forceinline__ int sort_row_of(const int64_t* __restrict__ tile_start, int rows, int64_t tile)
+{
+    int lo = 0, hi = rows;                                       // tile_start[lo] <= tile < tile_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---- digit histograms of all passes, per row; flag = a negative value was seen ----
+__global__ __launch_bounds__(kSortBlock) void sort_hist_kernel(const double* __restrict__ p, const int64_t* __restrict__ row_ptr,
+                                                               const int64_t* __restrict__ chunk_start, int rows, unsigned* __restrict__ ghist,
+                                                               unsigned* __restrict__ flags)
+{
+    __shared__ unsigned s_h[kSortPasses][kSortBins];
+    for (int i = threadIdx.x; i < kSortPasses * kSortBins; i += kSortBlock) (&s_h[0][0])[i] = 0u;
+    __syncthreads();
+    const int row = sort_row_of(chunk_start, rows, blockIdx.x);
+    const int64_t lo = row_ptr[row] + ((int64_t)blockIdx.x - chunk_start[row]) * kSortHistChunk;
+    const int64_t hi = lo + kSortHistChunk < row_ptr[row + 1] ? lo + kSortHistChunk : row_ptr[row + 1];
+    bool neg = false;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+        const uint64_t k = sort_key(__builtin_nontemporal_load(p + i));
+        neg |= !(k >> 63);
+        // (p-values crowd into one or two binades: the high digits of a wave's 64 keys are mostly ONE value, and 64 atomic adds
+        //  to one counter are 64 turns of the LDS -- a wave whose digit is uniform adds its count once)
+#pragma unroll
+        for (int pass = 0; pass < kSortPasses; ++pass) {
+            const unsigned d = sort_digit(k, pass);
+            if (pass >= 3) {
+                const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+                const uint64_t same = __ballot(d == d0);
+                if (same == __ballot(true)) {
+                    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(same)) atomicAdd(&s_h[pass][d0], (unsigned)__popcll(same));
+                    continue;
+                }
+            }
+            atomicAdd(&s_h[pass][d], 1u);
+        }
+    }
+    if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
+    __syncthreads();
+    unsigned* g = ghist + (int64_t)row * kSortPasses * kSortBins;
+    for (int i = threadIdx.x; i < kSortPasses * kSortBins; i += kSortBlock) {
+        const unsigned c = (&s_h[0][0])[i];
+        if (c) atomicAdd(g + i, c);
+    }
+}
+
+// ---- exclusive scan of every (row, pass) histogram: where a digit's elements start in the row ----
+__global__ __launch_bounds__(kSortBins) void sort_base_kernel(unsigned* __restrict__ ghist)
+{
+    __shared__ unsigned s[kSortBins];
+    unsigned* g = ghist + (int64_t)blockIdx.x * kSortBins;       // one workgroup per (row, pass)
+    const unsigned c = g[threadIdx.x];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 1; d < kSortBins; d <<= 1) {
+        const unsigned v = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    g[threadIdx.x] = s[threadIdx.x] - c;
+}
+
+// ---- one pass ----
+constexpr unsigned kFlagAgg = 1u << 30, kFlagPrefix = 2u << 30, kValMask = (1u << 30) - 1u;
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(
+    const double* __restrict__ p_in, const uint64_t* __restrict__ k_in, const unsigned* __restrict__ v_in, uint64_t* __restrict__ k_out,
+    unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ tile_start, int rows, int pass,
+    const unsigned* __restrict__ dbase, unsigned* __restrict__ status, unsigned* __restrict__ ticket, const unsigned* __restrict__ flags)
+{
+    if (pass == 7 && !(*flags & 1u)) return;                     // no negative value: bit 63 is the same everywhere
+    __shared__ unsigned s_cnt[kSortWaves][kSortBins];            // per-wave digit counts, then their exclusive prefix over the waves
+    __shared__ unsigned s_tpre[kSortBins];                       // where a digit starts in the regrouped tile
+    __shared__ int64_t s_gbase[kSortBins];                       // where the tile's elements of a digit go, minus s_tpre
+    __shared__ uint64_t s_key[kSortTile];
+    __shared__ unsigned s_val[kSortTile];
+    __shared__ unsigned s_wsum[kSortWaves];
+    __shared__ int64_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);      // tiles are taken in order: a tile waits only for tiles that run
+    for (int i = tid; i < kSortWaves * kSortBins; i += kSortBlock) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int row = sort_row_of(tile_start, rows, tile);
+    const int64_t t_in_row = tile - tile_start[row];
+    const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
+    const int64_t e0 = t_in_row * kSortTile;                     // first element of the tile, in the row
+    const int n_here = (int)(n_row - e0 < kSortTile ? n_row - e0 : kSortTile);
+    // ---- load: element j of the tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in) ----
+    uint64_t key[kSortItems];
+    unsigned val[kSortItems], loc[kSortItems];
+#pragma unroll
+    for (int e = 0; e < kSortItems; ++e) {
+        const int j = wave * (64 * kSortItems) + e * 64 + lane;
+        key[e] = ~0ull;
+        val[e] = 0u;
+        if (j < n_here) {
+            if (FIRST) {
+                key[e] = sort_key(__builtin_nontemporal_load(p_in + r0 + e0 + j));
+                val[e] = (unsigned)(e0 + j);
+            } else {
+                key[e] = __builtin_nontemporal_load(k_in + r0 + e0 + j);
+                val[e] = __builtin_nontemporal_load(v_in + r0 + e0 + j);
+            }
+        }
+    }
+    // ---- stable ranks inside the wave: the lanes with the same digit (nine ballots), in lane order, behind what the wave's
+    // earlier items counted ----
+#pragma unroll
+    for (int e = 0; e < kSortItems; ++e) {
+        const int j = wave * (64 * kSortItems) + e * 64 + lane;
+        const bool live = j < n_here;
+        const unsigned d = sort_digit(key[e], pass);
+        uint64_t peers = __ballot(live);
+#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 2)     // timing build: no match (wrong ranks)
+        peers = 1ull << lane;
+#else
+#pragma unroll
+        for (int b = 0; b < kSortBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t vote = __ballot(bit);
+            peers &= bit ? vote : ~vote;
+        }
+#endif
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+        const unsigned old = s_cnt[wave][d];
+        loc[e] = old + below;
+        if (live && below == 0u) s_cnt[wave][d] = old + (unsigned)__popcll(peers);
+    }
+    __syncthreads();
+    // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix ----
+    unsigned h = 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+        const unsigned c = s_cnt[w][tid];
+        s_cnt[w][tid] = h;
+        h += c;
+    }
+    unsigned* st = status + tile * kSortBins + tid;
+    if (t_in_row > 0) __hip_atomic_store(st, kFlagAgg | h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- look-back, first step: the words of the four tiles in front are requested NOW and looked at behind the regrouping
+    // (a word costs a trip to the L2 -- a microsecond under a streaming load; the barriers in between wait for LDS only).
+    // A word is its own flag (2 bits) and count (30 bits): nothing else has to be ordered.  (Four digits per thread and 16-byte
+    // accesses were slower: a wave's 64 words are one request already.) ----
+    constexpr int kWin0 = 4, kWin = 8;
+    auto word_of = [&](int64_t t_back) {                       // the word of tile t_back of this row (t_back < t_in_row); in front of the row: nothing
+        return t_back >= 0 ? __hip_atomic_load(st - (t_in_row - t_back) * kSortBins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
+    };
+    unsigned w0[kWin0];
+#pragma unroll
+    for (int i = 0; i < kWin0; ++i) w0[i] = word_of(t_in_row - 1 - i);
+    // (exclusive scan of h over the 512 digits: inside the wave by shuffles, then over the eight waves)
+    unsigned incl = h;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned v = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+    unsigned wbase = 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) wbase += w < wave ? s_wsum[w] : 0u;
+    const unsigned tpre = wbase + incl - h;
+    s_tpre[tid] = tpre;
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+    // ---- regroup the tile by digit in LDS ----
+#pragma unroll
+    for (int e = 0; e < kSortItems; ++e) {
+        const int j = wave * (64 * kSortItems) + e * 64 + lane;
+        if (j < n_here) {
+            const unsigned d = sort_digit(key[e], pass);
+            const unsigned pos = s_tpre[d] + s_cnt[wave][d] + loc[e];
+            s_key[pos] = key[e];
+            s_val[pos] = val[e];
+        }
+    }
+    // ---- look-back: the counts of this digit in the tiles in front, down to the first tile whose prefix is known ----
+    unsigned before = 0u;
+#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 1)     // timing build: no look-back (wrong places)
+    if (false) {
+#else
+    if (t_in_row > 0) {
+#endif
+        bool done = false;
+        auto take = [&](unsigned sw, int64_t t_back) {
+            if (done) return;
+            while ((sw >> 30) == 0u) {                           // not published yet: this word alone, until it is
+                __builtin_amdgcn_s_sleep(1);
+                sw = word_of(t_back);
+            }
+            before += sw & kValMask;
+            done = (sw >> 30) == 2u;
+        };
+#pragma unroll
+        for (int i = 0; i < kWin0; ++i) take(w0[i], t_in_row - 1 - i);
+        int64_t back = t_in_row - 1 - kWin0;
+        while (!done) {                                          // further back: eight words per step, requested together
+            unsigned w[kWin];
+#pragma unroll
+            for (int i = 0; i < kWin; ++i) w[i] = word_of(back - i);
+#pragma unroll
+            for (int i = 0; i < kWin; ++i) take(w[i], back - i);
+            back -= kWin;
+        }
+    }
+    __hip_atomic_store(st, kFlagPrefix | (before + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_gbase[tid] = r0 + (int64_t)dbase[((int64_t)row * kSortPasses + pass) * kSortBins + tid] + before - tpre;
+    // ---- every digit's run leaves in one piece ----
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kSortItems; ++e) {
+        const int pos = e * kSortBlock + tid;
+        if (pos < n_here) {
+            const uint64_t k = s_key[pos];
+            int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
+#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 8)     // timing build: the tile goes back where it came from (one contiguous piece)
+            dst = r0 + e0 + pos;
+#endif
+#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 4)     // timing build: no stores
+            if (k == 0x123456789ull)
+#endif
+            {
+                k_out[dst] = k;
+                v_out[dst] = s_val[pos];
+            }
+        }
+    }
+}
+
+// ---- Benjamini-Hochberg over the sorted keys of ragged rows ----
+constexpr int kBhrBlock = 256, kBhrItems = 16, kBhrChunk = kBhrBlock * kBhrItems;
+
+__device__ __forceinline__ double bhr_nan_min(double a, double b)      // np.minimum: NaN if either is
+{
+    return (a != a) ? a : ((b != b) ? b : (b < a ? b : a));
+}
+
+// reverse inclusive running minimum over a chunk of a row; MODE 0: the chunk's minimum -> chunk_min; MODE 1: q-values through
+// the payload (or in sorted order when `scatter` is 0), with the chunks behind (suffix) and the ranks behind (carry).
+// Keys and payloads are read lane after lane (whole 512-byte runs per wave-instruction) and change to the thread-owns-sixteen
+// arrangement of the running minimum in LDS (one pad per sixteen: the lanes' reads fall into different banks); the threads'
+// minima are combined by a shuffle scan per wave and one exchange of the four wave minima -- two barriers where the round-5
+// kernel (sixteen strided loads per thread, a 256-wide Hillis-Steele scan) had eighteen.
+template <int MODE>
+__global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __restrict__ k0, const uint64_t* __restrict__ k1,
+                                                              const unsigned* __restrict__ v0, const unsigned* __restrict__ v1,
+                                                              const unsigned* __restrict__ flags, const int64_t* __restrict__ row_ptr,
+                                                              const int64_t* __restrict__ chunk_start, int rows, const double* __restrict__ n_global,
+                                                              const int64_t* __restrict__ rank0, const double* __restrict__ carry,
+                                                              double* __restrict__ chunk_min, const double* __restrict__ suffix,
+                                                              double* __restrict__ q, int scatter)
+{
+    const bool eight = *flags & 1u;                              // the eighth pass ran: the sorted lists are in the other buffer
+    const uint64_t* ks = eight ? k1 : k0;
+    const unsigned* vs = eight ? v1 : v0;
+    constexpr int kPad = kBhrChunk + kBhrChunk / 16;
+    __shared__ uint64_t s_k[kPad];
+    __shared__ unsigned s_v[MODE == 1 ? kPad : 1];
+    __shared__ double s_wave[kBhrBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = sort_row_of(chunk_start, rows, blockIdx.x);
+    const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
+    const int64_t c0 = ((int64_t)blockIdx.x - chunk_start[row]) * kBhrChunk;       // first element of the chunk, in the row
+    const int n_here = (int)(n_row - c0 < kBhrChunk ? n_row - c0 : kBhrChunk);
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k) {
+        const int j = k * kBhrBlock + tid;
+        if (j < n_here) {
+            s_k[j + (j >> 4)] = __builtin_nontemporal_load(ks + r0 + c0 + j);
+            if (MODE == 1 && scatter) s_v[j + (j >> 4)] = __builtin_nontemporal_load(vs + r0 + c0 + j);
+        }
+    }
+    __syncthreads();
+    const double n_f = n_global[row];
+    const int64_t rk = rank0[row] + c0;
+    const int base = tid * kBhrItems;                            // this thread's sixteen elements of the chunk
+    double v[kBhrItems];
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k) {
+#pragma clang fp contract(off)
+        v[k] = base + k < n_here ? sort_value(s_k[base + k + tid]) / ((double)(rk + base + k + 1) / n_f) : inf;
+    }
+#pragma unroll
+    for (int k = kBhrItems - 2; k >= 0; --k) v[k] = bhr_nan_min(v[k], v[k + 1]);
+    // reverse inclusive scan of the threads' minima: down the wave by shuffles, then over the four waves
+    double sc = v[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_down(sc, d, 64);
+        if (lane + d < 64) sc = bhr_nan_min(sc, o);
+    }
+    if (lane == 0) s_wave[wave] = sc;
+    __syncthreads();
+    double after_waves = inf;                                    // the waves behind this one
+#pragma unroll
+    for (int w = kBhrBlock / 64 - 1; w >= 0; --w)
+        if (w > wave) after_waves = bhr_nan_min(s_wave[w], after_waves);
+    if (MODE == 0) {
+        if (tid == 0) chunk_min[blockIdx.x] = bhr_nan_min(sc, after_waves);
+        return;
+    }
+    double behind = __shfl_down(sc, 1, 64);                      // the threads behind this one in the wave ...
+    if (lane == 63) behind = inf;
+    behind = bhr_nan_min(behind, after_waves);                   // ... the waves behind, the chunks behind, the ranks behind
+    behind = bhr_nan_min(behind, suffix[blockIdx.x]);
+    behind = bhr_nan_min(behind, carry[row]);
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k)
+        if (base + k < n_here) {
+            const double m = bhr_nan_min(v[k], behind);
+            const double out = (m != m) ? m : (m < 1.0 ? m : 1.0);
+            q[r0 + (scatter ? (int64_t)s_v[base + k + tid] : c0 + base + k)] = out;
+        }
+}
+
+// suffix[c] = min of the chunk minima behind chunk c in its row (inf for the last); row_min[row] = min of all (may be NULL)
+__global__ __launch_bounds__(kBhrBlock) void bhr_suffix_kernel(const double* __restrict__ chunk_min, const int64_t* __restrict__ chunk_start,
+                                                               double* __restrict__ suffix, double* __restrict__ row_min)
+{
+    const int row = blockIdx.x;
+    const int64_t c0 = chunk_start[row], n_chunks = chunk_start[row + 1] - c0;
+    chunk_min += c0;
+    suffix += c0;
+    __shared__ double s_tot[kBhrBlock];
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double carry = inf;
+    for (int64_t hi = n_chunks; hi > 0; hi -= kBhrBlock) {
+        const int64_t c = hi - kBhrBlock + threadIdx.x;
+        s_tot[threadIdx.x] = c >= 0 ? chunk_min[c] : inf;
+        __syncthreads();
+        for (int d = 1; d < kBhrBlock; d <<= 1) {
+            const double mine = s_tot[threadIdx.x];
+            const double other = (int)threadIdx.x + d < kBhrBlock ? s_tot[threadIdx.x + d] : inf;
+            __syncthreads();
+            s_tot[threadIdx.x] = bhr_nan_min(mine, other);
+            __syncthreads();
+        }
+        const double after = (int)threadIdx.x + 1 < kBhrBlock ? s_tot[threadIdx.x + 1] : inf;
+        if (c >= 0) suffix[c] = bhr_nan_min(after, carry);
+        const double all = s_tot[0];
+        __syncthreads();
+        carry = bhr_nan_min(carry, all);
+    }
+    if (row_min && threadIdx.x == 0) row_min[row] = carry;
+}
+
+__global__ void sort_unpack_kernel(const uint64_t* __restrict__ k0, const uint64_t* __restrict__ k1, const unsigned* __restrict__ v0,
+                                   const unsigned* __restrict__ v1, const unsigned* __restrict__ flags, int64_t n, double* __restrict__ p_sorted,
+                                   unsigned* __restrict__ order)
+{
+    const bool eight = *flags & 1u;
+    const uint64_t* ks = eight ? k1 : k0;
+    const unsigned* vs = eight ? v1 : v0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (p_sorted) p_sorted[i] = sort_value(ks[i]);
+        if (order) order[i] = vs[i];
+    }
+}
+
+// layout of the workspace (all offsets from its 256-byte aligned start)
+struct SortLayout {
+    int64_t total_tiles, hist_chunks, bh_chunks;
+    int64_t off_k0, off_k1, off_v0, off_v1, off_status, off_ghist, off_small, off_rowptr, off_tilestart, off_histstart, off_bhstart, off_nglob,
+        off_rank0, off_carry, off_cmin, off_suffix, bytes;
+};
+static int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static SortLayout sort_layout(const int64_t* row_ptr, int64_t rows)
+{
+    SortLayout L{};
+    const int64_t n = rows > 0 ? row_ptr[rows] - row_ptr[0] : 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        L.total_tiles += (len + kSortTile - 1) / kSortTile;
+        L.hist_chunks += (len + kSortHistChunk - 1) / kSortHistChunk;
+        L.bh_chunks += (len + kBhrChunk - 1) / kBhrChunk;
+    }
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        const int64_t at = o;
+        o += up256(bytes);
+        return at;
+    };
+    L.off_k0 = take(n * 8);
+    L.off_k1 = take(n * 8);
+    L.off_v0 = take(n * 4);
+    L.off_v1 = take(n * 4);
+    L.off_status = take(L.total_tiles * kSortBins * 4 + 256);        // + the ticket counter behind it
+    L.off_ghist = take(rows * kSortPasses * kSortBins * 4);
+    L.off_small = take(256);                                          // flags
+    L.off_rowptr = take((rows + 1) * 8);
+    L.off_tilestart = take((rows + 1) * 8);
+    L.off_histstart = take((rows + 1) * 8);
+    L.off_bhstart = take((rows + 1) * 8);
+    L.off_nglob = take(rows * 8);
+    L.off_rank0 = take(rows * 8);
+    L.off_carry = take(rows * 8);
+    L.off_cmin = take(L.bh_chunks * 8);
+    L.off_suffix = take(L.bh_chunks * 8);
+    L.bytes = o + 256;
+    return L;
+}
+
+}  // namespace dig
+
+using namespace dig;
+
+namespace {
+
+struct SortPlan {
+    SortLayout L;
+    char* base;
+    int64_t n, rows;
+};
+
+// uploads the row tables and sorts; afterwards the sorted keys / payloads are in (k0, v0) -- or (k1, v1) when flags & 1
+int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* workspace, int64_t workspace_bytes, hipStream_t s, SortPlan& plan)
+{
+    plan.L = sort_layout(row_ptr, rows);
+    const SortLayout& L = plan.L;
+    DIG_REQUIRE(workspace && workspace_bytes >= L.bytes, "workspace of dig_bh_ragged_workspace(row_ptr, rows) bytes");
+    plan.base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    plan.n = row_ptr[rows] - row_ptr[0];
+    plan.rows = rows;
+    char* b = plan.base;
+    // row tables (relative to row_ptr[0] = 0 on the device side)
+    std::string host((size_t)(4 * (rows + 1) * 8), '\0');
+    int64_t* h = (int64_t*)host.data();
+    int64_t *h_rp = h, *h_ts = h + (rows + 1), *h_hs = h + 2 * (rows + 1), *h_bs = h + 3 * (rows + 1);
+    h_ts[0] = h_hs[0] = h_bs[0] = 0;
+    for (int64_t r = 0; r <= rows; ++r) h_rp[r] = row_ptr[r] - row_ptr[0];
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        h_ts[r + 1] = h_ts[r] + (len + kSortTile - 1) / kSortTile;
+        h_hs[r + 1] = h_hs[r] + (len + kSortHistChunk - 1) / kSortHistChunk;
+        h_bs[r + 1] = h_bs[r] + (len + kBhrChunk - 1) / kBhrChunk;
+    }
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rowptr, h_rp, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_tilestart, h_ts, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_histstart, h_hs, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_bhstart, h_bs, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipStreamSynchronize(s));            // (the host tables above go out of scope; 4 small copies)
+    if (plan.n == 0) return DIG_OK;
+    DIG_REQUIRE(L.total_tiles < (1ll << 31), "too many elements for one call");
+    const int64_t* d_rp = (const int64_t*)(b + L.off_rowptr);
+    const int64_t* d_ts = (const int64_t*)(b + L.off_tilestart);
+    const int64_t* d_hs = (const int64_t*)(b + L.off_histstart);
+    unsigned* ghist = (unsigned*)(b + L.off_ghist);
+    unsigned* flags = (unsigned*)(b + L.off_small);
+    unsigned* status = (unsigned*)(b + L.off_status);
+    unsigned* ticket = status + L.total_tiles * kSortBins;
+    uint64_t *k0 = (uint64_t*)(b + L.off_k0), *k1 = (uint64_t*)(b + L.off_k1);
+    unsigned *v0 = (unsigned*)(b + L.off_v0), *v1 = (unsigned*)(b + L.off_v1);
+    DIG_HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)(rows * kSortPasses * kSortBins * 4), s));
+    DIG_HIP_TRY(hipMemsetAsync(flags, 0, 256, s));
+    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)L.hist_chunks), dim3(kSortBlock), 0, s, p, d_rp, d_hs, (int)rows, ghist, flags);
+    hipLaunchKernelGGL(sort_base_kernel, dim3((unsigned)(rows * kSortPasses)), dim3(kSortBins), 0, s, ghist);
+    for (int pass = 0; pass < kSortPasses; ++pass) {
+        // pass 0: p -> (k0, v0); odd passes: (k0, v0) -> (k1, v1); even passes: (k1, v1) -> (k0, v0)
+        DIG_HIP_TRY(hipMemsetAsync(status, 0, (size_t)(L.total_tiles * kSortBins * 4 + 256), s));
+        const bool to0 = (pass & 1) == 0;
+        if (pass == 0)
+            hipLaunchKernelGGL((sort_pass_kernel<true>), dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, p, (const uint64_t*)nullptr,
+                               (const unsigned*)nullptr, k0, v0, d_rp, d_ts, (int)rows, pass, ghist, status, ticket, flags);
+        else
+            hipLaunchKernelGGL((sort_pass_kernel<false>), dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, (const double*)nullptr,
+                               to0 ? k1 : k0, to0 ? v1 : v0, to0 ? k0 : k1, to0 ? v0 : v1, d_rp, d_ts, (int)rows, pass, ghist, status, ticket, flags);
+    }
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dig_bh_ragged_workspace(const int64_t* row_ptr, int64_t rows)
+{
+    if (!row_ptr || rows <= 0) return 512;
+    return sort_layout(row_ptr, rows).bytes + 256;
+}
+
+// Sorted values and the order (position in the row of every sorted element) of ragged rows of doubles: p_sorted / order may be NULL.
+int dig_sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, double* p_sorted, uint32_t* order, void* workspace,
+                  int64_t workspace_bytes, void* stream)
+{
+    DIG_REQUIRE(rows >= 0 && (rows == 0 || row_ptr), "rows >= 0, row_ptr");
+    if (rows == 0) return DIG_OK;
+    for (int64_t r = 0; r < rows; ++r) DIG_REQUIRE(row_ptr[r + 1] >= row_ptr[r] && row_ptr[r + 1] - row_ptr[r] < (1ll << 30), "row lengths in [0, 2^30)");
+    DIG_REQUIRE(row_ptr[rows] == row_ptr[0] || p, "p");
+    SortPlan plan;
+    const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, (hipStream_t)stream, plan);
+    if (rc != DIG_OK || plan.n == 0) return rc;
+    char* b = plan.base;
+    const SortLayout& L = plan.L;
+    hipLaunchKernelGGL(sort_unpack_kernel, dim3((unsigned)grid_for(plan.n, 256)), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)(b + L.off_k0),
+                       (const uint64_t*)(b + L.off_k1), (const unsigned*)(b + L.off_v0), (const unsigned*)(b + L.off_v1),
+                       (const unsigned*)(b + L.off_small), plan.n, p_sorted ? p_sorted + row_ptr[0] : nullptr, order ? order + row_ptr[0] : nullptr);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+// Benjamini-Hochberg q-values of ragged rows of p-values, in place order (q[i] belongs to p[i]).  n_global / rank0 / carry (host
+// arrays, may be NULL: the row is the whole list): the row is the ranks rank0 .. of a list of n_global values whose elements
+// behind the row have the reverse running minimum `carry`.  row_min (device, may be NULL): the minimum of the row's
+// p / (rank / n) -- what the ranks in front need as their carry.  sorted_out != 0: q leaves in sorted order instead.
+int dig_bh_qvalues_ragged(const double* p, const int64_t* row_ptr, int64_t rows, const double* n_global, const int64_t* rank0,
+                          const double* carry, double* q, double* row_min, int sorted_out, void* workspace, int64_t workspace_bytes,
+                          void* stream)
+{
+    DIG_REQUIRE(rows >= 0 && (rows == 0 || row_ptr), "rows >= 0, row_ptr");
+    if (rows == 0) return DIG_OK;
+    for (int64_t r = 0; r < rows; ++r) DIG_REQUIRE(row_ptr[r + 1] >= row_ptr[r] && row_ptr[r + 1] - row_ptr[r] < (1ll << 30), "row lengths in [0, 2^30)");
+    DIG_REQUIRE(row_ptr[rows] == row_ptr[0] || (p && (q || row_min)), "p and q");
+    hipStream_t s = (hipStream_t)stream;
+    SortPlan plan;
+    const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, s, plan);
+    if (rc != DIG_OK) return rc;
+    char* b = plan.base;
+    const SortLayout& L = plan.L;
+    // per-row parameters
+    std::string host((size_t)(3 * rows * 8), '\0');
+    double* h_n = (double*)host.data();
+    int64_t* h_r = (int64_t*)(host.data() + rows * 8);
+    double* h_c = (double*)(host.data() + 2 * rows * 8);
+    const double inf = __builtin_inf();
+    for (int64_t r = 0; r < rows; ++r) {
+        h_n[r] = n_global ? n_global[r] : (double)(row_ptr[r + 1] - row_ptr[r]);
+        h_r[r] = rank0 ? rank0[r] : 0;
+        h_c[r] = carry ? carry[r] : inf;
+    }
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_nglob, h_n, rows * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rank0, h_r, rows * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_carry, h_c, rows * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipStreamSynchronize(s));
+    if (plan.n == 0) {
+        if (row_min) {
+            std::string infs((size_t)(rows * 8), '\0');
+            for (int64_t r = 0; r < rows; ++r) ((double*)infs.data())[r] = inf;
+            DIG_HIP_TRY(hipMemcpyAsync(row_min, infs.data(), rows * 8, hipMemcpyHostToDevice, s));
+            DIG_HIP_TRY(hipStreamSynchronize(s));
+        }
+        return DIG_OK;
+    }
+    const uint64_t *k0 = (const uint64_t*)(b + L.off_k0), *k1 = (const uint64_t*)(b + L.off_k1);
+    const unsigned *v0 = (const unsigned*)(b + L.off_v0), *v1 = (const unsigned*)(b + L.off_v1);
+    const unsigned* flags = (const unsigned*)(b + L.off_small);
+    const int64_t *d_rp = (const int64_t*)(b + L.off_rowptr), *d_bs = (const int64_t*)(b + L.off_bhstart);
+    const double *d_n = (const double*)(b + L.off_nglob), *d_c = (const double*)(b + L.off_carry);
+    const int64_t* d_r = (const int64_t*)(b + L.off_rank0);
+    double *cmin = (double*)(b + L.off_cmin), *suffix = (double*)(b + L.off_suffix);
+    hipLaunchKernelGGL((bhr_chunk_kernel<0>), dim3((unsigned)L.bh_chunks), dim3(kBhrBlock), 0, s, k0, k1, v0, v1, flags, d_rp, d_bs, (int)rows, d_n,
+                       d_r, d_c, cmin, (const double*)nullptr, (double*)nullptr, 0);
+    hipLaunchKernelGGL(bhr_suffix_kernel, dim3((unsigned)rows), dim3(kBhrBlock), 0, s, cmin, d_bs, suffix, row_min);
+    if (q)
+        hipLaunchKernelGGL((bhr_chunk_kernel<1>), dim3((unsigned)L.bh_chunks), dim3(kBhrBlock), 0, s, k0, k1, v0, v1, flags, d_rp, d_bs, (int)rows,
+                           d_n, d_r, d_c, (double*)nullptr, suffix, q + row_ptr[0], sorted_out ? 0 : 1);
+    DIG_HIP_TRY(hipGetLastError());
+    return DIG_OK;
+}
+
+}  // extern "C"

@@ -198,24 +198,40 @@ def nb_model(d_pr, idx, mu_lst, sigma_lst, f_tabix, f_fasta, n_up=2, n_down=2, b
         "MU": np.asarray(mu_lst, float)[reg], "SIGMA": np.asarray(sigma_lst, float)[reg], "REGION": labels[reg]})[cols]
 
 
-def get_q_vals_rows(p_rows):
-    """get_q_vals for every row of a [rows, n] device tensor at once (the cohorts of the per-base route: one segmented sort, one
-    pass of dig_bh_qvalues_sorted, one scatter instead of `rows` times five launches)."""
+def bh_ragged(p, row_ptr, n_global=None, rank0=None, carry=None, want_q=True, want_row_min=False, sorted_out=False):
+    """dig_bh_qvalues_ragged (csrc/dig_sort.hip): Benjamini-Hochberg q-values of ragged rows of one float64 device tensor -- the
+    library's own batched radix sort (63-bit keys, 32-bit payload, one kernel per pass), the Benjamini-Hochberg pass and the
+    way back to every p-value's place in one launch sequence.  row_ptr: host offsets (rows + 1).  n_global / rank0 / carry (host
+    arrays or None): the rows are ranges of longer lists (parallel.ShardedTiles' sample sort).  Returns (q or None, row_min or None)."""
     import torch
     from .. import _lib
+    p = p.contiguous()
+    assert p.dtype == torch.float64 and p.is_cuda
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    rows = rp.size - 1
+    h = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    ng, r0, ca = h(n_global, np.float64), h(rank0, np.int64), h(carry, np.float64)
+    q = torch.empty_like(p) if want_q else None
+    rmin = torch.empty(max(rows, 1), dtype=torch.float64, device=p.device) if want_row_min else None
+    wsb = int(_lib.load().dig_bh_ragged_workspace(_lib.host_ptr(rp), rows))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.call("dig_bh_qvalues_ragged", _lib.dev_ptr(p), _lib.host_ptr(rp), rows, _lib.host_ptr(ng), _lib.host_ptr(r0), _lib.host_ptr(ca),
+                  _lib.dev_ptr(q) if q is not None else None, _lib.dev_ptr(rmin) if rmin is not None else None, 1 if sorted_out else 0,
+                  _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
+    return q, (rmin[:rows] if rmin is not None else None)
+
+
+def get_q_vals_rows(p_rows):
+    """get_q_vals for every row of a [rows, n] device tensor at once (the cohorts of the per-base route): one call of
+    dig_bh_qvalues_ragged -- the library's radix sort of all rows, the Benjamini-Hochberg pass and the scatter behind it."""
+    import torch
     p = p_rows.to(torch.float64).contiguous()
     rows, n = p.shape
     if n == 0 or rows == 0:
         return p.clone()
-    ps, order = torch.sort(p, dim=1, stable=True)
-    q = torch.empty_like(ps)
-    wsb = int(_lib.load().dig_bh_workspace(n, rows))
-    ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
-    with torch.cuda.device(p.device):
-        _lib.call("dig_bh_qvalues_sorted", _lib.dev_ptr(ps), n, rows, _lib.dev_ptr(q), _lib.dev_ptr(ws), wsb, _lib.stream_ptr())
-    out = torch.empty_like(q)
-    out.scatter_(1, order, q)
-    return out
+    q, _ = bh_ragged(p.reshape(-1), np.arange(rows + 1, dtype=np.int64) * n)
+    return q.reshape(rows, n)
 
 
 def get_q_vals(pvals_lst):

@@ -34,7 +34,7 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 10  /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 11  /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
                              * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome), dig_write_tsv_host;
                              * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_*; 9: + DIG_PIPE_RECORDS, dig_element_records_* */
@@ -475,6 +475,27 @@ int dig_mutation_file_free_host(void *handle);
  * per-base route of BASELINE configs[4]). */
 int64_t dig_bh_workspace(int64_t n, int64_t rows);
 int dig_bh_qvalues_sorted(const double *p_sorted, int64_t n, int64_t rows, double *q_sorted, void *workspace, int64_t workspace_bytes,
+                          void *stream);
+/* Ranking p-values on the device (ABI 11, round 6; csrc/dig_sort.hip): a batched LSD radix sort written for this step (63-bit
+ * keys in 9-bit digits, 32-bit payload, one kernel per pass by decoupled look-back) with the Benjamini-Hochberg pass behind it --
+ * what nb_model.get_q_vals (nb_model.py:340-342) needs for every cohort of the per-base route at once.
+ *   rows: ragged lists in one array, row r = elements row_ptr[r] .. row_ptr[r + 1] - 1 (row_ptr: HOST array of rows + 1 offsets;
+ *       a row holds fewer than 2^30 elements).  p, q, p_sorted, order: DEVICE arrays indexed like p.
+ *   dig_sort_rows: p_sorted = the row's values ascending (every NaN last), order[j] = position in the row of the j-th smallest;
+ *       either may be NULL.
+ *   dig_bh_qvalues_ragged: q[i] = Benjamini-Hochberg q-value of p[i] among its row (statsmodels' operations, the bits of
+ *       dig_bh_qvalues_sorted behind a stable sort; equal p-values have equal q-values, so the order among them is free).
+ *       n_global, rank0, carry (HOST arrays of `rows`, each may be NULL): the row is the ranks rank0[r] + 1 .. of a list of
+ *       n_global[r] values whose elements behind the row have the running minimum carry[r] (+inf when NULL) -- a rank of a
+ *       sample sort finishes its range of the global order with them.  row_min (DEVICE, `rows`, may be NULL): the minimum of
+ *       p / (rank / n) over the row, without carry (what the ranks in front take as their carry).  q may be NULL when only
+ *       row_min is wanted.  sorted_out != 0: q leaves in ascending order of p instead of in place.
+ *   workspace: dig_bh_ragged_workspace(row_ptr, rows) bytes (24 bytes per element + tables). */
+int64_t dig_bh_ragged_workspace(const int64_t *row_ptr, int64_t rows);
+int dig_sort_rows(const double *p, const int64_t *row_ptr, int64_t rows, double *p_sorted, uint32_t *order, void *workspace,
+                  int64_t workspace_bytes, void *stream);
+int dig_bh_qvalues_ragged(const double *p, const int64_t *row_ptr, int64_t rows, const double *n_global, const int64_t *rank0,
+                          const double *carry, double *q, double *row_min, int sorted_out, void *workspace, int64_t workspace_bytes,
                           void *stream);
 
 /* get_ideal_overlaps(chrom, intervals, window)  genic_driver_tools.py:275-283, for a batch of

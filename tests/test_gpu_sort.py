@@ -1,0 +1,114 @@
+"""csrc/dig_sort.hip: the library's batched radix sort of p-values and the Benjamini-Hochberg pass behind it (nb_model.get_q_vals,
+nb_model.py:340-342 = statsmodels' fdrcorrection) against numpy: sorted values and order bit for bit, q-values bit for bit with
+the host form (whose operations are statsmodels' own), ragged rows, rows that are ranges of a longer list (the sample sort of
+parallel.ShardedTiles)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(rng, lengths, negatives=False):
+    out = []
+    for n in lengths:
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            p = rng.random(n)
+        elif kind == 1:
+            p = 10.0 ** rng.uniform(-320, 0, n)                      # every binade down to the subnormals
+        elif kind == 2:
+            p = rng.choice(rng.random(max(1, n // 50 + 1)), n)       # many ties
+        else:
+            p = np.minimum(1.0, rng.exponential(0.05, n))            # most of the mass in two binades, some at exactly 1
+        if n > 10:
+            p[rng.integers(0, n, 3)] = 0.0
+            p[rng.integers(0, n, 2)] = 1.0
+        if negatives and n > 4:
+            p[rng.integers(0, n, max(1, n // 7))] *= -1.0
+        out.append(p)
+    return out
+
+
+def _sort(p, rp, want_sorted=True, want_order=True):
+    import torch
+    from digdriver_amd import _lib
+    dev = torch.device("cuda:0")
+    t = torch.as_tensor(p, device=dev)
+    ps = torch.full_like(t, -7.0) if want_sorted else None
+    od = torch.full((t.numel(),), 0x7fffffff, dtype=torch.int32, device=dev) if want_order else None
+    wsb = int(_lib.load().dig_bh_ragged_workspace(_lib.host_ptr(rp), rp.size - 1))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.call("dig_sort_rows", _lib.dev_ptr(t), _lib.host_ptr(rp), rp.size - 1, _lib.dev_ptr(ps), _lib.dev_ptr(od), _lib.dev_ptr(ws), wsb,
+              _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return (ps.cpu().numpy() if want_sorted else None), (od.cpu().numpy().astype(np.int64) if want_order else None)
+
+
+@pytest.mark.parametrize("negatives", [False, True])
+def test_radix_sort_of_ragged_rows_equals_numpy_stable_sort(negatives):
+    """Sorted values and the order: bit for bit numpy's stable sort (NaN last), for rows of 0 ... 1.3 M elements -- tile edges
+    (4 095 / 4 096 / 4 097), a single element, an empty row in the middle; with negative values the eighth pass (bit 63) runs."""
+    rng = np.random.default_rng(5 + negatives)
+    lengths = [0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 0, 8193, 100_003, 1_300_001, 17]
+    rows = _rows(rng, lengths, negatives)
+    rows[10][[5, 77, 8000]] = np.nan                                 # NaNs sort last, among themselves in their order
+    rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    p = np.concatenate(rows)
+    ps, od = _sort(p, rp)
+    for r, row in enumerate(rows):
+        want_order = np.argsort(row, kind="stable")
+        got = ps[rp[r]:rp[r + 1]]
+        assert np.array_equal(got[~np.isnan(got)], row[want_order][~np.isnan(row[want_order])]), r      # (-0.0 == +0.0: one key)
+        assert np.isnan(got).sum() == np.isnan(row).sum() and (not np.isnan(got).any() or np.isnan(got[-np.isnan(row).sum():]).all())
+        assert np.array_equal(od[rp[r]:rp[r + 1]], want_order), r
+
+
+def test_bh_qvalues_of_ragged_rows_equal_the_host_form_bit_for_bit():
+    """dig_bh_qvalues_ragged against nb_model.get_q_vals' host form (numpy, statsmodels' own operations) for every row: in
+    place, bit for bit; a row with a NaN is all NaN (statsmodels); ties, zeros, subnormals; and the uniform [rows, n] form
+    get_q_vals_rows that the per-base route calls."""
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    rng = np.random.default_rng(11)
+    lengths = [5, 0, 4096, 77_777, 1, 300_001, 12_289]
+    rows = _rows(rng, lengths)
+    rows[3][[9, 70_000]] = np.nan
+    rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    p = torch.as_tensor(np.concatenate(rows), device="cuda:0")
+    q, rmin = nb_model.bh_ragged(p, rp, want_row_min=True)
+    q, rmin = q.cpu().numpy(), rmin.cpu().numpy()
+    for r, row in enumerate(rows):
+        want = nb_model.get_q_vals(row)
+        assert np.array_equal(q[rp[r]:rp[r + 1]], want, equal_nan=True), r
+        if len(row) and not np.isnan(row).any():
+            srt = np.sort(row)
+            assert rmin[r] == (srt / (np.arange(1, len(row) + 1) / float(len(row)))).min()
+    m = rng.random((37, 50_021)) ** 3
+    got = nb_model.get_q_vals_rows(torch.as_tensor(m, device="cuda:0")).cpu().numpy()
+    for c in (0, 17, 36):
+        assert np.array_equal(got[c], nb_model.get_q_vals(m[c]))
+
+
+def test_ranges_of_a_longer_list_finish_with_rank_offset_and_carry():
+    """What a rank of the sample sort does: a list cut into three ranges of its value order; every range as a row of its own with
+    rank0 = the number of smaller elements, n_global = the length of the whole list and carry = the minimum of the row_min of
+    the ranges behind it, gives the q-values of the whole list bit for bit."""
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    rng = np.random.default_rng(3)
+    p = np.minimum(1.0, rng.exponential(0.2, 250_000))
+    want = nb_model.get_q_vals(p)
+    cuts = np.quantile(p, [0.3, 0.8])
+    part = np.searchsorted(cuts, p, side="right")                  # 0 / 1 / 2 by value (equal values stay together)
+    pieces = [p[part == k] for k in range(3)]
+    rp = np.concatenate([[0], np.cumsum([len(x) for x in pieces])]).astype(np.int64)
+    rank0 = rp[:-1].copy()
+    n_glob = np.full(3, float(len(p)))
+    t = torch.as_tensor(np.concatenate(pieces), device="cuda:0")
+    _, rmin = nb_model.bh_ragged(t, rp, n_global=n_glob, rank0=rank0, want_q=False, want_row_min=True)
+    rmin = rmin.cpu().numpy()
+    carry = np.array([min(rmin[1], rmin[2]), rmin[2], np.inf])
+    q, _ = nb_model.bh_ragged(t, rp, n_global=n_glob, rank0=rank0, carry=carry)
+    q = q.cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(q[rp[k]:rp[k + 1]], want[part == k]), k
