@@ -461,46 +461,159 @@ class ShardedTiles:
 
     def q_values(self, cohort, gathered=None, offset=None):
         """Benjamini-Hochberg q-values (nb_model.get_q_vals) of the rank's tiles of one cohort among the tiles of ALL ranks:
-        [R_r, n_tiles], NaN where a bin has no such tile.  Default: the exchange is all_gather_rows over the process group.
-        `gathered` + `offset`: the caller did the exchange (one-device rank walks) -- the concatenation of
-        valid_pvalues() of all ranks in rank order, and the position of THIS rank's first p-value in it."""
+        [R_r, n_tiles], NaN where a bin has no such tile.  Default: the exchange is the sample sort of sample_sort_q_values over the
+        process group (no rank ever holds another rank's whole list).  `gathered` + `offset`: the caller did the exchange
+        (one-device rank walks) -- the concatenation of valid_pvalues() of all ranks in rank order, and the position of THIS
+        rank's first p-value in it."""
         import torch
         from .sequence_model import nb_model
         mine, mask = self.valid_pvalues(cohort)
-        if gathered is None:
-            counts = all_gather_rows(torch.tensor([mine.numel()], dtype=torch.int64, device=mine.device), self.group)
-            everything = all_gather_rows(mine.contiguous(), self.group)
-            before = int(counts[: self.rank].sum().item()) if counts.numel() > 1 else 0
-        else:
-            if offset is None:
-                raise ValueError("q_values(gathered=...) needs offset= (where this rank's p-values start in `gathered`)")
-            everything, before = gathered, int(offset)
-        q_all = nb_model.get_q_vals(everything) if everything.is_cuda else torch.as_tensor(nb_model.get_q_vals(everything.numpy()))
         out = torch.full(mask.shape, float("nan"), dtype=torch.float64, device=mine.device)
+        if gathered is None:
+            out[mask] = sample_sort_q_values(mine.reshape(1, -1).contiguous(), self.group)[0]
+            return out
+        if offset is None:
+            raise ValueError("q_values(gathered=...) needs offset= (where this rank's p-values start in `gathered`)")
+        everything, before = gathered, int(offset)
+        q_all = nb_model.get_q_vals(everything) if everything.is_cuda else torch.as_tensor(nb_model.get_q_vals(everything.numpy()))
         out[mask] = q_all[before:before + mine.numel()]
         return out
 
 
-def _sharded_tiles_q_values_all(self, max_elements=1 << 28):
-    """q_values() for ALL cohorts at once: [C, R_r, n_tiles] (NaN where a bin has no such tile).  One exchange (the ranks'
-    valid-tile p-values of every cohort, [n_valid, C] rows in rank order), then the cohorts' lists are sorted and taken through
-    the Benjamini-Hochberg pass in batches of whole cohorts (nb_model.get_q_vals_rows; at most `max_elements` values per batch)
-    instead of one cohort at a time: the same bits as q_values(c) for every c."""
+def _sorted_rows(p):
+    """Every row of a [C, n] float64 tensor ascending (NaN last) and the order: the library's radix sort on the device
+    (dig_sort_rows), numpy's stable sort for host tensors (the gloo tests of the exchange)."""
+    import torch
+    C, n = p.shape
+    if p.is_cuda:
+        from . import _lib
+        p = p.contiguous()
+        ps = torch.empty_like(p)
+        order = torch.empty((C, n), dtype=torch.int32, device=p.device)
+        rp = np.arange(C + 1, dtype=np.int64) * n
+        wsb = int(_lib.load().dig_bh_ragged_workspace(_lib.host_ptr(rp), C))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.call("dig_sort_rows", _lib.dev_ptr(p), _lib.host_ptr(rp), C, _lib.dev_ptr(ps), _lib.dev_ptr(order), _lib.dev_ptr(ws), wsb,
+                      _lib.stream_ptr())
+        return ps, order.long()
+    a = p.numpy()
+    order = np.argsort(a, axis=1, kind="stable")
+    return torch.from_numpy(np.take_along_axis(a, order, 1)), torch.from_numpy(order)
+
+
+def _bh_ranges(rows, row_ptr, n_global, rank0):
+    """(q, row_min) of ragged rows that are the ranks rank0 + 1 .. of lists of n_global values, without the ranks behind them:
+    dig_bh_qvalues_ragged on the device, the same operations in numpy for host tensors."""
     import torch
     from .sequence_model import nb_model
+    if rows.is_cuda:
+        return nb_model.bh_ragged(rows, row_ptr, n_global=n_global, rank0=rank0, want_row_min=True)
+    a = rows.numpy()
+    q = np.empty_like(a)
+    rmin = np.full(len(row_ptr) - 1, np.inf)
+    for r in range(len(row_ptr) - 1):
+        x = a[row_ptr[r]:row_ptr[r + 1]]
+        if x.size == 0:
+            continue
+        order = np.argsort(x, kind="stable")
+        v = x[order] / ((rank0[r] + np.arange(1, x.size + 1)) / float(n_global[r]))
+        v = np.minimum.accumulate(v[::-1])[::-1]
+        rmin[r] = v[0]
+        out = np.empty_like(v)
+        out[order] = np.minimum(v, 1.0)
+        q[row_ptr[r]:row_ptr[r + 1]] = out
+    return torch.from_numpy(q), torch.from_numpy(rmin)
+
+
+def sample_sort_q_values(p, group=None, samples=64):
+    """Benjamini-Hochberg q-values (nb_model.get_q_vals, nb_model.py:340-342) of this rank's p-values among the p-values of ALL
+    ranks, for every cohort at once: p [C, n_local] float64 (device tensor under RCCL, host tensor under gloo) -> q [C, n_local].
+
+    A sample sort: every rank sorts its own lists (dig_sort_rows), `samples` evenly spaced values per cohort and rank make the
+    world - 1 splitters of a cohort (all-gather of world x C x samples doubles), one all-to-all sends every value to the rank that
+    owns its range of the global order, that rank ranks its range (dig_bh_qvalues_ragged with rank0 = the number of smaller
+    values and n_global = the length of the whole list) and reports the minimum of p / (rank / n) over it; the ranks' minima
+    are all-gathered (world x C doubles), a range is finished with the minimum of the ranges behind it, and the q-values travel
+    back the way the p-values came.  Per link (world - 1) / world of a rank's OWN values cross twice -- round 5 all-gathered every
+    p-value of every rank to every rank (17 GB per genome x 37 at 8 ranks) and repeated the whole sort on each.  The result has
+    the bits of the single-process form: q depends on the value of p and its global rank only (equal p-values have equal q)."""
+    import torch
+    import torch.distributed as dist
+    from .sequence_model import nb_model
+    p = p.to(torch.float64)
+    C, n = p.shape
+    if not collectives_on(group):
+        if p.is_cuda:
+            return nb_model.get_q_vals_rows(p)
+        return torch.from_numpy(np.stack([nb_model.get_q_vals(row) for row in p.numpy()])) if C else p.clone()
+    world, rank, dev, inf = dist.get_world_size(group), dist.get_rank(group), p.device, float("inf")
+    ps, order = _sorted_rows(p)
+    # ---- splitters ----
+    if n > 0:
+        pos = torch.clamp(torch.div(torch.arange(1, samples + 1, device=dev) * n, samples + 1, rounding_mode="floor"), max=n - 1)
+        smp = torch.nan_to_num(ps[:, pos], nan=inf, posinf=inf)
+    else:
+        smp = torch.full((C, samples), inf, dtype=torch.float64, device=dev)
+    bufs = [torch.empty_like(smp) for _ in range(world)]
+    dist.all_gather(bufs, smp.contiguous(), group=group)
+    pool = torch.sort(torch.cat(bufs, dim=1), dim=1).values                    # [C, world * samples]: the same on every rank
+    split = pool[:, samples * torch.arange(1, world, device=dev)] if world > 1 else pool[:, :0]
+    search = torch.nan_to_num(ps, nan=inf, posinf=inf)                          # (a NaN counts as +inf: behind every splitter or with the +inf)
+    cut = torch.searchsorted(search, split.contiguous(), right=True) if n > 0 else torch.zeros((C, world - 1), dtype=torch.int64, device=dev)
+    bounds = torch.cat([torch.zeros((C, 1), dtype=torch.int64, device=dev), cut, torch.full((C, 1), n, dtype=torch.int64, device=dev)], 1)
+    counts = (bounds[:, 1:] - bounds[:, :-1]).contiguous()                      # [C, world]: what goes to every rank
+    cbufs = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(cbufs, counts, group=group)
+    counts_all = torch.stack(cbufs).cpu().numpy()                               # [source, C, destination]
+    bnd = bounds.cpu().numpy()
+    # ---- the values to their ranges: destination-major, cohort-minor ----
+    send = torch.cat([ps[c, bnd[c, k]:bnd[c, k + 1]] for k in range(world) for c in range(C)]) if C else ps.reshape(-1)
+    send_counts = [int(counts_all[rank, :, k].sum()) for k in range(world)]
+    recv_counts = [int(counts_all[s, :, rank].sum()) for s in range(world)]
+    recv = torch.empty(sum(recv_counts), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts, group=group)
+    # received: source-major, cohort-minor -> rows: cohort-major, source-minor
+    seg = counts_all[:, :, rank]                                                # [source, C]
+    src_off = np.concatenate([[0], np.cumsum(seg.reshape(-1))])                 # offsets in `recv`, (s, c) order
+    pieces = [(c, s, int(src_off[s * C + c]), int(seg[s, c])) for c in range(C) for s in range(world)]
+    rows = torch.cat([recv[o:o + m] for (_, _, o, m) in pieces]) if pieces else recv
+    row_ptr = np.concatenate([[0], np.cumsum(seg.sum(0))]).astype(np.int64)
+    n_global = counts_all.sum((0, 2)).astype(np.float64)
+    rank0 = counts_all[:, :, :rank].sum((0, 2)).astype(np.int64)
+    q_rows, row_min = _bh_ranges(rows.contiguous(), row_ptr, n_global, rank0)
+    # ---- the ranges behind: their minima, last rank first (np.minimum: a NaN makes everything in front of it NaN) ----
+    mbufs = [torch.empty(C, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(mbufs, row_min.to(dev).contiguous(), group=group)
+    mins = torch.stack(mbufs).cpu().numpy()
+    carry = np.full(C, inf)
+    for k in range(world - 1, rank, -1):
+        carry = np.minimum(mins[k], carry)
+    carry_t = torch.repeat_interleave(torch.as_tensor(carry, device=dev), torch.as_tensor(np.diff(row_ptr), device=dev))
+    q_rows = torch.minimum(q_rows, carry_t)
+    # ---- and back: source-major again, then this rank's sorted lists, then the places the p-values came from ----
+    row_off = row_ptr[:-1][:, None] + np.concatenate([np.zeros((C, 1), np.int64), np.cumsum(seg.T, 1)[:, :-1]], 1) if C else np.zeros((0, world), np.int64)
+    back = torch.cat([q_rows[int(row_off[c, s]):int(row_off[c, s]) + int(seg[s, c])] for s in range(world) for c in range(C)]) if C else q_rows
+    got = torch.empty(sum(send_counts), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(got, back.contiguous(), send_counts, recv_counts, group=group)
+    dst_off = np.concatenate([[0], np.cumsum(counts_all[rank].T.reshape(-1))])  # offsets in `got`, (k, c) order
+    q_sorted = torch.cat([got[int(dst_off[k * C + c]):int(dst_off[k * C + c + 1])] for c in range(C) for k in range(world)]).reshape(C, n) if C else got.reshape(C, n)
+    out = torch.empty_like(q_sorted)
+    out.scatter_(1, order, q_sorted)
+    return out
+
+
+def _sharded_tiles_q_values_all(self, max_elements=None):
+    """q_values() for ALL cohorts at once: [C, R_r, n_tiles] (NaN where a bin has no such tile): one sample sort over the process
+    group for the rank's valid-tile p-values of every cohort (sample_sort_q_values) -- the same bits as q_values(c) for every c
+    and as the single-process form.  (`max_elements` is accepted for callers of round 5 and ignored: nothing is gathered.)"""
+    import torch
     r = self.result
     t = torch.arange(self.n_tiles, device=r["pval"].device)[None, :]
     mask = t < r["n_valid"][:, None]
     mine = r["pval"][:, mask]                                   # [C, n_mine]
-    counts = all_gather_rows(torch.tensor([mine.shape[1]], dtype=torch.int64, device=mine.device), self.group)
-    everything = all_gather_rows(mine.t().contiguous(), self.group).t()      # [C, n_all] (a view: the batches below make it contiguous)
-    before = int(counts[: self.rank].sum().item()) if counts.numel() > 1 else 0
-    C, n_all = everything.shape
-    out = torch.full((C,) + tuple(mask.shape), float("nan"), dtype=torch.float64, device=mine.device)
-    step = max(1, int(max_elements // max(n_all, 1)))
-    for c0 in range(0, C, step):
-        q = nb_model.get_q_vals_rows(everything[c0:c0 + step])
-        out[c0:c0 + step][:, mask] = q[:, before:before + mine.shape[1]]
+    out = torch.full((mine.shape[0],) + tuple(mask.shape), float("nan"), dtype=torch.float64, device=mine.device)
+    out[:, mask] = sample_sort_q_values(mine.contiguous(), self.group)
     return out
 
 

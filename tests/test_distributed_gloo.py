@@ -275,6 +275,8 @@ def _tiles_worker(rank, world, port, tmp):
                 assert np.array_equal(q[mask].numpy(), want[before:before + mine.numel()], equal_nan=True)
                 assert fill is None or np.isfinite(q[mask].numpy()).all()
                 assert torch.isnan(q[~mask]).all()
+            q_all = sh.q_values_all()                                 # every cohort through ONE sample sort
+            assert np.array_equal(q_all.numpy(), np.stack([sh.q_values(c).numpy() for c in range(C)]), equal_nan=True)
         if rank == 0:
             np.save(os.path.join(tmp, "tiles_ok.npy"), np.ones(1))
     finally:
@@ -282,10 +284,56 @@ def _tiles_worker(rank, world, port, tmp):
 
 
 @pytest.mark.timeout(600)
-def test_sharded_tiles_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_tiles_gloo(tmp_path, world):
     port = _free_port()
-    mp.spawn(_tiles_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_tiles_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(tmp_path / "tiles_ok.npy")
+
+
+def _sample_sort_worker(rank, world, port, tmp):
+    """parallel.sample_sort_q_values over a real process group: ranks with very different numbers of p-values (one with none),
+    heavy ties (also across the splitters), zeros and ones, a cohort with a NaN (every q of that cohort NaN, as statsmodels), a cohort
+    whose values all sit on one rank's side of every splitter -- against the single-process Benjamini-Hochberg pass over the
+    concatenation of all ranks' values, bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from digdriver_amd.sequence_model import nb_model
+        C = 5
+        sizes = [0, 4001, 37, 12345][:world] if world > 2 else [2500, 0]
+        rng_all = [np.random.default_rng(100 + r) for r in range(world)]
+        parts = []
+        for r in range(world):
+            g, m = rng_all[r], sizes[r]
+            a = np.empty((C, m))
+            a[0] = g.random(m) ** 3
+            a[1] = g.choice(np.array([0.0, 1e-9, 0.25, 0.5, 1.0]), m)                       # five values: every splitter is a tie
+            a[2] = np.minimum(1.0, g.exponential(0.3, m))
+            a[3] = g.random(m) * 1e-3 + r                                                 # rank r's values lie in [r, r + 0.001): already apart
+            a[4] = g.random(m)
+            if m and r == max(k for k in range(world) if sizes[k]):
+                a[4, m // 2] = np.nan
+            parts.append(a)
+        whole = np.concatenate(parts, axis=1)
+        want = np.stack([nb_model.get_q_vals(whole[c]) for c in range(C)])
+        before = int(sum(sizes[:rank]))
+        got = parallel.sample_sort_q_values(torch.from_numpy(parts[rank].copy()), None, samples=8).numpy()
+        assert got.shape == parts[rank].shape
+        assert np.array_equal(got, want[:, before:before + sizes[rank]], equal_nan=True)
+        assert np.isnan(want[4]).all() and not np.isnan(want[:4]).any()
+        if rank == 0:
+            np.save(os.path.join(tmp, "ssort_ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sample_sort_q_values_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_sample_sort_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / "ssort_ok.npy")
 
 
 class _HostStore:
