@@ -825,8 +825,7 @@ def run_workload(args, mode, ctx, primary=True):
                                    td["ov_idx"], td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"],
                                    td["obs_indel"], out_acc=acc_k, out_stats=out_stats, compact=args.form == "auto",
                                    pack_bins=(pipes[0] if pipes else True) if args.pack_bins else False,      # (plan time; shared)
-                                   records_out=use_records[0] if records is None else records,
-                                   pack_counts=os.environ.get("BENCH_PACK_COUNTS", "0") == "1")      # (plan time; developer A/B switch)
+                                   records_out=use_records[0] if records is None else records)
     pipes = []
     torch.cuda.synchronize()
     t_one = time.perf_counter()

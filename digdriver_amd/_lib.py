@@ -15,7 +15,6 @@ LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_h
 
 DIG_F32, DIG_F64, DIG_I16, DIG_BF16 = 0, 1, 2, 3
 DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS, DIG_PIPE_WORKLIST_CLEAN, DIG_PIPE_COMPACT_L, DIG_PIPE_RECORDS = 1, 2, 4, 8, 16, 32
-DIG_PIPE_PACKED_COUNTS = 64
 DIG_REC_DOUBLES, DIG_REC_MU, DIG_REC_SIGMA, DIG_REC_ROBS_FLAG = 10, 7, 8, 9
 GENE_CLASSES = ("SYN", "MIS", "NONS", "SPL", "TRUNC", "NONSYN")
 GS_PLANES = tuple("EXP_" + c for c in GENE_CLASSES) + tuple("PVAL_%s_BURDEN" % c for c in GENE_CLASSES) + \
@@ -62,7 +61,6 @@ _SIGNATURES = {
     "dig_bin_records_pack": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     "dig_element_records_unpack": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
-    "dig_element_pipeline_pack_counts": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp],
     "dig_element_pipeline_host": [_vp] * 25 + [_i64, _i64, _i64, _int],
     "dig_gene_stats": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp],
     "dig_gene_stats_host": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _i64, _int],

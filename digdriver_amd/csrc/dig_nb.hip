@@ -101,7 +101,6 @@ struct ElementStatsArgs {
     // dot kernel left (ss.chunk_sums) and the observed totals, exactly as scale_factors_chunked_kernel forms them; every workgroup
     // keeps them in LDS and writes them to cj / cj_indel above (which then point at OUTPUT arrays)
     ScaleInside ss;
-    const unsigned long long* obs_pack;      // DIG_PIPE_PACKED_COUNTS: obs_snv | obs_samples << 21 | obs_indel << 42 per pair, or NULL
 #ifdef DIG_DEV_ABLATE
     int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
 #endif
@@ -906,16 +905,9 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         r.pi_s = __builtin_nontemporal_load(&a.pi_sum[s.i]);
         r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
         }
-        if (FUSED && a.obs_pack) {          // one 8-byte load instead of three of four bytes (plan time: dig_element_pipeline_pack_counts)
-            const unsigned long long w = __builtin_nontemporal_load(&a.obs_pack[s.i]);
-            r.k_snv = (int)(w & 0x1fffffull);
-            r.k_smp = (int)((w >> 21) & 0x1fffffull);
-            r.k_ind = (int)(w >> 42);
-        } else {
         r.k_snv = __builtin_nontemporal_load(&a.obs_snv[s.i]);
         r.k_smp = __builtin_nontemporal_load(&a.obs_samples[s.i]);
         r.k_ind = __builtin_nontemporal_load(&a.obs_indel[s.i]);
-        }
         if (FUSED && scaled) {
             r.cj = g_cj[0][s.c];
             r.cji = g_cj[1][s.c];
@@ -1583,7 +1575,6 @@ struct FusedRates {
     double *dot_P, *dot_P_INDEL;
     int32_t *dot_R_SIZE, *dot_ELT_SIZE;
     ScaleInside ss;            // dig_element_pipeline_scaled (chunk_sums NULL: not in use)
-    const unsigned long long* obs_pack;      // DIG_PIPE_PACKED_COUNTS: the three counts of a pair as one word, or NULL
 };
 
 // The shapes the one-kernel form is built for: the bench workload's 37 cohorts (two cohort tiles + two quads) down to 33.
@@ -1627,7 +1618,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ScaleInside{}, nullptr
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ScaleInside{}
 #ifdef DIG_DEV_ABLATE
                        , 0
 #endif
@@ -1643,7 +1634,6 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.dot_strand = fused->dot_strand; a.dot_d_pr = fused->dot_d_pr;
         a.dot_P = fused->dot_P; a.dot_P_INDEL = fused->dot_P_INDEL; a.dot_R_SIZE = fused->dot_R_SIZE; a.dot_ELT_SIZE = fused->dot_ELT_SIZE;
         a.ss = fused->ss;
-        a.obs_pack = fused->obs_pack;
         if (a.ss.chunk_sums) {
             DIG_REQUIRE(C <= 256 && which_form_takes_scale(), "scale factors inside the pipeline: C <= 256, the default form of the statistics kernel");
             a.cj = a.ss.cj;

@@ -38,7 +38,6 @@ struct FusedRates {
     double *dot_P, *dot_P_INDEL;
     int32_t *dot_R_SIZE, *dot_ELT_SIZE;
     ScaleInside ss;            // dig_element_pipeline_scaled (chunk_sums NULL: not in use)
-    const unsigned long long* obs_pack;      // DIG_PIPE_PACKED_COUNTS: the three counts of a pair as one word, or NULL
 };
 bool one_kernel_form_fits(int64_t E, int64_t C);
 
@@ -82,7 +81,7 @@ static ScaleScratch scale_scratch_layout(const int64_t* chunk_rows, int n_chunks
 
 // workspace of dig_element_pipeline: [accumulate: context rows + parameter table][statistics: worklist][compact L + flag]
 struct PipeLayout {
-    int64_t acc_bytes, stats_off, stats_bytes, lc_off, flag_off, counts_off, bytes;
+    int64_t acc_bytes, stats_off, stats_bytes, lc_off, flag_off, bytes;
 };
 static PipeLayout pipe_layout(int64_t E, int64_t C, int64_t acc, int64_t stats)
 {
@@ -93,8 +92,7 @@ static PipeLayout pipe_layout(int64_t E, int64_t C, int64_t acc, int64_t stats)
     p.stats_bytes = stats;
     p.lc_off = up(p.stats_off + stats);
     p.flag_off = up(p.lc_off + E * 64 * (int64_t)sizeof(int32_t));
-    p.counts_off = p.flag_off + 256;                         // dig_element_pipeline_pack_counts: one 8-byte word per pair
-    p.bytes = p.counts_off + up(E * C * (int64_t)sizeof(uint64_t));
+    p.bytes = p.flag_off + 256;
     return p;
 }
 
@@ -113,20 +111,6 @@ __global__ __launch_bounds__(256) void pack_bins_kernel(const double* __restrict
         neg |= yi < 0;
     }
     if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
-}
-
-// Plan-time packing of the three observed counts of a pair into one word: 21 bits each (dig_element_pipeline_pack_counts).
-__global__ __launch_bounds__(256) void pack_counts_kernel(const int32_t* __restrict__ snv, const int32_t* __restrict__ smp,
-                                                          const int32_t* __restrict__ ind, int64_t n, unsigned long long* __restrict__ out,
-                                                          int* __restrict__ bad)
-{
-    int b = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int a = snv[i], m = smp[i], d = ind[i];
-        b |= ((unsigned)a | (unsigned)m | (unsigned)d) >> 21;              // negative or >= 2^21: the packed form does not apply
-        out[i] = (unsigned long long)(unsigned)a | ((unsigned long long)(unsigned)m << 21) | ((unsigned long long)(unsigned)d << 42);
-    }
-    if (__any(b != 0) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
 // DIG_PIPE_RECORDS -> the plane form.  One workgroup per 64 x 64 block of the [E, C] grid when cohort_major (planes [C, E]:
@@ -209,29 +193,6 @@ int dig_element_pipeline_prepare(const int32_t* L, int64_t E, int64_t C, void* w
     DIG_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     DIG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     *compact_ok = bad ? 0 : 1;
-    return DIG_OK;
-}
-
-int dig_element_pipeline_pack_counts(const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, int64_t E, int64_t C,
-                                     void* workspace, int64_t workspace_bytes, int* packed_ok, void* stream)
-{
-    DIG_REQUIRE(E >= 0 && C >= 0 && packed_ok, "E, C >= 0, packed_ok non-null");
-    *packed_ok = 0;
-    if (E == 0 || C == 0) return DIG_OK;
-    DIG_REQUIRE(obs_snv && obs_samples && obs_indel, "non-null counts");
-    const int64_t need = dig_element_pipeline_workspace(E, C);
-    DIG_REQUIRE(workspace && need > 0 && workspace_bytes >= need, "workspace of at least dig_element_pipeline_workspace(E, C) bytes");
-    DIG_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace 256-byte aligned");
-    const PipeLayout lay = pipe_layout(E, C, dig_accumulate_workspace(E, C), dig_element_stats_workspace(E, C));
-    int* flag = (int*)((char*)workspace + lay.flag_off) + 1;                 // (word 0 is dig_element_pipeline_prepare's)
-    DIG_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), (hipStream_t)stream));
-    hipLaunchKernelGGL(pack_counts_kernel, dim3(grid_for(E * C, 256)), dim3(256), 0, (hipStream_t)stream, obs_snv, obs_samples, obs_indel,
-                       E * C, (unsigned long long*)((char*)workspace + lay.counts_off), flag);
-    DIG_HIP_TRY(hipGetLastError());
-    int bad = 1;
-    DIG_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    DIG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    *packed_ok = bad ? 0 : 1;
     return DIG_OK;
 }
 
@@ -386,8 +347,7 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
     const int compact = (stages & DIG_PIPE_COMPACT_L) != 0 && N >= 1;
     const int records = (stages & DIG_PIPE_RECORDS) != 0;
-    const int packed_counts = (stages & DIG_PIPE_PACKED_COUNTS) != 0;
-    stages &= ~(DIG_PIPE_WORKLIST_CLEAN | DIG_PIPE_COMPACT_L | DIG_PIPE_RECORDS | DIG_PIPE_PACKED_COUNTS);
+    stages &= ~(DIG_PIPE_WORKLIST_CLEAN | DIG_PIPE_COMPACT_L | DIG_PIPE_RECORDS);
     DIG_REQUIRE(stages >= 1 && stages <= 7, "stages: bit mask of DIG_PIPE_CONTEXTS, DIG_PIPE_DOT, DIG_PIPE_STATISTICS");
     DIG_REQUIRE(N >= 0 && E >= 0 && C >= 0, "N, E, C >= 0");
     if (E == 0 || C == 0) return DIG_OK;
@@ -416,7 +376,7 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
         FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, (const double2*)bin_records,
                      (const int32_t*)((const char*)bin_records + lay_r.yf_off), 1,
                      bin_ctx, (const int32_t*)((char*)workspace + lay.lc_off), gene_length, strand_minus, d_pr, P, P_INDEL, R_SIZE, ELT_SIZE,
-                     ScaleInside{}, packed_counts ? (const unsigned long long*)((char*)workspace + lay.counts_off) : nullptr};
+                     ScaleInside{}};
         return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel, out, E, C,
                                     (char*)workspace + acc_bytes, lay.stats_bytes, stream, &f, /* the kernel clears the header itself */ 1);
     }
@@ -439,8 +399,7 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     if (!(stages & 4)) return DIG_OK;
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
     FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records,
-                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale ? *scale : ScaleInside{},
-                 packed_counts ? (const unsigned long long*)((char*)workspace + lay.counts_off) : nullptr};
+                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale ? *scale : ScaleInside{}};
     if (records) {
         DIG_REQUIRE(bin_records, "DIG_PIPE_RECORDS needs bin_records (dig_bin_records_pack)");
         DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");

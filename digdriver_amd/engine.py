@@ -407,7 +407,7 @@ class PipelinePlan:
 
     def __init__(self, bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, d_pr, obs_snv,
                  obs_samples, obs_indel, out_acc=None, out_stats=None, gene_length=None, compact="auto", workspace=None,
-                 pack_bins=True, records_out=False, pack_counts=False):
+                 pack_bins=True, records_out=False):
         """compact: "auto" (default) checks ONCE, here, on the device whether L repeats every context count three times
         (sequence_tools.py:560-564: true for every elementModel / tiledModel / quickDriver set) and, if so, runs the
         64-context form of the accumulation (contexts + dot in one kernel, half the matrix work); False forces the
@@ -487,13 +487,6 @@ class PipelinePlan:
                           _lib.stream_ptr())
             self.compact = bool(ok.value)
         self._flags = (_lib.DIG_PIPE_COMPACT_L if self.compact else 0) | (_lib.DIG_PIPE_RECORDS if self.records_out else 0)
-        # pack_counts: the three observed counts of a pair as one 8-byte word in the workspace (ABI 10; 21 bits each: `packed_counts`
-        # says whether they fit; repack_counts() after changing a count array in place).  Same bits, 16 instead of 20 input bytes
-        # per pair -- and no gain: with record outputs the step is 3 us SLOWER (0.1822 -> 0.1854 ms), with planes equal within the
-        # noise (profiles/r05_stats_kernel_probes.txt item 11): off by default.
-        self.packed_counts = False
-        if pack_counts and self.N >= 1:
-            self.repack_counts()
 
     def unpack(self, cohort_major=False, stream=None, stats=None):
         """records_out plans: out_records -> the plane form (self.stats [7, E, C] and MU, SIGMA, R_OBS, FLAG of self.acc) on
@@ -513,18 +506,6 @@ class PipelinePlan:
             _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(st), p(o["MU"]), p(o["SIGMA"]),
                       p(o["R_OBS"]), p(o["FLAG"]), 0, _lib.stream_ptr(stream))
         return o, st
-
-    def repack_counts(self):
-        """(Re)pack obs_snv / obs_samples / obs_indel into the workspace on torch's current stream (waits for it)."""
-        import ctypes
-        import torch
-        ok = ctypes.c_int(0)
-        k = self.keep
-        with torch.cuda.device(self.dev):
-            _lib.call("dig_element_pipeline_pack_counts", _lib.dev_ptr(k[11]), _lib.dev_ptr(k[12]), _lib.dev_ptr(k[13]), self.E, self.C,
-                      self._ws, self.wsb, ctypes.byref(ok), _lib.stream_ptr())
-        self.packed_counts = bool(ok.value)
-        self._flags = (self._flags & ~_lib.DIG_PIPE_PACKED_COUNTS) | (_lib.DIG_PIPE_PACKED_COUNTS if self.packed_counts else 0)
 
     def repack_bins(self):
         """(Re)build the packed bin records from the plan's bin tables on torch's current stream (waits for it)."""

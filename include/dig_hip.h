@@ -203,13 +203,6 @@ int dig_accumulate_elements_host(const double *bin_mu, const double *bin_std, co
  * dig_element_records_unpack turns the blocks into the plane form (out7 [7, E, C], MU, SIGMA [E, C] doubles, R_OBS, FLAG
  * [E, C] int32; any destination may be NULL; cohort_major: every plane as [C, E]). */
 #define DIG_PIPE_RECORDS 32
-/* DIG_PIPE_PACKED_COUNTS (ABI 10): the statistics stage reads the three observed counts of a pair as ONE 8-byte word (21 bits each)
- * that dig_element_pipeline_pack_counts wrote into the workspace at plan time (packed_ok = 0: a count is negative or >= 2^21 -- do
- * not set the flag then).  Same bits; 16 instead of 20 input bytes per pair and two vector loads fewer per tile.  Repack when the
- * counts change. */
-#define DIG_PIPE_PACKED_COUNTS 64
-int dig_element_pipeline_pack_counts(const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel, int64_t E, int64_t C,
-                                     void *workspace, int64_t workspace_bytes, int *packed_ok, void *stream);
 #define DIG_REC_DOUBLES 10
 #define DIG_REC_MU 7
 #define DIG_REC_SIGMA 8

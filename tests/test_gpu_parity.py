@@ -876,34 +876,6 @@ def test_record_major_outputs_give_the_same_bits(torch_dev):
         engine.PipelinePlan(*args, records_out=True, pack_bins=False)
 
 
-def test_packed_counts_give_the_same_bits(torch_dev):
-    """DIG_PIPE_PACKED_COUNTS (ABI 10): the statistics stage reads the three observed counts of a pair as one word packed at plan time --
-    same bits as the three arrays, plane and record form; counts of 2^21 and more (or negative) are reported by the packing call
-    and the plan keeps the arrays."""
-    import torch
-    from bench import make_workload
-    from digdriver_amd import engine
-    for (nb, E, C, seed, bump) in ((9000, 7000, 37, 2, 0), (20000, 20000, 37, 31, 300), (700, 1601, 40, 9, 0), (400, 333, 1, 3, 3_000_000)):
-        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
-        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
-        td["obs_snv"] += bump
-        td["obs_samples"] += bump // 2
-        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
-                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
-        ref = engine.PipelinePlan(*args)
-        assert not ref.packed_counts
-        a0, s0 = ref.run(td["cj"], td["cj_indel"])
-        for records in (False, True):
-            plan = engine.PipelinePlan(*args, records_out=records, pack_bins=ref, pack_counts=True)
-            assert plan.packed_counts == (bump < 3_000_000)
-            plan.run(td["cj"], td["cj_indel"])
-            a1, s1 = plan.unpack() if records else (plan.acc, plan.stats)
-            torch.cuda.synchronize()
-            for k in a0:
-                assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, E, C)
-            assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (E, C, records)
-
-
 def test_scale_factors_formed_inside_the_pipeline_give_the_same_bits(torch_dev):
     """dig_element_pipeline_scaled (ABI 10): the dot kernel's waves also form the chunk sums of the rate table, the statistics
     kernel divides -- against ChunkedScaleFactorPlan.run() (own kernels) followed by the plain pipeline: cj, cj_indel, the sum and

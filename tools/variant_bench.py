@@ -28,8 +28,7 @@ def child(ref_path, write_ref):
     st = torch.empty((7, E, C), dtype=torch.float64, device=dev)
     plan = engine.PipelinePlan(td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"],
                                td["L"], td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"],
-                               out_acc=oa, out_stats=st, records_out=os.environ.get("DIG_PLAN_RECORDS", "0") == "1",
-                               pack_counts=os.environ.get("DIG_PLAN_PACK_COUNTS", "0") == "1")
+                               out_acc=oa, out_stats=st, records_out=os.environ.get("DIG_PLAN_RECORDS", "0") == "1")
     s = torch.cuda.current_stream(dev)
 
     def timed(stages, n):
