@@ -576,11 +576,12 @@ def parse_args(argv=None):
     ap.add_argument("--pack-bins", type=int, default=1,
                     help="1 (default): the plans gather from the packed bin records built at plan time (dig_bin_records_pack); "
                          "0: from the four bin tables as handed in (A/B)")
-    ap.add_argument("--outputs", choices=["auto", "planes", "records"], default="auto",
-                    help="layout of the statistics stage's ten outputs per pair: planes (eleven arrays, the form of dig_element_stats), "
-                         "records (DIG_PIPE_RECORDS: one aligned 5 120-byte run per 64-pair tile, unpacked by dig_element_records_unpack), "
-                         "auto (default): the plan times both on THIS card before the run (untimed, reported as output_form) and keeps "
-                         "the faster -- the pool's two kinds of MI355X differ (profiles/r05_stats_kernel_probes.txt)")
+    ap.add_argument("--outputs", choices=["auto", "planes", "records"], default="planes",
+                    help="layout of the statistics stage's ten outputs per pair: planes (default: eleven arrays, the form of dig_element_stats "
+                         "and what the product -- cohort_batch.run_element_cohorts, every consumer of a result frame -- reads: `value` is "
+                         "quoted on it); records (DIG_PIPE_RECORDS: one aligned 5 120-byte run per 64-pair tile; a consumer needs "
+                         "dig_element_records_unpack behind it, which is NOT in the timed step: developer A/B); auto: the plan times both "
+                         "on THIS card before the run and keeps the faster (round 5's default; output_form says what ran)")
     ap.add_argument("--aux", type=int, default=1,
                     help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
                          "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
@@ -589,11 +590,6 @@ def parse_args(argv=None):
                          "files) and time the drop-in from files to 37 results.txt, stage by stage (tools/e2e_bench.py; ~40 s, 1.7 GB "
                          "under --e2e-dir); reported as e2e; 0: skip")
     ap.add_argument("--e2e-dir", default=None, help="scratch directory of the e2e leg (default: a fresh directory under the system's temp)")
-    ap.add_argument("--scale-factors", choices=["auto", "inside", "side"], default="auto",
-                    help="where the cohort scale factors of a step are formed: inside = in the pipeline's own two kernels "
-                         "(dig_element_pipeline_scaled: the dot kernel's waves sum the rate table, the statistics kernel divides; one "
-                         "GPU, same bits; measured slower at this size), side = kernels of their own on a side stream (the only form when "
-                         "the bins are sharded: the chunk sums are all-gathered); auto = side")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -656,6 +652,9 @@ def launch_ranks(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, BENCH_LAUNCHED_BY="bench.py", BENCH_PARENT_IMPORTED_TORCH="0")
+    # (the pool's host driver supports dmabuf IPC only: with the legacy mode RCCL's buffer exchange between the ranks' processes fails
+    #  with `hipIpcGetMemHandle: invalid argument` -- a documented property of this image, where the variable is already exported; it is
+    #  kept for a launch from an environment that lost it.  Never observed by this repository on more than one device: no such box.)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
@@ -680,6 +679,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BENCH_LAUNCH_PROBE") == "fail":
+        # launcher self-check: rank 1 dies before anything touches a device (the parent must relay a non-zero code and no line)
+        if rank == 1:
+            raise SystemExit(3)
+        return
     if os.environ.get("BENCH_LAUNCH_PROBE") == "1":
         # launcher self-check (tests/test_bench_launcher.py, CPU): what a rank sees, before anything touches a device
         if rank == 0:
@@ -889,18 +893,8 @@ def run_workload(args, mode, ctx, primary=True):
     for k in range(1, PLAN_RING):
         pipes.append(make_plan(k))
     pipe = pipes[0]
-    # (auto = side: at the whole-genome size the rate table's 85 MB cost the dot kernel 12 us inside it and give the statistics kernel
-    #  4 - 9 us back: +1 ... +4 us per step; profiles/r05_stats_kernel_probes.txt item 10)
-    scale_inside = args.scale_factors == "inside" and not (use_dist and exchange)
-    if scale_inside:
-        assert pipe.compact and args.contexts_on == "main" and C <= 48, "--scale-factors inside: the compact accumulation, --contexts-on main, C <= 48"
-        for pl in pipes:
-            pl.attach_scale_factors(scale_plan)
-
     def run_pipe(plan, cj, cji, stages, stream):
-        """One dig_element_pipeline call (given scale factors) or one dig_element_pipeline_scaled call (cj, cji are written)."""
-        if scale_inside:
-            return plan.run_scaled(cj, cji, stages=stages, stream=stream)
+        """One dig_element_pipeline call with the scale factors the side stream formed."""
         return plan.run(cj, cji, stages=stages, stream=stream)
 
     def enqueue_scale_factors(t):
@@ -1022,7 +1016,7 @@ def run_workload(args, mode, ctx, primary=True):
             if k >= 3:
                 throttle_events[(k - 3) % len(throttle_events)].synchronize()
         # this step's (first call only) and the coming steps' scale factors; nothing beyond the last step of the run
-        while not scale_inside and queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps + EXTRA_STEPS - 1):
+        while queued[0] < min(t + SIDE_LEAD_STEPS, args.warmup + args.steps + EXTRA_STEPS - 1):
             queued[0] += 1
             enqueue_scale_factors(queued[0])
         cj, cji = cj_outs[b]
@@ -1030,8 +1024,7 @@ def run_workload(args, mode, ctx, primary=True):
             ev = slack_events.pop()
             ev.record(main_stream)
             slack_main[t] = ev
-        if not scale_inside:
-            main_stream.wait_event(side_done[b])
+        main_stream.wait_event(side_done[b])
         which = sample_which(t)
         plan = pipes[t % PLAN_RING]
         if which in ("dot", "statistics") and len(timer_pool) >= 3:      # (one timer stays for the self-test after the loop)
@@ -1104,9 +1097,6 @@ def run_workload(args, mode, ctx, primary=True):
     reh_cj, reh_cji = torch.empty_like(seq_cj), torch.empty_like(seq_cji)
     reh_ev = torch.cuda.Event()
     for _ in range(args.settle_passes):
-        if scale_inside:
-            run_pipe(pipe, reh_cj, reh_cji, 7, main_stream)
-            continue
         with torch.cuda.stream(side_stream):
             scale_plan.run(reh_cj, reh_cji, stream=side_stream)
             reh_ev.record(side_stream)
@@ -1221,6 +1211,24 @@ def run_workload(args, mode, ctx, primary=True):
         bool(torch.equal(ref_acc["MU"], out_acc["MU"])) and bool(torch.equal(ref_acc["P"], out_acc["P"]))
     if not same:
         raise SystemExit("bench: the overlapped step loop and the sequential evaluation disagree")
+    # which of the pool's two kinds of MI355X this is: the statistics kernel's own time WITH PLANE OUTPUTS on this workload
+    gpu_kind_us = (stage_ms.get("statistics") or 0.0) * 1e3 or None
+    if pipe.records_out:
+        gpu_kind_us = None
+        try:
+            pl = make_plan(0, records=False)
+            with torch.cuda.stream(main_stream):
+                pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(main_stream)
+                for _ in range(8):
+                    pl.run(td["cj"], td["cj_indel"], stages=4, stream=main_stream)
+                eb.record(main_stream)
+            torch.cuda.synchronize()
+            gpu_kind_us = ea.elapsed_time(eb) / 8 * 1e3
+            del pl
+        except Exception:                                    # (never at the cost of the bench line)
+            gpu_kind_us = None
     ws = getattr(pipe, "ws", None)                            # the plan's own workspace
     slow_frac = None
     if ws is not None:
@@ -1237,8 +1245,6 @@ def run_workload(args, mode, ctx, primary=True):
                        "statistics": E * C * (21.0 * nbar + 24 + 100)}
         if pipe.compact:            # one launch does the work of both accumulation stages (SURVEY's unfused count is kept)
             stage_bytes["dot"] += stage_bytes["contexts"]
-        if scale_inside:            # ... and sums the rate table for the scale factors (8 bytes per (bin, cohort): the pre-masked table)
-            stage_bytes["dot"] += 8.0 * N_own * C
         stage_kernels = {"contexts": ["acc_region"], "dot": ["acc_dot"], "statistics": ["element_stats_"]}
         default_shape = (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37) and world == 1
 
@@ -1326,8 +1332,7 @@ def run_workload(args, mode, ctx, primary=True):
                                     "replicas": "%d-bin genome replicated on each of %d GPUs, %d cohorts, %d elements in all (%d per GPU), "
                                                 "no exchange"}[mode] % (args.bins, world, C, E_total, E_total // world),
                        "mode": mode, "contexts_on": args.contexts_on,
-                       "scale_factors": "DEVELOPER PROBE (BENCH_NO_SIDE): formed ONCE, not per step -- not a valid bench line" if os.environ.get("BENCH_NO_SIDE") and not scale_inside else ("inside the pipeline's two kernels (dig_element_pipeline_scaled): the dot kernel's waves sum the rate table, "
-                                         "the statistics kernel divides before its first tile" if scale_inside else
+                       "scale_factors": "DEVELOPER PROBE (BENCH_NO_SIDE): formed ONCE, not per step -- not a valid bench line" if os.environ.get("BENCH_NO_SIDE") else (
                                          "kernels of their own on a side stream, several steps ahead" + (" (chunk sums all-gathered over RCCL)" if use_dist and exchange else "")),
                        "bins": args.bins, "bins_on_rank0": N, "cohorts": C, "elements_total": E_total,
                        "elements_on_rank0": E, "parallelism": "bins sharded x%d" % world if mode != "replicas" else "replicas x%d" % world},
@@ -1336,8 +1341,9 @@ def run_workload(args, mode, ctx, primary=True):
                                       "ranks); NOT part of `value`: the asked %d steps are %.1f ms of GPU time" % (args.steps, dt * 1e3)
                                       if ms_step_1000 is not None else None),
             "gpu": {"serial": gpu_serial_of(dev, ctx["gpu_serials"]), "cards_in_sysfs": len(ctx["gpu_serials"]),
-                    "kind": (None if pipe.records_out or not stage_ms.get("statistics") or not default_shape else
-                             "fast" if stage_ms["statistics"] * 1e3 < STATS_KERNEL_KIND_SPLIT_US else "common"),
+                    "kind": (None if not gpu_kind_us or not default_shape else "fast" if gpu_kind_us < STATS_KERNEL_KIND_SPLIT_US else "common"),
+                    "kind_from": ("the timed loop's own stage timer" if not pipe.records_out else
+                                  "eight launches of the plane form of the statistics stage behind the timed region (the loop ran the record form)"),
                     "kind_note": "the pool's MI355X fall into two groups by the statistics kernel's own time WITH PLANE OUTPUTS on this "
                                  "workload (split at %.0f us; DESIGN.md section 8): given when the run used that form; with the record "
                                  "form both groups run alike (output_form.pass_us has this card's two whole-pass times); `serial`: "

@@ -56,8 +56,6 @@ _SIGNATURES = {
     "dig_scale_factors_chunked": [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _vp],
     "dig_scale_factors_local": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dig_element_pipeline": [_vp] * 25 + [_i64, _i64, _i64, _vp, _int, _vp, _i64, _vp],
-    "dig_element_pipeline_scaled": [_vp] * 25 + [_i64, _i64, _i64, _vp, _int, _vp, _i64] + [_vp, _vp, _int, _vp, _vp, _vp, _i64, _vp],
-    "dig_element_pipeline_scaled_prepare": [_vp, _int, _i64, _vp, _i64, _vp],
     "dig_bin_records_pack": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
     "dig_element_records_unpack": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "dig_element_pipeline_prepare": [_vp, _i64, _i64, _vp, _i64, _vp, _vp],
@@ -112,12 +110,11 @@ _SIZE_QUERIES = {
     "dig_rbf_backward_partials": [_i64, _i64],
     "dig_bin_records_bytes": [_i64, _i64],
     "dig_element_records_bytes": [_i64, _i64],
-    "dig_element_pipeline_scaled_scratch": [_vp, _int, _i64],
     "dig_bh_workspace": [_i64, _i64],
     "dig_bh_ragged_workspace": [_vp, _i64],
 }
 
-ABI_VERSION = 11         # include/dig_hip.h: DIG_ABI_VERSION
+ABI_VERSION = 12         # include/dig_hip.h: DIG_ABI_VERSION
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + tuple(_SIZE_QUERIES) + ("dig_abi_version", "dig_last_error",
                                                                 "dig_device_count")

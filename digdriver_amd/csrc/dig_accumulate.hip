@@ -671,102 +671,17 @@ __global__ __launch_bounds__(256) void compact_L_kernel(const int32_t* __restric
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(mismatch, 1);
 }
 
-// dig_element_pipeline_scaled, first half: the dot kernel's waves also sum the rate table for the cohort scale factors -- the memory
-// system has room beside the matrix instructions (0.44 of HBM), whereas the same 85 MB read by a background kernel beside the
-// statistics kernel cost the step 10 - 20 us (profiles/r05_stats_kernel_probes.txt item 10).  A wave takes the blocks a
-// workgroup of suffstats_chunk_stage1 takes (16 passes of rpp = 256 / C rows) and forms the SAME sums in the same order: accumulator
-// a = row group * C + column (rpp * C <= 256 of them: four per lane) adds the entries base[k rpp C + a], k = 0 .. 15, one after
-// the other -- a pass is rpp * C consecutive doubles; then column c adds its rpp row-group sums first to last.  The wave that
-// completes a chunk (a device-scope counter per chunk) adds the chunk's block sums first to last as suffstats_chunk_stage2 does.
-// Block sums cross XCDs: written and read with device-scope atomic operations (no cache-wide fences).
-#ifndef DIG_SCALE_KB
-#define DIG_SCALE_KB 8      // (32 loads per lane in flight: 4 -> 56.4 us, 8 -> 54.4, 16 spills -> 74.5; the kernel without the sums: 42.7)
-#endif
-template <int KB>      // KB passes of the block in flight at once (4 KB loads per lane): 16 = the whole block
-__device__ __forceinline__ void scale_inside_blocks(const ScaleInside& ss, int C, double* part, int lane, int64_t first, int64_t step)
-{
-    const int rpp = 256 / C, nacc = rpp * C;
-    int rg[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rg[q] = (lane + 64 * q) / C;
-    for (int64_t blk = first; blk < ss.n_blocks; blk += step) {
-        const int64_t r0 = ss.blk_rows[2 * blk];
-        const int n_rows = (int)(ss.blk_rows[2 * blk + 1] - r0);
-        const double* base = ss.table + r0 * C;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        // (sixteen unconditional loads in flight -- an entry outside the block replays the block's first one and is not added; a
-        //  load under its own condition is a round trip of its own: 64 of them made the kernel 46 us longer.  The offsets are formed
-        //  per block from an opaque zero: as loop invariants the compiler keeps all 64 addresses, spills them at 128 registers and
-        //  reloads one in front of every load.)
-        int oz;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-        const int lim = n_rows * C;                              // entries of the block
-#pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += KB) {
-            double v[KB][4];
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int a = lane + 64 * q;
-                    const int off = (k0 + kk) * nacc + a + oz;   // = (row group + (k0 + kk) rpp) C + column
-                    v[kk][q] = __builtin_nontemporal_load(base + (a < nacc && off < lim ? off : 0));
-                }
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int a = lane + 64 * q;
-                    if (a < nacc && (k0 + kk) * nacc + a < lim) acc[q] += v[kk][q];
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (lane + 64 * q < nacc) part[lane + 64 * q] = acc[q];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < C) {
-            double s = 0.0;
-            for (int g = 0; g < rpp; ++g) s += part[g * C + lane];
-            __hip_atomic_store(&ss.partial[blk * C + lane], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0): the block's sums are out
-        const int j = ss.blk_chunk[blk];
-        const int b0 = ss.chunk_blk0[j], b1 = ss.chunk_blk0[j + 1];
-        int last = 0;
-        if (lane == 0) last = __hip_atomic_fetch_add(&ss.chunk_count[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)(b1 - b0);
-        if (__shfl(last, 0, 64)) {
-            if (lane < C) {
-                double s = 0.0;
-                for (int b = b0; b < b1; b += 3 * KB) {        // 3 KB loads in flight, then their additions first to last
-                    double v[3 * KB];
-#pragma unroll
-                    for (int i = 0; i < 3 * KB; ++i)
-                        v[i] = __hip_atomic_load(&ss.partial[(int64_t)(b + i < b1 ? b + i : b0) * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int i = 0; i < 3 * KB; ++i)
-                        if (b + i < b1) s += v[i];
-                }
-                ss.chunk_sums[(int64_t)j * C + lane] = s;
-            }
-            if (lane == 0) __hip_atomic_store(&ss.chunk_count[j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 template <int NT, int NQ>
 __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
     const int32_t* __restrict__ bin_ctx, const int64_t* __restrict__ ov_ptr, const int32_t* __restrict__ ov_idx,
     const uint8_t* __restrict__ strand_minus, const int32_t* __restrict__ Lc, const double* __restrict__ d_pr,
     const int32_t* __restrict__ gene_length, double* __restrict__ P, int32_t* __restrict__ R_SIZE,
     int32_t* __restrict__ ELT_SIZE, double* __restrict__ P_INDEL, int64_t E, int C, int c0, int write_sizes,
-    unsigned* __restrict__ zero_dwords, int n_zero, ScaleInside ss)
+    unsigned* __restrict__ zero_dwords, int n_zero)
 {
     constexpr int SL = NT + (NQ > 0 ? 1 : 0);
     constexpr int NTA = NT > 0 ? NT : 1, NQA = NQ > 0 ? NQ : 1;
     __shared__ double tab[kCtxSteps * SL * 64];       // tab[step = 4 t + u][slot][lane], as acc_write_mfma_table lays it out
-    __shared__ double ss_part[kCtxWaves][256];        // (dig_element_pipeline_scaled) a wave's accumulators of one block of the rate table
 
     // (pipeline only) clear the worklist header of the statistics stage that follows on the stream
     if (zero_dwords && blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_dwords[threadIdx.x] = 0u;
@@ -860,7 +775,7 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
     }
     Rows r_c = load_rows(b_c, x_c);
     __syncthreads();
-    if (tile >= t_end && !ss.table) return;
+    if (tile >= t_end) return;
 
     while (tile < t_end) {
         // (the table reads are invariant across tiles: without the opaque zero the compiler hoists them out of the loop and spills)
@@ -974,11 +889,6 @@ __global__ __launch_bounds__(kCtxWaves * 64) void acc_dot_ctx_kernel(
         b_n = b_nn;
         tile += stride;
     }
-    // (dealt to all waves behind their tiles.  Measured at the bench size: the kernel 42.7 -> 54.4 us by its stage timer -- the
-    //  85 MB do not hide behind the matrix work, the waves reach this point together when the tiles are done.  Slower still: the waves
-    //  with one tile fewer taking all blocks, blocks drawn from one device-wide counter, a 128-register form of the kernel with a
-    //  fourth wave per SIMD that only streams the table (71 us): profiles/r05_stats_kernel_probes.txt item 10)
-    if (ss.table) scale_inside_blocks<DIG_SCALE_KB>(ss, C, ss_part[wave], lane, (int64_t)blockIdx.x * kCtxWaves + wave, (int64_t)gridDim.x * kCtxWaves);
 }
 
 struct AccWorkspace {
@@ -1101,11 +1011,9 @@ int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t
 int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const uint8_t* strand_minus,
                               const int32_t* Lc, const int32_t* gene_length, const double* d_pr, double* P, int32_t* R_SIZE,
                               int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, void* stream, unsigned* zero_dwords,
-                              int n_zero, const ScaleInside* scale)
+                              int n_zero)
 {
     if (E == 0 || C == 0) return DIG_OK;
-    DIG_REQUIRE(!scale || (C <= kMfmaChunk && C <= 256), "scale factors inside the pipeline: one cohort chunk (C <= 48)");
-    const ScaleInside ss = scale ? *scale : ScaleInside{};
     DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && Lc && d_pr, "non-null inputs");
     DIG_REQUIRE(P && R_SIZE && ELT_SIZE && P_INDEL, "non-null outputs");
     const int64_t n_tiles = (E + 15) / 16;
@@ -1117,7 +1025,7 @@ int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, con
         auto go = [&](auto kern) -> int {
             DIG_LAUNCH_STAGE(DIG_PIPE_DOT, kern, dim3(grid), dim3(kCtxWaves * 64), 0, (hipStream_t)stream, bin_ctx, ov_ptr, ov_idx, strand_minus,
                                Lc, d_pr, gene_length, P, R_SIZE, ELT_SIZE, P_INDEL, E, (int)C, ch * kMfmaChunk, (int)(ch == 0),
-                               ch == 0 ? zero_dwords : nullptr, n_zero, ss);
+                               ch == 0 ? zero_dwords : nullptr, n_zero);
             DIG_HIP_TRY(hipGetLastError());
             return DIG_OK;
         };

@@ -80,22 +80,6 @@ void disarm_stage_timers();                    // end of a dig_element_pipeline 
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                           \
     } while (0)
 
-// dig_element_pipeline_scaled: the cohort scale factors formed inside the pipeline's two kernels.  Device-side state laid out by
-// dig_element_pipeline_scaled_prepare in the caller's scratch; `table` NULL = not in use.
-struct ScaleInside {
-    const double* table;          // [N, C] rate table, +0.0 where a bin is flagged
-    const int64_t* blk_rows;      // [n_blocks][2] first / one-past-last row of every block (dig_scale_suffstats_chunked's workgroups)
-    const int32_t* blk_chunk;     // [n_blocks] chunk of a block
-    const int32_t* chunk_blk0;    // [n_chunks + 1] first block of a chunk
-    double* partial;              // [n_blocks, C] block sums
-    unsigned* chunk_count;        // [n_chunks + 1] blocks of a chunk done (left at zero by the kernel); [n_chunks]: next block to hand out
-                                  // (set back to zero by the statistics kernel)
-    double* chunk_sums;           // [n_chunks, C]
-    int n_blocks, n_chunks;
-    const double* obs;            // [2, C] observed SNV / indel totals of the cohorts
-    double *cj, *cj_indel, *sum_out;     // outputs ([C] each; sum_out may be NULL)
-};
-
 // dig_tiles_rows.hip: the row walk of the tile probabilities, one launch per cohort pass; regions it does not take are left with
 // n_valid = -2 for the general kernel (dig_tiles.hip)
 int launch_tile_probs_rows(const uint32_t* words, int64_t n_words, const int64_t* chrom_off, const int64_t* chrom_len,

@@ -90,17 +90,6 @@ struct ElementStatsArgs {
     const double2* bin_pack;   // dig_bin_records_pack: {Y_PRED, STD^2} per (bin, cohort), or NULL
     const int32_t* bin_yf;     //                       Y_TRUE | (FLAG != 0) << 31
     int rec;              // DIG_PIPE_RECORDS: out is [ceil(n / 64) * 64][kRecOut] doubles (one record per pair) instead of seven planes
-    // one-kernel pipeline (element_pipeline_one_kernel_launch): the dot stage's arguments -- waves 0-3 of every workgroup form
-    // P = pi_sum and P_INDEL = pi_indel of the workgroup's elements and hand them to the statistics waves through LDS
-    const int32_t *dot_bin_ctx, *dot_Lc, *dot_gene_length;
-    const uint8_t* dot_strand;
-    const double* dot_d_pr;
-    double *dot_P, *dot_P_INDEL;
-    int32_t *dot_R_SIZE, *dot_ELT_SIZE;
-    // dig_element_pipeline_scaled: the scale factors cj / cj_indel are formed here, before the first tile, from the chunk sums the
-    // dot kernel left (ss.chunk_sums) and the observed totals, exactly as scale_factors_chunked_kernel forms them; every workgroup
-    // keeps them in LDS and writes them to cj / cj_indel above (which then point at OUTPUT arrays)
-    ScaleInside ss;
 #ifdef DIG_DEV_ABLATE
     int ablate;           // developer build only (tools/variant_bench.py): 1 no stores, 2 no recurrence, 4 no bin loop, 8 no arithmetic
 #endif
@@ -438,7 +427,6 @@ __shared__ unsigned g_queue_list[16][48];
 __shared__ unsigned g_queue_len, g_ovf_len, g_ovf_next;
 __shared__ unsigned g_tests[3 * kQueueCap];      // the open tests of the queue: record * 4 + role
 __shared__ unsigned g_n_tests, g_next_test;
-__shared__ double g_cj[2][256];             // dig_element_pipeline_scaled: the workgroup's copy of the scale factors
 constexpr int kSlowBlock = 256;
 constexpr int kSlowWaves = kSlowBlock / 64;
 constexpr int kSlowPairsPerWave = 8;        // (<= 16: the open tests of a round are indexed by 16 role + slot)
@@ -446,267 +434,6 @@ constexpr int kOverflowSlack = 64 * 1024;      // entries behind the n of the wo
 __device__ __forceinline__ void slow_round(const ElementStatsArgs& a, const unsigned* __restrict__ items, unsigned base,
                                            unsigned count, bool have_first, unsigned first_item, double (*sp_all)[10],
                                            unsigned* list, int64_t n);
-
-// ---- the one-kernel form of dig_element_pipeline (round 5) -----------------------------------------
-// acc_dot_ctx_kernel and the statistics kernel in ONE persistent launch.  A workgroup owns one CONTIGUOUS range of
-// statistics tiles (n_tiles b / G .. n_tiles (b + 1) / G: equal to a tile).  64 elements are exactly C tiles, a "chunk":
-// waves 0-3 (one per SIMD) are PRODUCERS -- each forms the 16 x C quotients P of one matrix tile of the chunk as the dot kernel
-// does (same instructions in the same order: same bits), writes them to `P` (an output of the call) and into one of two
-// chunk buffers in LDS; waves 4-15 are the statistics pipeline of the kernel below, which takes pi_sum / pi_indel of a
-// tile from the chunk buffer instead of from memory.  Hand-over by four LDS counters: f_prod[slot] counts producer waves
-// done with the slot's chunks, f_cons[slot] the tiles whose values have been read out of it; both only grow.  A chunk that
-// straddles two workgroups' ranges is formed by both (a tenth more producer work: the producers idle three quarters of
-// the time).  Queue of parked pairs: 640 records (the two chunk buffers and the dot table take 63 KB of the LDS).
-#ifdef DIG_FUSE_ABL
-#define DIG_FUSE_ABL_T 0
-#else
-#define DIG_FUSE_ABL_T 4
-#endif
-constexpr int kFuseMaxC = 37;                 // cohorts: two buffers of 64 x C doubles
-constexpr int kFuseQueueCap = 640;
-constexpr int kFuseProducers = 4;
-typedef double fuse_double4 __attribute__((ext_vector_type(4)));
-__shared__ double f_tab[16 * 3 * 64];         // the dot kernel's B operand: tab[step][slot][lane]
-__shared__ double f_P[2][64 * kFuseMaxC];
-__shared__ double f_PI[2][64];
-__shared__ unsigned f_prod[2], f_cons[2], f_cohort_bad[64];
-__shared__ double f_queue[kFuseQueueCap * 11];
-__shared__ unsigned f_tests[3 * kFuseQueueCap];
-
-__device__ __forceinline__ void fuse_wait(const unsigned* counter, unsigned want)
-{
-    while ((unsigned)__builtin_amdgcn_readfirstlane((int)*(const volatile unsigned*)counter) < want) __builtin_amdgcn_s_sleep(2);
-}
-
-// Stage the B operand (per-context sums of d_pr in the per-lane order of the matrix instructions), as acc_dot_ctx_kernel does.
-template <int NT, int NQ>
-__device__ __forceinline__ void fuse_stage_table(const double* __restrict__ d_pr, int C, int nthreads)
-{
-    constexpr int SL = NT + (NQ > 0 ? 1 : 0);
-    constexpr int kTotal = 16 * SL * 64;
-    for (int idx = threadIdx.x; idx < kTotal; idx += nthreads) {
-        const int lane_ = idx & 63, slot = (idx >> 6) % SL, step = idx / (SL * 64);
-        const bool tail = NQ > 0 && slot == NT;
-        const int kappa = 16 * (step >> 2) + 4 * (tail ? (lane_ >> 2) & 3 : lane_ >> 4) + (step & 3);
-        const int c = slot * 16 + (tail ? 4 * (lane_ >> 4) + (lane_ & 3) : lane_ & 15);
-        double v = 0.0;
-        if (c < C && (!tail || (lane_ >> 4) < NQ)) {
-            const double* d = d_pr + (int64_t)c * 192 + 3 * kappa;
-            const double d0 = d[0], d1 = d[1], d2 = d[2];
-            if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0)) atomicOr(&f_cohort_bad[c], 1u);
-            v = (d0 + d1) + d2;
-        }
-        f_tab[idx] = v;
-    }
-}
-
-// The producer's loop: chunks k_lo .. k_lo + nk - 1 of the workgroup, matrix tile p of each (elements 64 k + 16 p .. + 15).
-// want[slot] = the tiles of this workgroup's range [lo, hi) that read the slot's earlier chunks.
-template <int NT, int NQ>
-__device__ __forceinline__ void fuse_dot_producer(const ElementStatsArgs& a, int p, int lane, int64_t k_lo, int nk, int64_t lo, int64_t hi)
-{
-    constexpr int SL = NT + (NQ > 0 ? 1 : 0);
-    constexpr int NTA = NT > 0 ? NT : 1, NQA = NQ > 0 ? NQ : 1;
-    const int i = lane & 15, kq = lane >> 4;
-    const int toff = 4 * kq + (lane & 3);
-    const int C = (int)a.C;
-    const int64_t E = a.E;
-    const int4* ctx4 = reinterpret_cast<const int4*>(a.dot_bin_ctx);
-    const int4* L4 = reinterpret_cast<const int4*>(a.dot_Lc);
-    const int64_t nnz = a.ov_ptr[E];
-    const int32_t* oi_base = nnz > 0 ? a.ov_idx : reinterpret_cast<const int32_t*>(a.ov_ptr);
-    const int64_t oi_last = nnz > 0 ? nnz - 1 : 0;
-    struct Bounds { int64_t q0, row; int cnt, minus; };
-    auto load_bounds = [&](int64_t k) {
-        Bounds r;
-        r.row = min(k * 64 + 16 * p + i, E - 1);
-        r.q0 = a.ov_ptr[r.row];
-        r.cnt = (int)(a.ov_ptr[r.row + 1] - r.q0);
-        r.minus = a.dot_strand[r.row];
-        return r;
-    };
-    unsigned want[2] = {0u, 0u};
-    Bounds b_c = load_bounds(k_lo);
-    int i0 = oi_base[min(b_c.q0, oi_last)], i1 = oi_base[min(b_c.q0 + 1, oi_last)];
-    for (int j = 0; j < nk; ++j) {
-        const int64_t k = k_lo + j;
-        const int slot = j & 1;
-        const int64_t e0 = k * 64 + 16 * p;
-        const bool minus = b_c.minus != 0;
-        const int kk = minus ? 3 - kq : kq;
-        // ---- the element's context counts (sum of its bins' rows) and its L slices ----
-        int rcv[4][4], lv[4][4];
-        {
-            const int4* r0 = ctx4 + (int64_t)i0 * 16 + kk;
-            const int4* r1 = ctx4 + (int64_t)i1 * 16 + kk;
-            const int4* rl = L4 + b_c.row * 16 + kq;
-            int4 ra[4], rb[4], rlv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ra[t] = r0[4 * t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) rb[t] = r1[4 * t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) rlv[t] = rl[4 * t];
-            const int m0 = b_c.cnt > 0 ? -1 : 0, m1 = b_c.cnt > 1 ? -1 : 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                rcv[t][0] = (ra[t].x & m0) + (rb[t].x & m1);
-                rcv[t][1] = (ra[t].y & m0) + (rb[t].y & m1);
-                rcv[t][2] = (ra[t].z & m0) + (rb[t].z & m1);
-                rcv[t][3] = (ra[t].w & m0) + (rb[t].w & m1);
-                lv[t][0] = rlv[t].x; lv[t][1] = rlv[t].y; lv[t][2] = rlv[t].z; lv[t][3] = rlv[t].w;
-            }
-        }
-        if (__any(b_c.cnt > 2)) {
-            for (int jj = 2; jj < b_c.cnt; ++jj) {
-                const int4* r = ctx4 + (int64_t)a.ov_idx[b_c.q0 + jj] * 16 + kk;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int4 v = r[4 * t];
-                    rcv[t][0] += v.x; rcv[t][1] += v.y; rcv[t][2] += v.z; rcv[t][3] += v.w;
-                }
-            }
-        }
-        // the next chunk's bounds and first two bin indices travel during the matrix instructions
-        const Bounds b_n = load_bounds(min(k + 1, k_lo + nk - 1));
-        // ---- two [16 x 64] x [64 x C] products sharing their B operand (acc_dot_ctx_kernel's chains) ----
-        fuse_double4 den[NTA], num[NTA];
-        double denq[NQA], numq[NQA];
-#pragma unroll
-        for (int nt = 0; nt < NTA; ++nt) den[nt] = num[nt] = fuse_double4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < NQA; ++q) denq[q] = numq[q] = 0.0;
-        int rsum = 0, lsum = 0, lzero = 0;
-#ifdef DIG_FUSE_ABL                             // developer ablation (timing only, after a correct run): no matrix instructions, P and the
-        rsum = lsum = 1 + lv[0][0];             // sizes are what the previous call left in memory
-#endif
-#pragma unroll
-        for (int t = 0; t < (DIG_FUSE_ABL_T); ++t) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int vr = minus ? rcv[3 - u][3 - t] : rcv[t][u];
-                rsum += rcv[t][u];
-                lsum += lv[t][u];
-                lzero |= lv[t][u] == 0;
-                const double Ar = (double)vr, Al = (double)lv[t][u];
-                const double* b = f_tab + ((4 * t + u) * SL) * 64 + lane;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const double bv = b[nt * 64];
-                    den[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar, bv, den[nt], 0, 0, 0);
-                    num[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, bv, num[nt], 0, 0, 0);
-                }
-                if constexpr (NQ > 0) {
-                    const double* bq = f_tab + ((4 * t + u) * SL + NT) * 64 + toff;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const double bv = bq[q * 16];
-                        denq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ar, bv, denq[q], 0, 0, 0);
-                        numq[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(Al, bv, numq[q], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        {   // zero denominators (fix_zero_denominators of dig_accumulate.hip: genic_driver_tools.py:361-366)
-            bool z = false;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z |= den[nt][r] == 0.0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) z |= denq[q] == 0.0;
-            if (__any(z)) {
-                int lz = lzero;
-                lz |= __shfl_xor(lz, 16, 64);
-                lz |= __shfl_xor(lz, 32, 64);
-                const double nan = __longlong_as_double(0x7ff8000000000000ll);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rowzero = __shfl(lz, 4 * r + kq, 64);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        if (den[nt][r] == 0.0 && (rowzero || f_cohort_bad[nt * 16 + (lane & 15)])) num[nt][r] = nan;
-                }
-                if constexpr (NQ > 0) {
-                    const int rowzero = __shfl(lz, 4 * ((lane >> 2) & 3) + kq, 64);
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (denq[q] == 0.0 && (rowzero || f_cohort_bad[NT * 16 + 4 * q + (lane & 3)])) numq[q] = nan;
-                }
-            }
-        }
-        // ---- the slot is free when every tile of the chunk two back has been read ----
-        if (j >= 2) fuse_wait(&f_cons[slot], want[slot]);
-        double* sp = f_P[slot];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int el = 16 * p + 4 * r + kq;                  // D[i][j]: lane 16 (i % 4) + j, register i / 4
-            const int64_t e = k * 64 + el;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c = nt * 16 + i;
-                if (c < C) {
-#ifdef DIG_FUSE_ABL
-                    const double v = a.dot_P[min(e, E - 1) * C + c] + 0.0 * (num[nt][r] + den[nt][r]);
-#else
-                    const double v = num[nt][r] / den[nt][r];
-#endif
-                    sp[el * C + c] = v;
-                    if (e < E) a.dot_P[e * C + c] = v;
-                }
-            }
-        }
-        if constexpr (NQ > 0) {
-            const int el = 16 * p + 4 * ((lane >> 2) & 3) + kq;  // D[i][j] of block b: lane 16 i + 4 b + j
-            const int64_t e = k * 64 + el;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c = NT * 16 + 4 * q + (lane & 3);
-                if (c < C) {
-#ifdef DIG_FUSE_ABL
-                    const double v = a.dot_P[min(e, E - 1) * C + c] + 0.0 * (numq[q] + denq[q]);
-#else
-                    const double v = numq[q] / denq[q];
-#endif
-                    sp[el * C + c] = v;
-                    if (e < E) a.dot_P[e * C + c] = v;
-                }
-            }
-        }
-        {
-            rsum += __shfl_xor(rsum, 16, 64);
-            rsum += __shfl_xor(rsum, 32, 64);
-            lsum += __shfl_xor(lsum, 16, 64);
-            lsum += __shfl_xor(lsum, 32, 64);
-            const int64_t e = e0 + i;
-            if (kq == 0) {
-                const double numer = a.dot_gene_length ? (double)a.dot_gene_length[min(e, E - 1)] : (double)lsum;
-#ifdef DIG_FUSE_ABL
-                const double pind = a.dot_P_INDEL[min(e, E - 1)] + 0.0 * numer;
-#else
-                const double pind = numer / (double)rsum;            // genic_driver_tools.py:381 / :159
-#endif
-                f_PI[slot][16 * p + i] = pind;
-#ifndef DIG_FUSE_ABL
-                if (e < E) {
-                    a.dot_R_SIZE[e] = rsum;
-                    a.dot_ELT_SIZE[e] = lsum;
-                    a.dot_P_INDEL[e] = pind;
-                }
-#endif
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the chunk's values are in the buffer
-        if (lane == 0) atomicAdd(&f_prod[slot], 1u);
-        {   // tiles of this chunk inside the workgroup's range
-            const int64_t t0 = max(lo, k * C), t1 = min(hi, (k + 1) * C);
-            want[slot] += (unsigned)(t1 > t0 ? t1 - t0 : 0);
-        }
-        b_c = b_n;
-        i0 = oi_base[min(b_c.q0, oi_last)];
-        i1 = oi_base[min(b_c.q0 + 1, oi_last)];
-    }
-}
 
 #ifdef DIG_ES_TIMING
 // developer build: first / last clock (100 MHz) of every workgroup of the stream pass (tools/es_balance_probe.py)
@@ -726,27 +453,13 @@ __device__ unsigned long long g_es_t0[1024], g_es_t1[1024], g_es_b0[1024], g_es_
 // from the packed bin records of dig_bin_records_pack (two gathers per bin instead of four);
 // GIVEN = 1 / 2: dig_element_stats (mu / sigma handed in per pair; 2: separate indel parameters) -- the same pipeline,
 // tickets and in-kernel second pass without the CSR and bin stages.
-template <bool DOT> __device__ __forceinline__ double* es_queue()      // (only the arrays a kernel names are allocated for it)
-{
-    if constexpr (DOT) return f_queue;
-    else return g_queue;
-}
-template <bool DOT> __device__ __forceinline__ unsigned* es_tests()
-{
-    if constexpr (DOT) return f_tests;
-    else return g_tests;
-}
-
-// DNT >= 0: the one-kernel form (above) -- waves 0-3 produce P with DNT cohort tiles + DNQ quads, the tiles are one contiguous range.
-template <int TB, bool TICKETS, int GIVEN = 0, bool REC = false, int DNT = -1, int DNQ = 0>
+template <int TB, bool TICKETS, int GIVEN = 0, bool REC = false>
 __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementStatsArgs a)
 {
     static_assert(!REC || (TB == 1024 && TICKETS && (GIVEN == 0 || GIVEN == 3)), "record outputs: the pipeline's kernel only");
-    constexpr bool DOT = DNT >= 0;
-    static_assert(!DOT || (TB == 1024 && TICKETS && GIVEN == 3 && DIG_ES_INWAVE), "one-kernel form: the pipeline's kernel on packed bin records");
-    double* const queue = es_queue<DOT>();
-    unsigned* const tests = es_tests<DOT>();
-    constexpr int QCAP = DOT ? kFuseQueueCap : kQueueCap;
+    double* const queue = g_queue;
+    unsigned* const tests = g_tests;
+    constexpr int QCAP = kQueueCap;
 #ifdef DIG_ES_TIMING
     if (threadIdx.x == 0) g_es_t0[blockIdx.x & 1023] = wall_clock64();
 #endif
@@ -767,39 +480,6 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     const int64_t n_waves = ((int64_t)gridDim.x * TB) >> 6;
     int64_t tile = ((int64_t)blockIdx.x * TB + threadIdx.x) >> 6;
     if (!TICKETS && tile >= n_tiles) return;
-    // one-kernel form: this workgroup's tiles [dot_lo, dot_hi), its chunks dot_k_lo .. dot_k_lo + dot_nk - 1 (a chunk = 64 elements = C tiles)
-    const bool producer = DOT && (threadIdx.x >> 6) < kFuseProducers;
-    const int64_t dot_lo = DOT ? n_tiles * blockIdx.x / gridDim.x : 0, dot_hi = DOT ? n_tiles * (blockIdx.x + 1) / gridDim.x : 0;
-    const int64_t dot_k_lo = DOT ? dot_lo / a.C : 0;
-    const int dot_nk = DOT && dot_hi > dot_lo ? (int)((dot_hi - 1) / a.C - dot_k_lo + 1) : 0;
-    const bool scaled = FUSED && a.ss.chunk_sums != nullptr;
-    if (FUSED && scaled) {
-        // (the chunk sums go through the queue's LDS, which nothing uses yet: all loads at once, then one thread per cohort
-        //  adds its column first to last -- a loop of dependent-looking global loads per thread was 17 us of every launch)
-        const int nsum = a.ss.n_chunks * (int)a.C;             // <= 256 x 48 doubles = the first 96 KB... of at most kQueueCap x 11
-        double* stage = queue;
-        for (int i = threadIdx.x; i < nsum; i += TB) stage[i] = a.ss.chunk_sums[i];
-        __syncthreads();
-        for (int c = threadIdx.x; c < (int)a.C; c += TB) {
-            double e = 0.0, sn = 0.0, dn = 0.0;
-            for (int j = 0; j < a.ss.n_chunks; ++j) e += stage[j * (int)a.C + c];
-            sn += a.ss.obs[c];
-            dn += a.ss.obs[a.C + c];
-            const double cj = sn / e, cji = dn / e;            // transfer_tools.py:153-154
-            g_cj[0][c] = cj;
-            g_cj[1][c] = cji;
-            a.ss.cj[c] = cj;                                    // (every workgroup the same values: its own later reads of them hit its own writes)
-            a.ss.cj_indel[c] = cji;
-            if (a.ss.sum_out) a.ss.sum_out[c] = e;
-        }
-    }
-    if constexpr (DOT) {
-        if (threadIdx.x < 2) f_prod[threadIdx.x] = f_cons[threadIdx.x] = 0u;
-        if (threadIdx.x < 64) f_cohort_bad[threadIdx.x] = 0u;
-        if (blockIdx.x == 0 && threadIdx.x < kWorkHeader) a.worklist[threadIdx.x] = 0u;      // (diagnostic counts: added to at the workgroups' ends)
-        __syncthreads();
-        fuse_stage_table<DNT < 0 ? 0 : DNT, DNQ>(a.dot_d_pr, (int)a.C, TB);
-    }
     const int64_t step_pairs = n_waves * 64;
     const int64_t step_e = a.use_fastdiv ? fastdiv(step_pairs, a.divC) : step_pairs;
     const uint32_t step_c = (uint32_t)(step_pairs - step_e * a.C);
@@ -809,10 +489,8 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
     uint32_t cu = (uint32_t)(iu - eu * a.C);
     auto draw = [&]() -> int64_t {                    // next tile of this workgroup (wave-uniform)
         unsigned t = 0;
-        if (DOT && producer) return n_tiles;          // (the producer waves draw nothing: they run fuse_dot_producer behind the loop)
         if (lane == 0) t = atomicAdd(&s_ticket, 1u);
         t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-        if (DOT) return dot_lo + t < dot_hi ? dot_lo + t : n_tiles;
 #if DIG_ES_CONTIG      // developer A/B: every workgroup walks ONE contiguous range of tiles
         {
             const int64_t lo = n_tiles * blockIdx.x / gridDim.x, hi = n_tiles * (blockIdx.x + 1) / gridDim.x;
@@ -889,32 +567,13 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         }
         // the streamed inputs are read once: non-temporal loads keep them from displacing the bin records, which neighbouring
         // elements re-read, in L2 (same-box A/B, two pairs of runs: whole pass 172.8 -> 171.1 us; profiles/r05_stats_kernel_probes.txt)
-        if constexpr (DOT) {
-            // pi_sum / pi_indel of the tile out of its chunk's buffer: wait for the four producer waves, read, count the tile as read
-            r.pi_s = r.pi_i = 0.0;
-            if (s.ok) {
-                const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.e);
-                const int j = (int)((int64_t)(e_first >> 6) - dot_k_lo);
-                const int slot = j & 1;
-                fuse_wait(&f_prod[slot], (unsigned)(kFuseProducers * ((j >> 1) + 1)));
-                r.pi_s = f_P[slot][(int)((int64_t)s.i - (dot_k_lo + j) * 64 * a.C)];
-                r.pi_i = f_PI[slot][s.e & 63u];
-                if (lane == 0) atomicAdd(&f_cons[slot], 1u);        // (LDS operations of a wave execute in order: the reads are done)
-            }
-        } else {
         r.pi_s = __builtin_nontemporal_load(&a.pi_sum[s.i]);
         r.pi_i = a.pi_indel_per_cohort ? a.pi_indel[s.i] : a.pi_indel[s.e];
-        }
         r.k_snv = __builtin_nontemporal_load(&a.obs_snv[s.i]);
         r.k_smp = __builtin_nontemporal_load(&a.obs_samples[s.i]);
         r.k_ind = __builtin_nontemporal_load(&a.obs_indel[s.i]);
-        if (FUSED && scaled) {
-            r.cj = g_cj[0][s.c];
-            r.cji = g_cj[1][s.c];
-        } else {
         r.cj = a.cj[s.c];
         r.cji = a.cj_indel[s.c];
-        }
         return r;
     };
     auto fetch_bin = [&](const StageIn& r) {
@@ -1120,9 +779,6 @@ __global__ __launch_bounds__(TB) void element_stats_stream_fused_kernel(ElementS
         DIG_STREAM_STORE(&a.out[6 * n + i], pv_mut);
     }
     if (parked) flush(parked);
-    if constexpr (DOT) {
-        if (producer) fuse_dot_producer<DNT, DNQ>(a, (int)(threadIdx.x >> 6), lane, dot_k_lo, dot_nk, dot_lo, dot_hi);
-    }
 #if DIG_ES_INWAVE
     if (TB == 1024 && TICKETS) {
 #ifdef DIG_ES_TIMING
@@ -1568,30 +1224,13 @@ struct FusedRates {
     const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
     const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
     int records;               // DIG_PIPE_RECORDS: `out` holds one record of kRecOut doubles per pair
-    // one-kernel form (dot stage inside the statistics kernel): set dot_P, else all NULL
-    const int32_t *dot_bin_ctx, *dot_Lc, *dot_gene_length;
-    const uint8_t* dot_strand;
-    const double* dot_d_pr;
-    double *dot_P, *dot_P_INDEL;
-    int32_t *dot_R_SIZE, *dot_ELT_SIZE;
-    ScaleInside ss;            // dig_element_pipeline_scaled (chunk_sums NULL: not in use)
 };
-
-// The shapes the one-kernel form is built for: the bench workload's 37 cohorts (two cohort tiles + two quads) down to 33.
-bool one_kernel_form_fits(int64_t E, int64_t C)
-{
-    return E >= 1 && C >= 33 && C <= kFuseMaxC;
-}
 
 // DIG_ES_FORM / DIG_ES_BLOCKS_PER_CU are developer knobs for A/B runs (tools/variant_bench.py).
 static int stream_form()      // 1 = three-deep pipelined fused kernel (default), 0 = two-stage form
 {
     const char* e = getenv("DIG_ES_FORM");
     return e ? atoi(e) : 1;
-}
-static bool which_form_takes_scale()      // the 1024-thread ticket kernel (the default form)
-{
-    return stream_form() == 1 && (!getenv("DIG_ES_TICKETS") || atoi(getenv("DIG_ES_TICKETS")) == 1024);
 }
 static int stream_blocks_per_cu(int dflt)
 {
@@ -1618,7 +1257,6 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
     ElementStatsArgs a{mu, sigma, mu_indel, sigma_indel, pi_sum, pi_indel, obs_snv, obs_samples, obs_indel,
                        cj, cj_indel, out, E, C, pi_indel_per_cohort, wl, make_fastdiv(C), use_fd,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ScaleInside{}
 #ifdef DIG_DEV_ABLATE
                        , 0
 #endif
@@ -1630,15 +1268,6 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         a.small_index = fused->small_index;
         a.bin_pack = fused->bin_pack; a.bin_yf = fused->bin_yf;
         a.rec = fused->records;
-        a.dot_bin_ctx = fused->dot_bin_ctx; a.dot_Lc = fused->dot_Lc; a.dot_gene_length = fused->dot_gene_length;
-        a.dot_strand = fused->dot_strand; a.dot_d_pr = fused->dot_d_pr;
-        a.dot_P = fused->dot_P; a.dot_P_INDEL = fused->dot_P_INDEL; a.dot_R_SIZE = fused->dot_R_SIZE; a.dot_ELT_SIZE = fused->dot_ELT_SIZE;
-        a.ss = fused->ss;
-        if (a.ss.chunk_sums) {
-            DIG_REQUIRE(C <= 256 && which_form_takes_scale(), "scale factors inside the pipeline: C <= 256, the default form of the statistics kernel");
-            a.cj = a.ss.cj;
-            a.cj_indel = a.ss.cj_indel;
-        }
     }
 #ifdef DIG_DEV_ABLATE
     a.ablate = getenv("DIG_ABLATE") ? atoi(getenv("DIG_ABLATE")) : 0;
@@ -1678,11 +1307,7 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
         if (which == 2 && form == 1 && tickets == 1024) {
             // one 1024-thread workgroup per CU drawing tiles from an LDS counter (default)
             int rc;
-            if (a.dot_P) {
-                DIG_REQUIRE(a.rec && a.bin_pack && DIG_ES_INWAVE && one_kernel_form_fits(E, C), "one-kernel form: record outputs, packed bin records, 33 - 37 cohorts");
-                rc = C > 36 ? launch_fused(element_stats_stream_fused_kernel<1024, true, 3, true, 2, 2>)
-                            : launch_fused(element_stats_stream_fused_kernel<1024, true, 3, true, 2, 1>);
-            } else if (a.rec) {
+            if (a.rec) {
                 DIG_REQUIRE(a.bin_pack && DIG_ES_INWAVE, "DIG_PIPE_RECORDS needs the packed bin records (dig_bin_records_pack)");
                 rc = launch_fused(element_stats_stream_fused_kernel<1024, true, 3, true>);
             } else if (a.bin_pack)

@@ -31,15 +31,7 @@ struct FusedRates {
     const double2* bin_pack;   // dig_bin_records_pack's records, or NULL: {Y_PRED, STD^2} ...
     const int32_t* bin_yf;     // ... and Y_TRUE | (FLAG != 0) << 31 per (bin, cohort)
     int records;               // DIG_PIPE_RECORDS: `out` holds one record of DIG_REC_DOUBLES doubles per pair
-    // one-kernel form (dot stage inside the statistics kernel): set dot_P, else all NULL
-    const int32_t *dot_bin_ctx, *dot_Lc, *dot_gene_length;
-    const uint8_t* dot_strand;
-    const double* dot_d_pr;
-    double *dot_P, *dot_P_INDEL;
-    int32_t *dot_R_SIZE, *dot_ELT_SIZE;
-    ScaleInside ss;            // dig_element_pipeline_scaled (chunk_sums NULL: not in use)
 };
-bool one_kernel_form_fits(int64_t E, int64_t C);
 
 int accumulate_launch(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                       const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L, int n_class,
@@ -55,29 +47,8 @@ int element_stats_launch(const double* mu, const double* sigma, const double* mu
 int accumulate_compact_launch(const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const uint8_t* strand_minus,
                               const int32_t* Lc, const int32_t* gene_length, const double* d_pr, double* P, int32_t* R_SIZE,
                               int32_t* ELT_SIZE, double* P_INDEL, int64_t E, int64_t C, void* stream, unsigned* zero_dwords,
-                              int n_zero, const ScaleInside* scale);
+                              int n_zero);
 int compact_L_launch(const int32_t* L, int64_t E, int32_t* Lc, int* mismatch, void* stream);
-int64_t scale_chunk_rows_per_block(int64_t C);
-
-// scratch of dig_element_pipeline_scaled: block / chunk tables, counters, block sums, chunk sums
-struct ScaleScratch {
-    int64_t n_blocks, rows_off, chunk_off, blk0_off, count_off, partial_off, sums_off, bytes;
-};
-static ScaleScratch scale_scratch_layout(const int64_t* chunk_rows, int n_chunks, int64_t C)
-{
-    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
-    ScaleScratch l{};
-    const int64_t rpb = scale_chunk_rows_per_block(C);
-    for (int j = 0; j < n_chunks; ++j) l.n_blocks += (chunk_rows[j + 1] - chunk_rows[j] + rpb - 1) / rpb;
-    l.rows_off = 0;
-    l.chunk_off = up(l.rows_off + 2 * l.n_blocks * (int64_t)sizeof(int64_t));
-    l.blk0_off = up(l.chunk_off + l.n_blocks * (int64_t)sizeof(int32_t));
-    l.count_off = up(l.blk0_off + (n_chunks + 1) * (int64_t)sizeof(int32_t));
-    l.partial_off = up(l.count_off + (n_chunks + 1) * (int64_t)sizeof(unsigned));
-    l.sums_off = up(l.partial_off + std::max<int64_t>(l.n_blocks, 1) * C * (int64_t)sizeof(double));
-    l.bytes = up(l.sums_off + (int64_t)n_chunks * C * (int64_t)sizeof(double));
-    return l;
-}
 
 // workspace of dig_element_pipeline: [accumulate: context rows + parameter table][statistics: worklist][compact L + flag]
 struct PipeLayout {
@@ -241,14 +212,13 @@ int dig_bin_records_pack(const double* bin_mu, const double* bin_std, const int3
     return DIG_OK;
 }
 
-static int element_pipeline_impl(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+static int element_pipeline_run(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                          const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
                          const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
                          const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
                          const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
-                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream,
-                         const ScaleInside* scale);
+                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream);
 
 int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                          const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
@@ -258,91 +228,24 @@ int dig_element_pipeline(const double* bin_mu, const double* bin_std, const int3
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
                          const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
-    const int rc = element_pipeline_impl(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
-                                         obs_snv, obs_samples, obs_indel, cj, cj_indel, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE,
-                                         P_INDEL, out, N, E, C, bin_records, stages, workspace, workspace_bytes, stream, nullptr);
+    const int rc = element_pipeline_run(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
+                                        obs_snv, obs_samples, obs_indel, cj, cj_indel, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE,
+                                        P_INDEL, out, N, E, C, bin_records, stages, workspace, workspace_bytes, stream);
     // a stage timer armed for a stage this call did not launch through the timed path (another form of the kernel, a stage
     // the call did not include, C > 48: only the FIRST chunk's dot launch takes the timer) does not stay armed
     dig::disarm_stage_timers();
     return rc;
 }
 
-
-int64_t dig_element_pipeline_scaled_scratch(const int64_t* chunk_rows, int n_chunks, int64_t C)
-{
-    if (!chunk_rows || n_chunks < 1 || n_chunks > 256 || C < 1 || C > 48) return 0;
-    return scale_scratch_layout(chunk_rows, n_chunks, C).bytes;
-}
-
-int dig_element_pipeline_scaled_prepare(const int64_t* chunk_rows, int n_chunks, int64_t C, void* scratch, int64_t scratch_bytes, void* stream)
-{
-    DIG_REQUIRE(chunk_rows && n_chunks >= 1 && n_chunks <= 256 && C >= 1 && C <= 48, "1 .. 256 chunks (chunk_rows on the host), 1 <= C <= 48");
-    for (int j = 0; j < n_chunks; ++j) DIG_REQUIRE(chunk_rows[j] >= 0 && chunk_rows[j + 1] >= chunk_rows[j], "chunk_rows ascending");
-    const ScaleScratch l = scale_scratch_layout(chunk_rows, n_chunks, C);
-    DIG_REQUIRE(scratch && scratch_bytes >= l.bytes && ((uintptr_t)scratch & 255u) == 0, "scratch of dig_element_pipeline_scaled_scratch bytes, 256-byte aligned");
-    DIG_REQUIRE(l.n_blocks < 0x7fffffff, "block count fits 31 bits");
-    std::vector<int64_t> rows(2 * (size_t)l.n_blocks);
-    std::vector<int32_t> chunk((size_t)l.n_blocks), blk0((size_t)n_chunks + 1);
-    const int64_t rpb = scale_chunk_rows_per_block(C);
-    int64_t b = 0;
-    for (int j = 0; j < n_chunks; ++j) {
-        blk0[j] = (int32_t)b;
-        for (int64_t r = chunk_rows[j]; r < chunk_rows[j + 1]; r += rpb, ++b) {
-            rows[2 * b] = r;
-            rows[2 * b + 1] = std::min(r + rpb, chunk_rows[j + 1]);
-            chunk[b] = j;
-        }
-    }
-    blk0[n_chunks] = (int32_t)b;
-    hipStream_t s = (hipStream_t)stream;
-    char* base = (char*)scratch;
-    DIG_HIP_TRY(hipMemsetAsync(base, 0, (size_t)l.bytes, s));      // counters at zero; the sum of a chunk without rows stays +0.0
-    if (l.n_blocks) {
-        DIG_HIP_TRY(hipMemcpyAsync(base + l.rows_off, rows.data(), rows.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        DIG_HIP_TRY(hipMemcpyAsync(base + l.chunk_off, chunk.data(), chunk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    }
-    DIG_HIP_TRY(hipMemcpyAsync(base + l.blk0_off, blk0.data(), blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipStreamSynchronize(s));                           // (the host vectors go out of scope)
-    return DIG_OK;
-}
-
-int dig_element_pipeline_scaled(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
-                                const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
-                                const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
-                                const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, double* cj,
-                                double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
-                                int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
-                                const void* bin_records, int stages, void* workspace, int64_t workspace_bytes,
-                                const double* scale_table, const int64_t* chunk_rows, int n_chunks, const double* obs_totals,
-                                double* sum_out, void* scratch, int64_t scratch_bytes, void* stream)
-{
-    DIG_REQUIRE(scale_table && chunk_rows && obs_totals && cj && cj_indel && scratch, "non-null scale-factor arguments");
-    DIG_REQUIRE(n_chunks >= 1 && n_chunks <= 256 && C >= 1 && C <= 48, "1 .. 256 chunks, 1 <= C <= 48");
-    DIG_REQUIRE(chunk_rows[0] == 0 && chunk_rows[n_chunks] == N, "the chunks cover the N rows of the rate table");
-    DIG_REQUIRE((int64_t)n_chunks * C <= 7000, "n_chunks * C <= 7 000 (the statistics kernel stages the chunk sums in LDS)");
-    const ScaleScratch l = scale_scratch_layout(chunk_rows, n_chunks, C);
-    DIG_REQUIRE(scratch_bytes >= l.bytes && ((uintptr_t)scratch & 255u) == 0, "scratch as dig_element_pipeline_scaled_prepare left it");
-    char* base = (char*)scratch;
-    const ScaleInside ss{scale_table, (const int64_t*)(base + l.rows_off), (const int32_t*)(base + l.chunk_off),
-                         (const int32_t*)(base + l.blk0_off), (double*)(base + l.partial_off), (unsigned*)(base + l.count_off),
-                         (double*)(base + l.sums_off), (int)l.n_blocks, n_chunks, obs_totals, cj, cj_indel, sum_out};
-    const int rc = element_pipeline_impl(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, L, strand_minus, gene_length, d_pr,
-                                         obs_snv, obs_samples, obs_indel, cj, cj_indel, MU, SIGMA, R_OBS, FLAG, P, R_SIZE, ELT_SIZE,
-                                         P_INDEL, out, N, E, C, bin_records, stages, workspace, workspace_bytes, stream, &ss);
-    dig::disarm_stage_timers();
-    return rc;
-}
-
 }  // extern "C"
 
-static int element_pipeline_impl(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
+static int element_pipeline_run(const double* bin_mu, const double* bin_std, const int32_t* bin_y, const uint8_t* bin_flag,
                          const int32_t* bin_ctx, const int64_t* ov_ptr, const int32_t* ov_idx, const int32_t* L,
                          const uint8_t* strand_minus, const int32_t* gene_length, const double* d_pr,
                          const int32_t* obs_snv, const int32_t* obs_samples, const int32_t* obs_indel, const double* cj,
                          const double* cj_indel, double* MU, double* SIGMA, int32_t* R_OBS, int32_t* FLAG, double* P,
                          int32_t* R_SIZE, int32_t* ELT_SIZE, double* P_INDEL, double* out, int64_t N, int64_t E, int64_t C,
-                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream,
-                         const ScaleInside* scale)
+                         const void* bin_records, int stages, void* workspace, int64_t workspace_bytes, void* stream)
 {
     const int worklist_clean = (stages & DIG_PIPE_WORKLIST_CLEAN) != 0;
     const int compact = (stages & DIG_PIPE_COMPACT_L) != 0 && N >= 1;
@@ -360,26 +263,6 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     const int64_t acc_bytes = lay.acc_bytes;
     // the first kernel also clears the worklist header of the statistics stage (64 dwords): no separate memset node
     unsigned* wl = (unsigned*)((char*)workspace + acc_bytes);
-    // DIG_PIPE_FORM=one (developer switch, tools/variant_bench.py): dot + statistics stages of one call as ONE kernel -- record
-    // outputs, compact L, packed bin records, 33 - 37 cohorts; same bits (tests/test_gpu_parity.py)
-    static const bool want_one = []() {
-        const char* e = getenv("DIG_PIPE_FORM");
-        return e && e[0] == 'o';
-    }();
-    const bool one_kernel = want_one && !scale && compact && records && bin_records && (stages & 6) == 6 && one_kernel_form_fits(E, C);
-    DIG_REQUIRE(!scale || (compact && C <= 48), "dig_element_pipeline_scaled: the compact accumulation (dig_element_pipeline_prepare) and C <= 48");
-    if (one_kernel) {
-        DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && d_pr && P && R_SIZE && ELT_SIZE && P_INDEL, "non-null accumulation arguments");
-        DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");
-        const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
-        const BinRecords lay_r = bin_records_layout(N, C);
-        FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, (const double2*)bin_records,
-                     (const int32_t*)((const char*)bin_records + lay_r.yf_off), 1,
-                     bin_ctx, (const int32_t*)((char*)workspace + lay.lc_off), gene_length, strand_minus, d_pr, P, P_INDEL, R_SIZE, ELT_SIZE,
-                     ScaleInside{}};
-        return element_stats_launch(MU, SIGMA, nullptr, nullptr, P, P_INDEL, 0, obs_snv, obs_samples, obs_indel, cj, cj_indel, out, E, C,
-                                    (char*)workspace + acc_bytes, lay.stats_bytes, stream, &f, /* the kernel clears the header itself */ 1);
-    }
     if (compact) {
         // context-repeated L, compacted by dig_element_pipeline_prepare: contexts + dot are ONE kernel (the DOT stage; a
         // CONTEXTS-only call has nothing to enqueue)
@@ -387,7 +270,7 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
             DIG_REQUIRE(bin_ctx && ov_ptr && ov_idx && strand_minus && d_pr && P && R_SIZE && ELT_SIZE && P_INDEL,
                         "non-null accumulation arguments");
             int rc = accumulate_compact_launch(bin_ctx, ov_ptr, ov_idx, strand_minus, (const int32_t*)((char*)workspace + lay.lc_off),
-                                               gene_length, d_pr, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, stream, wl, 64, scale);
+                                               gene_length, d_pr, P, R_SIZE, ELT_SIZE, P_INDEL, E, C, stream, wl, 64);
             if (rc) return rc;
         }
     } else if (stages & 3) {
@@ -398,8 +281,7 @@ static int element_pipeline_impl(const double* bin_mu, const double* bin_std, co
     }
     if (!(stages & 4)) return DIG_OK;
     const int small_index = N < ((int64_t)1 << 24) && C < ((int64_t)1 << 24) && N * C < ((int64_t)1 << 32);
-    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records,
-                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale ? *scale : ScaleInside{}};
+    FusedRates f{bin_mu, bin_std, bin_y, bin_flag, ov_ptr, ov_idx, MU, SIGMA, R_OBS, FLAG, small_index, nullptr, nullptr, records};
     if (records) {
         DIG_REQUIRE(bin_records, "DIG_PIPE_RECORDS needs bin_records (dig_bin_records_pack)");
         DIG_REQUIRE(((uintptr_t)out & 255u) == 0, "record-major `out` 256-byte aligned");

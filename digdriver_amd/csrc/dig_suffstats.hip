@@ -236,7 +236,6 @@ __global__ void scale_factors_chunked_kernel(const double* __restrict__ chunk_su
 
 // Rows per workgroup of the chunked form: a function of C only (never of the device or of the table's size).
 static int64_t ss_chunk_rows_per_block(int64_t C) { return 16 * (kSsBlock / C); }
-int64_t scale_chunk_rows_per_block(int64_t C) { return ss_chunk_rows_per_block(C); }      // (dig_element_pipeline_scaled lays out the same blocks)
 
 static int ss_fill_chunk_table(const int64_t* chunk_rows, int n_chunks, int64_t C, ChunkTable* tab)
 {

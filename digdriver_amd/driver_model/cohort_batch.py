@@ -127,8 +127,9 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
     `f_element_data`.  scale_factors: (cj [C], cj_indel [C]) or None for the genome mode.
     timings: dict that receives seconds per stage; read_workers: threads that parse the C mutation files and read the C
     maps side by side (default: min(C, cores) from 8 cohorts on, else 1 = in this process).
-    on_frame(c, frame): called as soon as cohort c's frame exists (run_and_write_element_cohorts hands the frame to a
-    writer thread there, so that the result files are written while the next frames are assembled).
+    on_frame(c, frame, columns, index): called as soon as cohort c's frame exists -- the frame, the dict of column arrays it was
+    built from and its row index (run_and_write_element_cohorts hands them to a writer thread there, so that the result files
+    are written while the next frames are assembled).
     The three inputs are independent until the kernels need them, so they are read SIDE BY SIDE (round 5; one after the other
     they were 0.8 of the 1.5 s of a 37-cohort run): the maps (a thread per map), the element container, and the mutation
     files -- each parsed by the library's own parser and uploaded by its own thread as soon as it is parsed."""
@@ -257,7 +258,18 @@ def run_and_write_element_cohorts(f_muts, f_pretrained, f_element_data, save_key
             if not labels:
                 labels.append(mapfile.encode_labels(index))
             out_cols = [(k, np.asarray(v).astype(np.int64) if k in ('OBS_SAMPLES', 'OBS_SNV', 'OBS_INDEL') else np.asarray(v)) for k, v in cols.items()]
-            pending.append(pool.submit(mapfile.write_columns_tsv, paths[c], index.name, labels[0], out_cols, threads))
+
+            def write():
+                # (row labels or a column the native writer does not cover -- a quote, a tab or a newline in an element name, an
+                #  object column: encode_labels gives None / write_columns_tsv raises ValueError -- go the route write_results takes
+                #  for them: pandas.  ADVICE r5: the run used to abort here, behind all the device work.)
+                if labels[0] is not None:
+                    try:
+                        return mapfile.write_columns_tsv(paths[c], index.name, labels[0], out_cols, threads)
+                    except ValueError:
+                        pass
+                return _write_one(frame, paths[c], threads)
+            pending.append(pool.submit(write))
         frames = run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, on_frame=on_frame, **kw)
         for f in pending:
             f.result()

@@ -526,42 +526,6 @@ class PipelinePlan:
         return self.acc, self.stats
 
 
-    def attach_scale_factors(self, scale_plan):
-        """Form the cohort scale factors INSIDE this plan's kernels from now on (dig_element_pipeline_scaled, ABI 10; one GPU, compact
-        accumulation, C <= 48): the dot kernel's waves also sum `scale_plan`'s rate table -- the same chunk sums in the same order as
-        ChunkedScaleFactorPlan.run(), hence the same bits -- and the statistics kernel divides before its first tile.  No kernel of
-        its own reads the table any more (85 MB per call at the whole-genome size, which cost the step 10 - 20 us beside the
-        statistics kernel).  `scale_plan`: a ChunkedScaleFactorPlan over ALL chunks of the bin grid (world 1) with premask=True.
-        Then call run_scaled(cj_out, cj_indel_out) instead of scale_plan.run() + run()."""
-        import torch
-        assert self.compact, "the scale factors ride on the compact dot kernel (dig_element_pipeline_prepare)"
-        assert scale_plan.world == 1 and scale_plan.n_own == scale_plan.n_total and scale_plan.masked is not None and scale_plan.C == self.C
-        assert tuple(scale_plan.masked.shape) == (self.N, self.C) and self.C <= 48
-        lib = _lib.load()
-        nb = int(lib.dig_element_pipeline_scaled_scratch(_lib.host_ptr(scale_plan.chunk_rows), scale_plan.n_own, self.C))
-        if nb <= 0:
-            raise _lib.DigHipError("dig_element_pipeline_scaled_scratch: no layout for these chunks")
-        self._scale = scale_plan
-        self._scale_scratch = torch.empty(nb, dtype=torch.uint8, device=self.dev)
-        self._scale_obs = scale_plan.part[scale_plan.n_own:].contiguous()          # [2, C]: observed SNVs, observed indels
-        with torch.cuda.device(self.dev):
-            _lib.call("dig_element_pipeline_scaled_prepare", _lib.host_ptr(scale_plan.chunk_rows), scale_plan.n_own, self.C,
-                      _lib.dev_ptr(self._scale_scratch), nb, _lib.stream_ptr())
-        self._fn_scaled = getattr(lib, "dig_element_pipeline_scaled")
-        return self
-
-    def run_scaled(self, cj_out, cj_indel_out, out_sum=None, stages=7, stream=None):
-        """The pipeline with its scale factors formed inside (attach_scale_factors first): cj_out, cj_indel_out [C] are written."""
-        sp = self._scale
-        rc = self._fn_scaled(*self._head, _lib.dev_ptr(cj_out), _lib.dev_ptr(cj_indel_out), *self._tail, int(stages) | self._flags,
-                             self._ws, self.wsb, _lib.dev_ptr(sp.masked), _lib.host_ptr(sp.chunk_rows), sp.n_own,
-                             _lib.dev_ptr(self._scale_obs), _lib.dev_ptr(out_sum) if out_sum is not None else None,
-                             _lib.dev_ptr(self._scale_scratch), self._scale_scratch.numel(), _lib.stream_ptr(stream))
-        if rc != 0:
-            raise _lib.DigHipError("dig_element_pipeline_scaled failed (%d): %s" % (rc, _lib.last_error()))
-        return self.acc, self.stats
-
-
 class PlanRing:
     """Several PipelinePlans -- one per batch in flight, each with its own outputs and workspace -- taking turns on as
     many streams.  A pass is a chain of dependent kernels (contexts -> dot -> statistics) and each of them leaves part of

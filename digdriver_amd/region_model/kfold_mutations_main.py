@@ -27,19 +27,7 @@ from .data_aux import dataset_generator as dg
 from .nets.cnn_predictors import SimpleMultiTaskResNet
 from .predict import predict, predict_sharded, r2_score
 from .trainers import gp_trainer
-from .trainers.nn_trainer import NNTrainer
-
-
-def _adam(model, device):
-    """Adam(lr = 1e-3) as the reference builds it (mutations_main.py:256 / kfold_mutations_main.py:160); on the GPU the fused
-    multi-tensor form (one kernel for the 75 M parameters of a 37-task model instead of a chain of foreach kernels: 1.8 ->
-    0.5 ms of a 9.8 ms step) -- the model must already be on the device then."""
-    import torch
-    dev = torch.device(device)
-    if dev.type == "cuda":
-        model.to(dev)
-        return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False, fused=True)
-    return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+from .trainers.nn_trainer import NNTrainer, adam_for as _adam
 
 
 def get_cmd_arguments(text=None):

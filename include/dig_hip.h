@@ -34,10 +34,12 @@ extern "C" {
 #define DIG_EHIP (-2)     /* HIP runtime error */
 #define DIG_ENODEV (-3)   /* no usable gfx950 device */
 
-#define DIG_ABI_VERSION 11  /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
+#define DIG_ABI_VERSION 12  /* 2: + join, contexts, scale factors, pipeline entry points; 3: + chunked suff-stats, tile front half, RBF passes;
                              * a statistics stage leaves its worklist length in the header; 4: + dig_element_pipeline_prepare / DIG_PIPE_COMPACT_L;
                              * 5: + dig_bin_records_pack, `bin_records` argument of dig_element_pipeline; 6: + dig_count_contexts2 (2-bit genome), dig_write_tsv_host;
-                             * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_*; 9: + DIG_PIPE_RECORDS, dig_element_records_* */
+                             * 7: + dig_mutation_file_*_host; 8: + dig_stage_timer_*; 9: + DIG_PIPE_RECORDS, dig_element_records_*;
+                             * 12 (round 6): + dig_sort_rows, dig_bh_qvalues_ragged; - dig_element_pipeline_scaled*, dig_element_pipeline_pack_counts /
+                             * DIG_PIPE_PACKED_COUNTS (round 5's measured losers: tools/rejected/r05_*.patch) */
 
 /* dtype codes for dig_gather_bins */
 #define DIG_F32 0
@@ -250,30 +252,6 @@ int dig_element_pipeline(const double *bin_mu, const double *bin_std, const int3
                          const double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
                          int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
                          const void *bin_records, int stages, void *workspace, int64_t workspace_bytes, void *stream);
-/* dig_element_pipeline with the cohort scale factors formed INSIDE its two kernels (ABI 10; one GPU, compact accumulation, C <= 48):
- * calc_scale_factor_efficient (transfer_tools.py:148-156) is a column sum of the [N, C] rate table -- 8 N C bytes per call that a
- * kernel of its own has to read beside (or in front of) the pipeline's kernels.  Here the waves of the dot kernel, which leaves the
- * memory system room, also form the chunk sums of dig_scale_suffstats_chunked (the same additions in the same order: the same
- * bits), and every workgroup of the statistics kernel divides as dig_scale_factors_chunked does before its first tile.
- *   cj, cj_indel f64 [C]: OUTPUTS here;  scale_table f64 [N, C]: Y_PRED with +0.0 where the bin is flagged;
- *   chunk_rows i64 [n_chunks + 1] on the HOST: the canonical chunks (chunk_rows[0] = 0, chunk_rows[n_chunks] = N; n_chunks * C <= 7 000);
- *   obs_totals f64 [2, C]: observed SNVs, observed indels of the cohorts;  sum_out f64 [C] or NULL: sum(Y_PRED[~FLAG]);
- *   scratch: dig_element_pipeline_scaled_scratch bytes, 256-byte aligned, laid out ONCE by dig_element_pipeline_scaled_prepare
- *   (tables of the blocks and chunks, counters at zero; the call waits for `stream`) and owned by the calls that follow.
- * A call must hold the DOT stage before (or with) the STATISTICS stage that uses its sums; everything else as dig_element_pipeline. */
-int64_t dig_element_pipeline_scaled_scratch(const int64_t *chunk_rows, int n_chunks, int64_t C);
-int dig_element_pipeline_scaled_prepare(const int64_t *chunk_rows, int n_chunks, int64_t C, void *scratch, int64_t scratch_bytes,
-                                        void *stream);
-int dig_element_pipeline_scaled(const double *bin_mu, const double *bin_std, const int32_t *bin_y, const uint8_t *bin_flag,
-                                const int32_t *bin_ctx, const int64_t *ov_ptr, const int32_t *ov_idx, const int32_t *L,
-                                const uint8_t *strand_minus, const int32_t *gene_length, const double *d_pr,
-                                const int32_t *obs_snv, const int32_t *obs_samples, const int32_t *obs_indel, double *cj,
-                                double *cj_indel, double *MU, double *SIGMA, int32_t *R_OBS, int32_t *FLAG, double *P,
-                                int32_t *R_SIZE, int32_t *ELT_SIZE, double *P_INDEL, double *out, int64_t N, int64_t E, int64_t C,
-                                const void *bin_records, int stages, void *workspace, int64_t workspace_bytes,
-                                const double *scale_table, const int64_t *chunk_rows, int n_chunks, const double *obs_totals,
-                                double *sum_out, void *scratch, int64_t scratch_bytes, void *stream);
-
 /* ---- the gene route's statistics block as one launch (ABI 4) -------------------------------- *
  * gene_expected_muts_nb :331-340, gene_pvalue_burden_nb :394-456, gene_pvalue_burden_nb_by_sample :554-583,
  * gene_pvalue_indel :709-729 and the Fisher combination :860-861 of driver_model/transfer_tools.py, for G genes x C cohorts;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), "libdig_hip.so does not export %s" % sym
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "python binding table and header disagree"
-    assert lib.dig_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.dig_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_library_abi_version_matches_header_and_binding():

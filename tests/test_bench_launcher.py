@@ -29,10 +29,12 @@ def test_parent_launches_n_ranks_without_touching_a_device():
 
 
 def test_a_failing_rank_gives_a_non_zero_exit_code_and_no_line():
-    # no GPU here: the ranks fail at require_device(); the parent must relay the failure, not print a line
-    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bins", "2000", "--elements", "500", "--cohorts", "3", "--cpu-sample", "0"], {})
+    # BENCH_LAUNCH_PROBE=fail: rank 1 exits with an error before anything touches a device -- whatever the machine holds (ADVICE r5:
+    # the test used to rely on a box without GPUs); the parent must relay the failure, not print a line
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bins", "2000", "--elements", "500", "--cohorts", "3", "--cpu-sample", "0"],
+             {"BENCH_LAUNCH_PROBE": "fail"})
     assert p.returncode != 0
-    assert not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
 def test_launcher_module_does_not_import_torch_at_import_time():

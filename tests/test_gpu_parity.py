@@ -876,113 +876,6 @@ def test_record_major_outputs_give_the_same_bits(torch_dev):
         engine.PipelinePlan(*args, records_out=True, pack_bins=False)
 
 
-def test_scale_factors_formed_inside_the_pipeline_give_the_same_bits(torch_dev):
-    """dig_element_pipeline_scaled (ABI 10): the dot kernel's waves also form the chunk sums of the rate table, the statistics
-    kernel divides -- against ChunkedScaleFactorPlan.run() (own kernels) followed by the plain pipeline: cj, cj_indel, the sum and
-    every output of the pipeline bit for bit; plane and record form, 1 ... 48 cohorts, 1 ... 64 chunks, tables with fewer rows than
-    chunks (empty chunks), chunks shorter than a block, flagged bins; a second call on the same scratch (the counters are back
-    at zero); dot stage and statistics stage as two calls."""
-    import torch
-    from bench import make_workload
-    from digdriver_amd import engine, parallel
-    cases = ((9000, 7000, 37, 2, 64), (333, 900, 5, 3, 64), (40, 300, 48, 4, 64), (5000, 6000, 37, 5, 1), (2000, 1500, 17, 6, 7),
-             (70000, 20000, 37, 7, 64))
-    for (nb, E, C, seed, n_chunks) in cases:
-        w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed)
-        w["bin_flag"][::5] = 1
-        td = {k: torch.as_tensor(v, device=torch_dev) for k, v in w.items() if isinstance(v, np.ndarray)}
-        chunk_rows = parallel.canonical_chunks(nb, n_chunks)
-        sp = engine.ChunkedScaleFactorPlan(td["bin_mu"], td["bin_flag"], td["n_snv_obs"], td["n_ind_obs"], chunk_rows, n_chunks, world=1)
-        cj, cji, tot = (torch.empty(C, dtype=torch.float64, device=torch_dev) for _ in range(3))
-        sp.run(cj, cji, out_sum=tot)
-        args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
-                td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
-        ref = engine.PipelinePlan(*args)
-        assert ref.compact
-        a0, s0 = ref.run(cj, cji)
-        torch.cuda.synchronize()
-        for records in (False, True):
-            plan = engine.PipelinePlan(*args, records_out=records, pack_bins=ref).attach_scale_factors(sp)
-            for rep in range(2):
-                cj2, cji2, tot2 = (torch.full((C,), -3.0, dtype=torch.float64, device=torch_dev) for _ in range(3))
-                for v in plan.acc.values():
-                    v.fill_(-5)
-                if rep == 0:
-                    plan.run_scaled(cj2, cji2, out_sum=tot2)
-                else:                                   # the two stages as two calls
-                    plan.run_scaled(cj2, cji2, out_sum=tot2, stages=3)
-                    plan.run_scaled(cj2, cji2, out_sum=tot2, stages=4)
-                a1, s1 = plan.unpack() if records else (plan.acc, plan.stats)
-                torch.cuda.synchronize()
-                assert torch.equal(cj, cj2) and torch.equal(cji, cji2) and torch.equal(tot, tot2), (nb, C, n_chunks, records, rep)
-                for k in a0:
-                    assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, nb, C)
-                assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (nb, C, records, rep)
-
-
-_ONE_KERNEL_CHILD = r"""
-import sys
-import numpy as np
-import torch
-sys.path.insert(0, sys.argv[1])
-from bench import make_workload
-from digdriver_amd import _lib, engine
-dev = torch.device("cuda:0")
-# (bins, elements, cohorts, seed, most blocks per element, count bump, the one-kernel form applies)
-cases = ((900, 700, 37, 2, 3, 0, True), (700, 1601, 40, 9, 12, 0, False), (64, 1, 37, 8, 1, 0, True), (20000, 20000, 37, 31, 3, 300, True),
-         (9000, 12000, 37, 32, 3, 0, True), (3000, 2900, 33, 5, 12, 0, True), (3000, 4099, 36, 6, 2, 0, True), (500, 197, 35, 7, 40, 0, True))
-for (nb, E, C, seed, mb, bump, applies) in cases:
-    w = make_workload(n_bins=nb, n_elements=E, n_cohorts=C, seed=seed, max_blocks=mb)
-    w["bin_flag"][::7] = 1
-    w["strand_minus"][::3] = 1
-    td = {k: torch.as_tensor(v, device=dev) for k, v in w.items() if isinstance(v, np.ndarray)}
-    td["obs_snv"] += bump
-    td["obs_samples"] += bump // 2
-    args = (td["bin_mu"], td["bin_std"], td["bin_y"], td["bin_flag"], td["bin_ctx"], td["ov_ptr"], td["ov_idx"], td["L"],
-            td["strand_minus"], td["d_pr"], td["obs_snv"], td["obs_samples"], td["obs_indel"])
-    planes = engine.PipelinePlan(*args)                               # two kernels (the one-kernel form writes records only)
-    recs = engine.PipelinePlan(*args, records_out=True, pack_bins=planes)
-    recs.out_records.fill_(float("nan"))
-    for v in recs.acc.values():
-        v.fill_(-5)
-    a0, s0 = planes.run(td["cj"], td["cj_indel"])
-    tm = engine.StageTimer()
-    tm.arm(_lib.DIG_PIPE_DOT)
-    recs.run(td["cj"], td["cj_indel"])
-    torch.cuda.synchronize()
-    try:
-        tm.read_ms()
-        dot_kernel_ran = True
-    except Exception:
-        dot_kernel_ran = False
-    tm.close()
-    assert dot_kernel_ran == (not applies), (E, C, dot_kernel_ran)
-    a1, s1 = recs.unpack()
-    torch.cuda.synchronize()
-    for k in a0:
-        assert torch.equal(torch.nan_to_num(a0[k].double(), nan=-7.0), torch.nan_to_num(a1[k].double(), nan=-7.0)), (k, E, C)
-    assert torch.equal(torch.nan_to_num(s0, nan=-7.0), torch.nan_to_num(s1, nan=-7.0)), (E, C)
-    if bump:
-        assert torch.isfinite(s1[1]).all() and (s1[1] >= 0).all() and (s1[6] >= 0).all()
-print("ONE-KERNEL-OK")
-"""
-
-
-def test_one_kernel_form_of_the_pipeline_gives_the_same_bits():
-    """DIG_PIPE_FORM=one (developer switch; own process): dot and statistics stages of a dig_element_pipeline call as ONE
-    persistent kernel -- four producer waves per workgroup form P on the matrix cores and hand it to the statistics waves
-    through LDS (dig_nb.hip: fuse_dot_producer).  Against the two-kernel plane form: every output of the call (P, P_INDEL,
-    R_SIZE, ELT_SIZE, MU, SIGMA, R_OBS, FLAG, the seven statistics) bit for bit -- 33 ... 37 cohorts, elements over 0 ... 40 bins,
-    both strands, fewer elements than a chunk, a workload whose parked pairs overflow the (smaller) LDS queue; and the dot
-    kernel really did not run (its stage timer stays unlaunched).  VERDICT r4 item 3: built, measured, not the default."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DIG_PIPE_FORM="one")
-    p = subprocess.run([sys.executable, "-c", _ONE_KERNEL_CHILD, root], env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0 and "ONE-KERNEL-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
-
-
 def test_pipeline_when_most_pairs_need_the_second_pass(torch_dev):
     """The fused stream pass finishes its unfinished pairs itself: through the workgroup's LDS queue (1024 records) and, beyond
     that, through the workgroup's own segment of the worklist.  With every SNV count raised past the recurrence's range
