@@ -6,6 +6,7 @@ is missing or a call fails, a ``DigHipError`` is raised.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -28,6 +29,15 @@ class DigHipError(RuntimeError):
 
 
 _lib = None
+TORCH_FREE = False               # set (before the first call) by a process that only uses numpy arrays and the `_host` entry points
+_loaded_without_torch = False
+
+
+def _need_torch():
+    if _loaded_without_torch and "torch" not in sys.modules:
+        raise DigHipError("this process declared itself torch-free (digdriver_amd._lib.TORCH_FREE) and loaded libdig_hip.so first: "
+                          "device tensors are not available in it (PyTorch must be imported before the library)")
+
 
 _vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 
@@ -131,11 +141,17 @@ def load():
             "or `make -C digdriver_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
     # PyTorch-ROCm ships its own libamdhip64; if ours were the first HIP runtime in the process, torch
     # could no longer initialise its device layer (torch.cuda.is_available() -> False).  Import torch first
-    # so both use the runtime torch was built against.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # so both use the runtime torch was built against -- unless the process has declared that it stays on the `_host` entry
+    # points (TORCH_FREE: the single-cohort command lines, whose 1.5 s of `import torch` bought nothing; a later
+    # dev_ptr / stream_ptr in such a process is refused, see _need_torch).
+    global _loaded_without_torch
+    if TORCH_FREE and "torch" not in sys.modules:
+        _loaded_without_torch = True
+    else:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:
@@ -207,12 +223,14 @@ def dev_ptr(t):
     """void* of a contiguous torch CUDA tensor (None -> NULL)."""
     if t is None:
         return None
+    _need_torch()
     assert t.is_cuda and t.is_contiguous(), "device entry points need contiguous CUDA tensors"
     return ctypes.c_void_p(t.data_ptr())
 
 
 def stream_ptr(stream=None):
     """hipStream_t of a torch stream (default: torch's current stream)."""
+    _need_torch()
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)

@@ -170,14 +170,23 @@ def _overlap_pairs(m_chrom, m_start, m_end, b_chrom, b_start, b_end):
 
 def _bed12_to_bed6(df_bed12):
     """bedtools bed12tobed6: one row per block, keeping the parent's name and strand."""
-    rows = []
-    for chrom, start, name, strand, bsz, bst in zip(df_bed12[0], df_bed12[1], df_bed12[3], df_bed12[5], df_bed12[10],
-                                                    df_bed12[11]):
-        sizes = [int(x) for x in str(bsz).rstrip(',').split(',')]
-        starts = [int(x) for x in str(bst).rstrip(',').split(',')]
-        for s, z in zip(starts, sizes):
+    cols = ['CHROM', 'START', 'END', 'ELT', 'STRAND']
+    bsz = [str(x).rstrip(',') for x in df_bed12[10]]
+    bst = [str(x).rstrip(',') for x in df_bed12[11]]
+    n = np.fromiter((x.count(',') + 1 for x in bsz), np.int64, len(bsz))
+    if len(bsz) and np.array_equal(n, np.fromiter((x.count(',') + 1 for x in bst), np.int64, len(bst))):
+        # all rows at once (a Python loop over the blocks of 120 000 elements was 0.3 s of a command-line run)
+        sizes = np.array(",".join(bsz).split(','), dtype=np.int64)
+        starts = np.array(",".join(bst).split(','), dtype=np.int64)
+        rep = np.repeat(np.arange(len(bsz)), n)
+        s0 = np.asarray(df_bed12[1].values, np.int64)[rep] + starts
+        return pd.DataFrame({'CHROM': df_bed12[0].values[rep], 'START': s0, 'END': s0 + sizes, 'ELT': df_bed12[3].values[rep],
+                             'STRAND': df_bed12[5].values[rep]}, columns=cols)
+    rows = []                                      # (rows whose two lists differ in length: block by block, the shorter list counts)
+    for chrom, start, name, strand, z_, s_ in zip(df_bed12[0], df_bed12[1], df_bed12[3], df_bed12[5], bsz, bst):
+        for s, z in zip([int(x) for x in s_.split(',')], [int(x) for x in z_.split(',')]):
             rows.append((chrom, start + s, start + s + z, name, strand))
-    return pd.DataFrame(rows, columns=['CHROM', 'START', 'END', 'ELT', 'STRAND'])
+    return pd.DataFrame(rows, columns=cols)
 
 
 def tabulate_muts_per_sample_per_element(f_mut, f_elt_bed, bed12=False, drop_duplicates=False, unique_indels=True):
@@ -219,7 +228,7 @@ def tabulate_mutations_in_element(f_mut, f_elt_bed, bed12=False, drop_duplicates
     capped = per_pair.assign(OBS_SNV=per_pair.OBS_SNV.clip(upper=max_muts_per_elt_per_sample),
                              OBS_INDEL=per_pair.OBS_INDEL.clip(upper=max_muts_per_elt_per_sample))
     if len(capped):
-        summary = capped.groupby('ELT').agg(OBS_INDEL=('OBS_INDEL', 'sum'), OBS_SAMPLES=('SAMPLE', len), OBS_SNV=('OBS_SNV', 'sum'))
+        summary = capped.groupby('ELT').agg(OBS_INDEL=('OBS_INDEL', 'sum'), OBS_SAMPLES=('SAMPLE', 'size'), OBS_SNV=('OBS_SNV', 'sum'))        # ('size' = the reference's len per group, without a Python call per element: 0.5 s of a 120 000-element run)
     else:
         summary = pd.DataFrame({'OBS_SAMPLES': [], 'OBS_SNV': [], 'OBS_INDEL': [], 'ELT': []}).set_index('ELT')
     if all_elements:                                  # every element of the bed, zero counts included (:176-183)

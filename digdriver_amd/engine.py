@@ -28,6 +28,7 @@ def _is_cuda(x):
 
 
 def _t(x, dtype, device):
+    _lib._need_torch()
     import torch
     if x is None:
         return None

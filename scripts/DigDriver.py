@@ -169,6 +169,17 @@ def parse_args(text=None):
     return parser.parse_args(text.split()) if text else parser.parse_args()
 
 
-if __name__ == "__main__":
-    cli = parse_args()
+def main(text=None):
+    cli = parse_args(text)
+    if cli.func in (cmd_gene, cmd_target, cmd_element):
+        # these three read frames, hand numpy arrays to the library's `_host` entry points and write a frame: no tensor is ever made,
+        # so PyTorch (1.5 s of import and device-layer start for milliseconds of GPU work) is not loaded at all
+        from digdriver_amd import _lib
+        _lib.TORCH_FREE = True
     cli.func(cli)
+    if os.environ.get("DIG_CLI_ASSERT_NO_TORCH") == "1" and cli.func in (cmd_gene, cmd_target, cmd_element):
+        assert "torch" not in sys.modules, "a torch-free sub-command imported torch"         # (tests: the claim above)
+
+
+if __name__ == "__main__":
+    main()

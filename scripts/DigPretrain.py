@@ -171,6 +171,17 @@ def parse_args(text=None):
     return parser.parse_args(text.split()) if text else parser.parse_args()
 
 
-if __name__ == "__main__":
-    cli = parse_args()
+def main(text=None):
+    cli = parse_args(text)
+    if cli.func is pretrain_nonc_model:
+        # element frames are made from numpy arrays by the library's `_host` entry points: PyTorch (1.5 s of import and device-layer
+        # start) is not loaded for this sub-command (scripts/DigDriver.py does the same for its single-cohort commands)
+        from digdriver_amd import _lib
+        _lib.TORCH_FREE = True
     cli.func(cli)
+    if os.environ.get("DIG_CLI_ASSERT_NO_TORCH") == "1" and cli.func is pretrain_nonc_model:
+        assert "torch" not in sys.modules, "a torch-free sub-command imported torch"
+
+
+if __name__ == "__main__":
+    main()

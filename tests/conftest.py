@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the single-cohort command lines (geneDriver / targetDriver / elementDriver) promise not to load PyTorch: every CLI child of the
+# tests checks it (scripts/DigDriver.py)
+os.environ.setdefault("DIG_CLI_ASSERT_NO_TORCH", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
