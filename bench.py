@@ -354,6 +354,94 @@ def cpu_baseline_all_cores(w, want_seconds=8.0):
 # the other rows of SURVEY 8d (gather, CNN forward, per-base tiles, context counting): short legs run AFTER the timed
 # region, each timed per launch with HIP events on the stream it is launched on; reported as `aux_rooflines`
 # --------------------------------------------------------------------------------------
+def project_strong_scaling(dev, n_bins, n_elements, n_cohorts, seed, max_ranks=8, steps=200, warm=20):
+    """A one-GPU PROJECTION of the strong split of BASELINE configs[3] (no multi-GPU box exists for this
+    repository): for N = 1, 2, 4, ... max_ranks every rank's shard of the ONE configs[2] problem (make_shard_workload: its bins
+    + halo, its elements) is built and its step -- parallel.ShardedPipeline.step: own chunk sums, scale factors, dot kernel,
+    statistics kernel, on one stream -- is timed ON THIS GPU with HIP events; a rank's step keeps its own launch, staging and tail
+    costs (the dot kernel alone carries ~18 us of them).  projected step(N) = the slowest rank's step + the cost of one RCCL
+    all-gather call of the (64 / N + 2) x C doubles a rank exchanges, measured here at world 1 (launch + local copy: the ring's
+    hops over xGMI are NOT in it).  Not a measurement of N GPUs."""
+    import torch
+    from digdriver_amd import parallel
+    stream = torch.cuda.Stream(device=dev)
+    out = {"what": "PROJECTION from one GPU, not a multi-GPU measurement: every rank's shard of the strong configs[3] split timed on this "
+                   "GPU (parallel.ShardedPipeline.step on one stream, %d steps behind %d warm-up steps, HIP events), slowest rank + "
+                   "the world-1 cost of the all-gather call" % (steps, warm), "ranks": {}}
+    # the all-gather call, world 1, on a side stream of its own
+    ag_us = None
+    try:
+        import torch.distributed as dist
+        import socket
+        own = not dist.is_initialized()
+        if own:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        ag_us = {}
+        for N in (2, 4, 8):
+            x = torch.zeros((parallel.N_CHUNKS // N + 2) * n_cohorts, dtype=torch.float64, device=dev)
+            bufs = [torch.empty_like(x)]
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    dist.all_gather(bufs, x)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(stream)
+                for _ in range(200):
+                    dist.all_gather(bufs, x)
+                eb.record(stream)
+            torch.cuda.synchronize()
+            ag_us[N] = ea.elapsed_time(eb) / 200 * 1e3
+        if own:
+            dist.destroy_process_group()
+    except Exception as exc:                                  # (no RCCL here: the projection goes without the exchange, and says so)
+        out["all_gather_error"] = repr(exc)
+    out["all_gather_call_us_world1"] = ag_us
+    base = None
+    N = 1
+    while N <= max_ranks:
+        per_rank = []
+        for r in range(N):
+            shard, _ = make_shard_workload(r, N, n_bins, n_elements, n_cohorts, seed)
+            sp = parallel.ShardedPipeline(shard, dev, group=None, world=N)
+            # a rank's step without its peers: its own chunk sums, the first-to-last sum over a stacked [N, 64 / N + 2, C] array
+            # (its own part N times: the arithmetic of the real thing, dummy factors out) and the pipeline on the workload's own
+            # scale factors, so that the statistics kernel does its usual work
+            stacked = sp.scale.part.unsqueeze(0).repeat(N, 1, 1).contiguous()
+            true_cj = torch.as_tensor(shard["cj"], device=dev)
+            true_cji = torch.as_tensor(shard["cj_indel"], device=dev)
+
+            def one_step():
+                part = sp.scale.enqueue_part(stream)
+                stacked[r].copy_(part)
+                sp.scale.finish(stacked, sp.cj, sp.cj_indel, stream=stream)
+                if sp.pipe is not None:
+                    sp.pipe.run(true_cj, true_cji, stages=7, stream=stream)
+            with torch.cuda.stream(stream):
+                for _ in range(warm):
+                    one_step()
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(stream)
+                for _ in range(steps):
+                    one_step()
+                eb.record(stream)
+            torch.cuda.synchronize()
+            per_rank.append({"rank": r, "elements": int(sp.E), "bins_with_halo": int(sp.td["bin_mu"].shape[0]),
+                             "step_us": ea.elapsed_time(eb) / steps * 1e3})
+            del sp, shard
+            torch.cuda.empty_cache()
+        slowest = max(p["step_us"] for p in per_rank)
+        step_us = slowest + ((ag_us or {}).get(N, 0.0) if N > 1 else 0.0)
+        if N == 1:
+            base = step_us
+        out["ranks"][str(N)] = {"projected_step_us": step_us, "slowest_rank_step_us": slowest,
+                                "all_gather_call_us": (ag_us or {}).get(N) if N > 1 else 0.0,
+                                "projected_speedup": base / step_us, "projected_efficiency": base / step_us / N, "per_rank": per_rank}
+        N *= 2
+    return out
+
+
 def aux_rooflines(dev):
     import torch
     from digdriver_amd import _lib, engine
@@ -590,6 +678,10 @@ def parse_args(argv=None):
                          "files) and time the drop-in from files to 37 results.txt, stage by stage (tools/e2e_bench.py; ~40 s, 1.7 GB "
                          "under --e2e-dir); reported as e2e; 0: skip")
     ap.add_argument("--e2e-dir", default=None, help="scratch directory of the e2e leg (default: a fresh directory under the system's temp)")
+    ap.add_argument("--project-ranks", type=int, default=0,
+                    help="N > 1 (one GPU only): behind the timed region, build every rank's shard of the strong configs[3] split for 2, 4, ... N "
+                         "ranks, time each rank's step on THIS GPU and report the slowest + the world-1 cost of the all-gather call as "
+                         "projected_strong_scaling -- a projection, never part of `value` (about a minute of host time per 8 shards)")
     ap.add_argument("--side-lead", type=int, default=0,
                     help="the side stream starts the scale factors of step t when the main stream has finished step "
                          "t - SIDE_LEAD (0: free-running, the default; see DESIGN.md section 4)")
@@ -1393,6 +1485,24 @@ def run_workload(args, mode, ctx, primary=True):
             del td, pipes, seq_plan
             torch.cuda.empty_cache()
             res["aux_rooflines"] = aux_rooflines(dev)
+        if args.project_ranks > 1 and world == 1 and primary:
+            try:
+                del td, pipes, seq_plan
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)                                 # (RCCL prints its banner to the C stdout: stdout carries the JSON line only)
+            try:
+                res["projected_strong_scaling"] = project_strong_scaling(dev, args.bins, args.elements, args.cohorts, args.seed,
+                                                                         max_ranks=args.project_ranks)
+            except Exception as exc:                      # (never at the cost of the bench line)
+                res["projected_strong_scaling"] = {"error": repr(exc)}
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         if args.e2e and world == 1 and primary and (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37):
             # the number a user of the drop-in sees: files in, results.txt out; never mixed into `value`
             import tempfile
