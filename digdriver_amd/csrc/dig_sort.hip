@@ -8,17 +8,18 @@
 //     not negative, so the top bit of every key is set and SEVEN passes of 9-bit digits sort bits 0 .. 62; an eighth pass over
 //     bit 63 runs only when the histogram pass saw a negative value (a flag on the device, no host round trip);
 //   * payload = the 32-bit position in the row (n < 2^32): 12 bytes per element and pass instead of 16;
-//   * a pass is ONE kernel: a workgroup takes the next tile of 4 096 elements by ticket, ranks its elements stably (wave-wide
-//     match of the digit by ballots, per-wave digit counters in LDS), publishes its digit counts, finds the counts of the tiles
-//     in front of it by decoupled look-back over 4-byte {flag, count} words (one relaxed agent-scope store / load per word: the
-//     word is its own flag, nothing else has to be ordered), regroups the tile by digit in LDS and writes every digit's run
-//     contiguously; the digit histograms of all passes come from one pass over the input in front;
+//   * a pass = the digit histograms of the ranges (sixteen tiles of 4 096 elements), one scan per row, and the scatter: a
+//     workgroup walks its range tile by tile, ranks a tile's elements stably (wave-wide match of the digit by ballots, per-wave
+//     digit counters in LDS), regroups the tile by digit in LDS and writes every digit's run contiguously behind the runs its
+//     earlier tiles wrote; no workgroup waits for another one;
 //   * the Benjamini-Hochberg pass reads the sorted keys, and the q-values leave through the payload to their places: no
 //     separate scatter.  The same IEEE operations in the same order as the host form -- p / (rank / n), reverse running
 //     minimum (NaN-propagating), cap at 1 -- so the same bits as statsmodels' operations (q depends on the VALUE of p only:
 //     equal p-values get equal q whatever order a sort leaves them in).
 //   * rank0 / n_global / carry per row: a rank of parallel.ShardedTiles holds one contiguous range of the global order (sample
 //     sort) and finishes it with the minimum of the ranks behind it.
+#include <stdlib.h>
+
 #include "dig_common.hpp"
 
 namespace dig {
@@ -29,7 +30,6 @@ constexpr int kSortTile = kSortBlock * kSortItems;              // elements per 
 constexpr int kSortWaves = kSortBlock / 64;
 static_assert(kSortBlock == kSortBins, "a thread of the pass kernel = a digit");
 constexpr int kSortPasses = 8;                                  // 7 x 9 bits + the sign bit
-constexpr int kSortHistChunk = 16 * kSortTile;                  // elements a workgroup of the histogram pass takes
 
 __device__ __forceinline__ uint64_t sort_key(double p)
 {
@@ -60,53 +60,83 @@ __device__ __forceinline__ int sort_row_of(const int64_t* __restrict__ tile_star
     return lo;
 }
 
-// ---- digit histograms of all passes, per row; flag = a negative value was seen ----
-__global__ __launch_bounds__(kSortBlock) void sort_hist_kernel(const double* __restrict__ p, const int64_t* __restrict__ row_ptr,
-                                                               const int64_t* __restrict__ chunk_start, int rows, unsigned* __restrict__ ghist,
-                                                               unsigned* __restrict__ flags)
+// ---- a pass = three launches: (1) the digit histogram of every RANGE (sixteen consecutive tiles of a row), (2) per row: where
+// every (digit, range) starts -- digit-major, range-minor: the order of the pass's output --, (3) the ranges regrouped: a
+// workgroup walks the tiles of its range and keeps the running places of the 512 digits itself.  No workgroup waits for another
+// one.  (First build of the round: one kernel per pass with decoupled look-back over per-tile status words -- 2.6 ms per pass of
+// 266 M elements, of which 0.9 ms were the look-back: with two tiles per CU in flight the tiles whose counts are published
+// but whose prefix is not yet are dozens deep, and every step back is a trip to the L2; and 0.65 ms the scatter pattern -- 512
+// runs of eight elements per tile, neighbouring runs written by other CUs.  A range's runs are sixteen tiles long and written by
+// one CU.  profiles/r06_sort_probes.txt.) ----
+constexpr int kRangeTiles = 16;
+constexpr int kRangeElems = kRangeTiles * kSortTile;
+
+// wave-aggregated LDS histogram add: p-values crowd into one or two binades, the high digits of a wave's 64 keys are mostly ONE
+// value, and 64 atomic adds to one counter are 64 turns of the LDS -- a wave whose digit is uniform adds its count once
+__device__ __forceinline__ void sort_hist_add(unsigned* h, unsigned d, bool live, bool try_uniform)
 {
-    __shared__ unsigned s_h[kSortPasses][kSortBins];
-    for (int i = threadIdx.x; i < kSortPasses * kSortBins; i += kSortBlock) (&s_h[0][0])[i] = 0u;
-    __syncthreads();
-    const int row = sort_row_of(chunk_start, rows, blockIdx.x);
-    const int64_t lo = row_ptr[row] + ((int64_t)blockIdx.x - chunk_start[row]) * kSortHistChunk;
-    const int64_t hi = lo + kSortHistChunk < row_ptr[row + 1] ? lo + kSortHistChunk : row_ptr[row + 1];
-    bool neg = false;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
-        const uint64_t k = sort_key(__builtin_nontemporal_load(p + i));
-        neg |= !(k >> 63);
-        // (p-values crowd into one or two binades: the high digits of a wave's 64 keys are mostly ONE value, and 64 atomic adds
-        //  to one counter are 64 turns of the LDS -- a wave whose digit is uniform adds its count once)
-#pragma unroll
-        for (int pass = 0; pass < kSortPasses; ++pass) {
-            const unsigned d = sort_digit(k, pass);
-            if (pass >= 3) {
-                const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-                const uint64_t same = __ballot(d == d0);
-                if (same == __ballot(true)) {
-                    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(same)) atomicAdd(&s_h[pass][d0], (unsigned)__popcll(same));
-                    continue;
-                }
+    if (try_uniform) {
+        const uint64_t on = __ballot(live);
+        if (on) {
+            const unsigned d0 = __builtin_amdgcn_readlane(d, __builtin_ctzll(on));
+            const uint64_t same = __ballot(live && d == d0);
+            if (same == on) {
+                if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(on)) atomicAdd(&h[d0], (unsigned)__popcll(on));
+                return;
             }
-            atomicAdd(&s_h[pass][d], 1u);
         }
     }
-    if (__any(neg) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
-    __syncthreads();
-    unsigned* g = ghist + (int64_t)row * kSortPasses * kSortBins;
-    for (int i = threadIdx.x; i < kSortPasses * kSortBins; i += kSortBlock) {
-        const unsigned c = (&s_h[0][0])[i];
-        if (c) atomicAdd(g + i, c);
-    }
+    if (live) atomicAdd(&h[d], 1u);
 }
 
-// ---- exclusive scan of every (row, pass) histogram: where a digit's elements start in the row ----
-__global__ __launch_bounds__(kSortBins) void sort_base_kernel(unsigned* __restrict__ ghist)
+template <bool FIRST>
+__global__ __launch_bounds__(kSortBlock) void sort_range_hist_kernel(const double* __restrict__ p_in, const uint64_t* __restrict__ k_in,
+                                                                     const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ range_start,
+                                                                     int rows, int pass, unsigned* __restrict__ rhist, unsigned* __restrict__ flags, int gate)
 {
+    if (gate && !(*flags & 2u)) return;                          // the careful passes: only behind a fix-up that gave up
+    if (pass == 7 && !(*flags & 1u)) return;                     // no negative value: bit 63 is the same everywhere
+    __shared__ unsigned s_h[kSortBins];
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int row = sort_row_of(range_start, rows, blockIdx.x);
+    const int64_t lo = row_ptr[row] + ((int64_t)blockIdx.x - range_start[row]) * kRangeElems;
+    const int64_t hi = lo + kRangeElems < row_ptr[row + 1] ? lo + kRangeElems : row_ptr[row + 1];
+    bool neg = false;
+    for (int64_t i0 = lo; i0 < hi; i0 += kSortBlock) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < hi;
+        uint64_t k = ~0ull;
+        if (live) k = FIRST ? sort_key(__builtin_nontemporal_load(p_in + i)) : __builtin_nontemporal_load(k_in + i);
+        neg |= live && !(k >> 63);
+        sort_hist_add(s_h, sort_digit(k, pass), live, pass >= 3);
+    }
+    if (FIRST && __any(neg) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
+    __syncthreads();
+    rhist[(int64_t)blockIdx.x * kSortBins + threadIdx.x] = s_h[threadIdx.x];
+}
+
+// one workgroup per row, thread = digit: the digit totals, their exclusive scan, then the running place of the digit over the ranges
+__global__ __launch_bounds__(kSortBins) void sort_range_scan_kernel(unsigned* __restrict__ rhist, const int64_t* __restrict__ range_start, int pass,
+                                                                    const unsigned* __restrict__ flags, int gate)
+{
+    if (gate && !(*flags & 2u)) return;
+    if (pass == 7 && !(*flags & 1u)) return;
     __shared__ unsigned s[kSortBins];
-    unsigned* g = ghist + (int64_t)blockIdx.x * kSortBins;       // one workgroup per (row, pass)
-    const unsigned c = g[threadIdx.x];
-    s[threadIdx.x] = c;
+    const int64_t g0 = range_start[blockIdx.x], g1 = range_start[blockIdx.x + 1];
+    unsigned* h = rhist + g0 * kSortBins + threadIdx.x;
+    const int64_t ng = g1 - g0;
+    unsigned total = 0u;
+    int64_t g = 0;
+    for (; g + 8 <= ng; g += 8) {                                // (eight loads in flight: one after the other they are a memory trip each)
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h[(g + j) * kSortBins];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) total += v[j];
+    }
+    for (; g < ng; ++g) total += h[g * kSortBins];
+    s[threadIdx.x] = total;
     __syncthreads();
     for (int d = 1; d < kSortBins; d <<= 1) {
         const unsigned v = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
@@ -114,176 +144,199 @@ __global__ __launch_bounds__(kSortBins) void sort_base_kernel(unsigned* __restri
         s[threadIdx.x] += v;
         __syncthreads();
     }
-    g[threadIdx.x] = s[threadIdx.x] - c;
+    unsigned run = s[threadIdx.x] - total;
+    g = 0;
+    for (; g + 8 <= ng; g += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h[(g + j) * kSortBins];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[(g + j) * kSortBins] = run;
+            run += v[j];
+        }
+    }
+    for (; g < ng; ++g) {
+        const unsigned v = h[g * kSortBins];
+        h[g * kSortBins] = run;
+        run += v;
+    }
 }
 
-// ---- one pass ----
-constexpr unsigned kFlagAgg = 1u << 30, kFlagPrefix = 2u << 30, kValMask = (1u << 30) - 1u;
-
 template <bool FIRST>
-__global__ __launch_bounds__(kSortBlock) void sort_pass_kernel(
+__global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
     const double* __restrict__ p_in, const uint64_t* __restrict__ k_in, const unsigned* __restrict__ v_in, uint64_t* __restrict__ k_out,
-    unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ tile_start, int rows, int pass,
-    const unsigned* __restrict__ dbase, unsigned* __restrict__ status, unsigned* __restrict__ ticket, const unsigned* __restrict__ flags)
+    unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ range_start, int rows, int pass,
+    const unsigned* __restrict__ roff, const unsigned* __restrict__ flags, int gate)
 {
-    if (pass == 7 && !(*flags & 1u)) return;                     // no negative value: bit 63 is the same everywhere
+    if (gate && !(*flags & 2u)) return;
+    if (pass == 7 && !(*flags & 1u)) return;
     __shared__ unsigned s_cnt[kSortWaves][kSortBins];            // per-wave digit counts, then their exclusive prefix over the waves
     __shared__ unsigned s_tpre[kSortBins];                       // where a digit starts in the regrouped tile
     __shared__ int64_t s_gbase[kSortBins];                       // where the tile's elements of a digit go, minus s_tpre
     __shared__ uint64_t s_key[kSortTile];
     __shared__ unsigned s_val[kSortTile];
     __shared__ unsigned s_wsum[kSortWaves];
-    __shared__ int64_t s_tile;
+#ifdef DIG_SORT_PAD_LDS                                     // timing build: one workgroup per CU (half the open output lines per L2)
+    __shared__ unsigned s_pad[DIG_SORT_PAD_LDS / 4];
+    if (threadIdx.x == 0 && pass == 99) s_pad[blockIdx.x & 7] = 1u;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);      // tiles are taken in order: a tile waits only for tiles that run
-    for (int i = tid; i < kSortWaves * kSortBins; i += kSortBlock) (&s_cnt[0][0])[i] = 0u;
-    __syncthreads();
-    const int64_t tile = s_tile;
-    const int row = sort_row_of(tile_start, rows, tile);
-    const int64_t t_in_row = tile - tile_start[row];
+    const int row = sort_row_of(range_start, rows, blockIdx.x);
     const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
-    const int64_t e0 = t_in_row * kSortTile;                     // first element of the tile, in the row
-    const int n_here = (int)(n_row - e0 < kSortTile ? n_row - e0 : kSortTile);
-    // ---- load: element j of the tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in) ----
-    uint64_t key[kSortItems];
-    unsigned val[kSortItems], loc[kSortItems];
+    const int64_t range_e0 = ((int64_t)blockIdx.x - range_start[row]) * kRangeElems;     // first element of the range, in the row
+    unsigned running = roff[(int64_t)blockIdx.x * kSortBins + tid];                      // where this range's elements of digit tid go, in the row
+    for (int64_t e0 = range_e0; e0 < range_e0 + kRangeElems && e0 < n_row; e0 += kSortTile) {
+        const int n_here = (int)(n_row - e0 < kSortTile ? n_row - e0 : kSortTile);
+        // ---- load: element j of the tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in) ----
+        uint64_t key[kSortItems];
+        unsigned val[kSortItems], loc[kSortItems];
 #pragma unroll
-    for (int e = 0; e < kSortItems; ++e) {
-        const int j = wave * (64 * kSortItems) + e * 64 + lane;
-        key[e] = ~0ull;
-        val[e] = 0u;
-        if (j < n_here) {
-            if (FIRST) {
-                key[e] = sort_key(__builtin_nontemporal_load(p_in + r0 + e0 + j));
-                val[e] = (unsigned)(e0 + j);
-            } else {
-                key[e] = __builtin_nontemporal_load(k_in + r0 + e0 + j);
-                val[e] = __builtin_nontemporal_load(v_in + r0 + e0 + j);
+        for (int e = 0; e < kSortItems; ++e) {
+            const int j = wave * (64 * kSortItems) + e * 64 + lane;
+            key[e] = ~0ull;
+            val[e] = 0u;
+            if (j < n_here) {
+                if (FIRST) {
+                    key[e] = sort_key(__builtin_nontemporal_load(p_in + r0 + e0 + j));
+                    val[e] = (unsigned)(e0 + j);
+                } else {
+                    key[e] = __builtin_nontemporal_load(k_in + r0 + e0 + j);
+                    val[e] = __builtin_nontemporal_load(v_in + r0 + e0 + j);
+                }
             }
         }
-    }
-    // ---- stable ranks inside the wave: the lanes with the same digit (nine ballots), in lane order, behind what the wave's
-    // earlier items counted ----
+        for (int i = tid; i < kSortWaves * kSortBins; i += kSortBlock) (&s_cnt[0][0])[i] = 0u;
+        __syncthreads();                                         // (also: the tile before has left s_key / s_val)
+        // ---- stable ranks inside the wave: the lanes with the same digit (nine ballots), in lane order, behind what the wave's
+        // earlier items counted ----
 #pragma unroll
-    for (int e = 0; e < kSortItems; ++e) {
-        const int j = wave * (64 * kSortItems) + e * 64 + lane;
-        const bool live = j < n_here;
-        const unsigned d = sort_digit(key[e], pass);
-        uint64_t peers = __ballot(live);
-#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 2)     // timing build: no match (wrong ranks)
-        peers = 1ull << lane;
-#else
-#pragma unroll
-        for (int b = 0; b < kSortBits; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t vote = __ballot(bit);
-            peers &= bit ? vote : ~vote;
-        }
-#endif
-        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
-        const unsigned old = s_cnt[wave][d];
-        loc[e] = old + below;
-        if (live && below == 0u) s_cnt[wave][d] = old + (unsigned)__popcll(peers);
-    }
-    __syncthreads();
-    // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix ----
-    unsigned h = 0u;
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) {
-        const unsigned c = s_cnt[w][tid];
-        s_cnt[w][tid] = h;
-        h += c;
-    }
-    unsigned* st = status + tile * kSortBins + tid;
-    if (t_in_row > 0) __hip_atomic_store(st, kFlagAgg | h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- look-back, first step: the words of the four tiles in front are requested NOW and looked at behind the regrouping
-    // (a word costs a trip to the L2 -- a microsecond under a streaming load; the barriers in between wait for LDS only).
-    // A word is its own flag (2 bits) and count (30 bits): nothing else has to be ordered.  (Four digits per thread and 16-byte
-    // accesses were slower: a wave's 64 words are one request already.) ----
-    constexpr int kWin0 = 4, kWin = 8;
-    auto word_of = [&](int64_t t_back) {                       // the word of tile t_back of this row (t_back < t_in_row); in front of the row: nothing
-        return t_back >= 0 ? __hip_atomic_load(st - (t_in_row - t_back) * kSortBins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
-    };
-    unsigned w0[kWin0];
-#pragma unroll
-    for (int i = 0; i < kWin0; ++i) w0[i] = word_of(t_in_row - 1 - i);
-    // (exclusive scan of h over the 512 digits: inside the wave by shuffles, then over the eight waves)
-    unsigned incl = h;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const unsigned v = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += v;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
-    unsigned wbase = 0u;
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) wbase += w < wave ? s_wsum[w] : 0u;
-    const unsigned tpre = wbase + incl - h;
-    s_tpre[tid] = tpre;
-    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
-    // ---- regroup the tile by digit in LDS ----
-#pragma unroll
-    for (int e = 0; e < kSortItems; ++e) {
-        const int j = wave * (64 * kSortItems) + e * 64 + lane;
-        if (j < n_here) {
+        for (int e = 0; e < kSortItems; ++e) {
+            const int j = wave * (64 * kSortItems) + e * 64 + lane;
+            const bool live = j < n_here;
             const unsigned d = sort_digit(key[e], pass);
-            const unsigned pos = s_tpre[d] + s_cnt[wave][d] + loc[e];
-            s_key[pos] = key[e];
-            s_val[pos] = val[e];
-        }
-    }
-    // ---- look-back: the counts of this digit in the tiles in front, down to the first tile whose prefix is known ----
-    unsigned before = 0u;
-#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 1)     // timing build: no look-back (wrong places)
-    if (false) {
-#else
-    if (t_in_row > 0) {
-#endif
-        bool done = false;
-        auto take = [&](unsigned sw, int64_t t_back) {
-            if (done) return;
-            while ((sw >> 30) == 0u) {                           // not published yet: this word alone, until it is
-                __builtin_amdgcn_s_sleep(1);
-                sw = word_of(t_back);
+            uint64_t peers = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < kSortBits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t vote = __ballot(bit);
+                peers &= bit ? vote : ~vote;
             }
-            before += sw & kValMask;
-            done = (sw >> 30) == 2u;
-        };
-#pragma unroll
-        for (int i = 0; i < kWin0; ++i) take(w0[i], t_in_row - 1 - i);
-        int64_t back = t_in_row - 1 - kWin0;
-        while (!done) {                                          // further back: eight words per step, requested together
-            unsigned w[kWin];
-#pragma unroll
-            for (int i = 0; i < kWin; ++i) w[i] = word_of(back - i);
-#pragma unroll
-            for (int i = 0; i < kWin; ++i) take(w[i], back - i);
-            back -= kWin;
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+            const unsigned old = s_cnt[wave][d];
+            loc[e] = old + below;
+            if (live && below == 0u) s_cnt[wave][d] = old + (unsigned)__popcll(peers);
         }
-    }
-    __hip_atomic_store(st, kFlagPrefix | (before + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_gbase[tid] = r0 + (int64_t)dbase[((int64_t)row * kSortPasses + pass) * kSortBins + tid] + before - tpre;
-    // ---- every digit's run leaves in one piece ----
-    __syncthreads();
+        __syncthreads();
+        // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix ----
+        unsigned h = 0u;
 #pragma unroll
-    for (int e = 0; e < kSortItems; ++e) {
-        const int pos = e * kSortBlock + tid;
-        if (pos < n_here) {
-            const uint64_t k = s_key[pos];
-            int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
-#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 8)     // timing build: the tile goes back where it came from (one contiguous piece)
-            dst = r0 + e0 + pos;
-#endif
-#if defined(DIG_SORT_ABL) && (DIG_SORT_ABL & 4)     // timing build: no stores
-            if (k == 0x123456789ull)
-#endif
-            {
+        for (int w = 0; w < kSortWaves; ++w) {
+            const unsigned c = s_cnt[w][tid];
+            s_cnt[w][tid] = h;
+            h += c;
+        }
+        // (exclusive scan of h over the 512 digits: inside the wave by shuffles, then over the eight waves)
+        unsigned incl = h;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const unsigned v = __shfl_up(incl, dd, 64);
+            if (lane >= dd) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        unsigned wbase = 0u;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) wbase += w < wave ? s_wsum[w] : 0u;
+        const unsigned tpre = wbase + incl - h;
+        s_tpre[tid] = tpre;
+        s_gbase[tid] = r0 + (int64_t)running - tpre;
+        running += h;
+        __syncthreads();
+        // ---- regroup the tile by digit in LDS, then every digit's run leaves in one piece ----
+#pragma unroll
+        for (int e = 0; e < kSortItems; ++e) {
+            const int j = wave * (64 * kSortItems) + e * 64 + lane;
+            if (j < n_here) {
+                const unsigned d = sort_digit(key[e], pass);
+                const unsigned pos = s_tpre[d] + s_cnt[wave][d] + loc[e];
+                s_key[pos] = key[e];
+                s_val[pos] = val[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kSortItems; ++e) {
+            const int pos = e * kSortBlock + tid;
+            if (pos < n_here) {
+                const uint64_t k = s_key[pos];
+                const int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
                 k_out[dst] = k;
                 v_out[dst] = s_val[pos];
             }
         }
     }
+}
+
+// ---- the fix-up behind FOUR passes.  Passes 3 .. 6 (and 7) sort by bits 27 .. 63 -- sign, exponent and the upper 25 bits of the
+// mantissa: with p-values spread over a few binades, elements that share all 36 bits are pairs and triples (a tenth of 7.2 M
+// uniform values sits in such runs) or exact ties.  A run of equal upper bits of at most kFixRun elements is put in order here
+// (rank among the run by full key, then by position: a stable sort of the run), out of place; longer runs stay as they are, and
+// if one of them holds two different keys the fix-up GIVES UP: flags bit 1, and the seven careful passes that follow on the
+// stream (gated by that bit: 21 launches that return at once otherwise) sort the lists from the start.  Either way the sorted
+// lists end in the same buffer: (k0, v0), or (k1, v1) when a negative value made the sign pass run. ----
+__global__ void sort_giveup_kernel(unsigned* flags) { atomicOr(flags, 2u); }       // developer switch DIG_SORT_FORM=careful
+
+constexpr int kFixRun = 256;                                     // longest run the fix-up sorts = the halo on either side of a tile
+constexpr int kFixLowBits = 27;
+
+__global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __restrict__ k0, uint64_t* __restrict__ k1, unsigned* __restrict__ v0,
+                                                                unsigned* __restrict__ v1, const int64_t* __restrict__ row_ptr,
+                                                                const int64_t* __restrict__ tile_start, int rows, unsigned* __restrict__ flags)
+{
+    const bool neg = *flags & 1u;                                // pass 7 ran: the four-pass order is in (k0, v0), else in (k1, v1)
+    const uint64_t* ks = neg ? k0 : k1;
+    const unsigned* vs = neg ? v0 : v1;
+    uint64_t* kd = neg ? k1 : k0;
+    unsigned* vd = neg ? v1 : v0;
+    constexpr int kWin = kSortTile + 2 * kFixRun;
+    __shared__ uint64_t s_k[kWin];
+    const int tid = threadIdx.x;
+    const int row = sort_row_of(tile_start, rows, blockIdx.x);
+    const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
+    const int64_t e0 = ((int64_t)blockIdx.x - tile_start[row]) * kSortTile;          // first element the tile owns, in the row
+    const int64_t w0 = e0 - kFixRun;                             // first element of the window (may lie in front of the row)
+    for (int w = tid; w < kWin; w += kSortBlock) {
+        const int64_t i = w0 + w;
+        s_k[w] = (i >= 0 && i < n_row) ? ks[r0 + i] : 0ull;
+    }
+    __syncthreads();
+    bool give_up = false;
+#pragma unroll 1
+    for (int e = 0; e < kSortItems; ++e) {
+        const int w = kFixRun + e * kSortBlock + tid;            // window index of the element
+        const int64_t i = w0 + w;
+        if (i >= n_row) break;
+        const uint64_t key = s_k[w], pre = key >> kFixLowBits;
+        // the run of equal upper bits around the element, as far as kFixRun + 1 steps either way
+        int back = 0, ahead = 0;
+        while (back <= kFixRun && i - back - 1 >= 0 && (s_k[w - back - 1] >> kFixLowBits) == pre) ++back;
+        while (ahead <= kFixRun && i + ahead + 1 < n_row && (s_k[w + ahead + 1] >> kFixLowBits) == pre) ++ahead;
+        int64_t dst = i;
+        if (back + ahead + 1 <= kFixRun) {                       // the whole run is in sight (every element of it sees the same)
+            int rank = 0;
+            for (int j = -back; j <= ahead; ++j) {
+                const uint64_t o = s_k[w + j];
+                rank += (o < key) || (o == key && j < 0);
+            }
+            dst = i - back + rank;
+        } else if (back > 0 && s_k[w - 1] != key) {              // a long run with two different keys: not for this kernel
+            give_up = true;
+        }
+        kd[r0 + dst] = key;
+        vd[r0 + dst] = vs[r0 + i];
+    }
+    if (__any(give_up) && (tid & 63) == 0) atomicOr(flags, 2u);
 }
 
 // ---- Benjamini-Hochberg over the sorted keys of ragged rows ----
@@ -419,8 +472,8 @@ __global__ void sort_unpack_kernel(const uint64_t* __restrict__ k0, const uint64
 
 // layout of the workspace (all offsets from its 256-byte aligned start)
 struct SortLayout {
-    int64_t total_tiles, hist_chunks, bh_chunks;
-    int64_t off_k0, off_k1, off_v0, off_v1, off_status, off_ghist, off_small, off_rowptr, off_tilestart, off_histstart, off_bhstart, off_nglob,
+    int64_t total_ranges, total_tiles, bh_chunks;
+    int64_t off_k0, off_k1, off_v0, off_v1, off_rhist, off_small, off_rowptr, off_rangestart, off_tilestart, off_bhstart, off_nglob,
         off_rank0, off_carry, off_cmin, off_suffix, bytes;
 };
 static int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -430,8 +483,8 @@ static SortLayout sort_layout(const int64_t* row_ptr, int64_t rows)
     const int64_t n = rows > 0 ? row_ptr[rows] - row_ptr[0] : 0;
     for (int64_t r = 0; r < rows; ++r) {
         const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        L.total_ranges += (len + kRangeElems - 1) / kRangeElems;
         L.total_tiles += (len + kSortTile - 1) / kSortTile;
-        L.hist_chunks += (len + kSortHistChunk - 1) / kSortHistChunk;
         L.bh_chunks += (len + kBhrChunk - 1) / kBhrChunk;
     }
     int64_t o = 0;
@@ -444,12 +497,11 @@ static SortLayout sort_layout(const int64_t* row_ptr, int64_t rows)
     L.off_k1 = take(n * 8);
     L.off_v0 = take(n * 4);
     L.off_v1 = take(n * 4);
-    L.off_status = take(L.total_tiles * kSortBins * 4 + 256);        // + the ticket counter behind it
-    L.off_ghist = take(rows * kSortPasses * kSortBins * 4);
+    L.off_rhist = take(L.total_ranges * kSortBins * 4);
     L.off_small = take(256);                                          // flags
     L.off_rowptr = take((rows + 1) * 8);
+    L.off_rangestart = take((rows + 1) * 8);
     L.off_tilestart = take((rows + 1) * 8);
-    L.off_histstart = take((rows + 1) * 8);
     L.off_bhstart = take((rows + 1) * 8);
     L.off_nglob = take(rows * 8);
     L.off_rank0 = take(rows * 8);
@@ -485,46 +537,64 @@ int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* works
     // row tables (relative to row_ptr[0] = 0 on the device side)
     std::string host((size_t)(4 * (rows + 1) * 8), '\0');
     int64_t* h = (int64_t*)host.data();
-    int64_t *h_rp = h, *h_ts = h + (rows + 1), *h_hs = h + 2 * (rows + 1), *h_bs = h + 3 * (rows + 1);
-    h_ts[0] = h_hs[0] = h_bs[0] = 0;
+    int64_t *h_rp = h, *h_rs = h + (rows + 1), *h_bs = h + 2 * (rows + 1), *h_ts = h + 3 * (rows + 1);
+    h_rs[0] = h_bs[0] = h_ts[0] = 0;
     for (int64_t r = 0; r <= rows; ++r) h_rp[r] = row_ptr[r] - row_ptr[0];
     for (int64_t r = 0; r < rows; ++r) {
         const int64_t len = row_ptr[r + 1] - row_ptr[r];
-        h_ts[r + 1] = h_ts[r] + (len + kSortTile - 1) / kSortTile;
-        h_hs[r + 1] = h_hs[r] + (len + kSortHistChunk - 1) / kSortHistChunk;
+        h_rs[r + 1] = h_rs[r] + (len + kRangeElems - 1) / kRangeElems;
         h_bs[r + 1] = h_bs[r] + (len + kBhrChunk - 1) / kBhrChunk;
+        h_ts[r + 1] = h_ts[r] + (len + kSortTile - 1) / kSortTile;
     }
-    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rowptr, h_rp, (rows + 1) * 8, hipMemcpyHostToDevice, s));
     DIG_HIP_TRY(hipMemcpyAsync(b + L.off_tilestart, h_ts, (rows + 1) * 8, hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_histstart, h_hs, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rowptr, h_rp, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rangestart, h_rs, (rows + 1) * 8, hipMemcpyHostToDevice, s));
     DIG_HIP_TRY(hipMemcpyAsync(b + L.off_bhstart, h_bs, (rows + 1) * 8, hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipStreamSynchronize(s));            // (the host tables above go out of scope; 4 small copies)
+    DIG_HIP_TRY(hipStreamSynchronize(s));            // (the host tables above go out of scope; 3 small copies)
     if (plan.n == 0) return DIG_OK;
-    DIG_REQUIRE(L.total_tiles < (1ll << 31), "too many elements for one call");
+    DIG_REQUIRE(L.total_ranges < (1ll << 31), "too many elements for one call");
     const int64_t* d_rp = (const int64_t*)(b + L.off_rowptr);
-    const int64_t* d_ts = (const int64_t*)(b + L.off_tilestart);
-    const int64_t* d_hs = (const int64_t*)(b + L.off_histstart);
-    unsigned* ghist = (unsigned*)(b + L.off_ghist);
+    const int64_t* d_rs = (const int64_t*)(b + L.off_rangestart);
+    unsigned* rhist = (unsigned*)(b + L.off_rhist);
     unsigned* flags = (unsigned*)(b + L.off_small);
-    unsigned* status = (unsigned*)(b + L.off_status);
-    unsigned* ticket = status + L.total_tiles * kSortBins;
     uint64_t *k0 = (uint64_t*)(b + L.off_k0), *k1 = (uint64_t*)(b + L.off_k1);
     unsigned *v0 = (unsigned*)(b + L.off_v0), *v1 = (unsigned*)(b + L.off_v1);
-    DIG_HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)(rows * kSortPasses * kSortBins * 4), s));
     DIG_HIP_TRY(hipMemsetAsync(flags, 0, 256, s));
-    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)L.hist_chunks), dim3(kSortBlock), 0, s, p, d_rp, d_hs, (int)rows, ghist, flags);
-    hipLaunchKernelGGL(sort_base_kernel, dim3((unsigned)(rows * kSortPasses)), dim3(kSortBins), 0, s, ghist);
-    for (int pass = 0; pass < kSortPasses; ++pass) {
-        // pass 0: p -> (k0, v0); odd passes: (k0, v0) -> (k1, v1); even passes: (k1, v1) -> (k0, v0)
-        DIG_HIP_TRY(hipMemsetAsync(status, 0, (size_t)(L.total_tiles * kSortBins * 4 + 256), s));
-        const bool to0 = (pass & 1) == 0;
-        if (pass == 0)
-            hipLaunchKernelGGL((sort_pass_kernel<true>), dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, p, (const uint64_t*)nullptr,
-                               (const unsigned*)nullptr, k0, v0, d_rp, d_ts, (int)rows, pass, ghist, status, ticket, flags);
+    const dim3 grid_r((unsigned)L.total_ranges), grid_rows((unsigned)rows);
+    const int64_t* d_ts = (const int64_t*)(b + L.off_tilestart);
+    // one pass: source (p or the keys / payloads of one buffer) -> the other buffer
+    auto pass_from = [&](int pass, bool first, bool to0, int gate) {
+        const uint64_t* ki = to0 ? k1 : k0;
+        const unsigned* vi = to0 ? v1 : v0;
+        if (first)
+            hipLaunchKernelGGL((sort_range_hist_kernel<true>), grid_r, dim3(kSortBlock), 0, s, p, (const uint64_t*)nullptr, d_rp, d_rs, (int)rows, pass,
+                               rhist, flags, gate);
         else
-            hipLaunchKernelGGL((sort_pass_kernel<false>), dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, (const double*)nullptr,
-                               to0 ? k1 : k0, to0 ? v1 : v0, to0 ? k0 : k1, to0 ? v0 : v1, d_rp, d_ts, (int)rows, pass, ghist, status, ticket, flags);
+            hipLaunchKernelGGL((sort_range_hist_kernel<false>), grid_r, dim3(kSortBlock), 0, s, (const double*)nullptr, ki, d_rp, d_rs, (int)rows, pass,
+                               rhist, flags, gate);
+        hipLaunchKernelGGL(sort_range_scan_kernel, grid_rows, dim3(kSortBins), 0, s, rhist, d_rs, pass, (const unsigned*)flags, gate);
+        if (first)
+            hipLaunchKernelGGL((sort_range_scatter_kernel<true>), grid_r, dim3(kSortBlock), 0, s, p, (const uint64_t*)nullptr, (const unsigned*)nullptr,
+                               to0 ? k0 : k1, to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
+        else
+            hipLaunchKernelGGL((sort_range_scatter_kernel<false>), grid_r, dim3(kSortBlock), 0, s, (const double*)nullptr, ki, vi, to0 ? k0 : k1,
+                               to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
+    };
+    static const bool careful_only = getenv("DIG_SORT_FORM") && getenv("DIG_SORT_FORM")[0] == 'c';      // developer switch: seven passes always
+    if (!careful_only) {
+        // four passes over bits 27 .. 62 (+ the sign pass when a negative value exists): p -> 0 -> 1 -> 0 -> 1 (-> 0), then the fix-up
+        // into the other buffer
+        pass_from(3, true, true, 0);
+        pass_from(4, false, false, 0);
+        pass_from(5, false, true, 0);
+        pass_from(6, false, false, 0);
+        pass_from(7, false, true, 0);
+        hipLaunchKernelGGL(sort_fixup_kernel, dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, k0, k1, v0, v1, d_rp, d_ts, (int)rows, flags);
+    } else {
+        hipLaunchKernelGGL(sort_giveup_kernel, dim3(1), dim3(1), 0, s, flags);
     }
+    // the careful form: all eight passes from the start, only when the fix-up gave up (bit 1 of the flags)
+    for (int pass = 0; pass < kSortPasses; ++pass) pass_from(pass, pass == 0, (pass & 1) == 0, 1);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

@@ -2,6 +2,8 @@
 nb_model.py:340-342 = statsmodels' fdrcorrection) against numpy: sorted values and order bit for bit, q-values bit for bit with
 the host form (whose operations are statsmodels' own), ragged rows, rows that are ranges of a longer list (the sample sort of
 parallel.ShardedTiles)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -61,6 +63,42 @@ def test_radix_sort_of_ragged_rows_equals_numpy_stable_sort(negatives):
         assert np.array_equal(got[~np.isnan(got)], row[want_order][~np.isnan(row[want_order])]), r      # (-0.0 == +0.0: one key)
         assert np.isnan(got).sum() == np.isnan(row).sum() and (not np.isnan(got).any() or np.isnan(got[-np.isnan(row).sum():]).all())
         assert np.array_equal(od[rp[r]:rp[r + 1]], want_order), r
+
+
+@pytest.mark.parametrize("form", ["default", "careful"])
+def test_sort_fix_up_and_the_careful_passes_behind_it(form):
+    """The sort is four passes over the upper 36 bits + a fix-up of the runs that share them (csrc/dig_sort.hip): (a) ties far longer
+    than the fix-up's reach (5 000 copies of one value) stay a run and are right; (b) 1 000 values that share their upper 36 bits
+    and differ below make the fix-up give up, and the seven careful passes behind it sort the lists from the start; (c) the same
+    lists with DIG_SORT_FORM=careful (own process): the careful passes alone.  Values and order against numpy's stable sort."""
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    rng = np.random.default_rng(41)
+    a = rng.random(70_001)
+    b = np.concatenate([rng.random(30_000), np.full(5_000, 0.75)])                                 # (a)
+    c = np.concatenate([rng.random(20_000), 0.5 + np.arange(1_000) * 2.0 ** -40, [np.nan, 0.0]])      # (b): upper 36 bits shared, low bits differ
+    rng.shuffle(b)
+    rng.shuffle(c)
+    rows = [a, b, c, a[:300]]
+    rp = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    p = np.concatenate(rows)
+    if form == "default":
+        ps, od = _sort(p, rp)
+    else:
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_sort as t; d = np.load(sys.argv[1]); "
+                "ps, od = t._sort(d['p'], d['rp']); np.savez(sys.argv[2], ps=ps, od=od)") % (ROOT, os.path.join(ROOT, "tests"))
+        with tempfile.TemporaryDirectory() as tmp:
+            np.savez(os.path.join(tmp, "in.npz"), p=p, rp=rp)
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")],
+                                  env=dict(os.environ, DIG_SORT_FORM="careful"))
+            got = np.load(os.path.join(tmp, "out.npz"))
+            ps, od = got["ps"], got["od"]
+    for r, row in enumerate(rows):
+        want = np.argsort(row, kind="stable")
+        assert np.array_equal(od[rp[r]:rp[r + 1]], want), r
+        assert np.array_equal(ps[rp[r]:rp[r + 1]], row[want], equal_nan=True), r
 
 
 def test_bh_qvalues_of_ragged_rows_equal_the_host_form_bit_for_bit():
