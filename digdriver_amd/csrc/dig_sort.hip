@@ -310,9 +310,15 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
         const int64_t i = w0 + w;
         s_k[w] = (i >= 0 && i < n_row) ? ks[r0 + i] : 0ull;
     }
+    unsigned val[kSortItems];                                    // (the payloads travel while the keys are looked at: a load per element
+#pragma unroll                                                   //  inside the loop was a memory trip per element, 16 of the tile's 20 us)
+    for (int e = 0; e < kSortItems; ++e) {
+        const int64_t i = e0 + e * kSortBlock + tid;
+        val[e] = i < n_row ? __builtin_nontemporal_load(vs + r0 + i) : 0u;
+    }
     __syncthreads();
     bool give_up = false;
-#pragma unroll 1
+#pragma unroll
     for (int e = 0; e < kSortItems; ++e) {
         const int w = kFixRun + e * kSortBlock + tid;            // window index of the element
         const int64_t i = w0 + w;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
             give_up = true;
         }
         kd[r0 + dst] = key;
-        vd[r0 + dst] = vs[r0 + i];
+        vd[r0 + dst] = val[e];
     }
     if (__any(give_up) && (tid & 63) == 0) atomicOr(flags, 2u);
 }
