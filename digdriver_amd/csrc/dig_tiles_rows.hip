@@ -42,7 +42,7 @@ __device__ unsigned long long g_rw_prof[8];
 #endif
 
 constexpr int kRwMaxPos = 10240;                       // positions of a region whose bases are staged
-constexpr int kRwEntries = (kRwMaxPos + 7 + 4 + 15) / 16 + 2;       // 16-base entries {bases, flags}; + 1 read past the end, + 1 spare
+constexpr int kRwEntries = (kRwMaxPos + 7 + 4 + 15) / 16 + 3;       // 16-base entries {bases, flags}; + 2 read past the end (a window = three words), + 1 spare
 constexpr int kRwLds = 163840;                         // bytes of LDS per CU
 
 struct RwRegion {                                      // wave-uniform description of a region
@@ -71,7 +71,7 @@ __device__ __forceinline__ RwRegion rw_region(int chrom, int64_t start, int64_t 
     const int64_t ga0 = q.g0 - U;                      // leftmost base of the first window
     q.w0 = (ga0 >> 3) + 1;                             // array word = genome word + 1 (leading pad word)
     q.sh0 = (int)(ga0 & 7);
-    q.ne = (q.n_pos > 0 && !q.deferred) ? (int)((q.sh0 + q.n_pos + 2 * U - 1) >> 4) + 2 : 0;
+    q.ne = (q.n_pos > 0 && !q.deferred) ? (int)((q.sh0 + q.n_pos + 2 * U - 1) >> 4) + 3 : 0;
     return q;
 }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
     constexpr int kCapTiles = (kRwLds - 64 - (1 << (2 * 5)) * 128 - 128 - kEntBytes) / (17 * 8);      // the cap of the 16-cohort pass, for every pass
     constexpr int kSumDoubles = kCapTiles * SS;
     static_assert(kTabBytes + kEntBytes + kSumDoubles * 8 + 64 <= kRwLds, "LDS budget");
-    static_assert(TP + 2 * U <= 16, "a trip's windows come out of one 16-base window");
+    static_assert(TP + 2 * U <= 16 || (TP > 12 && TP + 2 * U <= 32), "a trip's windows come out of a 16-base or a 32-base window");
     static_assert(kCapTiles <= 256, "the output phase holds four tile sums per lane");
     // ONE block of LDS, the table at address 0: a row address is then (window >> k) & mask | lane offset -- two instructions per
     // position; with the table anywhere else it is three
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
             constexpr int kPerTicket = 64 / LW;
             constexpr int kRowLog = LW == 8 ? 7 : (LW == 4 ? 6 : 5);           // log2 of the bytes of a table row
             const int n_trips = (binsize + TP - 1) / TP;                        // of a full tile (wave-uniform)
-            const int b_last = (q.ne - 2) << 4;                                 // (windows are read from entries b >> 4 and the next)
+            const int b_last = (q.ne - 3) << 4;                                 // (windows are read from entries b >> 4 and the two behind it)
             int ticket = wave;
             while (ticket * kPerTicket < tiles_valid) {
                 int next = 0;
@@ -289,14 +289,22 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
                 double acc0 = 0.0, acc1 = 0.0;
                 // A trip's window is read a trip ahead (it returns in front of the row reads issued behind it); two register sets
                 // take turns, so that no copy -- and no wait -- stands between the read and its use a trip later.
-                auto window = [&](int bb, uint32_t (&z)[4]) {
+                // Trips of up to 12 positions come out of a 32-bit window (two staged words), trips of 13 .. 28 out of a 64-bit
+                // window (three words): a tile of 50 positions is two trips of 25 instead of five of 10 -- the ~10 instructions around
+                // a trip (window, shifts, the clean test, the loop) are a fifth of a 10-position trip's instructions.
+                constexpr bool WIDE = TP > 12;
+                constexpr int NZ = WIDE ? 3 : 2;                                // staged words per window
+                constexpr int BATCH = WIDE ? 9 : TP;                            // rows in flight at once (36 registers)
+                auto window = [&](int bb, uint32_t (&z)[6]) {
                     const int m = (bb < b_last ? bb : b_last) >> 4;
-                    z[0] = s_ent[m].x, z[1] = s_ent[m + 1].x;
-                    if (HASN) z[2] = s_ent[m].y, z[3] = s_ent[m + 1].y;
+#pragma unroll
+                    for (int k = 0; k < NZ; ++k) z[k] = s_ent[m + k].x;
+                    if (HASN) {
+#pragma unroll
+                        for (int k = 0; k < NZ; ++k) z[3 + k] = s_ent[m + k].y;
+                    }
                 };
-                auto row_of = [&](uint32_t win, int i) {                      // the row of position i, this lane's two cohorts
-                    const int sh = (32 - 2 * W - 2 * i) - kRowLog;              // the field sits at bits [32 - 2 W - 2 i, 32 - 2 i)
-                    const uint32_t x = sh >= 0 ? win >> (sh >= 0 ? sh : 0) : win << (sh < 0 ? -sh : 0);
+                auto read_row = [&](uint32_t x) {                             // x: the field of a position at the row bits
                     uint32_t off;                                               // (the compiler turns the | of disjoint bits into an add
                     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(x), "v"(amask), "v"(abase));       //  and then has no fused form)
 #if defined(DIG_RW_ABL) && DIG_RW_ABL == 1         // timing builds: every walker reads row 0 / paired walkers rows of different parity / of the same parity
@@ -308,28 +316,45 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
 #endif
                     return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(s_all) + off);
                 };
-                auto trip = [&](const uint32_t (&z)[4], uint32_t (&zn)[4]) {
+                // the row of position i of a trip whose bases sit at bits 63 - 2 j of (hi, lo) (32-bit windows: hi only)
+                auto row_of = [&](uint32_t hi, uint32_t lo, int i) {
+                    const int pos = (WIDE ? 64 : 32) - 2 * i - 2 * W - kRowLog;     // the field starts at bit pos + kRowLog of the window
+                    uint32_t x;
+                    if (!WIDE) x = pos >= 0 ? hi >> (pos >= 0 ? pos : 0) : hi << (pos < 0 ? -pos : 0);
+                    else if (pos >= 32) x = hi >> (pos - 32 >= 0 ? pos - 32 : 0);
+                    else if (pos >= 0) x = __builtin_amdgcn_alignbit(hi, lo, pos >= 0 && pos < 32 ? pos : 0);
+                    else x = lo << (pos < 0 ? -pos : 0);
+                    return read_row(x);
+                };
+                auto trip = [&](const uint32_t (&z)[6], uint32_t (&zn)[6]) {
                     const int o = b & 15;
-                    const uint32_t win = (uint32_t)(((((uint64_t)z[0] << 32) | z[1]) << (2 * o)) >> 32);      // base i of the trip at bits 31 - 2 i
-                    const uint32_t fw = HASN ? (z[2] | (z[3] >> 16)) << o : 0u;                                // flag of base i at bit 31 - i
+                    const uint32_t hi = (uint32_t)(((((uint64_t)z[0] << 32) | z[1]) << (2 * o)) >> 32);       // base j of the trip at bits 31 - 2 j
+                    const uint32_t lo = WIDE ? (uint32_t)(((((uint64_t)z[1] << 32) | z[2]) << (2 * o)) >> 32) : 0u;      // ... bases 16 .. 31
+                    uint64_t fw = 0ull;                                         // flag of base j at bit 63 - j
+                    if (HASN) fw = ((((uint64_t)(z[3] | (z[4] >> 16))) << 32) | (WIDE ? (uint64_t)z[5] : 0ull)) << o;
                     b += TP;
                     window(b, zn);                      // (also behind the last trip: a read that depends on nothing costs less than a branch around it)
-                    const bool clean = (fw >> (32 - TP - 2 * U)) == 0u && rem >= TP;
+                    const bool clean = (fw >> (64 - TP - 2 * U)) == 0ull && rem >= TP;
                     if (__all(clean)) {
-                        double2 v[TP];
 #pragma unroll
-                        for (int i = 0; i < TP; ++i) v[i] = row_of(win, i);
+                        for (int i0 = 0; i0 < TP; i0 += BATCH) {
+                            double2 v[BATCH];
 #pragma unroll
-                        for (int i = 0; i < TP; ++i) {
-                            acc0 += v[i].x;
-                            acc1 += v[i].y;
+                            for (int i = 0; i < BATCH; ++i)
+                                if (i0 + i < TP) v[i] = row_of(hi, lo, i0 + i);
+#pragma unroll
+                            for (int i = 0; i < BATCH; ++i)
+                                if (i0 + i < TP) {
+                                    acc0 += v[i].x;
+                                    acc1 += v[i].y;
+                                }
                         }
                     } else {                            // a short last trip or a window with a non-ACGT base: position by position,
-                        uint32_t w2 = win, f2 = fw;     // what does not count adds nothing
+                        uint64_t w2 = ((uint64_t)hi << 32) | lo, f2 = fw;     // what does not count adds nothing
 #pragma unroll 1
                         for (int i = 0; i < TP; ++i, w2 <<= 2, f2 <<= 1) {
-                            if (i < rem && (f2 >> (32 - W)) == 0u) {
-                                const double2 v = row_of(w2, 0);
+                            if (i < rem && (f2 >> (64 - W)) == 0ull) {
+                                const double2 v = read_row((uint32_t)(w2 >> (64 - 2 * W - kRowLog)));
                                 acc0 += v.x;
                                 acc1 += v.y;
                             }
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(1024) void base_tile_probs_rows_kernel(
                     }
                     rem -= TP;
                 };
-                uint32_t za[4] = {0u, 0u, 0u, 0u}, zb[4] = {0u, 0u, 0u, 0u};
+                uint32_t za[6] = {0u, 0u, 0u, 0u, 0u, 0u}, zb[6] = {0u, 0u, 0u, 0u, 0u, 0u};
                 window(b, za);
                 for (int k = 0; k < n_trips; k += 2) {
                     trip(za, zb);
@@ -436,12 +461,14 @@ int launch_tile_probs_rows(const uint32_t* words, int64_t n_words, const int64_t
     int tp = 12;
     {
         int best = -1;
-        const int cand[3] = {12, 10, 8};
-        for (int k = 0; k < 3; ++k) {
+        const int cand[4] = {25, 12, 10, 8};
+        for (int k = 0; k < 4; ++k) {
             const int waste = (binsize + cand[k] - 1) / cand[k] * cand[k] - binsize;
             if (best < 0 || waste < best) best = waste, tp = cand[k];
         }
     }
+    static const int forced_tp = getenv("DIG_ROWS_TP") ? atoi(getenv("DIG_ROWS_TP")) : 0;      // developer switch (A/B)
+    if (forced_tp == 25 || forced_tp == 12 || forced_tp == 10 || forced_tp == 8) tp = forced_tp;
     const int grid = grid_for(R * 1024, 1024, 1);
     int c0 = 0;
     bool first = true;
@@ -458,7 +485,10 @@ int launch_tile_probs_rows(const uint32_t* words, int64_t n_words, const int64_t
         }
         auto go = [&](auto u_c, auto lw_c) {
             constexpr int UU = decltype(u_c)::value, LL = decltype(lw_c)::value;
-            if (tp == 12)
+            if (tp == 25)
+                launch_rows<UU, LL, 25>(permute, grid, 64 * n_waves, stream, words, n_words, chrom_off, chrom_len, reg_chrom, reg_start, reg_end,
+                                        R, s_prob, c0, cc, binsize, n_tiles, pt, first_pos, n_valid, first ? 1 : 0);
+            else if (tp == 12)
                 launch_rows<UU, LL, 12>(permute, grid, 64 * n_waves, stream, words, n_words, chrom_off, chrom_len, reg_chrom, reg_start, reg_end,
                                         R, s_prob, c0, cc, binsize, n_tiles, pt, first_pos, n_valid, first ? 1 : 0);
             else if (tp == 10)
