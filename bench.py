@@ -586,7 +586,7 @@ def aux_rooflines(dev):
     dt = timeit(lambda: _lib.call("dig_base_tile_probs_ctx", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S5), 37,
                                   2, 50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=2, warm=1)
     reads = float(chunk) * window * 37
-    out.append({"kernel": "dig_base_tile_probs_ctx, n_up = 2 (penta-nucleotide contexts, the reference's default: base_tile_probs_ctx_kernel<2>)",
+    out.append({"kernel": "dig_base_tile_probs_ctx, n_up = 2 (penta-nucleotide contexts, the reference's default: base_tile_probs_rows_kernel, passes of 16 + 16 + 5 cohorts)",
                 "bound": "lds", "achieved": reads * 8.0 / dt / 1e12, "peak": 150.0, "unit": "TB/s of LDS reads (8 B per position and cohort)",
                 "frac": reads * 8.0 / dt / 150e12, "algorithmic_bytes_per_launch": chunk * window * 0.5 + tiles * 37 * 8.0,
                 "hbm_frac": (chunk * window * 0.5 + tiles * 37 * 8.0) / dt / HBM_PEAK, "avg_launch_ms": dt * 1e3,
@@ -632,6 +632,9 @@ def aux_rooflines(dev):
                     "bound": "hbm", "achieved": 28.0 * tiles_r / (t_run + t_q) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": 28.0 * tiles_r / (t_run + t_q) / HBM_PEAK, "algorithmic_bytes_per_launch": 28.0 * tiles_r,
                     "avg_launch_ms": (t_run + t_q) * 1e3, "kernels_ms": t_run * 1e3, "q_values_ms": t_q * 1e3,
+                    "kernels_frac": 28.0 * tiles_r / t_run / HBM_PEAK,
+                    "q_values_how": "dig_bh_qvalues_ragged: the library's radix sort of all 37 lists (four passes over the upper 36 bits + a "
+                                    "fix-up, 32-bit payload), the Benjamini-Hochberg pass and the scatter to the tiles' places",
                     "tile_cohort_tests_per_s": tiles_r / (t_run + t_q),
                     "contexts": "trinucleotide (64-entry tables)" if n_up == 1 else "penta-nucleotide (1 024-entry tables: the reference's default)",
                     "workload": "36 000 10-kb bins x 200 tiles of 50 positions x 37 cohorts, 500 000 mutations; host clock, device drained "

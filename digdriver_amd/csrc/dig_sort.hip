@@ -324,10 +324,18 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
         const int64_t i = w0 + w;
         if (i >= n_row) break;
         const uint64_t key = s_k[w], pre = key >> kFixLowBits;
-        // the run of equal upper bits around the element, as far as kFixRun + 1 steps either way
+        // the run of equal upper bits around the element.  The lists are in order of those bits, so the element kFixRun places
+        // away tells at once whether the run is a long one (exact ties by the hundred thousand -- every tile without a mutation
+        // has p = 1 -- would otherwise walk 2 x 256 places per element); a short run is walked, one or two steps as a rule
         int back = 0, ahead = 0;
-        while (back <= kFixRun && i - back - 1 >= 0 && (s_k[w - back - 1] >> kFixLowBits) == pre) ++back;
-        while (ahead <= kFixRun && i + ahead + 1 < n_row && (s_k[w + ahead + 1] >> kFixLowBits) == pre) ++ahead;
+        if (i > 0 && (s_k[w - 1] >> kFixLowBits) == pre) {
+            if (i >= kFixRun && (s_k[w - kFixRun] >> kFixLowBits) == pre) back = kFixRun;
+            else { back = 1; while (i - back - 1 >= 0 && (s_k[w - back - 1] >> kFixLowBits) == pre) ++back; }
+        }
+        if (i + 1 < n_row && (s_k[w + 1] >> kFixLowBits) == pre) {
+            if (i + kFixRun < n_row && (s_k[w + kFixRun] >> kFixLowBits) == pre) ahead = kFixRun;
+            else { ahead = 1; while (i + ahead + 1 < n_row && (s_k[w + ahead + 1] >> kFixLowBits) == pre) ++ahead; }
+        }
         int64_t dst = i;
         if (back + ahead + 1 <= kFixRun) {                       // the whole run is in sight (every element of it sees the same)
             int rank = 0;

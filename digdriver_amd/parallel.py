@@ -611,9 +611,13 @@ def _sharded_tiles_q_values_all(self, max_elements=None):
     r = self.result
     t = torch.arange(self.n_tiles, device=r["pval"].device)[None, :]
     mask = t < r["n_valid"][:, None]
-    mine = r["pval"][:, mask]                                   # [C, n_mine]
-    out = torch.full((mine.shape[0],) + tuple(mask.shape), float("nan"), dtype=torch.float64, device=mine.device)
-    out[:, mask] = sample_sort_q_values(mine.contiguous(), self.group)
+    C = r["pval"].shape[0]
+    flat = r["pval"].reshape(C, -1)
+    if int(mask.sum()) == mask.numel():                         # every bin is whole: the lists are the planes as they lie
+        return sample_sort_q_values(flat, self.group).reshape(r["pval"].shape)
+    idx = mask.reshape(-1).nonzero().squeeze(1)                 # (a boolean index per cohort plane would look for these 37 times)
+    out = torch.full(r["pval"].shape, float("nan"), dtype=torch.float64, device=flat.device)
+    out.reshape(C, -1).index_copy_(1, idx, sample_sort_q_values(flat.index_select(1, idx), self.group))
     return out
 
 

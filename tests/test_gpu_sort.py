@@ -101,6 +101,27 @@ def test_sort_fix_up_and_the_careful_passes_behind_it(form):
         assert np.array_equal(ps[rp[r]:rp[r + 1]], row[want], equal_nan=True), r
 
 
+@pytest.mark.parametrize("longest", [255, 256, 257, 600])
+def test_sort_runs_at_the_edge_of_the_fix_up(longest):
+    """Runs of values that share their upper 36 bits and differ below, of every length up to `longest`, among exact ties by the
+    thousand (p = 1: tiles without a mutation) and spread over tile borders: up to 256 the fix-up orders them, one longer run sends
+    the lists through the careful passes; the far-end test of the run (csrc/dig_sort.hip) must call neither too early."""
+    rng = np.random.default_rng(longest)
+    parts = [np.ones(9_000), rng.random(3_000)]
+    for j, m in enumerate([2, 3, 17, 100, longest - 1, longest, longest]):
+        base = 0.25 + 0.01 * j
+        parts.append(base + rng.permutation(m) * 2.0 ** -42)
+    row = np.concatenate(parts)
+    rng.shuffle(row)
+    rows = [row, np.concatenate([np.ones(20_000), 0.5 + rng.permutation(longest) * 2.0 ** -45]), row[:4097]]
+    rp = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    ps, od = _sort(np.concatenate(rows), rp)
+    for r, x in enumerate(rows):
+        want = np.argsort(x, kind="stable")
+        assert np.array_equal(od[rp[r]:rp[r + 1]], want), r
+        assert np.array_equal(ps[rp[r]:rp[r + 1]], x[want]), r
+
+
 def test_bh_qvalues_of_ragged_rows_equal_the_host_form_bit_for_bit():
     """dig_bh_qvalues_ragged against nb_model.get_q_vals' host form (numpy, statsmodels' own operations) for every row: in
     place, bit for bit; a row with a NaN is all NaN (statsmodels); ties, zeros, subnormals; and the uniform [rows, n] form
