@@ -39,4 +39,4 @@ def old(p_rows):
 t_new, q_new = timeit(lambda: nb_model.get_q_vals_rows(p))
 t_old, q_old = timeit(lambda: old(p))
 print(json.dumps({"rows": rows, "n": n, "ms_library_sort_bh": t_new, "ms_torch_sort_bh_scatter": t_old, "same_bits": bool(torch.equal(q_new, q_old)),
-                  "bytes_per_element": 8 + 7 * 24 + 8 + 8 + 4 + 8, "tb_per_s": rows * n * (8 + 7 * 24 + 28) / (t_new * 1e-3) / 1e12}))
+                  "bytes_per_element": 176, "tb_per_s": rows * n * 176.0 / (t_new * 1e-3) / 1e12}))
