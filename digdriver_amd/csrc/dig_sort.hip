@@ -33,10 +33,11 @@ constexpr int kSortPasses = 8;                                  // 7 x 9 bits + 
 
 __device__ __forceinline__ uint64_t sort_key(double p)
 {
-    const int64_t b = __double_as_longlong(p);
-    if (p != p) return ~0ull;                                    // every NaN: the largest key
-    if (p == 0.0) return 0x8000000000000000ull;                  // -0.0 = +0.0, as a comparison sort has it
-    return b < 0 ? ~(uint64_t)b : (uint64_t)b | 0x8000000000000000ull;
+    const uint64_t b = (uint64_t)__double_as_longlong(p), mag = b & 0x7fffffffffffffffull;      // (integer selects only: no branches)
+    uint64_t k = (b >> 63) ? ~b : b | 0x8000000000000000ull;
+    k = mag == 0ull ? 0x8000000000000000ull : k;                 // -0.0 = +0.0, as a comparison sort has it
+    k = mag > 0x7ff0000000000000ull ? ~0ull : k;                 // every NaN: the largest key
+    return k;
 }
 __device__ __forceinline__ double sort_value(uint64_t k)
 {
@@ -70,6 +71,15 @@ __device__ __forceinline__ int sort_row_of(const int64_t* __restrict__ tile_star
 // one CU.  profiles/r06_sort_probes.txt.) ----
 constexpr int kRangeTiles = 16;
 constexpr int kRangeElems = kRangeTiles * kSortTile;
+
+// a barrier that orders LDS only: __syncthreads() also waits for every global load and store of the wave (its fence covers global
+// memory), which would end the scatter kernel's look-ahead loads at the first barrier behind them
+__device__ __forceinline__ void sort_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // wave-aggregated LDS histogram add: p-values crowd into one or two binades, the high digits of a wave's 64 keys are mostly ONE
 // value, and 64 atomic adds to one counter are 64 turns of the LDS -- a wave whose digit is uniform adds its count once
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kSortBins) void sort_range_scan_kernel(unsigned* __
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
+__global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
     const double* __restrict__ p_in, const uint64_t* __restrict__ k_in, const unsigned* __restrict__ v_in, uint64_t* __restrict__ k_out,
     unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ range_start, int rows, int pass,
     const unsigned* __restrict__ roff, const unsigned* __restrict__ flags, int gate)
@@ -185,35 +195,51 @@ __global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
     const int row = sort_row_of(range_start, rows, blockIdx.x);
     const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
     const int64_t range_e0 = ((int64_t)blockIdx.x - range_start[row]) * kRangeElems;     // first element of the range, in the row
+    const int64_t range_e1 = range_e0 + kRangeElems < n_row ? range_e0 + kRangeElems : n_row;
+    const int64_t whole_e1 = range_e0 + ((range_e1 - range_e0) / kSortTile) * kSortTile;  // behind the range's last whole tile
     unsigned running = roff[(int64_t)blockIdx.x * kSortBins + tid];                      // where this range's elements of digit tid go, in the row
-    for (int64_t e0 = range_e0; e0 < range_e0 + kRangeElems && e0 < n_row; e0 += kSortTile) {
-        const int n_here = (int)(n_row - e0 < kSortTile ? n_row - e0 : kSortTile);
-        // ---- load: element j of the tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in) ----
-        uint64_t key[kSortItems];
-        unsigned val[kSortItems], loc[kSortItems];
+    asm volatile("" : "+v"(running) : : "memory");               // (arrived before the loop: its wait inside would end every look-ahead)
+    // Element j of a tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in).  A WHOLE tile's
+    // loads are issued a tile ahead and cross the barriers of the tile in front of them (the barriers order LDS only:
+    // sort_lds_barrier) -- with two workgroups per CU and load -> rank -> regroup -> store in turn, a CU had loads in flight a
+    // third of the time.  One scalar base per tile + one lane offset + constant distances: eight 64-bit addresses per stream
+    // were spilled.  A row's last, partial tile is loaded when its turn comes.
+    uint64_t nkey[kSortItems], key[kSortItems];
+    unsigned nval[kSortItems], val[kSortItems], loc[kSortItems];
+    const unsigned j0 = (unsigned)(wave * (64 * kSortItems) + lane);
+    auto request = [&](int64_t e0) {
+        const double* pb = p_in + r0 + e0;
+        const uint64_t* kb = k_in + r0 + e0;
+        const unsigned* vb = v_in + r0 + e0;
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {
-            const int j = wave * (64 * kSortItems) + e * 64 + lane;
-            key[e] = ~0ull;
-            val[e] = 0u;
-            if (j < n_here) {
-                if (FIRST) {
-                    key[e] = sort_key(__builtin_nontemporal_load(p_in + r0 + e0 + j));
-                    val[e] = (unsigned)(e0 + j);
-                } else {
-                    key[e] = __builtin_nontemporal_load(k_in + r0 + e0 + j);
-                    val[e] = __builtin_nontemporal_load(v_in + r0 + e0 + j);
-                }
+            if (FIRST) {
+                nkey[e] = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(pb + j0 + e * 64));
+            } else {
+                nkey[e] = __builtin_nontemporal_load(kb + j0 + e * 64);
+                nval[e] = __builtin_nontemporal_load(vb + j0 + e * 64);
             }
         }
-        for (int i = tid; i < kSortWaves * kSortBins; i += kSortBlock) (&s_cnt[0][0])[i] = 0u;
-        __syncthreads();                                         // (also: the tile before has left s_key / s_val)
+    };
+    auto take = [&](int64_t e0) {                                // the requested tile becomes the current one (waits for its loads)
+#pragma unroll
+        for (int e = 0; e < kSortItems; ++e) {
+            key[e] = FIRST ? sort_key(__longlong_as_double((int64_t)nkey[e])) : nkey[e];
+            val[e] = FIRST ? (unsigned)(e0 + j0 + e * 64) : nval[e];
+            asm volatile("" : "+v"(key[e]), "+v"(val[e]) : : "memory");                  // (here, not sunk to the next use)
+        }
+    };
+    // one tile: key / val hold it; `ahead`: the tile behind it has been requested and is taken in front of this tile's stores (the
+    // wait for its loads would otherwise wait for the stores as well: one counter for both)
+    auto tile = [&](int64_t e0, int n_here, bool ahead) {
+        // the wave's own row of counters: nobody else touches it between the prefix of the tile before and this tile's prefix
+#pragma unroll
+        for (int i = 0; i < kSortBins / 64; ++i) s_cnt[wave][i * 64 + lane] = 0u;
         // ---- stable ranks inside the wave: the lanes with the same digit (nine ballots), in lane order, behind what the wave's
         // earlier items counted ----
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {
-            const int j = wave * (64 * kSortItems) + e * 64 + lane;
-            const bool live = j < n_here;
+            const bool live = (int)(j0 + e * 64) < n_here;
             const unsigned d = sort_digit(key[e], pass);
             uint64_t peers = __ballot(live);
 #pragma unroll
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
             loc[e] = old + below;
             if (live && below == 0u) s_cnt[wave][d] = old + (unsigned)__popcll(peers);
         }
-        __syncthreads();
+        sort_lds_barrier();
         // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix ----
         unsigned h = 0u;
 #pragma unroll
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
             if (lane >= dd) incl += v;
         }
         if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
+        sort_lds_barrier();
         unsigned wbase = 0u;
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) wbase += w < wave ? s_wsum[w] : 0u;
@@ -252,29 +278,51 @@ __global__ __launch_bounds__(kSortBlock) void sort_range_scatter_kernel(
         s_tpre[tid] = tpre;
         s_gbase[tid] = r0 + (int64_t)running - tpre;
         running += h;
-        __syncthreads();
+        sort_lds_barrier();
         // ---- regroup the tile by digit in LDS, then every digit's run leaves in one piece ----
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {
-            const int j = wave * (64 * kSortItems) + e * 64 + lane;
-            if (j < n_here) {
+            if ((int)(j0 + e * 64) < n_here) {
                 const unsigned d = sort_digit(key[e], pass);
                 const unsigned pos = s_tpre[d] + s_cnt[wave][d] + loc[e];
                 s_key[pos] = key[e];
                 s_val[pos] = val[e];
             }
         }
-        __syncthreads();
+        if (ahead) take(e0 + kSortTile);
+        sort_lds_barrier();
+#pragma unroll
+        for (int e = 0; e < kSortItems; ++e) {                   // (unconditional stores: a lane past the end of a row's last tile
+            int pos = e * kSortBlock + tid;                      //  writes the tile's last element once more -- stores that may
+            pos = pos < n_here ? pos : n_here - 1;               //  or may not happen cannot be counted past by the waits in front
+            const uint64_t k = s_key[pos];                       //  of the next tile's loads)
+            const int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
+            k_out[dst] = k;
+            v_out[dst] = s_val[pos];
+        }
+    };
+    if (range_e0 < whole_e1) {
+        request(range_e0);
+        take(range_e0);
+        for (int64_t e0 = range_e0; e0 < whole_e1; e0 += kSortTile) {
+            const bool ahead = e0 + kSortTile < whole_e1;
+            if (ahead) request(e0 + kSortTile);
+            tile(e0, kSortTile, ahead);
+        }
+    }
+    if (whole_e1 < range_e1) {                                   // the row's last tile: a lane past the end holds the largest key, masked
+        const int n_here = (int)(range_e1 - whole_e1);
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {
-            const int pos = e * kSortBlock + tid;
-            if (pos < n_here) {
-                const uint64_t k = s_key[pos];
-                const int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
-                k_out[dst] = k;
-                v_out[dst] = s_val[pos];
+            const int64_t j = j0 + e * 64;
+            key[e] = ~0ull;
+            val[e] = 0u;
+            if (j < n_here) {
+                key[e] = FIRST ? sort_key(p_in[r0 + whole_e1 + j]) : k_in[r0 + whole_e1 + j];
+                val[e] = FIRST ? (unsigned)(whole_e1 + j) : v_in[r0 + whole_e1 + j];
             }
         }
+        tile(whole_e1, n_here, false);
     }
 }
 

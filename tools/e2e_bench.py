@@ -170,6 +170,14 @@ def run_e2e(bins=288_000, elements=120_091, cohorts=37, mut_rows=300_000, seed=3
                                "--outdir", os.path.join(workdir, "cli_out"), "--outpfx", "cohort00"],
                               env=env, stdout=subprocess.DEVNULL)
         t2 = time.perf_counter()
+        if os.environ.get("DIG_E2E_CLI_PROFILE"):                 # developer: where the elementDriver process spends its time
+            import pstats
+            prof = os.path.join(workdir, "cli.prof")
+            subprocess.check_call([sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "scripts", "DigDriver.py"), "elementDriver",
+                                   paths["mut"][0], pre0, "elts", "--f-bed", paths["bed"], "--scale-factor-manual", "1.0",
+                                   "--scale-factor-indel-manual", "0.1", "--outdir", os.path.join(workdir, "cli_out"), "--outpfx", "cohort00"],
+                                  env=env, stdout=subprocess.DEVNULL)
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         res["cli_one_cohort"] = {"what": "scripts/DigPretrain.py elementModel + scripts/DigDriver.py elementDriver, one cohort, two fresh processes "
                                          "(interpreter start, imports and device initialisation included)",
                                  "DigPretrain_elementModel_s": t1 - t0, "DigDriver_elementDriver_s": t2 - t1, "elements_per_s": elements / (t2 - t0)}
