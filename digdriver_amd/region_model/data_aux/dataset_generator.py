@@ -128,6 +128,13 @@ class BinTrackStore:
 
     def batch(self, bin_rows, channels_first=True, out_dtype="f32"):
         """x_data[bin_rows, :, tracks] (mut_dataset.py:76-81) for a batch, optionally as [B, T, L]."""
+        import torch
         if self.row_offset:
-            bin_rows = np.asarray(bin_rows) - self.row_offset
-        return engine.gather_bins(self.x, bin_rows, self.tracks, out_dtype=out_dtype, transpose=channels_first)
+            bin_rows = (bin_rows if torch.is_tensor(bin_rows) else np.asarray(bin_rows)) - self.row_offset
+        tracks = self.tracks
+        if tracks is not None and torch.is_tensor(self.x) and self.x.is_cuda:
+            # (the track list goes to the device once: an upload per batch cannot be part of a captured training step)
+            if getattr(self, "_tracks_dev", None) is None or self._tracks_dev.device != self.x.device:
+                self._tracks_dev = torch.as_tensor(np.ascontiguousarray(tracks), dtype=torch.int32, device=self.x.device)
+            tracks = self._tracks_dev
+        return engine.gather_bins(self.x, bin_rows, tracks, out_dtype=out_dtype, transpose=channels_first)

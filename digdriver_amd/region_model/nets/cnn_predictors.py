@@ -32,6 +32,79 @@ _CONV_SPEC = [
 _FLAT = 1024 * 13          # cnn_predictors.py:126,160: L = 100 -> 98 -> 49 -> 25 -> 13 positions
 
 
+class _TapConv(torch.autograd.Function):
+    """conv1d on channels-last activations x [B, L, Cin] -> [B, Lout, Cout] as k accumulated GEMMs (one per filter tap, no im2col
+    copy: SimpleMultiTaskResNet._conv_gemm describes the row arithmetic), with its OWN backward.  Left to autograd, the same
+    forward costs one zero-filled gradient buffer + one strided copy + one add per TAP for the input gradient, and a copy of every
+    tap's weight slice per GEMM (a [Cin, Cout] view of the [Cout, Cin, k] parameter has no unit stride): 194 strided copies, 96
+    fills and 46 adds per step at batch 128, a quarter of the step's kernel time (tools/nntrainer_prof.py).  Here the weight is
+    brought to [k, Cin, Cout] once per call, the input gradient is accumulated by k in-place GEMMs into ONE buffer, the weight
+    gradient is k GEMMs into one [k, Cin, Cout] buffer.  Same sums as the autograd form up to the order of the taps' additions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k, pad, stride):
+        B, L, C = x.shape
+        Lout = (L + 2 * pad - k) // stride + 1
+        extra = (-(L + 2 * pad)) % stride                      # make Lp a multiple of the stride
+        Lp = L + 2 * pad + extra
+        flat = F.pad(x, (0, 0, pad, pad + extra)).view(B * Lp, C)
+        w = weight.permute(2, 1, 0).contiguous()               # [k, Cin, Cout]
+        rows_out = B * Lp // stride
+        m = (B * Lp - (k - 1) + stride - 1) // stride          # output rows that have all k taps inside `flat`
+        full = torch.empty((rows_out, w.shape[2]), dtype=x.dtype, device=x.device)
+        head = full[:m]
+        torch.addmm(bias, flat[0:(m - 1) * stride + 1:stride], w[0], out=head)
+        for tap in range(1, k):
+            head.addmm_(flat[tap:tap + (m - 1) * stride + 1:stride], w[tap])
+        ctx.save_for_backward(flat, w)
+        ctx.geom = (B, L, C, Lout, Lp, k, pad, stride, m, rows_out)
+        return full.view(B, Lp // stride, -1)[:, :Lout].contiguous()      # (rows m .. of `full` lie behind Lout: never read)
+
+    @staticmethod
+    def backward(ctx, dy):
+        flat, w = ctx.saved_tensors
+        B, L, C, Lout, Lp, k, pad, stride, m, rows_out = ctx.geom
+        Cout = w.shape[2]
+        dfull = torch.zeros((rows_out, Cout), dtype=dy.dtype, device=dy.device)
+        dfull.view(B, Lp // stride, Cout)[:, :Lout].copy_(dy)
+        dhead = dfull[:m]
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dwk = torch.empty_like(w)
+            for tap in range(k):
+                torch.mm(flat[tap:tap + (m - 1) * stride + 1:stride].t(), dhead, out=dwk[tap])
+            dw = dwk.permute(2, 1, 0)
+        if ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 1))
+        if ctx.needs_input_grad[0]:
+            dflat = torch.zeros_like(flat)
+            for tap in range(k):
+                dflat[tap:tap + (m - 1) * stride + 1:stride].addmm_(dhead, w[tap].t())
+            dx = dflat.view(B, Lp, C)[:, pad:pad + L]
+        return dx, dw, db, None, None, None
+
+
+class _HeadRows(torch.autograd.Function):
+    """big [C, ...] whose rows are the storage of the C parameters `rows`: forward = big itself; backward hands every parameter ITS
+    row of the gradient as a view (set or added to `.grad` here: returned to the engine, each row would be cloned by the
+    parameter's gradient accumulator -- the 252 MB the stack's backward used to copy)."""
+
+    @staticmethod
+    def forward(ctx, big, *rows):
+        ctx.rows = rows
+        return big.view_as(big)
+
+    @staticmethod
+    def backward(ctx, g):
+        for p, gi in zip(ctx.rows, g.contiguous().unbind(0)):    # (rows in the parameters' layout: the fused Adam's fast path)
+            if p.requires_grad:
+                if p.grad is None:
+                    p.grad = gi
+                else:
+                    p.grad += gi
+        return (None,) * (1 + len(ctx.rows))
+
+
 class SimpleMultiTaskResNet(nn.Module):
     def __init__(self, shape, task_num, get_attention_maps=False):
         super().__init__()
@@ -74,17 +147,41 @@ class SimpleMultiTaskResNet(nn.Module):
         return x.reshape(-1, _FLAT), att
 
     # ---- heads ------------------------------------------------------------------------------
+    _HEAD_PARTS = (("fc1_lst", "weight"), ("fc1_lst", "bias"), ("fc2_lst", "weight"), ("fc2_lst", "bias"), ("fc3_lst", "weight"),
+                   ("fc3_lst", "bias"))
+
+    def _stacked_heads(self):
+        """The heads' six parameter kinds as six tensors [C, ...] WITHOUT a copy per step: the C parameters of a kind live in one
+        buffer (their `.data` are rows of it), `_HeadRows` hands that buffer to autograd and deals the gradient's rows back to the
+        parameters as views.  torch.stack copied 252 MB forward (37 heads x [128, 13312]) and its backward + the gradient
+        accumulators copied them back; state_dict, load_state_dict and the optimizer see the same C parameters as before.  The
+        buffers are rebuilt when something replaced the parameters' storage (.to(), .double(), a fresh copy of the module)."""
+        st = self.__dict__.get("_stacked")
+        out = []
+        for j, (lst, attr) in enumerate(self._HEAD_PARTS):
+            ps = [getattr(m, attr) for m in getattr(self, lst)]
+            big = st[j] if st is not None else None
+            step = ps[0].numel() * ps[0].element_size()
+            if (big is None or big.dtype != ps[0].dtype or big.device != ps[0].device
+                    or any(p.data_ptr() != big.data_ptr() + i * step for i, p in enumerate(ps))):
+                big = torch.stack([p.data for p in ps])
+                for i, p in enumerate(ps):
+                    p.data = big[i]
+                if st is None:
+                    st = self.__dict__["_stacked"] = [None] * len(self._HEAD_PARTS)
+                st[j] = big
+            out.append(_HeadRows.apply(big, *ps))
+        return out
+
     def heads(self, flat):
         """All task heads as batched matmuls: [B, 13312] -> outputs [C, B], features [C, B, 16]."""
-        W1 = torch.stack([m.weight for m in self.fc1_lst])          # [C, 128, 13312]
-        b1 = torch.stack([m.bias for m in self.fc1_lst])
-        W2 = torch.stack([m.weight for m in self.fc2_lst])          # [C, 16, 128]
-        b2 = torch.stack([m.bias for m in self.fc2_lst])
-        W3 = torch.stack([m.weight for m in self.fc3_lst])          # [C, 1, 16]
-        b3 = torch.stack([m.bias for m in self.fc3_lst])
-        h1 = F.relu(torch.einsum("bk,cok->cbo", flat, W1) + b1[:, None, :])
-        h2 = F.relu(torch.bmm(h1, W2.transpose(1, 2)) + b2[:, None, :])
-        out = (torch.bmm(h2, W3.transpose(1, 2)) + b3[:, None, :]).squeeze(-1)
+        W1, b1, W2, b2, W3, b3 = self._stacked_heads()               # [C, 128, 13312], [C, 128], [C, 16, 128], ...
+        C, B = W1.shape[0], flat.shape[0]
+        # the first layer of all heads as ONE GEMM [B, 13312] x [13312, C * 128]: its weight gradient comes out as [C * 128, 13312],
+        # i.e. in the parameters' own layout (an einsum over (c, o) left it k-major: a 252 MB re-layout per step in front of Adam)
+        h1 = F.relu(F.linear(flat, W1.view(C * self.fc2_dim, -1), b1.view(-1))).view(B, C, self.fc2_dim).transpose(0, 1)
+        h2 = F.relu(torch.baddbmm(b2[:, None, :], h1, W2.transpose(1, 2)))
+        out = torch.baddbmm(b3[:, None, :], h2, W3.transpose(1, 2)).squeeze(-1)
         return out, h2
 
     def forward_channels_first(self, x):
@@ -107,24 +204,12 @@ class SimpleMultiTaskResNet(nn.Module):
         T = 735, measured; profiles/r05_aux.json).  BatchNorm sees the [B * Lout, C] matrix: per-channel statistics over batch
         and positions, exactly BatchNorm1d on [B, C, Lout]."""
         conv, bn = getattr(self, "conv" + name), getattr(self, "bn" + name)
-        k, pad, stride = conv.kernel_size[0], conv.padding[0], conv.stride[0]
-        B, L, C = x.shape
-        Lout = (L + 2 * pad - k) // stride + 1
-        extra = (-(L + 2 * pad)) % stride
-        Lp = L + 2 * pad + extra
-        flat = F.pad(x, (0, 0, pad, pad + extra)).reshape(B * Lp, C)
-        m = (B * Lp - (k - 1) + stride - 1) // stride          # output rows that have all k taps inside `flat`
-        w = conv.weight.permute(2, 1, 0)                       # [k, Cin, Cout] (a view: gradients reach conv.weight)
-        y = torch.addmm(conv.bias, flat[0:(m - 1) * stride + 1:stride], w[0])
-        for tap in range(1, k):
-            y = torch.addmm(y, flat[tap:tap + (m - 1) * stride + 1:stride], w[tap])
-        rows_out = B * Lp // stride
-        if m < rows_out:
-            y = F.pad(y, (0, 0, 0, rows_out - m))
-        y = y.view(B, Lp // stride, -1)[:, :Lout].reshape(B * Lout, -1)     # the valid output positions
+        y = _TapConv.apply(x, conv.weight, conv.bias, conv.kernel_size[0], conv.padding[0], conv.stride[0])   # [B, Lout, Cout]
+        B, Lout, Cout = y.shape
+        y = y.view(B * Lout, Cout)
         if not self._folded:
             y = bn(y)
-        return F.relu(y).view(B, Lout, -1)
+        return F.relu(y).view(B, Lout, Cout)
 
     def forward_rows_stacked(self, x):
         """x [B, L, T] row-major (what dig_gather_bins produces without a transpose) -> (outputs [C, B], features [C, B, 16]),

@@ -38,6 +38,64 @@ class NNTrainer:
         return (hasattr(self.model, "forward_rows") and not getattr(self.model, "get_attention_maps", False)
                 and torch.device(self.device).type == "cuda")
 
+    # ---- the training step as a hipGraph -------------------------------------------------------------------------------------
+    # A step at batch 128 is ~ 600 kernels of 5.7 ms together, and the interpreter needs 8 - 9 ms to enqueue them (autograd nodes,
+    # the tap loops, 75 M parameters in 100 tensors): the GPU idles a third of the step.  Whole batches of the stacked route are
+    # therefore captured ONCE -- gather, forward, the 37 losses, backward, fused Adam, the scores -- and replayed with the batch's
+    # rows copied into a static index buffer; the first two batches of a trainer (and a last, smaller batch) run eagerly.  One
+    # device, no process group (a collective inside a captured step is not attempted), fused + capturable Adam (adam_for).
+    # DIG_NN_GRAPH=0 switches it off; a capture that raises leaves the trainer on the eager path.
+    def _graph_ready(self, n_rows, j):
+        import os
+        if getattr(self, "_graph_off", False) or os.environ.get("DIG_NN_GRAPH", "1") == "0":
+            return False
+        if (self.world > 1 or parallel.collectives_on(self.group) or n_rows != self.bs or torch.device(self.device).type != "cuda"
+                or not hasattr(torch.cuda, "CUDAGraph") or not self.optimizer.defaults.get("capturable", False)
+                or not self.optimizer.defaults.get("fused", False) or self.store.x.device != torch.device(self.device)
+                or self.store.row_offset):
+            return False
+        self._eager_steps = getattr(self, "_eager_steps", 0)
+        if getattr(self, "_graph", None) is None and self._eager_steps < 2:
+            self._eager_steps += 1                             # (optimizer state, hipBLASLt's choices and the allocator settle first)
+            return False
+        return True
+
+    def _step_body(self, r, lab_all):
+        """One batch of the stacked route (all tasks with one chain of kernels: the labels as one [C, N] tensor, nn.MSELoss with the
+        default mean reduction as one ((Y - T)^2).mean(1)): rows r (device tensor) -> (Y [C, B], features [C, B, 16], T, losses [C]
+        float64, scores [C]), all detached."""
+        x = self.store.batch(r, channels_first=False)
+        if x.device != self.device:                            # (a store on the host or on another device, as in _forward)
+            x = x.to(self.device)
+        Y, FV = self.model.forward_rows_stacked(x.float())
+        Tm = lab_all[:, r]
+        losses = ((Y - Tm) ** 2).mean(dim=1)
+        loss = losses.sum()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        parallel.average_gradients(list(self.model.parameters()), self.group)
+        self.optimizer.step()
+        return Y.detach(), FV.detach(), Tm, losses.detach().double(), _predict.r2_rows(Tm, Y.detach())
+
+    def _graph_step(self, r, lab_all):
+        if getattr(self, "_graph", None) is None:
+            try:
+                self._g_rows = r.clone()
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._g_out = self._step_body(self._g_rows, lab_all)
+                self._graph = g
+            except Exception as e:                             # the capture recorded nothing that ran: the batch is done eagerly
+                self._graph_off, self._graph = True, None
+                print("NNTrainer: training step not captured (%s: %s); eager steps" % (type(e).__name__, e))
+                torch.cuda.synchronize(self.device)
+                return self._step_body(r, lab_all)
+        self._g_rows.copy_(r)
+        self._graph.replay()
+        Y, FV, Tm, losses, acc = self._g_out
+        return Y.clone(), FV.clone(), Tm.clone(), losses, acc     # (losses / acc are added to the epoch's sums before the next replay)
+
     def _forward(self, rows):
         rows_form = self._rows_form()
         x = self.store.batch(rows, channels_first=not rows_form)
@@ -64,7 +122,9 @@ class NNTrainer:
         # the default mean reduction as one ((Y - T)^2).mean(1) over the stacked outputs (37 tasks: 37 gathers + 37 losses +
         # their backward nodes per batch otherwise -- most of a 13 ms step at batch 128 was launches)
         stacked = self._rows_form() and isinstance(self.loss_fn, torch.nn.MSELoss) and self.loss_fn.reduction == "mean"
-        lab_all = torch.stack(self.labels) if stacked else None
+        if stacked and getattr(self, "_lab_all", None) is None:
+            self._lab_all = torch.stack(self.labels)
+        lab_all = self._lab_all if stacked else None
         for j in range(n_batches):
             rows = order[j * self.bs:(j + 1) * self.bs][self.rank::self.world]
             if len(rows) == 0:
@@ -72,22 +132,15 @@ class NNTrainer:
             seen.append(rows)
             r = torch.as_tensor(rows, device=self.device)
             if stacked:
-                x = self.store.batch(rows, channels_first=False)
-                if x.device != self.device:                  # (a store on the host or on another device, as in _forward)
-                    x = x.to(self.device)
-                Y, FV = self.model.forward_rows_stacked(x.float())
-                Tm = lab_all[:, r]
-                losses = ((Y - Tm) ** 2).mean(dim=1)
-                feats[0].append(FV.detach())
-                preds[0].append(Y.detach())
+                # (the step in a function of its own: nothing of its autograd graph survives it -- a captured step must not meet
+                # gradient accumulators of an earlier, eager step that live on another stream)
+                step = self._graph_step if self._graph_ready(len(rows), j) else self._step_body
+                Y, FV, Tm, losses, acc = step(r, lab_all)
+                feats[0].append(FV)
+                preds[0].append(Y)
                 true[0].append(Tm)
-                loss = losses.sum()
-                self.optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                parallel.average_gradients(list(self.model.parameters()), self.group)
-                self.optimizer.step()
-                loss_dev += losses.detach().double()
-                acc_dev += _predict.r2_rows(Tm, Y.detach())
+                loss_dev += losses
+                acc_dev += acc
                 if n_batches >= 10 and j % max(1, int(n_batches * print_interval / 100)) == 0 and j > 0:
                     print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {}'.format(epoch, j, n_batches, 100. * j / n_batches,
                                                                               loss_dev.cpu().numpy() / (j + 1)))
@@ -171,5 +224,5 @@ def adam_for(model, device):
     dev = torch.device(device)
     if dev.type == "cuda":
         model.to(dev)
-        return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False, fused=True)
+        return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False, fused=True, capturable=True)   # (capturable: the step count lives on the device)
     return optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
