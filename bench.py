@@ -494,13 +494,13 @@ def aux_rooflines(dev):
     del net
     # f4: one NNTrainer training step -- gather-fed, T = 735, 37 heads, batch 128: the defaults of kfold_mutations_main.py:52-76 --
     # train-mode forward, summed per-task MSE, backward, Adam (nn_trainer.py:40-91), by the REAL trainer object over 64 batches
-    from digdriver_amd.region_model.trainers.nn_trainer import NNTrainer
+    from digdriver_amd.region_model.trainers.nn_trainer import NNTrainer, adam_for
     import contextlib
     import io
     bs_t, n_tr = 128, 64 * 128
     torch.manual_seed(0)
     net_t = SimpleMultiTaskResNet((bs_t, L, T), C_heads).to(dev)
-    opt = torch.optim.Adam(net_t.parameters(), lr=1e-4, fused=True)
+    opt = adam_for(net_t, dev)                        # what mutations_main / kfold_mutations_main build (fused, capturable Adam)
     lab = [np.random.default_rng(9 + c).gamma(9.0, 3.0, N) for c in range(C_heads)]
     tr = NNTrainer(net_t, opt, torch.nn.MSELoss(), bs_t, list(range(C_heads)), store, np.arange(n_tr), np.arange(n_tr, n_tr + 256), lab, dev, seed=1)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -516,7 +516,8 @@ def aux_rooflines(dev):
                 "unit": "TFLOP/s", "frac": fl / dt / 157.3e12, "algorithmic_flops_per_launch": fl, "avg_launch_ms": dt * 1e3,
                 "flops_note": "3 x the forward's algorithmic flops (forward, input-gradient and weight-gradient products)",
                 "workload": "one epoch of 64 batches of 128 bins, T = 735, 37 heads, host clock over the whole epoch (the trainer's "
-                            "per-epoch bookkeeping included)", "bins_per_s": bs_t / dt, "epoch_288000_bins_s": 288_000 / (bs_t / dt)})
+                            "per-epoch bookkeeping included); whole batches are replayed as one captured graph (NNTrainer._graph_step)",
+                "captured_graph": getattr(tr, "_graph", None) is not None, "bins_per_s": bs_t / dt, "epoch_288000_bins_s": 288_000 / (bs_t / dt)})
     del net_t, opt, tr, store, x16
     torch.cuda.empty_cache()
     # a18 back half: per-tile exact NB test, 37 cohorts x 8 000 bins x 200 tiles

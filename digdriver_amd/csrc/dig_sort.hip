@@ -71,6 +71,15 @@ __device__ __forceinline__ int sort_row_of(const int64_t* __restrict__ tile_star
 // one CU.  profiles/r06_sort_probes.txt.) ----
 constexpr int kRangeTiles = 16;
 constexpr int kRangeElems = kRangeTiles * kSortTile;
+// the scatter kernel's own workgroup: 16 waves x 8 keys = tiles of 8 192, so that a digit's run out of a tile is sixteen elements
+// on average with random digits (128 B of keys, 64 B of payloads: the passes over the mantissa's digits are bound by how the
+// memory system takes these runs -- with runs of eight they took 2.4 ms, the passes over the concentrated upper digits 1.3 ms,
+// whatever the occupancy); a range stays 65 536 elements (the histogram and scan kernels do not change)
+#ifndef DIG_SORT_SCAT_WAVES
+#define DIG_SORT_SCAT_WAVES 16
+#endif
+constexpr int kScatWaves = DIG_SORT_SCAT_WAVES, kScatBlock = kScatWaves * 64, kScatTile = kScatBlock * kSortItems;
+static_assert(kRangeElems % kScatTile == 0 && kScatBlock >= kSortBins, "whole scatter tiles per range; a thread per digit");
 
 // a barrier that orders LDS only: __syncthreads() also waits for every global load and store of the wave (its fence covers global
 // memory), which would end the scatter kernel's look-ahead loads at the first barrier behind them
@@ -174,19 +183,19 @@ __global__ __launch_bounds__(kSortBins) void sort_range_scan_kernel(unsigned* __
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
+__global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_range_scatter_kernel(
     const double* __restrict__ p_in, const uint64_t* __restrict__ k_in, const unsigned* __restrict__ v_in, uint64_t* __restrict__ k_out,
     unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ range_start, int rows, int pass,
     const unsigned* __restrict__ roff, const unsigned* __restrict__ flags, int gate)
 {
     if (gate && !(*flags & 2u)) return;
     if (pass == 7 && !(*flags & 1u)) return;
-    __shared__ unsigned s_cnt[kSortWaves][kSortBins];            // per-wave digit counts, then their exclusive prefix over the waves
+    __shared__ unsigned s_cnt[kScatWaves][kSortBins];            // per-wave digit counts, then their exclusive prefix over the waves
     __shared__ unsigned s_tpre[kSortBins];                       // where a digit starts in the regrouped tile
     __shared__ int64_t s_gbase[kSortBins];                       // where the tile's elements of a digit go, minus s_tpre
-    __shared__ uint64_t s_key[kSortTile];
-    __shared__ unsigned s_val[kSortTile];
-    __shared__ unsigned s_wsum[kSortWaves];
+    __shared__ uint64_t s_key[kScatTile];
+    __shared__ unsigned s_val[kScatTile];
+    __shared__ unsigned s_wsum[kSortBins / 64];
 #ifdef DIG_SORT_PAD_LDS                                     // timing build: one workgroup per CU (half the open output lines per L2)
     __shared__ unsigned s_pad[DIG_SORT_PAD_LDS / 4];
     if (threadIdx.x == 0 && pass == 99) s_pad[blockIdx.x & 7] = 1u;
@@ -196,8 +205,8 @@ __global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
     const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
     const int64_t range_e0 = ((int64_t)blockIdx.x - range_start[row]) * kRangeElems;     // first element of the range, in the row
     const int64_t range_e1 = range_e0 + kRangeElems < n_row ? range_e0 + kRangeElems : n_row;
-    const int64_t whole_e1 = range_e0 + ((range_e1 - range_e0) / kSortTile) * kSortTile;  // behind the range's last whole tile
-    unsigned running = roff[(int64_t)blockIdx.x * kSortBins + tid];                      // where this range's elements of digit tid go, in the row
+    const int64_t whole_e1 = range_e0 + ((range_e1 - range_e0) / kScatTile) * kScatTile;  // behind the range's last whole tile
+    unsigned running = tid < kSortBins ? roff[(int64_t)blockIdx.x * kSortBins + tid] : 0u;                      // where this range's elements of digit tid go, in the row
     asm volatile("" : "+v"(running) : : "memory");               // (arrived before the loop: its wait inside would end every look-ahead)
     // Element j of a tile = (wave, item, lane): j = wave * 512 + item * 64 + lane (the order ranks are taken in).  A WHOLE tile's
     // loads are issued a tile ahead and cross the barriers of the tile in front of them (the barriers order LDS only:
@@ -254,30 +263,34 @@ __global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
             if (live && below == 0u) s_cnt[wave][d] = old + (unsigned)__popcll(peers);
         }
         sort_lds_barrier();
-        // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix ----
-        unsigned h = 0u;
+        // ---- the tile's count of digit tid: the waves' counts become their exclusive prefix (thread = digit: the first 512) ----
+        unsigned h = 0u, incl = 0u;
+        if (tid < kSortBins) {
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) {
-            const unsigned c = s_cnt[w][tid];
-            s_cnt[w][tid] = h;
-            h += c;
-        }
-        // (exclusive scan of h over the 512 digits: inside the wave by shuffles, then over the eight waves)
-        unsigned incl = h;
+            for (int w = 0; w < kScatWaves; ++w) {
+                const unsigned c = s_cnt[w][tid];
+                s_cnt[w][tid] = h;
+                h += c;
+            }
+            // (exclusive scan of h over the 512 digits: inside the wave by shuffles, then over the eight waves)
+            incl = h;
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const unsigned v = __shfl_up(incl, dd, 64);
-            if (lane >= dd) incl += v;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const unsigned v = __shfl_up(incl, dd, 64);
+                if (lane >= dd) incl += v;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
         }
-        if (lane == 63) s_wsum[wave] = incl;
         sort_lds_barrier();
-        unsigned wbase = 0u;
+        if (tid < kSortBins) {
+            unsigned wbase = 0u;
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) wbase += w < wave ? s_wsum[w] : 0u;
-        const unsigned tpre = wbase + incl - h;
-        s_tpre[tid] = tpre;
-        s_gbase[tid] = r0 + (int64_t)running - tpre;
-        running += h;
+            for (int w = 0; w < kSortBins / 64; ++w) wbase += w < wave ? s_wsum[w] : 0u;
+            const unsigned tpre = wbase + incl - h;
+            s_tpre[tid] = tpre;
+            s_gbase[tid] = r0 + (int64_t)running - tpre;
+            running += h;
+        }
         sort_lds_barrier();
         // ---- regroup the tile by digit in LDS, then every digit's run leaves in one piece ----
 #pragma unroll
@@ -289,11 +302,11 @@ __global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
                 s_val[pos] = val[e];
             }
         }
-        if (ahead) take(e0 + kSortTile);
+        if (ahead) take(e0 + kScatTile);
         sort_lds_barrier();
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {                   // (unconditional stores: a lane past the end of a row's last tile
-            int pos = e * kSortBlock + tid;                      //  writes the tile's last element once more -- stores that may
+            int pos = e * kScatBlock + tid;                      //  writes the tile's last element once more -- stores that may
             pos = pos < n_here ? pos : n_here - 1;               //  or may not happen cannot be counted past by the waits in front
             const uint64_t k = s_key[pos];                       //  of the next tile's loads)
             const int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
@@ -304,10 +317,10 @@ __global__ __launch_bounds__(kSortBlock, 4) void sort_range_scatter_kernel(
     if (range_e0 < whole_e1) {
         request(range_e0);
         take(range_e0);
-        for (int64_t e0 = range_e0; e0 < whole_e1; e0 += kSortTile) {
-            const bool ahead = e0 + kSortTile < whole_e1;
-            if (ahead) request(e0 + kSortTile);
-            tile(e0, kSortTile, ahead);
+        for (int64_t e0 = range_e0; e0 < whole_e1; e0 += kScatTile) {
+            const bool ahead = e0 + kScatTile < whole_e1;
+            if (ahead) request(e0 + kScatTile);
+            tile(e0, kScatTile, ahead);
         }
     }
     if (whole_e1 < range_e1) {                                   // the row's last tile: a lane past the end holds the largest key, masked
@@ -636,10 +649,10 @@ int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* works
                                rhist, flags, gate);
         hipLaunchKernelGGL(sort_range_scan_kernel, grid_rows, dim3(kSortBins), 0, s, rhist, d_rs, pass, (const unsigned*)flags, gate);
         if (first)
-            hipLaunchKernelGGL((sort_range_scatter_kernel<true>), grid_r, dim3(kSortBlock), 0, s, p, (const uint64_t*)nullptr, (const unsigned*)nullptr,
+            hipLaunchKernelGGL((sort_range_scatter_kernel<true>), grid_r, dim3(kScatBlock), 0, s, p, (const uint64_t*)nullptr, (const unsigned*)nullptr,
                                to0 ? k0 : k1, to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
         else
-            hipLaunchKernelGGL((sort_range_scatter_kernel<false>), grid_r, dim3(kSortBlock), 0, s, (const double*)nullptr, ki, vi, to0 ? k0 : k1,
+            hipLaunchKernelGGL((sort_range_scatter_kernel<false>), grid_r, dim3(kScatBlock), 0, s, (const double*)nullptr, ki, vi, to0 ? k0 : k1,
                                to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
     };
     static const bool careful_only = getenv("DIG_SORT_FORM") && getenv("DIG_SORT_FORM")[0] == 'c';      // developer switch: seven passes always
