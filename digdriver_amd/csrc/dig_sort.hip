@@ -367,15 +367,29 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
     const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
     const int64_t e0 = ((int64_t)blockIdx.x - tile_start[row]) * kSortTile;          // first element the tile owns, in the row
     const int64_t w0 = e0 - kFixRun;                             // first element of the window (may lie in front of the row)
-    for (int w = tid; w < kWin; w += kSortBlock) {
-        const int64_t i = w0 + w;
-        s_k[w] = (i >= 0 && i < n_row) ? ks[r0 + i] : 0ull;
-    }
     unsigned val[kSortItems];                                    // (the payloads travel while the keys are looked at: a load per element
-#pragma unroll                                                   //  inside the loop was a memory trip per element, 16 of the tile's 20 us)
-    for (int e = 0; e < kSortItems; ++e) {
-        const int64_t i = e0 + e * kSortBlock + tid;
-        val[e] = i < n_row ? __builtin_nontemporal_load(vs + r0 + i) : 0u;
+    {                                                            //  inside the loop was a memory trip per element, 16 of the tile's 20 us)
+        // the window's nine keys and the tile's eight payloads per thread in flight together: clamped addresses, masked afterwards
+        constexpr int kPer = kWin / kSortBlock;
+        static_assert(kWin % kSortBlock == 0, "whole rounds of the workgroup over the window");
+        uint64_t lk[kPer];
+#pragma unroll
+        for (int c = 0; c < kPer; ++c) {
+            int64_t i = w0 + c * kSortBlock + tid;
+            i = i < 0 ? 0 : (i < n_row ? i : n_row - 1);
+            lk[c] = ks[r0 + i];
+        }
+#pragma unroll
+        for (int e = 0; e < kSortItems; ++e) {
+            int64_t i = e0 + e * kSortBlock + tid;
+            i = i < n_row ? i : n_row - 1;
+            val[e] = __builtin_nontemporal_load(vs + r0 + i);
+        }
+#pragma unroll
+        for (int c = 0; c < kPer; ++c) {
+            const int64_t i = w0 + c * kSortBlock + tid;
+            s_k[c * kSortBlock + tid] = (i >= 0 && i < n_row) ? lk[c] : 0ull;
+        }
     }
     __syncthreads();
     bool give_up = false;
@@ -450,12 +464,26 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
     const int64_t c0 = ((int64_t)blockIdx.x - chunk_start[row]) * kBhrChunk;       // first element of the chunk, in the row
     const int n_here = (int)(n_row - c0 < kBhrChunk ? n_row - c0 : kBhrChunk);
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    {   // (every load issued before the first LDS write, and unconditional -- a lane past the end reads the chunk's last element:
+        //  a guarded load-then-store loop is a memory round trip per element, sixteen of them in turn)
+        uint64_t lk[kBhrItems];
+        unsigned lv[kBhrItems];
+        const uint64_t* kb = ks + r0 + c0;
+        const unsigned* vb = vs + r0 + c0;
 #pragma unroll
-    for (int k = 0; k < kBhrItems; ++k) {
-        const int j = k * kBhrBlock + tid;
-        if (j < n_here) {
-            s_k[j + (j >> 4)] = __builtin_nontemporal_load(ks + r0 + c0 + j);
-            if (MODE == 1 && scatter) s_v[j + (j >> 4)] = __builtin_nontemporal_load(vs + r0 + c0 + j);
+        for (int k = 0; k < kBhrItems; ++k) {
+            int j = k * kBhrBlock + tid;
+            j = j < n_here ? j : n_here - 1;
+            lk[k] = __builtin_nontemporal_load(kb + j);
+            if (MODE == 1) lv[k] = scatter ? __builtin_nontemporal_load(vb + j) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kBhrItems; ++k) {
+            const int j = k * kBhrBlock + tid;
+            if (j < n_here) {
+                s_k[j + (j >> 4)] = lk[k];
+                if (MODE == 1) s_v[j + (j >> 4)] = lv[k];
+            }
         }
     }
     __syncthreads();
@@ -463,13 +491,66 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
     const int64_t rk = rank0[row] + c0;
     const int base = tid * kBhrItems;                            // this thread's sixteen elements of the chunk
     double v[kBhrItems];
+    if (MODE == 0) {
+        // Only the chunk's minimum is wanted here, and two IEEE divisions per element (266 M elements: 0.75 of this kernel's 0.8 ms)
+        // are the cost: the quotients are first formed approximately (reciprocal of the rank + two Newton steps: relative
+        // error < 1e-15), a thread's candidates for its minimum are the elements within 1e-12 of the smallest approximate
+        // quotient -- one, as a rule -- and only those are divided exactly.  A thread that meets a NaN, or magnitudes where the
+        // approximation is not to be trusted (subnormal quotients, overflow), divides all sixteen.
+        double a[kBhrItems], pv[kBhrItems];
+        double amin = inf;
+        bool all_exact = false;
 #pragma unroll
-    for (int k = 0; k < kBhrItems; ++k) {
+        for (int k = 0; k < kBhrItems; ++k) {
+            const bool on = base + k < n_here;
+            pv[k] = on ? sort_value(s_k[base + k + tid]) : inf;
+            const double r = (double)(rk + base + k + 1);
+            double y = __builtin_amdgcn_rcp(r);
+            y = __builtin_fma(__builtin_fma(-r, y, 1.0), y, y);
+            y = __builtin_fma(__builtin_fma(-r, y, 1.0), y, y);
+            a[k] = on ? pv[k] * (n_f * y) : inf;
+            all_exact |= on && !(a[k] == a[k]);
+            amin = a[k] < amin ? a[k] : amin;
+        }
+        const double mag = amin < 0.0 ? -amin : amin;
+        all_exact |= !(mag == 0.0 || (mag > 1e-280 && mag < 1e280));
+        const double thr = amin + mag * 1e-12;
+        double pc = inf, rc = 1.0;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kBhrItems; ++k) {
+            const bool c = base + k < n_here && a[k] <= thr;
+            if (c && cnt == 0) {
+                pc = pv[k];
+                rc = (double)(rk + base + k + 1);
+            }
+            cnt += c;
+        }
+        double vmin;
+        {
 #pragma clang fp contract(off)
-        v[k] = base + k < n_here ? sort_value(s_k[base + k + tid]) / ((double)(rk + base + k + 1) / n_f) : inf;
-    }
+            vmin = pc / (rc / n_f);
+        }
+        if (__any(all_exact || cnt > 1)) {                       // (rare: near-ties of the quotient, or the cases above)
 #pragma unroll
-    for (int k = kBhrItems - 2; k >= 0; --k) v[k] = bhr_nan_min(v[k], v[k + 1]);
+            for (int k = 0; k < kBhrItems; ++k) {
+                if (base + k < n_here && (all_exact || (cnt > 1 && a[k] <= thr))) {
+#pragma clang fp contract(off)
+                    const double e = pv[k] / ((double)(rk + base + k + 1) / n_f);
+                    vmin = bhr_nan_min(e, vmin);
+                }
+            }
+        }
+        v[0] = vmin;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kBhrItems; ++k) {
+#pragma clang fp contract(off)
+            v[k] = base + k < n_here ? sort_value(s_k[base + k + tid]) / ((double)(rk + base + k + 1) / n_f) : inf;
+        }
+#pragma unroll
+        for (int k = kBhrItems - 2; k >= 0; --k) v[k] = bhr_nan_min(v[k], v[k + 1]);
+    }
     // reverse inclusive scan of the threads' minima: down the wave by shuffles, then over the four waves
     double sc = v[0];
 #pragma unroll
