@@ -478,11 +478,13 @@ def run_element_region_model(f_mut, f_bed, f_h5_pretrain, pretrain_key, scale_fa
     """transfer_tools.py:969-1096.  `fused=True` computes the statistics block with the single fused kernel
     (element_statistics_block) instead of the reference's column-by-column sequence; results are identical."""
     run = CohortRun(f_mut, f_h5_pretrain)
-    model = load_pretrained_model(f_h5_pretrain, key=pretrain_key, restrict_cols=True)
+    # (the tabulation -- host work -- in front of the model: load_pretrained_model makes the process's first device call, and a
+    # command line that started the HIP runtime on a thread of its own, _lib.prewarm_in_background, finds it ready by then)
     _say('Tabulating mutations')
     table, blacklist = mutation_tools.tabulate_mutations_in_element(
         f_mut, f_bed, bed12=True, drop_duplicates=True, max_muts_per_sample=max_muts_per_sample,
         max_muts_per_elt_per_sample=max_muts_per_elt_per_sample, return_blacklist=True)
+    model = load_pretrained_model(f_h5_pretrain, key=pretrain_key, restrict_cols=True)
     if scale_by_expectation:
         _say('scaling by expected number of mutations')
         genes = run.gene_model()

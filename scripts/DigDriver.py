@@ -176,6 +176,7 @@ def main(text=None):
         # so PyTorch (1.5 s of import and device-layer start for milliseconds of GPU work) is not loaded at all
         from digdriver_amd import _lib
         _lib.TORCH_FREE = True
+        _lib.prewarm_in_background()            # (the HIP runtime starts while pandas is imported and the files are parsed)
     cli.func(cli)
     if os.environ.get("DIG_CLI_ASSERT_NO_TORCH") == "1" and cli.func in (cmd_gene, cmd_target, cmd_element):
         assert "torch" not in sys.modules, "a torch-free sub-command imported torch"         # (tests: the claim above)

@@ -178,6 +178,7 @@ def main(text=None):
         # start) is not loaded for this sub-command (scripts/DigDriver.py does the same for its single-cohort commands)
         from digdriver_amd import _lib
         _lib.TORCH_FREE = True
+        _lib.prewarm_in_background()            # (the HIP runtime starts while pandas is imported and the files are parsed)
     cli.func(cli)
     if os.environ.get("DIG_CLI_ASSERT_NO_TORCH") == "1" and cli.func is pretrain_nonc_model:
         assert "torch" not in sys.modules, "a torch-free sub-command imported torch"
