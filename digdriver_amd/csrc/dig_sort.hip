@@ -196,10 +196,6 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
     __shared__ uint64_t s_key[kScatTile];
     __shared__ unsigned s_val[kScatTile];
     __shared__ unsigned s_wsum[kSortBins / 64];
-#ifdef DIG_SORT_PAD_LDS                                     // timing build: one workgroup per CU (half the open output lines per L2)
-    __shared__ unsigned s_pad[DIG_SORT_PAD_LDS / 4];
-    if (threadIdx.x == 0 && pass == 99) s_pad[blockIdx.x & 7] = 1u;
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = sort_row_of(range_start, rows, blockIdx.x);
     const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
