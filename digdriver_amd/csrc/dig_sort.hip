@@ -2,16 +2,18 @@
 // Benjamini-Hochberg pass behind it (nb_model.get_q_vals, nb_model.py:340-342 = statsmodels' fdrcorrection, method 'indep').
 //
 // Until round 5 the per-base route of BASELINE configs[4] ended in torch.sort (rocPRIM: 64-bit keys + 64-bit indices, eight
-// 8-bit passes) + dig_bh_qvalues_sorted + scatter_: 40 of the route's 43 ms per eighth of the genome x 37 cohorts.  Here:
+// 8-bit passes) + dig_bh_qvalues_sorted + scatter_: 40 of the route's 43 ms per eighth of the genome x 37 cohorts.  Here (15.7 -
+// 16.0 ms; what was measured on the way: profiles/r06_sort_probes.txt):
 //   * rows = lists (cohorts), ragged (row_ptr): all rows in one launch sequence; a row's keys never leave its range;
-//   * key = the double's bits made monotone (sign handled; every NaN = the largest key, as torch.sort places it); p-values are
-//     not negative, so the top bit of every key is set and SEVEN passes of 9-bit digits sort bits 0 .. 62; an eighth pass over
-//     bit 63 runs only when the histogram pass saw a negative value (a flag on the device, no host round trip);
-//   * payload = the 32-bit position in the row (n < 2^32): 12 bytes per element and pass instead of 16;
-//   * a pass = the digit histograms of the ranges (sixteen tiles of 4 096 elements), one scan per row, and the scatter: a
-//     workgroup walks its range tile by tile, ranks a tile's elements stably (wave-wide match of the digit by ballots, per-wave
+//   * key = the double's bits made monotone (sign handled; every NaN = the largest key, as torch.sort places it; -0 = +0);
+//     payload = the 32-bit position in the row (rows < 2^30 elements): 12 bytes per element and pass instead of 16;
+//   * a pass = the digit histograms of the ranges (65 536 elements), one scan per row, and the scatter: a workgroup walks its
+//     range tile by tile (8 192 elements), ranks a tile's elements stably (wave-wide match of the 9-bit digit by ballots, per-wave
 //     digit counters in LDS), regroups the tile by digit in LDS and writes every digit's run contiguously behind the runs its
 //     earlier tiles wrote; no workgroup waits for another one;
+//   * FOUR passes over bits 27 .. 62 (a fifth over the sign only when a device flag says a negative value exists), then a
+//     fix-up of the short runs that share those 36 bits; a long run with two different keys sets a device flag and eight gated
+//     "careful" passes over all 63 bits redo the sort (launches that return at once otherwise);
 //   * the Benjamini-Hochberg pass reads the sorted keys, and the q-values leave through the payload to their places: no
 //     separate scatter.  The same IEEE operations in the same order as the host form -- p / (rank / n), reverse running
 //     minimum (NaN-propagating), cap at 1 -- so the same bits as statsmodels' operations (q depends on the VALUE of p only:
