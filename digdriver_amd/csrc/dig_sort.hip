@@ -29,7 +29,6 @@ namespace dig {
 constexpr int kSortBits = 9, kSortBins = 1 << kSortBits;        // digit
 constexpr int kSortBlock = 512, kSortItems = 8;                 // threads per workgroup, elements per thread
 constexpr int kSortTile = kSortBlock * kSortItems;              // elements per tile
-constexpr int kSortWaves = kSortBlock / 64;
 static_assert(kSortBlock == kSortBins, "a thread of the pass kernel = a digit");
 constexpr int kSortPasses = 8;                                  // 7 x 9 bits + the sign bit
 
@@ -184,8 +183,10 @@ __global__ __launch_bounds__(kSortBins) void sort_range_scan_kernel(unsigned* __
     }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_range_scatter_kernel(
+// PAY: the 32-bit payloads travel with the keys (the order is wanted: dig_sort_rows, or the q-values go to their places through
+// it); without, only the keys are sorted (the q-values are looked up by value afterwards: bh_lookup_kernel)
+template <bool FIRST, bool PAY>
+__global__ __launch_bounds__(kScatBlock, 4) void sort_range_scatter_kernel(
     const double* __restrict__ p_in, const uint64_t* __restrict__ k_in, const unsigned* __restrict__ v_in, uint64_t* __restrict__ k_out,
     unsigned* __restrict__ v_out, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ range_start, int rows, int pass,
     const unsigned* __restrict__ roff, const unsigned* __restrict__ flags, int gate)
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
     __shared__ unsigned s_tpre[kSortBins];                       // where a digit starts in the regrouped tile
     __shared__ int64_t s_gbase[kSortBins];                       // where the tile's elements of a digit go, minus s_tpre
     __shared__ uint64_t s_key[kScatTile];
-    __shared__ unsigned s_val[kScatTile];
+    __shared__ unsigned s_val[PAY ? kScatTile : 1];
     __shared__ unsigned s_wsum[kSortBins / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = sort_row_of(range_start, rows, blockIdx.x);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
                 nkey[e] = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(pb + j0 + e * 64));
             } else {
                 nkey[e] = __builtin_nontemporal_load(kb + j0 + e * 64);
-                nval[e] = __builtin_nontemporal_load(vb + j0 + e * 64);
+                if (PAY) nval[e] = __builtin_nontemporal_load(vb + j0 + e * 64);
             }
         }
     };
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
 #pragma unroll
         for (int e = 0; e < kSortItems; ++e) {
             key[e] = FIRST ? sort_key(__longlong_as_double((int64_t)nkey[e])) : nkey[e];
-            val[e] = FIRST ? (unsigned)(e0 + j0 + e * 64) : nval[e];
-            asm volatile("" : "+v"(key[e]), "+v"(val[e]) : : "memory");                  // (here, not sunk to the next use)
+            val[e] = !PAY ? 0u : (FIRST ? (unsigned)(e0 + j0 + e * 64) : nval[e]);
+            if (PAY) asm volatile("" : "+v"(key[e]), "+v"(val[e]) : : "memory");         // (here, not sunk to the next use)
+            else asm volatile("" : "+v"(key[e]) : : "memory");
         }
     };
     // one tile: key / val hold it; `ahead`: the tile behind it has been requested and is taken in front of this tile's stores (the
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
                 const unsigned d = sort_digit(key[e], pass);
                 const unsigned pos = s_tpre[d] + s_cnt[wave][d] + loc[e];
                 s_key[pos] = key[e];
-                s_val[pos] = val[e];
+                if (PAY) s_val[pos] = val[e];
             }
         }
         if (ahead) take(e0 + kScatTile);
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
             const uint64_t k = s_key[pos];                       //  of the next tile's loads)
             const int64_t dst = s_gbase[sort_digit(k, pass)] + pos;
             k_out[dst] = k;
-            v_out[dst] = s_val[pos];
+            if (PAY) v_out[dst] = s_val[pos];
         }
     };
     if (range_e0 < whole_e1) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(kScatBlock, kScatBlock == 512 ? 4 : 4) void sort_ra
             val[e] = 0u;
             if (j < n_here) {
                 key[e] = FIRST ? sort_key(p_in[r0 + whole_e1 + j]) : k_in[r0 + whole_e1 + j];
-                val[e] = FIRST ? (unsigned)(whole_e1 + j) : v_in[r0 + whole_e1 + j];
+                val[e] = !PAY ? 0u : (FIRST ? (unsigned)(whole_e1 + j) : v_in[r0 + whole_e1 + j]);
             }
         }
         tile(whole_e1, n_here, false);
@@ -349,6 +351,7 @@ __global__ void sort_giveup_kernel(unsigned* flags) { atomicOr(flags, 2u); }    
 constexpr int kFixRun = 256;                                     // longest run the fix-up sorts = the halo on either side of a tile
 constexpr int kFixLowBits = 27;
 
+template <bool PAY>
 __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __restrict__ k0, uint64_t* __restrict__ k1, unsigned* __restrict__ v0,
                                                                 unsigned* __restrict__ v1, const int64_t* __restrict__ row_ptr,
                                                                 const int64_t* __restrict__ tile_start, int rows, unsigned* __restrict__ flags)
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
         for (int e = 0; e < kSortItems; ++e) {
             int64_t i = e0 + e * kSortBlock + tid;
             i = i < n_row ? i : n_row - 1;
-            val[e] = __builtin_nontemporal_load(vs + r0 + i);
+            val[e] = PAY ? __builtin_nontemporal_load(vs + r0 + i) : 0u;
         }
 #pragma unroll
         for (int c = 0; c < kPer; ++c) {
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
             give_up = true;
         }
         kd[r0 + dst] = key;
-        vd[r0 + dst] = val[e];
+        if (PAY) vd[r0 + dst] = val[e];
     }
     if (__any(give_up) && (tid & 63) == 0) atomicOr(flags, 2u);
 }
@@ -447,7 +450,8 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
                                                               const int64_t* __restrict__ chunk_start, int rows, const double* __restrict__ n_global,
                                                               const int64_t* __restrict__ rank0, const double* __restrict__ carry,
                                                               double* __restrict__ chunk_min, const double* __restrict__ suffix,
-                                                              double* __restrict__ q, int scatter)
+                                                              double* __restrict__ q, int scatter, unsigned* __restrict__ rec_cnt = nullptr,
+                                                              unsigned short* __restrict__ rec_mask = nullptr)
 {
     const bool eight = *flags & 1u;                              // the eighth pass ran: the sorted lists are in the other buffer
     const uint64_t* ks = eight ? k1 : k0;
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
     const int64_t rk = rank0[row] + c0;
     const int base = tid * kBhrItems;                            // this thread's sixteen elements of the chunk
     double v[kBhrItems];
+    double vo[MODE == 2 ? kBhrItems : 1];                        // (MODE 2: the quotients themselves, next to their running minima)
     if (MODE == 0) {
         // Only the chunk's minimum is wanted here, and two IEEE divisions per element (266 M elements: 0.75 of this kernel's 0.8 ms)
         // are the cost: the quotients are first formed approximately (reciprocal of the rank + two Newton steps: relative
@@ -546,6 +551,10 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
 #pragma clang fp contract(off)
             v[k] = base + k < n_here ? sort_value(s_k[base + k + tid]) / ((double)(rk + base + k + 1) / n_f) : inf;
         }
+        if (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < kBhrItems; ++k) vo[k] = v[k];
+        }
 #pragma unroll
         for (int k = kBhrItems - 2; k >= 0; --k) v[k] = bhr_nan_min(v[k], v[k + 1]);
     }
@@ -571,6 +580,32 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_chunk_kernel(const uint64_t* __
     behind = bhr_nan_min(behind, after_waves);                   // ... the waves behind, the chunks behind, the ranks behind
     behind = bhr_nan_min(behind, suffix[blockIdx.x]);
     behind = bhr_nan_min(behind, carry[row]);
+    if (MODE == 2) {
+        // RECORDS of the reverse running minimum: element r with v_r < min(v_s, s > r) -- its q-value is its own quotient, and every
+        // element between the record in front of it and itself shares it (equal p-values: only the last of them can be a record).
+        // q is therefore a step function of p with one step per record: sixteen record bits per thread and the chunk's count leave here,
+        // bh_table_kernel writes the (key, quotient) pairs, bh_lookup_kernel finds every element's q by its VALUE.
+        unsigned bits = 0u;
+#pragma unroll
+        for (int k = 0; k < kBhrItems; ++k) {
+            const double later = k + 1 < kBhrItems ? bhr_nan_min(v[k + 1 < kBhrItems ? k + 1 : k], behind) : behind;
+            bits |= (base + k < n_here && vo[k] < later) ? 1u << k : 0u;
+        }
+        rec_mask[(int64_t)blockIdx.x * kBhrBlock + tid] = (unsigned short)bits;
+        unsigned c = (unsigned)__popc(bits);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        __shared__ unsigned s_c[kBhrBlock / 64];
+        if (lane == 0) s_c[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t = 0u;
+#pragma unroll
+            for (int w = 0; w < kBhrBlock / 64; ++w) t += s_c[w];
+            rec_cnt[blockIdx.x] = t;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kBhrItems; ++k)
         if (base + k < n_here) {
@@ -611,6 +646,153 @@ __global__ __launch_bounds__(kBhrBlock) void bhr_suffix_kernel(const double* __r
     if (row_min && threadIdx.x == 0) row_min[row] = carry;
 }
 
+// ---- q-values by VALUE: the table of records (bhr_chunk_kernel<2>) and the lookup ----
+// where row r's table lies in the payload buffers a keys-only sort leaves unused (8-byte entries over the row's 4-byte slots)
+__device__ __host__ __forceinline__ int64_t bh_table_start(int64_t r0) { return (r0 + 1) >> 1; }
+__device__ __host__ __forceinline__ int64_t bh_table_cap(int64_t r0, int64_t len) { return ((r0 + len) >> 1) - ((r0 + 1) >> 1); }
+
+// per row: where every chunk's records start in the row's table, the number of records, and whether they fit (flags bit 2 if not)
+__global__ __launch_bounds__(kBhrBlock) void bh_count_scan_kernel(const unsigned* __restrict__ rec_cnt, const int64_t* __restrict__ chunk_start,
+                                                                  const int64_t* __restrict__ row_ptr, unsigned* __restrict__ rec_off,
+                                                                  unsigned* __restrict__ row_k, unsigned* __restrict__ flags)
+{
+    const int row = blockIdx.x;
+    const int64_t c0 = chunk_start[row], n_chunks = chunk_start[row + 1] - c0;
+    __shared__ unsigned s[kBhrBlock];
+    unsigned carry = 0u;
+    for (int64_t lo = 0; lo < n_chunks; lo += kBhrBlock) {
+        const int64_t c = lo + threadIdx.x;
+        const unsigned mine = c < n_chunks ? rec_cnt[c0 + c] : 0u;
+        s[threadIdx.x] = mine;
+        __syncthreads();
+        for (int d = 1; d < kBhrBlock; d <<= 1) {
+            const unsigned o = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += o;
+            __syncthreads();
+        }
+        if (c < n_chunks) rec_off[c0 + c] = carry + s[threadIdx.x] - mine;
+        const unsigned all = s[kBhrBlock - 1];
+        __syncthreads();
+        carry += all;
+    }
+    if (threadIdx.x == 0) {
+        row_k[row] = carry;
+        const int64_t r0 = row_ptr[row];
+        if ((int64_t)carry > bh_table_cap(r0, row_ptr[row + 1] - r0)) atomicOr(flags, 4u);
+    }
+}
+
+// the records of a chunk -> the row's table: ascending keys, the record's own quotient beside its key
+__global__ __launch_bounds__(kBhrBlock) void bh_table_kernel(const uint64_t* __restrict__ k0, const uint64_t* __restrict__ k1,
+                                                             const unsigned* __restrict__ flags, const int64_t* __restrict__ row_ptr,
+                                                             const int64_t* __restrict__ chunk_start, int rows, const double* __restrict__ n_global,
+                                                             const int64_t* __restrict__ rank0, const unsigned short* __restrict__ rec_mask,
+                                                             const unsigned* __restrict__ rec_off, uint64_t* __restrict__ tab_k,
+                                                             double* __restrict__ tab_q)
+{
+    const uint64_t* ks = (*flags & 1u) ? k1 : k0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned bits = rec_mask[(int64_t)blockIdx.x * kBhrBlock + tid];
+    unsigned cnt = (unsigned)__popc(bits), incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    __shared__ unsigned s_w[kBhrBlock / 64];
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - cnt;
+#pragma unroll
+    for (int w = 0; w < kBhrBlock / 64; ++w) before += w < wave ? s_w[w] : 0u;
+    if (!bits) return;
+    const int row = sort_row_of(chunk_start, rows, blockIdx.x);
+    const int64_t r0 = row_ptr[row];
+    const int64_t c0 = ((int64_t)blockIdx.x - chunk_start[row]) * kBhrChunk;
+    const double n_f = n_global[row];
+    const int64_t rk = rank0[row] + c0;
+    int64_t at = bh_table_start(r0) + rec_off[blockIdx.x] + before;
+    for (int k = 0; k < kBhrItems; ++k)
+        if (bits >> k & 1u) {
+            const int j = tid * kBhrItems + k;
+            const uint64_t key = ks[r0 + c0 + j];
+            double v;
+            {
+#pragma clang fp contract(off)
+                v = sort_value(key) / ((double)(rk + j + 1) / n_f);
+            }
+            tab_k[at] = key;
+            tab_q[at] = v;
+            ++at;
+        }
+}
+
+// q of every element, in the elements' own order: the first record whose key is not below the element's key (behind the last
+// record: the carry of the ranks behind the row).  256 evenly spaced keys of the row's table in LDS, the rest of the search in the
+// table itself (a few thousand records as a rule: it lives in the L2); sixteen independent searches per thread.
+__global__ __launch_bounds__(kBhrBlock) void bh_lookup_kernel(const double* __restrict__ p, const int64_t* __restrict__ row_ptr,
+                                                              const int64_t* __restrict__ chunk_start, int rows,
+                                                              const unsigned* __restrict__ row_k, const uint64_t* __restrict__ tab_k,
+                                                              const double* __restrict__ tab_q, const double* __restrict__ row_min,
+                                                              const double* __restrict__ carry, double* __restrict__ q)
+{
+    constexpr int kSamp = 256;
+    __shared__ uint64_t s_samp[kSamp];
+    const int tid = threadIdx.x;
+    const int row = sort_row_of(chunk_start, rows, blockIdx.x);
+    const int64_t r0 = row_ptr[row], n_row = row_ptr[row + 1] - r0;
+    const int64_t c0 = ((int64_t)blockIdx.x - chunk_start[row]) * kBhrChunk;
+    const int n_here = (int)(n_row - c0 < kBhrChunk ? n_row - c0 : kBhrChunk);
+    const int64_t K = row_k[row], t0 = bh_table_start(r0);
+    const int64_t stride = (K + kSamp - 1) / kSamp > 0 ? (K + kSamp - 1) / kSamp : 1;       // records per sample block
+    {   // sample j = the LAST key of block j (blocks of `stride` records); blocks past the table: the largest key
+        const int64_t last = (int64_t)(tid + 1) * stride - 1;
+        s_samp[tid] = (int64_t)tid * stride < K ? tab_k[t0 + (last < K ? last : K - 1)] : ~0ull;
+    }
+    uint64_t key[kBhrItems];
+    const double* pb = p + r0 + c0;
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k) {
+        int j = k * kBhrBlock + tid;
+        j = j < n_here ? j : n_here - 1;
+        key[k] = sort_key(__builtin_nontemporal_load(pb + j));
+    }
+    __syncthreads();
+    const double cr = carry[row], rm = row_min[row];
+    const bool nan_row = rm != rm || cr != cr;                   // a NaN anywhere in the list (or behind it) makes every q NaN
+    int64_t lo[kBhrItems], len[kBhrItems];
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k) {                        // the block: the number of samples below the key
+        int pos = 0;
+#pragma unroll
+        for (int st = kSamp / 2; st >= 1; st >>= 1) pos += s_samp[pos + st - 1] < key[k] ? st : 0;
+        pos += s_samp[pos] < key[k] ? 1 : 0;
+        lo[k] = (int64_t)pos * stride;
+        lo[k] = lo[k] < K ? lo[k] : K;
+        const int64_t hi = lo[k] + stride < K ? lo[k] + stride : K;
+        len[k] = hi - lo[k];
+    }
+    for (int64_t span = stride; span > 0; span >>= 1) {          // (the same number of steps for every search: ceil(log2(stride + 1)))
+#pragma unroll
+        for (int k = 0; k < kBhrItems; ++k) {
+            const int64_t half = len[k] >> 1;
+            const bool go = len[k] > 0 && tab_k[t0 + lo[k] + half] < key[k];
+            lo[k] = go ? lo[k] + half + 1 : lo[k];
+            len[k] = len[k] > 0 ? (go ? len[k] - half - 1 : half) : 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kBhrItems; ++k) {
+        const int j = k * kBhrBlock + tid;
+        if (j < n_here) {
+            const double m = lo[k] < K ? tab_q[t0 + lo[k]] : cr;
+            const double out = nan_row ? __longlong_as_double(0x7ff8000000000000LL) : (m != m) ? m : (m < 1.0 ? m : 1.0);
+            q[r0 + c0 + j] = out;
+        }
+    }
+}
+
 __global__ void sort_unpack_kernel(const uint64_t* __restrict__ k0, const uint64_t* __restrict__ k1, const unsigned* __restrict__ v0,
                                    const unsigned* __restrict__ v1, const unsigned* __restrict__ flags, int64_t n, double* __restrict__ p_sorted,
                                    unsigned* __restrict__ order)
@@ -628,7 +810,7 @@ __global__ void sort_unpack_kernel(const uint64_t* __restrict__ k0, const uint64
 struct SortLayout {
     int64_t total_ranges, total_tiles, bh_chunks;
     int64_t off_k0, off_k1, off_v0, off_v1, off_rhist, off_small, off_rowptr, off_rangestart, off_tilestart, off_bhstart, off_nglob,
-        off_rank0, off_carry, off_cmin, off_suffix, bytes;
+        off_rank0, off_carry, off_cmin, off_suffix, off_reccnt, off_recoff, off_recmask, off_rowk, off_rowmin, bytes;
 };
 static int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 static SortLayout sort_layout(const int64_t* row_ptr, int64_t rows)
@@ -662,6 +844,11 @@ static SortLayout sort_layout(const int64_t* row_ptr, int64_t rows)
     L.off_carry = take(rows * 8);
     L.off_cmin = take(L.bh_chunks * 8);
     L.off_suffix = take(L.bh_chunks * 8);
+    L.off_reccnt = take(L.bh_chunks * 4);                              // (the lookup form of the q-values: records per chunk, ...)
+    L.off_recoff = take(L.bh_chunks * 4);
+    L.off_recmask = take(L.bh_chunks * kBhrBlock * 2);
+    L.off_rowk = take(rows * 4);
+    L.off_rowmin = take(rows * 8);
     L.bytes = o + 256;
     return L;
 }
@@ -679,7 +866,8 @@ struct SortPlan {
 };
 
 // uploads the row tables and sorts; afterwards the sorted keys / payloads are in (k0, v0) -- or (k1, v1) when flags & 1
-int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* workspace, int64_t workspace_bytes, hipStream_t s, SortPlan& plan)
+int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* workspace, int64_t workspace_bytes, hipStream_t s, SortPlan& plan,
+              bool pay)
 {
     plan.L = sort_layout(row_ptr, rows);
     const SortLayout& L = plan.L;
@@ -727,12 +915,14 @@ int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* works
             hipLaunchKernelGGL((sort_range_hist_kernel<false>), grid_r, dim3(kSortBlock), 0, s, (const double*)nullptr, ki, d_rp, d_rs, (int)rows, pass,
                                rhist, flags, gate);
         hipLaunchKernelGGL(sort_range_scan_kernel, grid_rows, dim3(kSortBins), 0, s, rhist, d_rs, pass, (const unsigned*)flags, gate);
-        if (first)
-            hipLaunchKernelGGL((sort_range_scatter_kernel<true>), grid_r, dim3(kScatBlock), 0, s, p, (const uint64_t*)nullptr, (const unsigned*)nullptr,
-                               to0 ? k0 : k1, to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
-        else
-            hipLaunchKernelGGL((sort_range_scatter_kernel<false>), grid_r, dim3(kScatBlock), 0, s, (const double*)nullptr, ki, vi, to0 ? k0 : k1,
-                               to0 ? v0 : v1, d_rp, d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate);
+#define DIG_SCATTER(FIRSTV, PAYV, PIN, KIN, VIN)                                                                                                  \
+    hipLaunchKernelGGL((sort_range_scatter_kernel<FIRSTV, PAYV>), grid_r, dim3(kScatBlock), 0, s, PIN, KIN, VIN, to0 ? k0 : k1, to0 ? v0 : v1, d_rp, \
+                       d_rs, (int)rows, pass, (const unsigned*)rhist, (const unsigned*)flags, gate)
+        if (first && pay) DIG_SCATTER(true, true, p, (const uint64_t*)nullptr, (const unsigned*)nullptr);
+        else if (first) DIG_SCATTER(true, false, p, (const uint64_t*)nullptr, (const unsigned*)nullptr);
+        else if (pay) DIG_SCATTER(false, true, (const double*)nullptr, ki, vi);
+        else DIG_SCATTER(false, false, (const double*)nullptr, ki, vi);
+#undef DIG_SCATTER
     };
     static const bool careful_only = getenv("DIG_SORT_FORM") && getenv("DIG_SORT_FORM")[0] == 'c';      // developer switch: seven passes always
     if (!careful_only) {
@@ -743,7 +933,8 @@ int sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, void* works
         pass_from(5, false, true, 0);
         pass_from(6, false, false, 0);
         pass_from(7, false, true, 0);
-        hipLaunchKernelGGL(sort_fixup_kernel, dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, k0, k1, v0, v1, d_rp, d_ts, (int)rows, flags);
+        if (pay) hipLaunchKernelGGL(sort_fixup_kernel<true>, dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, k0, k1, v0, v1, d_rp, d_ts, (int)rows, flags);
+        else hipLaunchKernelGGL(sort_fixup_kernel<false>, dim3((unsigned)L.total_tiles), dim3(kSortBlock), 0, s, k0, k1, v0, v1, d_rp, d_ts, (int)rows, flags);
     } else {
         hipLaunchKernelGGL(sort_giveup_kernel, dim3(1), dim3(1), 0, s, flags);
     }
@@ -772,7 +963,7 @@ int dig_sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, double*
     for (int64_t r = 0; r < rows; ++r) DIG_REQUIRE(row_ptr[r + 1] >= row_ptr[r] && row_ptr[r + 1] - row_ptr[r] < (1ll << 30), "row lengths in [0, 2^30)");
     DIG_REQUIRE(row_ptr[rows] == row_ptr[0] || p, "p");
     SortPlan plan;
-    const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, (hipStream_t)stream, plan);
+    const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, (hipStream_t)stream, plan, true);
     if (rc != DIG_OK || plan.n == 0) return rc;
     char* b = plan.base;
     const SortLayout& L = plan.L;
@@ -787,6 +978,13 @@ int dig_sort_rows(const double* p, const int64_t* row_ptr, int64_t rows, double*
 // arrays, may be NULL: the row is the whole list): the row is the ranks rank0 .. of a list of n_global values whose elements
 // behind the row have the reverse running minimum `carry`.  row_min (device, may be NULL): the minimum of the row's
 // p / (rank / n) -- what the ranks in front need as their carry.  sorted_out != 0: q leaves in sorted order instead.
+//
+// Two forms of the way back to the elements' places.  LOOKUP (the default): q is a step function of p with one step per record of
+// the reverse running minimum, so only the KEYS are sorted (8 instead of 12 bytes per element and pass), the records go into a
+// small table per row and every element finds its q by binary search with its own value -- p read and q written in order, instead
+// of 266 M random 8-byte stores through a payload (4.5 of the payload form's 15.8 ms).  A few thousand records per row of 7.2 M
+// p-values as a rule (null-dominated lists); a list with more records than half its length (q strictly increasing almost
+// everywhere) is sent through the PAYLOAD form, which is also what DIG_BH_FORM=payload selects (developer switch, tests).
 int dig_bh_qvalues_ragged(const double* p, const int64_t* row_ptr, int64_t rows, const double* n_global, const int64_t* rank0,
                           const double* carry, double* q, double* row_min, int sorted_out, void* workspace, int64_t workspace_bytes,
                           void* stream)
@@ -795,49 +993,76 @@ int dig_bh_qvalues_ragged(const double* p, const int64_t* row_ptr, int64_t rows,
     if (rows == 0) return DIG_OK;
     for (int64_t r = 0; r < rows; ++r) DIG_REQUIRE(row_ptr[r + 1] >= row_ptr[r] && row_ptr[r + 1] - row_ptr[r] < (1ll << 30), "row lengths in [0, 2^30)");
     DIG_REQUIRE(row_ptr[rows] == row_ptr[0] || (p && (q || row_min)), "p and q");
+    static const bool payload_only = getenv("DIG_BH_FORM") && getenv("DIG_BH_FORM")[0] == 'p';
     hipStream_t s = (hipStream_t)stream;
-    SortPlan plan;
-    const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, s, plan);
-    if (rc != DIG_OK) return rc;
-    char* b = plan.base;
-    const SortLayout& L = plan.L;
-    // per-row parameters
-    std::string host((size_t)(3 * rows * 8), '\0');
-    double* h_n = (double*)host.data();
-    int64_t* h_r = (int64_t*)(host.data() + rows * 8);
-    double* h_c = (double*)(host.data() + 2 * rows * 8);
-    const double inf = __builtin_inf();
-    for (int64_t r = 0; r < rows; ++r) {
-        h_n[r] = n_global ? n_global[r] : (double)(row_ptr[r + 1] - row_ptr[r]);
-        h_r[r] = rank0 ? rank0[r] : 0;
-        h_c[r] = carry ? carry[r] : inf;
-    }
-    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_nglob, h_n, rows * 8, hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rank0, h_r, rows * 8, hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipMemcpyAsync(b + L.off_carry, h_c, rows * 8, hipMemcpyHostToDevice, s));
-    DIG_HIP_TRY(hipStreamSynchronize(s));
-    if (plan.n == 0) {
-        if (row_min) {
-            std::string infs((size_t)(rows * 8), '\0');
-            for (int64_t r = 0; r < rows; ++r) ((double*)infs.data())[r] = inf;
-            DIG_HIP_TRY(hipMemcpyAsync(row_min, infs.data(), rows * 8, hipMemcpyHostToDevice, s));
-            DIG_HIP_TRY(hipStreamSynchronize(s));
+    for (int attempt = payload_only ? 1 : 0; attempt < 2; ++attempt) {
+        const bool lookup = attempt == 0 && q && !sorted_out;        // (no q, or q in sorted order: keys only anyway, no table)
+        const bool pay = attempt == 1 && q && !sorted_out;
+        SortPlan plan;
+        const int rc = sort_rows(p + row_ptr[0], row_ptr, rows, workspace, workspace_bytes, s, plan, pay);
+        if (rc != DIG_OK) return rc;
+        char* b = plan.base;
+        const SortLayout& L = plan.L;
+        // per-row parameters
+        std::string host((size_t)(3 * rows * 8), '\0');
+        double* h_n = (double*)host.data();
+        int64_t* h_r = (int64_t*)(host.data() + rows * 8);
+        double* h_c = (double*)(host.data() + 2 * rows * 8);
+        const double inf = __builtin_inf();
+        for (int64_t r = 0; r < rows; ++r) {
+            h_n[r] = n_global ? n_global[r] : (double)(row_ptr[r + 1] - row_ptr[r]);
+            h_r[r] = rank0 ? rank0[r] : 0;
+            h_c[r] = carry ? carry[r] : inf;
         }
-        return DIG_OK;
+        DIG_HIP_TRY(hipMemcpyAsync(b + L.off_nglob, h_n, rows * 8, hipMemcpyHostToDevice, s));
+        DIG_HIP_TRY(hipMemcpyAsync(b + L.off_rank0, h_r, rows * 8, hipMemcpyHostToDevice, s));
+        DIG_HIP_TRY(hipMemcpyAsync(b + L.off_carry, h_c, rows * 8, hipMemcpyHostToDevice, s));
+        DIG_HIP_TRY(hipStreamSynchronize(s));
+        if (plan.n == 0) {
+            if (row_min) {
+                std::string infs((size_t)(rows * 8), '\0');
+                for (int64_t r = 0; r < rows; ++r) ((double*)infs.data())[r] = inf;
+                DIG_HIP_TRY(hipMemcpyAsync(row_min, infs.data(), rows * 8, hipMemcpyHostToDevice, s));
+                DIG_HIP_TRY(hipStreamSynchronize(s));
+            }
+            return DIG_OK;
+        }
+        const uint64_t *k0 = (const uint64_t*)(b + L.off_k0), *k1 = (const uint64_t*)(b + L.off_k1);
+        const unsigned *v0 = (const unsigned*)(b + L.off_v0), *v1 = (const unsigned*)(b + L.off_v1);
+        unsigned* flags = (unsigned*)(b + L.off_small);
+        const int64_t *d_rp = (const int64_t*)(b + L.off_rowptr), *d_bs = (const int64_t*)(b + L.off_bhstart);
+        const double *d_n = (const double*)(b + L.off_nglob), *d_c = (const double*)(b + L.off_carry);
+        const int64_t* d_r = (const int64_t*)(b + L.off_rank0);
+        double *cmin = (double*)(b + L.off_cmin), *suffix = (double*)(b + L.off_suffix), *rowmin_own = (double*)(b + L.off_rowmin);
+        const dim3 grid_c((unsigned)L.bh_chunks), block_c(kBhrBlock);
+        hipLaunchKernelGGL((bhr_chunk_kernel<0>), grid_c, block_c, 0, s, k0, k1, v0, v1, (const unsigned*)flags, d_rp, d_bs, (int)rows, d_n, d_r, d_c, cmin,
+                           (const double*)nullptr, (double*)nullptr, 0, (unsigned*)nullptr, (unsigned short*)nullptr);
+        hipLaunchKernelGGL(bhr_suffix_kernel, dim3((unsigned)rows), block_c, 0, s, cmin, d_bs, suffix, rowmin_own);
+        if (row_min) DIG_HIP_TRY(hipMemcpyAsync(row_min, rowmin_own, rows * 8, hipMemcpyDeviceToDevice, s));
+        if (!q) break;
+        if (!lookup) {
+            hipLaunchKernelGGL((bhr_chunk_kernel<1>), grid_c, block_c, 0, s, k0, k1, v0, v1, (const unsigned*)flags, d_rp, d_bs, (int)rows, d_n, d_r, d_c,
+                               (double*)nullptr, (const double*)suffix, q + row_ptr[0], sorted_out ? 0 : 1, (unsigned*)nullptr, (unsigned short*)nullptr);
+            break;
+        }
+        unsigned *rec_cnt = (unsigned*)(b + L.off_reccnt), *rec_off = (unsigned*)(b + L.off_recoff), *row_k = (unsigned*)(b + L.off_rowk);
+        unsigned short* rec_mask = (unsigned short*)(b + L.off_recmask);
+        hipLaunchKernelGGL((bhr_chunk_kernel<2>), grid_c, block_c, 0, s, k0, k1, v0, v1, (const unsigned*)flags, d_rp, d_bs, (int)rows, d_n, d_r, d_c,
+                           (double*)nullptr, (const double*)suffix, (double*)nullptr, 0, rec_cnt, rec_mask);
+        hipLaunchKernelGGL(bh_count_scan_kernel, dim3((unsigned)rows), block_c, 0, s, (const unsigned*)rec_cnt, d_bs, d_rp, rec_off, row_k, flags);
+        unsigned h_flags = 0u;
+        DIG_HIP_TRY(hipMemcpyAsync(&h_flags, flags, 4, hipMemcpyDeviceToHost, s));
+        DIG_HIP_TRY(hipStreamSynchronize(s));
+        if (h_flags & 4u) continue;                                 // more records than the table holds: the payload form
+        // the tables live in the payload buffers (unused by a keys-only sort): keys in v0's, quotients in v1's
+        uint64_t* tab_k = (uint64_t*)(b + L.off_v0);
+        double* tab_q = (double*)(b + L.off_v1);
+        hipLaunchKernelGGL(bh_table_kernel, grid_c, block_c, 0, s, k0, k1, (const unsigned*)flags, d_rp, d_bs, (int)rows, d_n, d_r,
+                           (const unsigned short*)rec_mask, (const unsigned*)rec_off, tab_k, tab_q);
+        hipLaunchKernelGGL(bh_lookup_kernel, grid_c, block_c, 0, s, p + row_ptr[0], d_rp, d_bs, (int)rows, (const unsigned*)row_k,
+                           (const uint64_t*)tab_k, (const double*)tab_q, (const double*)rowmin_own, d_c, q + row_ptr[0]);
+        break;
     }
-    const uint64_t *k0 = (const uint64_t*)(b + L.off_k0), *k1 = (const uint64_t*)(b + L.off_k1);
-    const unsigned *v0 = (const unsigned*)(b + L.off_v0), *v1 = (const unsigned*)(b + L.off_v1);
-    const unsigned* flags = (const unsigned*)(b + L.off_small);
-    const int64_t *d_rp = (const int64_t*)(b + L.off_rowptr), *d_bs = (const int64_t*)(b + L.off_bhstart);
-    const double *d_n = (const double*)(b + L.off_nglob), *d_c = (const double*)(b + L.off_carry);
-    const int64_t* d_r = (const int64_t*)(b + L.off_rank0);
-    double *cmin = (double*)(b + L.off_cmin), *suffix = (double*)(b + L.off_suffix);
-    hipLaunchKernelGGL((bhr_chunk_kernel<0>), dim3((unsigned)L.bh_chunks), dim3(kBhrBlock), 0, s, k0, k1, v0, v1, flags, d_rp, d_bs, (int)rows, d_n,
-                       d_r, d_c, cmin, (const double*)nullptr, (double*)nullptr, 0);
-    hipLaunchKernelGGL(bhr_suffix_kernel, dim3((unsigned)rows), dim3(kBhrBlock), 0, s, cmin, d_bs, suffix, row_min);
-    if (q)
-        hipLaunchKernelGGL((bhr_chunk_kernel<1>), dim3((unsigned)L.bh_chunks), dim3(kBhrBlock), 0, s, k0, k1, v0, v1, flags, d_rp, d_bs, (int)rows,
-                           d_n, d_r, d_c, (double*)nullptr, suffix, q + row_ptr[0], sorted_out ? 0 : 1);
     DIG_HIP_TRY(hipGetLastError());
     return DIG_OK;
 }

@@ -65,8 +65,11 @@ class _TapConv(torch.autograd.Function):
         flat, w = ctx.saved_tensors
         B, L, C, Lout, Lp, k, pad, stride, m, rows_out = ctx.geom
         Cout = w.shape[2]
-        dfull = torch.zeros((rows_out, Cout), dtype=dy.dtype, device=dy.device)
-        dfull.view(B, Lp // stride, Cout)[:, :Lout].copy_(dy)
+        dfull = torch.empty((rows_out, Cout), dtype=dy.dtype, device=dy.device)     # (only the rows behind Lout are zero-filled)
+        dview = dfull.view(B, Lp // stride, Cout)
+        dview[:, :Lout].copy_(dy)
+        if Lp // stride > Lout:
+            dview[:, Lout:].zero_()
         dhead = dfull[:m]
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
@@ -77,8 +80,15 @@ class _TapConv(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1))
         if ctx.needs_input_grad[0]:
-            dflat = torch.zeros_like(flat)
-            for tap in range(k):
+            if stride == 1:                                    # tap 0 WRITES its rows (0 .. m - 1); only the k - 1 rows behind them are filled
+                dflat = torch.empty_like(flat)
+                torch.mm(dhead, w[0].t(), out=dflat[:m])
+                dflat[m:].zero_()
+                first = 1
+            else:
+                dflat = torch.zeros_like(flat)
+                first = 0
+            for tap in range(first, k):
                 dflat[tap:tap + (m - 1) * stride + 1:stride].addmm_(dhead, w[tap].t())
             dx = dflat.view(B, Lp, C)[:, pad:pad + L]
         return dx, dw, db, None, None, None

@@ -171,3 +171,53 @@ def test_ranges_of_a_longer_list_finish_with_rank_offset_and_carry():
     q = q.cpu().numpy()
     for k in range(3):
         assert np.array_equal(q[rp[k]:rp[k + 1]], want[part == k]), k
+
+
+@pytest.mark.parametrize("form", ["lookup", "payload"])
+def test_q_values_by_lookup_and_through_the_payload_are_the_host_form(form):
+    """The two ways back to the elements' places (csrc/dig_sort.hip): LOOKUP -- keys-only sort, a table of the records of the reverse
+    running minimum per row, every element finds its q by its own value -- and PAYLOAD (DIG_BH_FORM=payload, own process): both the
+    host form bit for bit.  Rows: a null-dominated list (a few records), a list whose q strictly increases (every element a record: more
+    than the table holds -> the call falls back to the payload form by itself), heavy ties, a single value repeated, odd row starts
+    (the tables are 8-byte entries over 4-byte slots), a list with +inf, an empty row, a row with a NaN."""
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    from digdriver_amd.sequence_model import nb_model
+    rng = np.random.default_rng(23)
+    n = 60_001
+    rows = [rng.random(n),                                                  # null
+            ((np.arange(n) + 1.0) / n) ** 2,                                # every element a record
+            rng.choice(rng.random(50), 33_333),                             # ties
+            np.full(4_097, 0.3),
+            np.concatenate([rng.random(7) ** 3, [np.inf, np.inf]]),
+            np.zeros(0),
+            np.concatenate([rng.random(5_000), [np.nan]]),
+            np.where(rng.random(40_000) < 0.02, rng.random(40_000) ** 6 * 1e-3, rng.random(40_000))]      # a signal among nulls
+    for x in rows:
+        rng.shuffle(x)
+    rp = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    p = np.concatenate(rows)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from digdriver_amd.sequence_model import nb_model; d = np.load(sys.argv[1]); "
+            "q, m = nb_model.bh_ragged(torch.as_tensor(d['p'], device='cuda:0'), d['rp'], want_row_min=True); "
+            "np.savez(sys.argv[2], q=q.cpu().numpy(), m=m.cpu().numpy())") % ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), p=p, rp=rp)
+        env = dict(os.environ)
+        env.pop("DIG_BH_FORM", None)
+        if form == "payload":
+            env["DIG_BH_FORM"] = "payload"
+        subprocess.check_call([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")], env=env)
+        got = np.load(os.path.join(tmp, "out.npz"))
+    for r, x in enumerate(rows):
+        want = nb_model.get_q_vals(x) if len(x) else x
+        assert np.array_equal(got["q"][rp[r]:rp[r + 1]], want, equal_nan=True), r
+    # the lists without the one that overflows the table: the lookup form proper (no fallback), same answer
+    import torch
+    keep = [0, 2, 3, 4, 7]
+    rp2 = np.concatenate([[0], np.cumsum([len(rows[r]) for r in keep])]).astype(np.int64)
+    q2, _ = nb_model.bh_ragged(torch.as_tensor(np.concatenate([rows[r] for r in keep]), device="cuda:0"), rp2)
+    q2 = q2.cpu().numpy()
+    for j, r in enumerate(keep):
+        assert np.array_equal(q2[rp2[j]:rp2[j + 1]], nb_model.get_q_vals(rows[r])), r
