@@ -634,8 +634,9 @@ def aux_rooflines(dev):
                     "frac": 28.0 * tiles_r / (t_run + t_q) / HBM_PEAK, "algorithmic_bytes_per_launch": 28.0 * tiles_r,
                     "avg_launch_ms": (t_run + t_q) * 1e3, "kernels_ms": t_run * 1e3, "q_values_ms": t_q * 1e3,
                     "kernels_frac": 28.0 * tiles_r / t_run / HBM_PEAK,
-                    "q_values_how": "dig_bh_qvalues_ragged: the library's radix sort of all 37 lists (four passes over the upper 36 bits + a "
-                                    "fix-up, 32-bit payload), the Benjamini-Hochberg pass and the scatter to the tiles' places",
+                    "q_values_how": "dig_bh_qvalues_ragged: the library's radix sort of the KEYS of all 37 lists (four passes over the upper 36 bits "
+                                    "+ a fix-up), the records of the reverse running minimum as a small table per list, every tile's q-value "
+                                    "looked up by its own p-value",
                     "tile_cohort_tests_per_s": tiles_r / (t_run + t_q),
                     "contexts": "trinucleotide (64-entry tables)" if n_up == 1 else "penta-nucleotide (1 024-entry tables: the reference's default)",
                     "workload": "36 000 10-kb bins x 200 tiles of 50 positions x 37 cohorts, 500 000 mutations; host clock, device drained "

@@ -14,6 +14,9 @@ g = torch.Generator(device=dev).manual_seed(1)
 p = torch.exp(-torch.rand((rows, n), device=dev, generator=g, dtype=torch.float64) * 0.1)
 small = torch.rand((rows, n), device=dev, generator=g) < 0.01
 p[small] = torch.rand(int(small.sum()), device=dev, generator=g, dtype=torch.float64) ** 4
+if os.environ.get("ROUTE"):                                  # like the route's mid-p values: most of them in [0.5, 0.6), a few small ones
+    p = 0.5 + 0.1 * torch.rand((rows, n), device=dev, generator=g, dtype=torch.float64)
+    p[small] = torch.rand(int(small.sum()), device=dev, generator=g, dtype=torch.float64) ** 4
 if os.environ.get("TIES"):                                   # what the route has: p = 1 wherever a tile has no mutation (99.8 %)
     p[~small] = 1.0
     p[small & (torch.rand((rows, n), device=dev, generator=g) < 0.8)] = 1.0
