@@ -6,6 +6,7 @@ import pytest
 # the single-cohort command lines (geneDriver / targetDriver / elementDriver) promise not to load PyTorch: every CLI child of the
 # tests checks it (scripts/DigDriver.py)
 os.environ.setdefault("DIG_CLI_ASSERT_NO_TORCH", "1")
+os.environ.setdefault("DIG_NN_TUNE", "0")       # (GEMM tuning of NNTrainer: seconds per process and run-to-run choices; one test switches it on)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
