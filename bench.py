@@ -484,10 +484,12 @@ def aux_rooflines(dev):
     net = SimpleMultiTaskResNet((Bc, L, T), C_heads).eval().to(dev).fold_batchnorm()
     store = BinTrackStore(x16)
     crow = rows[:Bc].cpu().numpy()
+    from digdriver_amd.region_model import predict as _predict
+    _predict.tune_gemms(dev)                          # (as predict() and NNTrainer do: the GEMM shapes are timed once, in the warm-up calls)
     with torch.no_grad():
         dt = timeit(lambda: net.forward_gemm(store.batch(crow, channels_first=False)), n=5, warm=2)
     fl = float(flops_per_bin(T, C_heads)) * Bc
-    out.append({"kernel": "gather + SimpleMultiTaskResNet forward (fp32, BN folded, tap-accumulated hipBLASLt GEMMs)", "bound": "mfma",
+    out.append({"kernel": "gather + SimpleMultiTaskResNet forward (fp32, BN folded, tap-accumulated GEMMs, tuned per shape)", "bound": "mfma",
                 "achieved": fl / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": fl / dt / 157.3e12,
                 "algorithmic_flops_per_launch": fl, "avg_launch_ms": dt * 1e3, "workload": "%d bins, T = 735, 37 heads" % Bc,
                 "bins_per_s": Bc / dt})

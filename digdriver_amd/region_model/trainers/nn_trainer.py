@@ -217,31 +217,7 @@ class NNTrainer:
         return losses, accs, cat(feats), cat(preds), cat(true), None
 
 
-def tune_gemms(device):
-    """PyTorch's TunableOp for the trainer's GEMMs: every GEMM shape of the step is timed over hipBLASLt's / rocBLAS's solutions the first
-    time it is met (the trainer's two eager batches; a few seconds per process, results kept in `DIG_NN_TUNE_FILE` or
-    ~/.cache/digdriver_amd/tunableop.csv for the next one) instead of taking the library's heuristic choice -- the step's
-    weight-gradient products (a few output tiles, K = 1 664 .. 12 544 rows) are where the heuristic is off: 5.56 -> 4.87 ms per
-    batch of 128.  Same arithmetic, another summation order inside a GEMM (fp32 rounding differences of 1e-7 relative).  DIG_NN_TUNE=0
-    switches it off (the test-suite does, but for one test)."""
-    import os
-    if torch.device(device).type != "cuda" or os.environ.get("DIG_NN_TUNE", "1") == "0":
-        return False
-    try:
-        import torch.cuda.tunable as tunable
-        if not tunable.is_enabled():
-            path = os.environ.get("DIG_NN_TUNE_FILE") or os.path.join(os.path.expanduser("~"), ".cache", "digdriver_amd", "tunableop.csv")
-            try:
-                os.makedirs(os.path.dirname(path), exist_ok=True)
-                tunable.set_filename(path, insert_device_ordinal=True)
-            except OSError:
-                pass                                           # (no place to keep the results: tuned again next time)
-            tunable.enable(True)
-            tunable.tuning_enable(True)
-        return True
-    except Exception as e:                                     # (a build of torch without it: the heuristic choice, as before)
-        print("NNTrainer: GEMM tuning not available (%s)" % e)
-        return False
+tune_gemms = _predict.tune_gemms          # (one switch for the trainer's and the predictor's GEMMs)
 
 
 def adam_for(model, device):
