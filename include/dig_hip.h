@@ -448,8 +448,9 @@ int64_t dig_bh_workspace(int64_t n, int64_t rows);
 int dig_bh_qvalues_sorted(const double *p_sorted, int64_t n, int64_t rows, double *q_sorted, void *workspace, int64_t workspace_bytes,
                           void *stream);
 /* Ranking p-values on the device (ABI 11, round 6; csrc/dig_sort.hip): a batched LSD radix sort written for this step (63-bit
- * keys in 9-bit digits, 32-bit payload, one kernel per pass by decoupled look-back) with the Benjamini-Hochberg pass behind it --
- * what nb_model.get_q_vals (nb_model.py:340-342) needs for every cohort of the per-base route at once.
+ * keys in 9-bit digits, four passes over the upper 36 bits + a fix-up of the short runs that share them; ranges of 65 536
+ * elements: histogram, scan, scatter -- no workgroup waits for another one) with the Benjamini-Hochberg pass behind it -- what
+ * nb_model.get_q_vals (nb_model.py:340-342) needs for every cohort of the per-base route at once.
  *   rows: ragged lists in one array, row r = elements row_ptr[r] .. row_ptr[r + 1] - 1 (row_ptr: HOST array of rows + 1 offsets;
  *       a row holds fewer than 2^30 elements).  p, q, p_sorted, order: DEVICE arrays indexed like p.
  *   dig_sort_rows: p_sorted = the row's values ascending (every NaN last), order[j] = position in the row of the j-th smallest;
@@ -461,7 +462,11 @@ int dig_bh_qvalues_sorted(const double *p_sorted, int64_t n, int64_t rows, doubl
  *       sample sort finishes its range of the global order with them.  row_min (DEVICE, `rows`, may be NULL): the minimum of
  *       p / (rank / n) over the row, without carry (what the ranks in front take as their carry).  q may be NULL when only
  *       row_min is wanted.  sorted_out != 0: q leaves in ascending order of p instead of in place.
- *   workspace: dig_bh_ragged_workspace(row_ptr, rows) bytes (24 bytes per element + tables). */
+ *       The way back to the elements' places: q is a step function of p (one step per record of the reverse running minimum),
+ *       so only the keys are sorted, the records go into a table per row and every element finds its q by its own value; a row
+ *       with more records than half its length makes the call sort again with a 32-bit payload and write q through it.  The
+ *       call synchronises `stream` (row tables go up, one flag word comes back).
+ *   workspace: dig_bh_ragged_workspace(row_ptr, rows) bytes (24.2 bytes per element + tables). */
 int64_t dig_bh_ragged_workspace(const int64_t *row_ptr, int64_t rows);
 int dig_sort_rows(const double *p, const int64_t *row_ptr, int64_t rows, double *p_sorted, uint32_t *order, void *workspace,
                   int64_t workspace_bytes, void *stream);
