@@ -392,13 +392,39 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
             s_k[c * kSortBlock + tid] = (i >= 0 && i < n_row) ? lk[c] : 0ull;
         }
     }
+    __shared__ unsigned short s_list[kSortTile];                 // window indices of the tile's elements that sit in a run
+    __shared__ unsigned s_n;
+    if (tid == 0) s_n = 0u;
     __syncthreads();
-    bool give_up = false;
+    // ---- phase 1, every element: a neighbour with the same upper bits?  No (nine in ten, as a rule): the element stays where it is.
+    // Yes: its window index goes to a list (one LDS atomic per wave and step) -- the walk along the run and the rank inside it are
+    // done by ALL lanes on list entries afterwards, not by the one lane in ten of a wave that meets a run. ----
 #pragma unroll
     for (int e = 0; e < kSortItems; ++e) {
         const int w = kFixRun + e * kSortBlock + tid;            // window index of the element
         const int64_t i = w0 + w;
-        if (i >= n_row) break;
+        const bool on = i < n_row;
+        const uint64_t key = s_k[w], pre = key >> kFixLowBits;
+        const bool in_run = on && ((i > 0 && (s_k[w - 1] >> kFixLowBits) == pre) || (i + 1 < n_row && (s_k[w + 1] >> kFixLowBits) == pre));
+        if (on && !in_run) {
+            kd[r0 + i] = key;
+            if (PAY) vd[r0 + i] = val[e];
+        }
+        const uint64_t m = __ballot(in_run);
+        if (m) {
+            unsigned base = 0u;
+            if ((tid & 63) == 0) base = atomicAdd(&s_n, (unsigned)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (in_run) s_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)w;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2, the members of runs ----
+    bool give_up = false;
+    const int n_list = (int)s_n;
+    for (int t = tid; t < n_list; t += kSortBlock) {
+        const int w = s_list[t];
+        const int64_t i = w0 + w;
         const uint64_t key = s_k[w], pre = key >> kFixLowBits;
         // the run of equal upper bits around the element.  The lists are in order of those bits, so the element kFixRun places
         // away tells at once whether the run is a long one (exact ties by the hundred thousand -- every tile without a mutation
@@ -424,7 +450,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_fixup_kernel(uint64_t* __rest
             give_up = true;
         }
         kd[r0 + dst] = key;
-        if (PAY) vd[r0 + dst] = val[e];
+        if (PAY) vd[r0 + dst] = vs[r0 + i];                      // (the tile's payloads were read a moment ago: an L2 hit)
     }
     if (__any(give_up) && (tid & 63) == 0) atomicOr(flags, 2u);
 }
