@@ -671,12 +671,14 @@ def parse_args(argv=None):
     ap.add_argument("--pack-bins", type=int, default=1,
                     help="1 (default): the plans gather from the packed bin records built at plan time (dig_bin_records_pack); "
                          "0: from the four bin tables as handed in (A/B)")
-    ap.add_argument("--outputs", choices=["auto", "planes", "records"], default="planes",
-                    help="layout of the statistics stage's ten outputs per pair: planes (default: eleven arrays, the form of dig_element_stats "
-                         "and what the product -- cohort_batch.run_element_cohorts, every consumer of a result frame -- reads: `value` is "
-                         "quoted on it); records (DIG_PIPE_RECORDS: one aligned 5 120-byte run per 64-pair tile; a consumer needs "
-                         "dig_element_records_unpack behind it, which is NOT in the timed step: developer A/B); auto: the plan times both "
-                         "on THIS card before the run and keeps the faster (round 5's default; output_form says what ran)")
+    ap.add_argument("--outputs", choices=["auto", "planes", "records"], default="records",
+                    help="layout of the statistics stage's ten outputs per pair.  records (default; DIG_PIPE_RECORDS: one aligned 5 120-byte "
+                         "run per 64-pair tile) = what the product runs: driver_model.cohort_batch consumes them through "
+                         "dig_element_records_unpack, which writes every plane cohort-major -- what its result frames read -- in one kernel.  "
+                         "planes: eleven [E, C] arrays, the form of dig_element_stats (cohort_batch(output_form='planes') transposes every plane "
+                         "on the device behind the pass).  auto: engine.records_form_is_faster times whole passes of both forms on THIS card "
+                         "and keeps the faster (developer A/B; the pool's cards differ in which one wins).  No re-layout is part of the timed "
+                         "step in any form; same bits")
     ap.add_argument("--aux", type=int, default=1,
                     help="1: after the timed region (N = 1 only) run short legs of the other SURVEY 8d kernels -- track gather, CNN "
                          "forward, per-base tiles, context counting -- and report them as aux_rooflines; 0: skip")
@@ -944,7 +946,8 @@ def run_workload(args, mode, ctx, primary=True):
                         "with given scale factors and its synchronisation (first_run); the timed loop below runs on warm plans")
     # --outputs auto: which layout of the statistics stage's outputs is faster on THIS card (untimed, a property of the plan
     # like the compact form: the statistics stage alone, three rounds of 25 launches of each form, HIP events)
-    output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs %s" % args.outputs}
+    output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs %s" % args.outputs,
+                   "consumer": "driver_model.cohort_batch runs the record form (dig_element_records_unpack -> cohort-major planes)"}
     # canonical-chunk form: the same bits for every sharding of the bins (dig_scale_suffstats_chunked); a "replicas" rank
     # exchanges nothing (its plan has world = 1)
     exchange = use_dist and (sharded or world == 1)
@@ -953,35 +956,15 @@ def run_workload(args, mode, ctx, primary=True):
 
     if args.outputs == "auto" and args.pack_bins:
         try:
+            # developer A/B (engine.records_form_is_faster): whole passes of a plane plan and of a record plan, timed once on this
+            # card; a tie keeps the planes
             alt = make_plan(0, records=True)
-            cal = {}
-            cal_cj = (torch.empty(C, dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev))
-            beside = not exchange                            # (the sharded plan's run() is a collective: kept out of the calibration)
-
-            def cal_pass(pl):
-                # what a step of the loop puts on the device: the scale factors' kernels on the side stream, free-running, and one
-                # whole pass on the main stream (which form is faster depends on what runs beside it: in isolation the two tie on
-                # cards where the record form is 5 - 8 us per step ahead in the loop)
-                if beside:
-                    scale_plan.run(cal_cj[0], cal_cj[1], stream=side_stream)
-                pl.run(td["cj"], td["cj_indel"], stages=7, stream=main_stream)
-            for name, pl in (("planes", pipes[0]), ("records", alt)):
-                best = []
-                for _ in range(3):
-                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    for _w in range(8):
-                        cal_pass(pl)
-                    ea.record(main_stream)
-                    for _r in range(25):
-                        cal_pass(pl)
-                    eb.record(main_stream)
-                    torch.cuda.synchronize()
-                    best.append(ea.elapsed_time(eb) / 25 * 1e3)
-                cal[name] = min(best)
-            use_records[0] = cal["records"] < cal["planes"] - 1.5           # (us; a tie keeps the plane form)
-            output_form = {"chosen": "records" if use_records[0] else "planes", "how": "--outputs auto: whole passes (dot + statistics kernel, "
-                           "given scale factors%s), best of three rounds of 25 of each form on this card, before the run (untimed)"
-                           % (", the scale factors' kernels running beside them on the side stream as in the loop" if beside else ""),
+            chosen, cal = engine.records_form_is_faster(pipes[0], alt, td["cj"], td["cj_indel"])
+            torch.cuda.synchronize()
+            use_records[0] = bool(chosen)
+            output_form = {"chosen": "records" if use_records[0] else "planes",
+                           "how": "--outputs auto = engine.records_form_is_faster: whole passes (dot + statistics kernel, given scale factors) "
+                                  "of both forms timed once on this card before the run (untimed)",
                            "pass_us": {k: round(v, 1) for k, v in cal.items()}}
             if use_records[0]:
                 pipes[0] = alt

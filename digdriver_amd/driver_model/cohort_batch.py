@@ -121,7 +121,8 @@ class _Stages:
 
 
 def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_factors=None, max_muts_per_sample=3e9,
-                        max_muts_per_elt_per_sample=3e9, device=0, timings=None, read_workers=None, on_frame=None):
+                        max_muts_per_elt_per_sample=3e9, device=0, timings=None, read_workers=None, on_frame=None,
+                        output_form="records"):
     """One result frame per cohort (index ELT, the columns of run_element_region_model) for the mutation files
     `f_muts[c]` against the pretrained maps `f_pretrained[c]` (one bin grid) and the element set `save_key` of
     `f_element_data`.  scale_factors: (cj [C], cj_indel [C]) or None for the genome mode.
@@ -130,6 +131,7 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
     on_frame(c, frame, columns, index): called as soon as cohort c's frame exists -- the frame, the dict of column arrays it was
     built from and its row index (run_and_write_element_cohorts hands them to a writer thread there, so that the result files
     are written while the next frames are assembled).
+    output_form: "records" (default) or "planes" -- the layout the statistics stage writes on the device (see below; same frames).
     The three inputs are independent until the kernels need them, so they are read SIDE BY SIDE (round 5; one after the other
     they were 0.8 of the 1.5 s of a 37-cohort run): the maps (a thread per map), the element container, and the mutation
     files -- each parsed by the library's own parser and uploaded by its own thread as soon as it is parsed."""
@@ -202,15 +204,34 @@ def run_element_cohorts(f_muts, f_pretrained, f_element_data, save_key, scale_fa
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
     args = (*dev_tables, t(ctx), t(ov_ptr), t(ov_idx), t(elts['L']), t(elts['strand_minus']), t(d_pr))
     st_.mark("h2d")
-    acc, st = engine.element_pipeline(*args, obs_snv, obs_smp, obs_ind, cj, cji)
-    alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
-    st_.mark("kernels")
-    # every [E, C] plane comes back cohort-major ([C, E], transposed on the device): a cohort's column is then one contiguous
-    # row -- read with a stride of C values, the 24 columns of 37 frames were 0.35 s of cache misses on the host
+    # The pass.  The statistics stage writes tile-blocked RECORDS (DIG_PIPE_RECORDS: one aligned run per 64-pair tile instead of
+    # eleven store streams) and dig_element_records_unpack turns them into what the frames below want -- every plane cohort-major
+    # ([C, E]: a cohort's column is one contiguous row; read with a stride of C values, the 24 columns of 37 frames were 0.35 s of
+    # cache misses on the host) -- in ONE kernel; the plane form (`output_form="planes"`: eleven [E, C] arrays) needs a transpose per
+    # plane behind the pass.  Same bits.  The general (192-substitution) form of the accumulation, as the per-cohort route runs it:
+    # the same P to the last bit.
     host = lambda x: x.cpu().numpy()
     by_cohort = lambda x: host(x.transpose(-1, -2).contiguous())
-    A = {k: (by_cohort(v) if v.dim() == 2 else host(v)) for k, v in acc.items() if k != 'P'}                # (P [E, 1, C]: its one class below)
-    S, al, th = by_cohort(st), by_cohort(alpha), by_cohort(theta)
+    plan = engine.PipelinePlan(*args, obs_snv, obs_smp, obs_ind, compact=False, pack_bins=True, records_out=(output_form == "records"))
+    if plan.records_out:
+        acc, _ = plan.run(cj, cji)
+        st_cm = torch.empty((len(engine.ES_PLANES), plan.C, plan.E), dtype=torch.float64, device=dev)
+        rates = {"MU": torch.empty((plan.C, plan.E), dtype=torch.float64, device=dev),
+                 "SIGMA": torch.empty((plan.C, plan.E), dtype=torch.float64, device=dev),
+                 "R_OBS": torch.empty((plan.C, plan.E), dtype=torch.int32, device=dev),
+                 "FLAG": torch.empty((plan.C, plan.E), dtype=torch.int32, device=dev)}
+        plan.unpack(cohort_major=True, stats=st_cm, rates=rates)
+        alpha, theta = nb_model.normal_params_to_gamma(rates["MU"], rates["SIGMA"])
+        st_.mark("kernels")
+        A = {k: host(v) for k, v in acc.items() if k not in ('P', 'MU', 'SIGMA', 'R_OBS', 'FLAG')}
+        A.update({k: host(v) for k, v in rates.items()})
+        S, al, th = host(st_cm), host(alpha), host(theta)
+    else:
+        acc, st = plan.run(cj, cji)
+        alpha, theta = nb_model.normal_params_to_gamma(acc["MU"], acc["SIGMA"])
+        st_.mark("kernels")
+        A = {k: (by_cohort(v) if v.dim() == 2 else host(v)) for k, v in acc.items() if k != 'P'}            # (P [E, 1, C]: its one class below)
+        S, al, th = by_cohort(st), by_cohort(alpha), by_cohort(theta)
     P0 = host(acc['P'][:, 0, :].transpose(0, 1).contiguous())
     cj_h, cji_h = host(cj), host(cji)
     o_snv, o_smp, o_ind = by_cohort(obs_snv), by_cohort(obs_smp), by_cohort(obs_ind)

@@ -399,6 +399,39 @@ def element_pipeline(bin_mu, bin_std, bin_y, bin_flag, bin_ctx, ov_ptr, ov_idx, 
     return o, st
 
 
+_RECORDS_FASTER = {}          # device index -> whether the record form of the statistics outputs is the faster one there
+
+
+def records_form_is_faster(plane_plan, record_plan, cj, cj_indel, rounds=2, warm=8, launches=25):
+    """Which layout of the statistics stage's outputs is the faster one on THIS card: eleven planes, or tile-blocked records
+    (PipelinePlan(records_out=True))?  The pool's MI355X fall into two kinds -- on most the eleven store streams of the plane
+    form cost ~ 10 us of a 180-us pass in a loop, on the others the record form does.  Developer A/B
+    (`bench.py --outputs auto`): whole passes of the two plans (same inputs), best of `rounds` x `launches` behind `warm` untimed
+    ones (bursts of five measure the clocks coming up, not the forms), HIP events on torch's current stream; a tie keeps the
+    planes; once per process and device.  Returns (bool, {"planes": us, "records": us})."""
+    import torch
+    key = plane_plan.dev.index
+    if key in _RECORDS_FASTER:
+        return _RECORDS_FASTER[key]
+    us = {}
+    with torch.cuda.device(plane_plan.dev):
+        for name, pl in (("planes", plane_plan), ("records", record_plan)):
+            best = float("inf")
+            for _ in range(rounds):
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _w in range(warm):
+                    pl.run(cj, cj_indel)
+                ea.record()
+                for _r in range(launches):
+                    pl.run(cj, cj_indel)
+                eb.record()
+                eb.synchronize()
+                best = min(best, ea.elapsed_time(eb) / launches * 1e3)
+            us[name] = best
+    _RECORDS_FASTER[key] = (us["records"] < us["planes"] - 1.5, us)
+    return _RECORDS_FASTER[key]
+
+
 class PipelinePlan:
     """dig_element_pipeline / dig_scale_factors_local with the argument marshalling done ONCE, for loops that run
     the same tensors many times (the driver's cohort loop, bench.py): a call is then one ctypes invocation (~10 us of
@@ -489,10 +522,11 @@ class PipelinePlan:
             self.compact = bool(ok.value)
         self._flags = (_lib.DIG_PIPE_COMPACT_L if self.compact else 0) | (_lib.DIG_PIPE_RECORDS if self.records_out else 0)
 
-    def unpack(self, cohort_major=False, stream=None, stats=None):
+    def unpack(self, cohort_major=False, stream=None, stats=None, rates=None):
         """records_out plans: out_records -> the plane form (self.stats [7, E, C] and MU, SIGMA, R_OBS, FLAG of self.acc) on
         `stream`; cohort_major=True writes every plane as [C, E] instead (a result frame's column is then one contiguous row)
-        into `stats` [7, C, E] (required then) and leaves self.acc alone."""
+        into `stats` [7, C, E] (required then) and, when given, `rates` = dict(MU, SIGMA: float64 [C, E]; R_OBS, FLAG: int32
+        [C, E]); self.acc is left alone."""
         import torch
         assert self.records_out
         p = _lib.dev_ptr
@@ -500,8 +534,11 @@ class PipelinePlan:
         with torch.cuda.device(self.dev):
             if cohort_major:
                 assert stats is not None and tuple(stats.shape) == (len(ES_PLANES), self.C, self.E)
-                _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(stats), None, None, None, None, 1,
-                          _lib.stream_ptr(stream))
+                r = rates or {}
+                assert all(tuple(v.shape) == (self.C, self.E) and v.is_contiguous() for v in r.values())
+                assert all(r[k].dtype == (torch.float64 if k in ("MU", "SIGMA") else torch.int32) for k in r)
+                _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(stats), p(r.get("MU")), p(r.get("SIGMA")),
+                          p(r.get("R_OBS")), p(r.get("FLAG")), 1, _lib.stream_ptr(stream))
                 return stats
             st = self.stats if stats is None else stats
             _lib.call("dig_element_records_unpack", p(self.out_records), self.E, self.C, p(st), p(o["MU"]), p(o["SIGMA"]),

@@ -67,7 +67,11 @@ def test_cohort_batch_equals_per_cohort_route(tmp_path):
     sequence_tools.preprocess_nonc(base["bed"], ed, pres[0], L, "elts", window)
     for manual in (True, False):
         sf = (np.array([0.004, 0.002, 0.008]), np.array([0.0007, 0.0003, 0.001])) if manual else None
+        # both layouts of the statistics stage's outputs on the device (records: the default; planes): the same frames
         frames = cohort_batch.run_element_cohorts(muts, pres, ed, "elts", scale_factors=sf)
+        planes = cohort_batch.run_element_cohorts(muts, pres, ed, "elts", scale_factors=sf, output_form="planes")
+        for fa, fb in zip(frames, planes):
+            pd.testing.assert_frame_equal(fa, fb)
         assert len(frames) == C
         for c in range(C):
             frame = genic_driver_tools.nonc_model_parallel(pres[c], ed, "elts", 1)
