@@ -574,7 +574,7 @@ def aux_rooflines(dev):
     first = torch.empty(chunk, dtype=torch.int64, device=dev)
     nval = torch.empty(chunk, dtype=torch.int32, device=dev)
     dt = timeit(lambda: _lib.call("dig_base_tile_probs", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S), 37,
-                                  50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=3, warm=1)
+                                  50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=3, warm=2)
     tiles = chunk * 200
     fl = 2.0 * 64 * 37 * tiles
     out.append({"kernel": "dig_base_tile_probs (base_tile_probs_roles_kernel: walker + multiplier waves, v_mfma_f64_16x16x4 + 4x4x4 quads)", "bound": "mfma", "achieved": fl / dt / 1e12,
@@ -587,7 +587,7 @@ def aux_rooflines(dev):
     # the reference's DEFAULT contexts (n_up = n_down = 2, 1 024-entry tables): a gather-sum through the LDS
     S5 = torch.rand((37, 1024), device=dev, generator=g, dtype=torch.float64) * 1e-2
     dt = timeit(lambda: _lib.call("dig_base_tile_probs_ctx", p(words), words.numel(), p(off), p(ln), 1, p(rc), p(rs), p(re_), chunk, p(S5), 37,
-                                  2, 50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=2, warm=1)
+                                  2, 50, 200, p(ptile), p(first), p(nval), _lib.stream_ptr()), n=3, warm=2)
     reads = float(chunk) * window * 37
     out.append({"kernel": "dig_base_tile_probs_ctx, n_up = 2 (penta-nucleotide contexts, the reference's default: base_tile_probs_rows_kernel, passes of 16 + 16 + 5 cohorts)",
                 "bound": "lds", "achieved": reads * 8.0 / dt / 1e12, "peak": 150.0, "unit": "TB/s of LDS reads (8 B per position and cohort)",
