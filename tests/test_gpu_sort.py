@@ -221,3 +221,59 @@ def test_q_values_by_lookup_and_through_the_payload_are_the_host_form(form):
     q2 = q2.cpu().numpy()
     for j, r in enumerate(keep):
         assert np.array_equal(q2[rp2[j]:rp2[j + 1]], nb_model.get_q_vals(rows[r])), r
+
+
+def test_q_values_of_random_lists_and_ranges_fuzz():
+    """Forty random calls of dig_bh_qvalues_ragged (the default lookup form, its fallback included where a list overflows its table):
+    one to nine lists of 0 .. 30 000 values from mixtures of uniform values, powers, heavy ties, exact zeros and ones, subnormals and
+    +inf; half of the calls as RANGES of longer lists (rank0, n_global, carry) -- against the host form's operations in numpy, bit for
+    bit, q-values and row minima."""
+    import torch
+    from digdriver_amd.sequence_model import nb_model
+    rng = np.random.default_rng(2024)
+
+    def values(n):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            x = rng.random(n)
+        elif kind == 1:
+            x = rng.random(n) ** rng.integers(2, 9)
+        elif kind == 2:
+            x = rng.choice(rng.random(max(1, n // rng.integers(2, 200) + 1)), n)
+        elif kind == 3:
+            x = ((np.arange(n) + 1.0) / max(n, 1)) ** 2                       # every element a record
+            rng.shuffle(x)
+        elif kind == 4:
+            x = np.where(rng.random(n) < 0.03, rng.random(n) ** 8 * 1e-4, 0.5 + 0.1 * rng.random(n))
+        else:
+            x = 10.0 ** rng.uniform(-320, 0, n)
+        if n > 6:
+            x[rng.integers(0, n, 2)] = 0.0
+            x[rng.integers(0, n, 2)] = 1.0
+            if rng.random() < 0.3:
+                x[rng.integers(0, n)] = np.inf
+        return x
+
+    for call in range(40):
+        rows = [values(int(rng.integers(0, 30_000)) if rng.random() < 0.9 else int(rng.integers(0, 4))) for _ in range(int(rng.integers(1, 10)))]
+        rp = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+        as_ranges = call % 2 == 1
+        n_glob = np.array([len(x) + (int(rng.integers(0, 5000)) if as_ranges else 0) for x in rows], dtype=np.float64)
+        rank0 = np.array([int(rng.integers(0, int(n_glob[r]) - len(x) + 1)) if as_ranges else 0 for r, x in enumerate(rows)], dtype=np.int64)
+        carry = np.array([(rng.random() * 2.0 if rng.random() < 0.7 else np.inf) if as_ranges else np.inf for _ in rows])
+        p = torch.as_tensor(np.concatenate(rows) if rp[-1] else np.zeros(0), device="cuda:0")
+        q, rmin = nb_model.bh_ragged(p, rp, n_global=n_glob, rank0=rank0, carry=carry, want_row_min=True)
+        q, rmin = q.cpu().numpy(), rmin.cpu().numpy()
+        for r, x in enumerate(rows):
+            if len(x) == 0:
+                assert rmin[r] == np.inf
+                continue
+            order = np.argsort(x, kind="stable")
+            with np.errstate(all="ignore"):
+                v = x[order] / ((rank0[r] + np.arange(1, len(x) + 1)) / n_glob[r])
+            want_min = v.min()
+            run = np.minimum.accumulate(np.minimum(v, carry[r])[::-1])[::-1]
+            want = np.empty_like(run)
+            want[order] = np.minimum(run, 1.0)
+            assert np.array_equal(q[rp[r]:rp[r + 1]], want), (call, r)
+            assert rmin[r] == want_min, (call, r)
