@@ -97,7 +97,8 @@ class _TapConv(torch.autograd.Function):
 class _HeadRows(torch.autograd.Function):
     """big [C, ...] whose rows are the storage of the C parameters `rows`: forward = big itself; backward hands every parameter ITS
     row of the gradient as a view (set or added to `.grad` here: returned to the engine, each row would be cloned by the
-    parameter's gradient accumulator -- the 252 MB the stack's backward used to copy)."""
+    parameter's gradient accumulator -- the 252 MB the stack's backward used to copy).  For `loss.backward()` -- what the trainers
+    do; `torch.autograd.grad` with the head parameters as inputs sees no gradient for them (the engine is handed None)."""
 
     @staticmethod
     def forward(ctx, big, *rows):
