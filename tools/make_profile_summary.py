@@ -35,10 +35,18 @@ def main(tag, known_suffstats_bytes):
     stats = glob.glob(base + "a/**/*kernel_stats.csv", recursive=True)[0]
     shutil.copy(stats, "profiles/%s_kernel_stats.csv" % tag)
     # the kernels of bench.py's aux_rooflines legs (gather, CNN forward GEMMs, per-base tiles, context counting), same trace
+    # (the library's own kernels of those legs in full -- the sort and Benjamini-Hochberg kernels of the per-base route included --;
+    #  of the GEMM kernels the thirty with the most time: the GEMM tuner's trials are a thousand more names)
     with open(stats) as f, open("profiles/%s_aux_kernel_stats.csv" % tag, "w") as g:
+        gemm = []
         for i, line in enumerate(f):
-            if i == 0 or any(k in line for k in ("gather_", "Cijk_", "base_tile_probs", "tiled_nb", "context_count", "tile_mut")):
+            if i == 0 or any(k in line for k in ("gather_", "base_tile_probs", "tiled_nb", "context_count", "tile_mut", "dig::sort_", "dig::bhr_",
+                                                 "dig::bh_", "batch_norm", "multi_tensor_apply")):
                 g.write(line)
+            elif "Cijk_" in line:
+                gemm.append(line)
+        gemm.sort(key=lambda l: -float(l.rsplit('",', 1)[1].split(",")[1]))
+        g.writelines(gemm[:30])
     fetch = {k: v.get("FETCH_SIZE", 0.0) for k, v in counters(base + "f").items()}
     write = {k: v.get("WRITE_SIZE", 0.0) for k, v in counters(base + "w").items()}
     cal = [k for k in fetch if "suffstats_chunk_stage1" in k or "suffstats_stage1" in k][0]
