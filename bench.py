@@ -649,6 +649,14 @@ def aux_rooflines(dev):
     return out
 
 # --------------------------------------------------------------------------------------
+def _flush_c_stdout():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1483,6 +1491,7 @@ def run_workload(args, mode, ctx, primary=True):
                 res["aux_rooflines"] = [{"kernel": "aux legs", "error": repr(exc)}]
             finally:
                 sys.stdout.flush()
+                _flush_c_stdout()                        # (C-level prints -- RCCL's banner -- sit in libc's buffer when stdout is a file)
                 os.dup2(saved, 1)
                 os.close(saved)
         if args.project_ranks > 1 and world == 1 and primary:
@@ -1501,6 +1510,7 @@ def run_workload(args, mode, ctx, primary=True):
                 res["projected_strong_scaling"] = {"error": repr(exc)}
             finally:
                 sys.stdout.flush()
+                _flush_c_stdout()                        # (C-level prints -- RCCL's banner -- sit in libc's buffer when stdout is a file)
                 os.dup2(saved, 1)
                 os.close(saved)
         if args.e2e and world == 1 and primary and (args.bins, args.elements, args.cohorts) == (288_000, 120_091, 37):
@@ -1518,6 +1528,7 @@ def run_workload(args, mode, ctx, primary=True):
                 res["e2e"] = {"error": repr(exc)}
             finally:
                 sys.stdout.flush()
+                _flush_c_stdout()                        # (C-level prints -- RCCL's banner -- sit in libc's buffer when stdout is a file)
                 os.dup2(saved, 1)
                 os.close(saved)
         if args.cpu_sample > 0 and world == 1:
