@@ -9,8 +9,10 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 B="python3 bench.py --cpu-sample 0 --e2e 0"
 rocm-smi --showserial --showmemvendor 2>/dev/null | grep -i "Serial N\|vendor" > $OUT/${TAG}_gpu.txt      # which GPU of the pool
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}a -- $B --steps 300 --warmup 20 > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}a.err
+export DIG_NN_TUNE_FILE=/tmp/dig_tune_$TAG/t.csv      # the GEMM tuner's results of the unprofiled run below serve the profiled one (its
+                                                      # trials were 417 000 extra launches in round 6's trace)
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_steps20.json 2> $OUT/${TAG}_b20.err      # the driver's command: e2e and aux legs included
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}a -- $B --steps 300 --warmup 20 > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}a.err
 python3 bench.py --cpu-sample 0 --aux 0 --e2e 0 --steps 1000 --warmup 50 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_b1000.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}f -- $B --aux 0 --steps 40 --warmup 5 > /dev/null 2> $OUT/${TAG}f.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}w -- $B --aux 0 --steps 40 --warmup 5 > /dev/null 2> $OUT/${TAG}w.err
